@@ -1,0 +1,135 @@
+/*
+ * npore_amd.h -- C ABI of libnpore_amd.so: the MI355X (gfx950) implementation of
+ * nPoRe's per-read realignment DP.
+ *
+ * The reference has no FFI layer; its boundary for this path is the Cython
+ * extension module `aln` (reference src/aln.pyx), star-imported by its callers
+ * (src/realign.py:11, src/bam.pyx:12).  The entry points below are what a
+ * ctypes binding replacing that module needs; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all buffers are caller-owned;
+ *   - base codes: N=0 A=1 C=2 G=3 T=4 (reference src/cfg.py:11-26);
+ *   - a CIGAR is the *expanded* op string over "=XMID" with S/H already
+ *     stripped (what src/bam.pyx:59 hands to align());
+ *   - every function returns 0 on success or a negative NPORE_E_* code and
+ *     leaves a message retrievable with npore_last_error() (thread local).
+ *     The reference prints "ERROR ..." and exit(1)s or silently truncates
+ *     (src/aln.pyx:689-716); here the same conditions are reported per read
+ *     in `status` (NPORE_ST_* bits) and the truncated string is still returned.
+ *   - one context per GPU; a context is not re-entrant (one call at a time).
+ */
+#ifndef NPORE_AMD_H
+#define NPORE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NPORE_ABI_VERSION 1
+
+/* return codes */
+#define NPORE_OK 0
+#define NPORE_E_INVALID (-1)   /* bad argument */
+#define NPORE_E_NODEVICE (-2)  /* no usable HIP device / wrong architecture */
+#define NPORE_E_HIP (-3)       /* HIP runtime error (see npore_last_error) */
+#define NPORE_E_NOMEM (-4)
+#define NPORE_E_UNSUPPORTED (-5) /* parameter outside what the kernels cover */
+
+/* per-read status bits (0 = clean) */
+#define NPORE_ST_ROW_NEG 1      /* reference: "ERROR: row < 0"   src/aln.pyx:689 */
+#define NPORE_ST_COL_NEG 2      /* reference: "ERROR: col < 0"   src/aln.pyx:699 */
+#define NPORE_ST_RUN_LT1 4      /* reference: "ERROR: run 0"     src/aln.pyx:708 */
+#define NPORE_ST_BAD_TYPE 8     /* reference: unknown matrix type src/aln.pyx:737 */
+#define NPORE_ST_OUT_OF_CHUNK 16 /* traceback left the chunk (UB in the reference) */
+#define NPORE_ST_BAD_INPUT 32   /* CIGAR/sequence lengths disagree, bad op or base code */
+#define NPORE_ST_OUT_CAP 64     /* caller's output slot too small */
+
+typedef struct npore_ctx npore_ctx;
+
+/* ABI version of the loaded library (== NPORE_ABI_VERSION it was built with). */
+int npore_abi_version(void);
+
+/* Message for the last failure on this thread ("" if none). */
+const char *npore_last_error(void);
+
+/* Number of visible gfx950 devices (0 if none / HIP unavailable). */
+int npore_device_count(void);
+
+/*
+ * Create a context on HIP device `device_id` holding the penalty tables.
+ *   sub_scores f32[5][5], np_scores f32[max_n][max_l+1][max_l+1]: the outputs of
+ *   calc_score_matrices (reference src/aln.pyx:62-96), which align() receives as
+ *   arguments (src/aln.pyx:380).  max_n/max_l replace the reads of
+ *   cfg.args.max_n / cfg.args.max_l (src/aln.pyx:436-437).
+ * Returns NULL on failure.
+ */
+npore_ctx *npore_ctx_create(const float *sub_scores, const float *np_scores,
+                            int max_n, int max_l, int device_id);
+void npore_ctx_destroy(npore_ctx *ctx);
+
+/*
+ * Batched replacement for align() (reference src/aln.pyx:379-787); one call of
+ * the reference == a batch of one.  Host buffers in, host buffers out.
+ *   refs/seqs/cigars: concatenated byte buffers; *_off: int64[n_reads+1] prefix
+ *   offsets.  out: caller buffer; read i may use out[out_off[i] .. out_off[i+1]);
+ *   its length goes to out_len[i] (an alignment never exceeds |ref|+|seq| ops).
+ *   status[i]: NPORE_ST_* bits.
+ * Results are bit-identical to the reference for the same
+ * (read, r, max_b_rows, indel_start, indel_extend, max_n, max_l, tables).
+ */
+int npore_align_batch(npore_ctx *ctx, int64_t n_reads,
+                      const uint8_t *refs, const int64_t *ref_off,
+                      const uint8_t *seqs, const int64_t *seq_off,
+                      const char *cigars, const int64_t *cig_off,
+                      float indel_start, float indel_extend,
+                      int max_b_rows, int r,
+                      char *out, const int64_t *out_off,
+                      int64_t *out_len, int32_t *status);
+
+/*
+ * Device-resident variant used by bench.py and by pipelines that already hold
+ * the reads in HBM: same arguments, but every pointer except ctx is a DEVICE
+ * pointer (hipMalloc'ed by the caller, e.g. a torch.cuda tensor's data_ptr()).
+ * `stream` is a hipStream_t passed as void* (NULL = the context's own stream).
+ * Asynchronous with respect to the host unless `sync` is non-zero.
+ */
+int npore_align_batch_device(npore_ctx *ctx, int64_t n_reads,
+                             const uint8_t *d_refs, const int64_t *d_ref_off,
+                             const uint8_t *d_seqs, const int64_t *d_seq_off,
+                             const char *d_cigars, const int64_t *d_cig_off,
+                             float indel_start, float indel_extend,
+                             int max_b_rows, int r,
+                             char *d_out, const int64_t *d_out_off,
+                             int64_t *d_out_len, int32_t *d_status,
+                             void *stream, int sync);
+
+/*
+ * get_np_info (reference src/aln.pyx:179-251): n-polymer annotation of one
+ * sequence.  out is int32[len][2][max_n] ([pos][0=L,1=L_IDX][n-1]).
+ */
+int npore_get_np_info(npore_ctx *ctx, const uint8_t *seq, int64_t len, int32_t *out);
+
+/*
+ * Timing of the stages of the last npore_align_batch* call on this context,
+ * measured with HIP events on the stream the kernels ran on (milliseconds):
+ *   ms[0] device prep, ms[1] fill kernel(s), ms[2] traceback kernel(s),
+ *   ms[3] H2D, ms[4] D2H, ms[5] host prep, ms[6] cells processed (count),
+ *   ms[7] fill-kernel launches.
+ */
+int npore_last_timing(npore_ctx *ctx, double *ms, int n);
+
+/* Tunables: key in {"tb_budget_mb","force_nw","force_ng","host_threads"}. */
+int npore_ctx_set(npore_ctx *ctx, const char *key, int64_t value);
+
+/* Debug self-test: out128[l] = value lane l receives from lane l-1 (l>0),
+ * out128[64+l] = value from lane l+1 (l<63); checks the DPP wave-shift
+ * directions the fill kernel relies on. */
+int npore_debug_dpp(uint32_t *out128);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NPORE_AMD_H */

@@ -1,0 +1,74 @@
+"""ctypes binding of libnpore_amd.so (include/npore_amd.h).
+
+The library holds the gfx950 kernels; there is no CPU implementation of the DP
+behind this module.  Loading fails loudly if the shared object has not been
+built (python __graft_entry__.py build) and context creation fails loudly if
+no MI355X is visible.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnpore_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+_LIB = None
+
+# name -> (restype, argtypes): must list every symbol include/npore_amd.h declares
+SIGNATURES = {
+    "npore_abi_version": (C.c_int, []),
+    "npore_last_error": (C.c_char_p, []),
+    "npore_device_count": (C.c_int, []),
+    "npore_ctx_create": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "npore_ctx_destroy": (None, [C.c_void_p]),
+    "npore_align_batch": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 6 +
+                          [C.c_float, C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 4),
+    "npore_align_batch_device": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 6 +
+                                 [C.c_float, C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 4 +
+                                 [C.c_void_p, C.c_int]),
+    "npore_get_np_info": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "npore_last_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "npore_ctx_set": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "npore_debug_dpp": (C.c_int, [C.c_void_p]),
+}
+
+
+def sources():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + \
+        [os.path.join(_HERE, "..", "include", "npore_amd.h")]
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> npore_amd/libnpore_amd.so (in-tree)."""
+    if not force and os.path.exists(LIB_PATH) and \
+            all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in sources()):
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           "-Wall", "-Wno-unused-function", "-o", LIB_PATH, os.path.join(CSRC, "npore_api.cpp")]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def load():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
+                "(hipcc --offload-arch=gfx950).  npore_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError if the header and the library diverge
+            fn.restype = res
+            fn.argtypes = args
+        if lib.npore_abi_version() != 1:
+            raise ImportError("libnpore_amd.so ABI version mismatch")
+        _LIB = lib
+    return _LIB
+
+
+def last_error():
+    return load().npore_last_error().decode()

@@ -1,0 +1,374 @@
+// kernels.hpp -- gfx950 (CDNA4, wave64) kernels of the realignment path.
+//
+//   fill_kernel<NG>   one wavefront per chunk.  Band column c of the current
+//                     anti-diagonal lives in lane c / NG, register slot c % NG
+//                     (NG consecutive columns per lane), so "column +-1" is a
+//                     register rename inside a lane and one DPP wave shift at the
+//                     lane boundary.  Per step (anti-diagonal) each cell needs its
+//                     top / left / diagonal neighbours (previous two
+//                     anti-diagonals: registers) and, for the n-polymer LEN/SHR
+//                     states, values from up to 6 anti-diagonals back (LDS ring of
+//                     NS rows).  The read/reference annotation words travel
+//                     through the lanes systolically: an 'I' step of the input
+//                     path shifts the read words one column up, a 'D' step shifts
+//                     the reference words one column down; the word entering at
+//                     the band edge comes from a 64-entry per-wave queue register.
+//                     The only per-cell HBM traffic is one 32-bit traceback word.
+//   traceback_kernel  one lane per chunk: follows MAT.TYP/MAT.RUN words
+//                     (reference src/aln.pyx:670-742), writes ops right-aligned
+//                     into the chunk's output slot.
+//   gather_kernel     one workgroup per read: concatenates its chunks' op
+//                     strings into the caller's output buffer (src/aln.pyx:742).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "cell.hpp"
+#include "layout.hpp"
+
+namespace npore {
+
+constexpr int NS = 8;  // history ring rows (>= MAX_PERIOD + 1)
+
+struct KParams {
+    const ChunkDesc *descs;
+    const int32_t *sched;   // block -> chunk index (largest chunks first)
+    const uint8_t *steps;
+    const int32_t *inss;
+    const uint32_t *seqw;
+    const uint2 *refw;
+    const uint2 *refl;      // 8 bytes per reference position
+    uint32_t *tb;
+    const float *sub_scores;  // [5][5]
+    const float *np_scores;   // [max_n][max_l+1][max_l+1]
+    int max_l;
+    int r;
+    int tbstride;
+    float indel_start, indel_extend;
+};
+
+// value of the previous / next lane (lane 0 / 63 keep their own)
+__device__ __forceinline__ uint32_t lane_prev(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t lane_next(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float lane_prev(float v) { return __uint_as_float(lane_prev(__float_as_uint(v))); }
+__device__ __forceinline__ float lane_next(float v) { return __uint_as_float(lane_next(__float_as_uint(v))); }
+
+template <int NG>
+struct DevEnv {
+    static constexpr int WP = 64 * NG;
+    const float *lds_sub;     // [8][8] padded copy of sub_scores
+    const float *np_scores;
+    const uint8_t *refl_p;    // this chunk's refl bytes
+    float *hist;              // LDS: [4][NS][WP]  (matv, lenstart, shrstart, runs)
+    int np_dim, clampv, slot;
+
+    __device__ __forceinline__ static int colidx(int col)
+    {
+        if constexpr (NG == 1) return col;
+        else return (col % NG) * 64 + col / NG;
+    }
+    __device__ __forceinline__ int at(int arr, int n, int col) const
+    {
+        return (arr * NS + ((slot - n) & (NS - 1))) * WP + colidx(col);
+    }
+    __device__ __forceinline__ float sub(uint32_t s, uint32_t r) const { return lds_sub[s * 8 + r]; }
+    __device__ __forceinline__ float np(int n_idx, int a, int b) const
+    {
+        return np_scores[((size_t)n_idx * np_dim + a) * np_dim + b];
+    }
+    __device__ __forceinline__ int clamp() const { return clampv; }
+    __device__ __forceinline__ int refl(int j, int n_idx) const { return refl_p[(size_t)j * 8 + n_idx]; }
+    __device__ __forceinline__ float h_mat(int n, int col) const { return hist[at(0, n, col)]; }
+    __device__ __forceinline__ float h_lens(int n, int col) const { return hist[at(1, n, col)]; }
+    __device__ __forceinline__ float h_shrs(int n, int col) const { return hist[at(2, n, col)]; }
+    __device__ __forceinline__ uint32_t h_runs(int n, int col) const { return __float_as_uint(hist[at(3, n, col)]); }
+    __device__ __forceinline__ bool any(bool x) const { return __builtin_amdgcn_ballot_w64(x) != 0ull; }
+};
+
+template <int NG>
+__global__ __launch_bounds__(64) void fill_kernel(KParams p)
+{
+    constexpr int WP = 64 * NG;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *lds_sub = lds;        // 64 floats
+    float *hist = lds + 64;      // 4 * NS * WP floats
+
+    const int lane = threadIdx.x;
+    const ChunkDesc d = p.descs[p.sched[blockIdx.x]];
+    const int r = p.r;
+    const int W = 2 * r + 1;
+
+    lds_sub[lane] = ((lane >> 3) < 5 && (lane & 7) < 5) ? p.sub_scores[(lane >> 3) * 5 + (lane & 7)] : 0.0f;
+    __syncthreads();
+
+    DevEnv<NG> env;
+    env.lds_sub = lds_sub;
+    env.np_scores = p.np_scores;
+    env.refl_p = reinterpret_cast<const uint8_t *>(p.refl + d.refw_off);
+    env.hist = hist;
+    env.np_dim = p.max_l + 1;
+    env.clampv = p.max_l - 1;
+    env.slot = 0;
+
+    const uint32_t *seqw_g = p.seqw + d.seqw_off;
+    const uint2 *refw_g = p.refw + d.refw_off;
+    const uint8_t *steps_g = p.steps + d.steps_off + d.brk;   // steps_g[k] = step from local row k to k+1
+    uint32_t *tb_g = p.tb + d.tb_off;
+
+    // per-cell state of the previous anti-diagonal
+    float matv[NG], insv[NG], delv[NG], LMv[NG], TMv[NG];
+    uint32_t R1[NG], R2[NG], LT[NG];   // matrun|insrun<<16, matrun|delrun<<16, LMrun|TMrun<<16
+    uint32_t seqw[NG], refx[NG], refy[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        matv[g] = insv[g] = delv[g] = LMv[g] = TMv[g] = 0.0f;
+        R1[g] = R2[g] = LT[g] = 0u;
+        const int col = lane * NG + g;
+        const int i = r - col, j = col - r;
+        seqw[g] = (i >= 0 && i <= d.drows) ? seqw_g[i] : SEQW_SENTINEL;
+        uint2 rw = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint2(REFW_SENTINEL, 0u);
+        refx[g] = rw.x;
+        refy[g] = rw.y;
+    }
+    // queues of words that will enter at column 0 (read) / column WP-1 (reference)
+    int sq_base = r + 1;              // next read index entering at column 0 is ins_l + r
+    int rq_base = WP - r;             // next reference index entering at column WP-1 is del_l + WP-1 - r
+    uint32_t seq_q, refx_q, refy_q;
+    {
+        const int i = sq_base + lane;
+        seq_q = (i <= d.drows) ? seqw_g[i] : SEQW_SENTINEL;
+        const int j = rq_base + lane;
+        uint2 rw = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint2(REFW_SENTINEL, 0u);
+        refx_q = rw.x;
+        refy_q = rw.y;
+    }
+
+    StepInfo st;
+    st.r = r;
+    st.drows = d.drows;
+    st.dcols = d.dcols;
+    st.indel_start = p.indel_start;
+    st.indel_extend = p.indel_extend;
+    int ins_l = 0;
+    uint32_t hist6 = 0;
+    unsigned long long stepmask = 0ull;
+
+    for (int bl = 0; bl < d.nrows; bl++) {
+        int I = 0;
+        if (bl > 0) {
+            const int k = bl - 1;              // step k leads from local row k to k+1
+            if ((k & 63) == 0)                 // 64 steps per (coalesced) load; buffer is padded
+                stepmask = __builtin_amdgcn_ballot_w64(steps_g[k + lane] != 0);
+            I = (int)((stepmask >> (k & 63)) & 1ull);
+            ins_l += I;
+            hist6 = ((hist6 << 1) | (uint32_t)I) & 63u;
+        }
+        st.b_local = bl;
+        st.ins_l = ins_l;
+        st.del_l = bl - ins_l;
+#pragma unroll
+        for (int n = 1; n <= MAX_PERIOD; n++) st.dI[n] = __builtin_popcount(hist6 & ((1u << n) - 1u));
+        env.slot = bl & (NS - 1);
+
+        CellIn in[NG];
+        if (bl > 0 && I) {
+            // read words move one column up; word for row ins_l + r enters at column 0
+            const int qi = ins_l + r - sq_base;
+            if (qi >= 64) {   // uniform
+                sq_base += 64;
+                const int i = sq_base + lane;
+                seq_q = (i <= d.drows) ? seqw_g[i] : SEQW_SENTINEL;
+            }
+            const uint32_t incoming = (uint32_t)__builtin_amdgcn_readlane((int)seq_q, (ins_l + r - sq_base) & 63);
+            const float pm = lane_prev(matv[NG - 1]), pd = lane_prev(delv[NG - 1]);
+            const uint32_t pr = lane_prev(R2[NG - 1]);
+            uint32_t ps = lane_prev(seqw[NG - 1]);
+            if (lane == 0) ps = incoming;
+#pragma unroll
+            for (int g = NG - 1; g >= 0; g--) {
+                in[g].topM = matv[g]; in[g].topI = insv[g]; in[g].topIrun = (int)(R1[g] >> 16);
+                in[g].leftM = g ? matv[g - 1] : pm;
+                in[g].leftD = g ? delv[g - 1] : pd;
+                const uint32_t lr = g ? R2[g - 1] : pr;
+                in[g].leftDrun = (int)(lr >> 16);
+                in[g].diagM = LMv[g];
+                in[g].diagMrun = (int)(LT[g] & 0xFFFFu);
+                LT[g] = (lr & 0xFFFFu) | (R1[g] << 16);
+                seqw[g] = g ? seqw[g - 1] : ps;
+            }
+        } else if (bl > 0) {
+            // reference words move one column down; word for col del_l + WP-1 - r enters at column WP-1
+            const int del_l = bl - ins_l;
+            const int qj = del_l + WP - 1 - r - rq_base;
+            if (qj >= 64) {
+                rq_base += 64;
+                const int j = rq_base + lane;
+                uint2 rw = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint2(REFW_SENTINEL, 0u);
+                refx_q = rw.x;
+                refy_q = rw.y;
+            }
+            const int ql = (del_l + WP - 1 - r - rq_base) & 63;
+            const uint32_t inx = (uint32_t)__builtin_amdgcn_readlane((int)refx_q, ql);
+            const uint32_t iny = (uint32_t)__builtin_amdgcn_readlane((int)refy_q, ql);
+            const float nm = lane_next(matv[0]), ni = lane_next(insv[0]);
+            const uint32_t nr = lane_next(R1[0]);
+            uint32_t nx = lane_next(refx[0]), ny = lane_next(refy[0]);
+            if (lane == 63) { nx = inx; ny = iny; }
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                in[g].leftM = matv[g]; in[g].leftD = delv[g]; in[g].leftDrun = (int)(R2[g] >> 16);
+                in[g].topM = (g < NG - 1) ? matv[g + 1] : nm;
+                in[g].topI = (g < NG - 1) ? insv[g + 1] : ni;
+                const uint32_t tr = (g < NG - 1) ? R1[g + 1] : nr;
+                in[g].topIrun = (int)(tr >> 16);
+                in[g].diagM = TMv[g];
+                in[g].diagMrun = (int)(LT[g] >> 16);
+                LT[g] = (R2[g] & 0xFFFFu) | (tr << 16);
+                refx[g] = (g < NG - 1) ? refx[g + 1] : nx;
+                refy[g] = (g < NG - 1) ? refy[g + 1] : ny;
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                in[g].topM = in[g].topI = in[g].leftM = in[g].leftD = in[g].diagM = 0.0f;
+                in[g].topIrun = in[g].leftDrun = in[g].diagMrun = 0;
+            }
+        }
+
+        CellOut o[NG];
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            in[g].c = lane * NG + g;
+            in[g].seqw = seqw[g];
+            in[g].refx = refx[g];
+            in[g].refy = refy[g];
+            cell_update(env, st, in[g], o[g]);
+        }
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            LMv[g] = in[g].leftM;
+            TMv[g] = in[g].topM;
+            matv[g] = o[g].matv;
+            insv[g] = o[g].insv;
+            delv[g] = o[g].delv;
+            R1[g] = (uint32_t)o[g].matrun | ((uint32_t)o[g].insrun << 16);
+            R2[g] = (uint32_t)o[g].matrun | ((uint32_t)o[g].delrun << 16);
+            const int hi = env.slot * WP + DevEnv<NG>::colidx(lane * NG + g);
+            hist[0 * NS * WP + hi] = o[g].matv;
+            hist[1 * NS * WP + hi] = o[g].lenstart;
+            hist[2 * NS * WP + hi] = o[g].shrstart;
+            hist[3 * NS * WP + hi] = __uint_as_float((uint32_t)o[g].lenrun_h | ((uint32_t)o[g].shrrun_h << 16));
+            const int col = lane * NG + g;
+            if (col < W) tb_g[(size_t)bl * p.tbstride + col] = o[g].tb;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+struct TParams {
+    const ChunkDesc *descs;
+    int n_chunks;
+    const int32_t *inss;
+    const uint32_t *tb;
+    const uint8_t *seqs, *refs;
+    uint8_t *chunk_out;        // per-chunk slots, ops right-aligned
+    int32_t *chunk_len;        // ops emitted
+    int32_t *chunk_status;
+    int r;
+    int tbstride;
+};
+
+__global__ __launch_bounds__(64) void traceback_kernel(TParams p)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= p.n_chunks) return;
+    const ChunkDesc d = p.descs[k];
+    const int32_t *inss = p.inss + d.inss_off;
+    const uint32_t *tb = p.tb + d.tb_off;
+    const uint8_t *seq = p.seqs + d.seq_off, *ref = p.refs + d.ref_off;
+    uint8_t *out = p.chunk_out + d.out_off;
+    const int W = 2 * p.r + 1;
+    int a_row = d.row0 + d.drows, a_col = d.col0 + d.dcols;
+    int pos = d.out_cap;   // write backwards
+    int status = 0;
+    while (a_row > d.row0 || a_col > d.col0) {
+        const int bl = a_row + a_col - d.brk;
+        if (a_row < d.row0 || a_col < d.col0 || bl < 0 || bl >= d.nrows) { status |= 16; break; }
+        const int bc = inss[a_row + a_col] - a_row + p.r;
+        if (bc < 0 || bc >= W) { status |= 16; break; }
+        const uint32_t w = tb[(size_t)bl * p.tbstride + bc];
+        const int typ = (int)(w & 7u), run = (int)(w >> 3);
+        if (run < 1) { status |= 4; break; }
+        if (run > pos) { status |= 16; break; }
+        if (typ == T_LEN || typ == T_INS) {
+            for (int q = 0; q < run; q++) out[--pos] = 'I';
+            a_row -= run;
+        } else if (typ == T_SHR || typ == T_DEL) {
+            for (int q = 0; q < run; q++) out[--pos] = 'D';
+            a_col -= run;
+        } else if (typ == T_MAT) {
+            bool bad = false;
+            for (int q = 0; q < run; q++) {
+                a_row--; a_col--;
+                if (a_row < d.row0 || a_col < d.col0) { bad = true; break; }
+                out[--pos] = (ref[a_col] == seq[a_row]) ? '=' : 'X';
+            }
+            if (bad) { status |= 16; break; }
+        } else { status |= 8; break; }
+    }
+    p.chunk_len[k] = d.out_cap - pos;
+    p.chunk_status[k] = status;
+}
+
+// ---------------------------------------------------------------------------
+struct GParams {
+    const ChunkDesc *descs;
+    const int32_t *read_first_chunk;   // [n_reads+1]
+    const uint8_t *chunk_out;
+    const int32_t *chunk_len, *chunk_status;
+    const int32_t *read_status_in;     // prep status per read (bad input)
+    uint8_t *out;
+    const int64_t *out_off;            // [n_reads+1] in the caller's buffer
+    int64_t *out_len;
+    int32_t *status;
+    int64_t read_base;                 // index of this group's first read in the caller's arrays
+};
+
+__global__ __launch_bounds__(256) void gather_kernel(GParams p)
+{
+    const int rd = blockIdx.x;
+    const int64_t grd = p.read_base + rd;
+    const int c0 = p.read_first_chunk[rd], c1 = p.read_first_chunk[rd + 1];
+    int st = p.read_status_in[rd];
+    int64_t total = 0;
+    for (int c = c0; c < c1; c++) { total += p.chunk_len[c]; st |= p.chunk_status[c]; }
+    const int64_t cap = p.out_off[grd + 1] - p.out_off[grd];
+    if (st & 32) total = -1;
+    else if (total > cap) { st |= 64; total = -1; }
+    if (threadIdx.x == 0) { p.out_len[grd] = total; p.status[grd] = st; }
+    if (total < 0) return;
+    uint8_t *dst = p.out + p.out_off[grd];
+    int64_t w = 0;
+    for (int c = c0; c < c1; c++) {
+        const ChunkDesc d = p.descs[c];
+        const int len = p.chunk_len[c];
+        const uint8_t *src = p.chunk_out + d.out_off + (d.out_cap - len);
+        for (int q = threadIdx.x; q < len; q += blockDim.x) dst[w + q] = src[q];
+        w += len;
+    }
+}
+
+// DPP direction self-test: out[l] = lane_prev(l), out[64+l] = lane_next(l)
+__global__ void dpp_selftest_kernel(uint32_t *out)
+{
+    const uint32_t l = threadIdx.x;
+    out[l] = lane_prev(l);
+    out[64 + l] = lane_next(l);
+}
+
+}  // namespace npore

@@ -1,0 +1,69 @@
+// layout.hpp -- data layout shared by host orchestration and the gfx950 kernels.
+//
+// Work unit: a CHUNK = one independent stretch of <= max_b_rows anti-diagonals
+// ("b-rows") of one read (reference src/aln.pyx:344-358, 445-456).  A chunk is a
+// rectangle [row0,row0+drows] x [col0,col0+dcols] of the read's alignment
+// matrix ("A" coordinates: row = bases of the read consumed, col = bases of the
+// reference consumed) swept along anti-diagonals inside a band of half-width r
+// around the input alignment path ("B" coordinates, src/aln.pyx:317-338):
+//   b_row = a_row + a_col,  b_col = inss[b_row] - a_row + r.
+//
+// Per-chunk packed annotation words (one entry per local row i / local col j):
+//
+//   seqw[i]  (i = a_row-row0, 0..drows)     "what a cell in row i needs to know"
+//     bits  0-17  the 6 read bases before row i, oldest first: code(seq[i-6+k])<<3k
+//                 (code 7 = before the chunk slice); the cell's own base seq[i-1]
+//                 is bits 15-17.
+//     bits 18-23  bit n-1: read position i-n lies in an n-polymer  (L_seq != 0)
+//     bits 24-29  bit n-1: ... and is its first copy               (L_IDX_seq == 0)
+//   refw[j].x (j = a_col-col0, 0..dcols)
+//     bits  0-17  the 6 reference bases from col j on: code(ref[j+k])<<3k
+//                 (code 6 = past the chunk slice)
+//     bits 18-23  bit n-1: reference position j starts an n-polymer (L != 0 && L_IDX == 0)
+//     bits 24-26  the cell's own reference base ref[j-1]
+//   refw[j].y
+//     bits  0-5   bit n-1: reference position j-n lies in an n-polymer (L != 0)
+//     bits  6-11  bit n-1: ... and is its first copy                  (L_IDX == 0)
+//   refl[j]  8 bytes: byte n-1 = L of reference position j for period n (0..max_l)
+//
+// n-polymer annotation follows get_np_info (reference src/aln.pyx:179-251) on the
+// chunk's own slices (src/aln.pyx:453-456); flags are stored from the point of
+// view of the cell that RECEIVES a lengthen/shorten move (see kernels.hpp).
+//
+// Traceback word per cell (the only per-cell HBM traffic): typ | run<<3, the
+// MAT.TYP / MAT.RUN pair the reference's traceback reads (src/aln.pyx:684-685).
+#pragma once
+#include <stdint.h>
+
+namespace npore {
+
+enum : int { T_MAT = 0, T_INS = 1, T_LEN = 2, T_DEL = 3, T_SHR = 4 };
+
+constexpr uint32_t SEQW_SENTINEL = 0x3FFFFu;  // six code-7 bases, no flags
+constexpr uint32_t REFW_SENTINEL = 0x36DB6u;  // six code-6 bases, no flags
+constexpr int MAX_PERIOD = 6;                  // kernels are specialised for max_n <= 6
+constexpr float INF_F = 100.0f;                // reference src/aln.pyx:428
+
+struct alignas(16) ChunkDesc {
+    int32_t read_id;
+    int32_t brk;      // first global b-row of the chunk
+    int32_t nrows;    // b-rows in the chunk (next_brk - brk + 1)
+    int32_t row0;     // inss[brk]
+    int32_t col0;     // dels[brk]
+    int32_t drows;    // inss[next_brk] - row0
+    int32_t dcols;    // dels[next_brk] - col0
+    int32_t out_cap;  // drows + dcols: upper bound on ops emitted
+    int64_t steps_off;  // index of this READ's step 0 in the steps byte array
+    int64_t inss_off;   // index of this READ's inss[0] in the inss int32 array
+    int64_t seqw_off;   // index of seqw[0] of this chunk
+    int64_t refw_off;   // index of refw[0] / refl[0] of this chunk
+    int64_t tb_off;     // index (in uint32) of this chunk's traceback block
+    int64_t out_off;    // byte offset of this chunk's output slot
+    int64_t seq_off;    // byte offset of the READ's first base in the seqs buffer (for '='/'X')
+    int64_t ref_off;    // byte offset of the READ's first reference base in the refs buffer
+};
+
+// traceback row stride (uint32 words) for band half-width r: 2r+1 rounded up to 4
+static inline int tb_stride(int r) { return ((2 * r + 1) + 3) & ~3; }
+
+}  // namespace npore

@@ -1,0 +1,151 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the
+golden fixtures and against the oracle on seeded inputs.  Bit-exact strings."""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from npore_amd import _lib, aln, synth
+from conftest import load_json, enc, expand_cigar, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(s):
+    return hashlib.sha256(s.encode()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def ctx(tables):
+    sub, nps = tables
+    c = aln.Context(sub, nps, max_n=6, max_l=100, device=0)
+    yield c
+    c.close()
+
+
+def test_library_is_gfx950_and_loaded():
+    lib = _lib.load()
+    assert lib.npore_device_count() >= 1
+
+
+def test_dpp_directions():
+    lib = _lib.load()
+    out = (C.c_uint32 * 128)()
+    assert lib.npore_debug_dpp(out) == 0
+    prev, nxt = list(out[:64]), list(out[64:])
+    assert prev[1:] == list(range(0, 63)) and prev[0] == 0
+    assert nxt[:63] == list(range(1, 64)) and nxt[63] == 63
+
+
+def test_unit_aligns(ctx):
+    cases = load_json("unit_aligns.json")
+    refs = [enc(c["ref"]) for c in cases]
+    seqs = [enc(c["seq"]) for c in cases]
+    cigs = [expand_cigar(c["cigar"]) for c in cases]
+    a, st = ctx.align_batch(refs, seqs, cigs, max_b_rows=20, r=10, return_status=True)
+    assert not st.any()
+    assert a == [c["aln_20_10"] for c in cases]
+    b = ctx.align_batch(refs, seqs, cigs)
+    assert b == [c["aln_default"] for c in cases]
+
+
+def test_reads_e2e_raw(ctx):
+    fasta = "".join(l.strip() for l in open(os.path.join(GOLDEN, "data", "ref.fasta")) if not l.startswith(">")).upper()
+    want = {r["name"]: r for r in load_json("reads_e2e.json")}
+    names, refs, seqs, cigs = [], [], [], []
+    for line in open(os.path.join(GOLDEN, "data", "reads.sam")):
+        if line.startswith("@"):
+            continue
+        f = line.rstrip("\n").split("\t")
+        ex = expand_cigar(f[5]).replace("S", "").replace("H", "")
+        start = int(f[3]) - 1
+        rlen = sum(1 for ch in ex if ch in "XD=M")
+        names.append(f[0]); refs.append(enc(fasta[start:start + rlen])); seqs.append(enc(f[9])); cigs.append(ex)
+    got, st = ctx.align_batch(refs, seqs, cigs, return_status=True)
+    assert not st.any()
+    for n, g in zip(names, got):
+        assert g == want[n]["raw_align"], n
+
+
+def test_synthetic_golden(ctx):
+    recs = load_json("synthetic.json")
+    groups = {}
+    for r in recs:
+        groups.setdefault((r["r"], r["max_b_rows"]), []).append(r)
+    for (r, mbr), rs in groups.items():
+        trip = [synth.make_pair(x["base_seed"], x["index"], x["ref_len"], x["p_np"], x["p_cnv"], x["mixed"]) for x in rs]
+        got, st = ctx.align_batch([t[0] for t in trip], [t[1] for t in trip], [t[2] for t in trip],
+                                  r=r, max_b_rows=mbr, return_status=True)
+        assert not st.any(), (r, mbr)
+        for x, g in zip(rs, got):
+            assert len(g) == x["len"] and sha(g) == x["sha256"], x
+
+
+@pytest.mark.parametrize("r", [1, 2, 5, 10, 30, 31, 32, 50, 63, 64, 100, 127, 128, 200])
+def test_fuzz_vs_oracle(ctx, tables, r):
+    sub, nps = tables
+    rng = np.random.default_rng(1000 + r)
+    refs, seqs, cigs = [], [], []
+    for k in range(24):
+        ref_len = int(rng.integers(1, 700))
+        ref, seq, cig = synth.make_pair(500 + r, k, ref_len, float(rng.choice([0.0, 0.05, 0.15, 0.4])),
+                                        float(rng.choice([0.0, 0.3, 0.9])))
+        if k % 5 == 0 and len(ref) > 3:
+            ref = ref.copy(); ref[rng.integers(0, len(ref), size=2)] = 0
+        if k % 7 == 0 and len(seq) > 3:
+            seq = seq.copy(); seq[rng.integers(0, len(seq), size=2)] = 0
+        refs.append(ref); seqs.append(seq); cigs.append(cig)
+    for mbr, ist, iex in ((20000, 5, 1), (64, 5, 1), (7, 5, 1), (2, 5, 1), (300, 3, 0), (300, 7, 2)):
+        got, st = ctx.align_batch(refs, seqs, cigs, indel_start=ist, indel_extend=iex, r=r, max_b_rows=mbr,
+                                  return_status=True)
+        for k in range(len(refs)):
+            want, wst = oracle.align(refs[k], seqs[k], cigs[k], sub, nps, indel_start=ist, indel_extend=iex,
+                                     r=r, max_b_rows=mbr, return_status=True)
+            assert got[k] == want and st[k] == wst, (r, mbr, ist, iex, k)
+
+
+def test_edge_inputs(ctx):
+    got, st = ctx.align_batch([enc(""), enc("ACGT"), enc(""), enc("ACGT"), enc("ACGT")],
+                              [enc(""), enc(""), enc("ACGT"), enc("ACGT"), enc("ACGT")],
+                              ["", "DDDD", "IIII", "===", "==N="], return_status=True)
+    assert got[:3] == ["", "DDDD", "IIII"]
+    assert st[:3].tolist() == [0, 0, 0]
+    assert st[3] & 32 and st[4] & 32
+    assert ctx.align_batch([], [], []) == []
+
+
+def test_align_signature_drop_in(tables):
+    sub, nps = tables
+    c = load_json("unit_aligns.json")[8]
+    s = aln.align(enc(c["ref"]), enc(c["seq"]), expand_cigar(c["cigar"]), sub, nps, max_b_rows=20, r=10)
+    assert s == c["aln_20_10"]
+    info = aln.get_np_info(enc("ATATATATTTTTTAAAGCGCGC"))
+    assert info[:, 0, 0].tolist() == [0, 0, 0, 0, 0, 0, 0, 6, 6, 6, 6, 6, 6, 3, 3, 3, 0, 0, 0, 0, 0, 0]
+
+
+def test_10kb_properties(ctx, tables):
+    """Full-size reads: size-independent properties (ops consume exactly the read
+    and the reference; '=' / 'X' agree with the bases) plus oracle equality on 2."""
+    sub, nps = tables
+    refs, seqs, cigs = synth.make_batch(2, 32, ref_len=10_000)
+    got, st = ctx.align_batch(refs, seqs, cigs, r=100, return_status=True)
+    assert not st.any()
+    for ref, seq, g in zip(refs, seqs, got):
+        ops = np.frombuffer(g.encode(), np.uint8)
+        assert np.isin(ops, [ord("="), ord("X"), ord("I")]).sum() == len(seq)
+        assert np.isin(ops, [ord("="), ord("X"), ord("D")]).sum() == len(ref)
+        i = j = 0
+        for op in g:
+            if op == "=":
+                assert ref[j] == seq[i]; i += 1; j += 1
+            elif op == "X":
+                assert ref[j] != seq[i]; i += 1; j += 1
+            elif op == "I":
+                i += 1
+            else:
+                j += 1
+    for k in (0, 17):
+        assert got[k] == oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=100)
