@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- realigned reads/s of the align() hot path on MI355X.
+
+A "step" is one pass of the whole path (path conversion, n-polymer annotation,
+banded DP fill, traceback, output gather) over one batch of synthetic ONT-like
+reads that is already resident in HBM.  Default workload = BASELINE.json
+configs[1]: 1 000 reads of 10 kb, band half-width r=100 ("band=100"),
+guppy5_stats penalties, max_b_rows=20000.
+With --gpus N every rank runs the same-sized, different batch (weak scaling,
+reads dealt by index); the only collective is the final max/sum reduction.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def pack(seqs):
+    off = np.zeros(len(seqs) + 1, np.int64)
+    np.cumsum([len(s) for s in seqs], out=off[1:])
+    buf = np.concatenate([np.frombuffer(s, np.uint8) if isinstance(s, bytes) else s for s in seqs] +
+                         [np.zeros(64, np.uint8)])
+    return buf, off
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=1000, help="reads per GPU per step")
+    ap.add_argument("--ref-len", type=int, default=10_000)
+    ap.add_argument("--r", type=int, default=100)
+    ap.add_argument("--max-b-rows", type=int, default=20000)
+    ap.add_argument("--base-seed", type=int, default=2)
+    ap.add_argument("--cpu-sample", type=int, default=8, help="reads timed on one host core with the oracle")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from npore_amd import _lib, aln, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible (the HIP path has no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    sub, nps, _, _ = aln.load_default_tables()
+    ctx = aln.Context(sub, nps, max_n=6, max_l=100, device=local)
+    lib = _lib.load()
+
+    # ---- synthetic batch for this rank (reads rank, rank+world, ... : round-robin by index)
+    n = args.reads
+    refs, seqs, cigs = synth.make_batch(args.base_seed, n, ref_len=args.ref_len, first=rank, stride=world)
+    rb, ro = pack(refs)
+    sb, so = pack(seqs)
+    cb, co = pack(cigs)
+    oo = np.zeros(n + 1, np.int64)
+    np.cumsum([len(a) + len(b) for a, b in zip(refs, seqs)], out=oo[1:])
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d_rb, d_ro, d_sb, d_so, d_cb, d_co, d_oo = map(t, (rb, ro, sb, so, cb, co, oo))
+    d_out = torch.zeros(int(oo[-1]) + 64, dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+
+    def step():
+        rc = lib.npore_align_batch_device(
+            ctx.handle, n, d_rb.data_ptr(), d_ro.data_ptr(), d_sb.data_ptr(), d_so.data_ptr(),
+            d_cb.data_ptr(), d_co.data_ptr(), 5.0, 1.0, args.max_b_rows, args.r,
+            d_out.data_ptr(), d_oo.data_ptr(), d_len.data_ptr(), d_st.data_ptr(), None, 1)
+        if rc != 0:
+            raise RuntimeError(f"npore_align_batch_device: {rc} {_lib.last_error()}")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    fill_ms, tb_ms, prep_ms = [], [], []
+    for _ in range(args.steps):
+        step()
+        tm = ctx.timing()           # HIP events recorded on the library's own stream
+        fill_ms.append(tm["fill_ms"]); tb_ms.append(tm["traceback_ms"]); prep_ms.append(tm["host_prep_ms"] + tm["dev_prep_ms"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+        bad = torch.tensor([int((d_st != 0).sum().item())], dtype=torch.int64, device=dev)
+        dist.all_reduce(bad, op=dist.ReduceOp.SUM)
+        n_bad = int(bad.item())
+    else:
+        n_bad = int((d_st != 0).sum().item())
+
+    total_reads = n * world * args.steps
+    value = total_reads / elapsed
+
+    # ---- roofline of the dominant kernel (fill): algorithmic bytes per launch / measured duration
+    out_len = d_len.cpu().numpy()
+    W = 2 * args.r + 1
+    bytes_alg = sum(4 * (len(s) + len(r_) + 1) * W + 2 * (len(s) + len(r_)) + int(ol)
+                    for s, r_, ol in zip(seqs, refs, out_len))
+    fill_avg_ms = float(np.mean(fill_ms))
+    achieved = bytes_alg / (fill_avg_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "kernel": "fill_kernel", "kernel_ms": round(fill_avg_ms, 3),
+                "bytes_alg_per_launch": int(bytes_alg)}
+
+    # ---- CPU baseline: the oracle (plain-C port of the reference DP) on one host core, bounded sample
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        import oracle
+        oracle.build()
+        k = min(args.cpu_sample, n)
+        out_host = d_out.cpu().numpy()
+        tc = time.perf_counter()
+        want, st = oracle.align_batch(refs[:k], seqs[:k], cigs[:k], sub, nps, max_b_rows=args.max_b_rows, r=args.r)
+        dt = time.perf_counter() - tc
+        got = [out_host[oo[i]:oo[i] + out_len[i]].tobytes().decode() for i in range(k)]
+        if got != want:
+            raise RuntimeError("bench.py: GPU output differs from the oracle on the CPU sample")
+        cpu = {"value": round(k / dt, 3), "unit": "reads/s", "cores": 1, "kind": "port",
+               "sample": f"first {k} reads of the same batch, oracle/npore_oracle.c single thread, "
+                         f"checked equal to the GPU output; host has {os.cpu_count()} cores"}
+
+    if rank == 0:
+        line = {
+            "metric": "realigned reads/sec (10 kb ONT-like)", "value": round(value, 1), "unit": "reads/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{n} synthetic {args.ref_len // 1000} kb reads per GPU, r={args.r} "
+                                   f"(band={args.r}), max_b_rows={args.max_b_rows}, guppy5_stats penalties "
+                                   f"(SURVEY 8d C2 generator, base_seed={args.base_seed})",
+                       "reads_per_gpu": n, "ref_len": args.ref_len, "r": args.r, "parallelism": f"reads x{world}"},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "stage_ms": {"fill": round(fill_avg_ms, 2), "traceback_gather": round(float(np.mean(tb_ms)), 2),
+                         "prep": round(float(np.mean(prep_ms)), 2)},
+            "bad_reads": n_bad,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

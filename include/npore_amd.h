@@ -121,7 +121,7 @@ int npore_get_np_info(npore_ctx *ctx, const uint8_t *seq, int64_t len, int32_t *
  */
 int npore_last_timing(npore_ctx *ctx, double *ms, int n);
 
-/* Tunables: key in {"tb_budget_mb","force_nw","force_ng","host_threads"}. */
+/* Tunables: key in {"tb_budget_mb","force_ng","force_waves","host_threads"}. */
 int npore_ctx_set(npore_ctx *ctx, const char *key, int64_t value);
 
 /* Debug self-test: out128[l] = value lane l receives from lane l-1 (l>0),

@@ -19,6 +19,14 @@
 // matter through the RUN they leave behind (always failing those guards), which
 // is stored as 0 in the history.
 //
+// SIMT shape.  A lane rarely has more than one or two live candidates, but which
+// period n is live differs from lane to lane, so instead of twelve
+// (n, LEN/SHR) blocks the candidates are consumed by a loop in which every lane
+// takes its own highest remaining n (per-lane n), for LEN and SHR and for all NG
+// cells of the lane at once, branch-free inside the loop so that the LDS reads
+// of the 2*NG evaluations overlap.  The loop runs max-over-lanes(#candidates)
+// times (wave-uniform `any`).
+//
 // Arithmetic is IEEE fp32: one add per candidate, strict '<' compares, in the
 // reference's order.  No FMA contraction is possible (adds only).
 #pragma once
@@ -36,12 +44,13 @@ namespace npore {
 
 // Wave-uniform quantities of one anti-diagonal (b-row) of one chunk.
 struct StepInfo {
-    int b_local;   // 0-based b-row inside the chunk
-    int ins_l;     // inss[b] - row0 : local row of the input path on this anti-diagonal
-    int del_l;     // dels[b] - col0 = b_local - ins_l
+    int b_local;     // 0-based b-row inside the chunk
+    int ins_l;       // inss[b] - row0 : local row of the input path on this anti-diagonal
+    int del_l;       // dels[b] - col0 = b_local - ins_l
     int r;
     int drows, dcols;
-    int dI[MAX_PERIOD + 1];  // dI[n] = inss[b] - inss[b-n], n = 1..6 (0 where b-n < chunk start)
+    uint32_t hist6;  // bit k: input-path step (b-1-k) -> (b-k) was an 'I'; so
+                     // inss[b]-inss[b-n] = popcount(hist6 & ((1<<n)-1))
     float indel_start, indel_extend;
 };
 
@@ -65,172 +74,228 @@ struct CellOut {
     uint32_t tb;               // MAT.TYP | MAT.RUN << 3
 };
 
-// Env supplies (all const, all inlined):
-//   float sub(uint32_t seq_base, uint32_t ref_base)            sub_scores[s][r]
-//   float np(int n_idx, int ref_len_clamped, int call_len_clamped)  np_scores[n_idx][.][.]
-//   int   clamp()                                              max_l - 1 (see np_score below)
-//   int   refl(int j, int n_idx)                               L of local ref position j
-//   float h_mat(int n, int col), h_lens(int n, int col), h_shrs(int n, int col)
-//   uint32_t h_runs(int n, int col)      history of anti-diagonal b-n at band column col
-//   bool  any(bool)                      wave-level "any lane" (identity on the host)
-template <class Env>
-NPORE_HD float np_score(const Env &env, int n, int ref_np_len, int indel_len)
+NPORE_HD int popc32(uint32_t x)
 {
-    // reference src/aln.pyx:257-274; callers pass max_l where the signature says
-    // max_n, so lengths clamp to max_l-1 and the `n > max_n` test is dead.
-    if (ref_np_len <= 0) return 100.0f;
-    if (ref_np_len + indel_len < 0) return 100.0f;
-    int call = ref_np_len + indel_len;
-    const int cl = env.clamp();
-    if (ref_np_len > cl) ref_np_len = cl;
-    if (call > cl) call = cl;
-    return env.np(n - 1, ref_np_len, call);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popc(x);
+#else
+    return __builtin_popcount(x);
+#endif
+}
+NPORE_HD int top_bit(uint32_t m)   // 1-based index of the highest set bit, 0 if none
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return 32 - __clz((int)m);
+#else
+    return m ? 32 - __builtin_clz(m) : 0;
+#endif
+}
+// run / n for 0 <= run < 65536, 1 <= n <= 6.  On the device a float reciprocal
+// plus a bias is exact on that domain (checked exhaustively by the GPU tests).
+NPORE_HD int div_small(int run, int n)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)((float)run * __frcp_rn((float)n) + 0.03f);
+#else
+    return run / n;
+#endif
 }
 
-template <class Env>
-NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, CellOut &o)
+// Env supplies (all const, all inlined):
+//   float sub(uint32_t seq_base, uint32_t ref_base)            sub_scores[s][r]
+//   template<int K> void np_many(const int (&n_idx)[K], const int (&a)[K], const int (&b)[K],
+//                                const bool (&active)[K], float (&out)[K])
+//                                     out[k] = np_scores[n_idx][a][b] (a, b already clamped)
+//   int   clamp()                                              max_l - 1 (see np_score_index below)
+//   int   refl(int j, int n_idx)                               L of local ref position j
+//   float h_val(int arr, int n, int col)   arr 0: MAT.VAL, 1: lenstart, 2: shrstart
+//   uint32_t h_runs(int n, int col)        LEN.RUN | SHR.RUN << 16
+//                                          of anti-diagonal b-n at band column col
+//   bool  any(bool)                        wave-level "any lane" (identity on the host)
+
+// np_score, reference src/aln.pyx:257-274, split into index formation and lookup.
+// Callers pass max_l where the signature says max_n, so lengths clamp to max_l-1
+// and the `n > max_n` test is dead.  Returns true if the score is the constant 100.
+NPORE_HD bool np_score_index(int clampv, int ref_np_len, int indel_len, int &a, int &call)
 {
-    const int c = in.c;
-    const int i = st.ins_l + st.r - c;   // local a_row
-    const int j = st.del_l - st.r + c;   // local a_col
-    const bool first_row = (i == 0), first_col = (j == 0);
+    call = ref_np_len + indel_len;
+    const bool invalid = (ref_np_len <= 0) || (call < 0);
+    a = ref_np_len < 0 ? 0 : ref_np_len;
+    if (a > clampv) a = clampv;
+    if (call < 0) call = 0;
+    if (call > clampv) call = clampv;
+    return invalid;
+}
 
-    // ---- INS, src/aln.pyx:525-543
-    float insv;
-    int insrun;
-    if (first_row) {
-        insv = (float)(100 * (j + 1));
-        insrun = j;
-    } else {
-        const float v1 = in.topM + st.indel_start;
-        const float v2 = in.topI + st.indel_extend;
-        if (v2 < v1) { insv = v2; insrun = (i == 1) ? 1 : in.topIrun + 1; }
-        else { insv = v1; insrun = 1; }
-    }
-    // ---- DEL, src/aln.pyx:547-565
-    float delv;
-    int delrun;
-    if (first_col) {
-        delv = (float)(100 * (i + 1));
-        delrun = i;
-    } else {
-        const float v1 = in.leftM + st.indel_start;
-        const float v2 = in.leftD + st.indel_extend;
-        if (v2 < v1) { delv = v2; delrun = (j == 1) ? 1 : in.leftDrun + 1; }
-        else { delv = v1; delrun = 1; }
-    }
-
-    // ---- LEN / SHR as seen by this cell (pull form of src/aln.pyx:601-633, 642-667)
+template <int NG, class Env>
+NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in)[NG], CellOut (&o)[NG])
+{
+    const int r2 = 2 * st.r;
+    float insv[NG], delv[NG], lenv[NG], shrv[NG], lenstart[NG], shrstart[NG];
+    int insrun[NG], delrun[NG], lenrun[NG], shrrun[NG], ii[NG], jj[NG];
+    uint32_t lm[NG], sm[NG];
     const float init = (float)(100 * st.b_local);    // src/aln.pyx:473,476
-    float lenv = init, shrv = init, lenstart = 0.0f, shrstart = 0.0f;
-    int lenrun = 0, shrrun = 0;
+    uint32_t pend = 0;
 
-    const uint32_t len_flags = (in.refx >> 18) & (in.seqw >> 18) & 63u;  // ref starts n-polymer & read pos i-n inside one
-    const uint32_t shr_flags = in.refy & 63u;                            // ref pos j-n inside an n-polymer
-    const bool interior = (c >= 1) && (c <= 2 * st.r - 1) && (i >= 0) && (j >= 0) && (i <= st.drows) && (j <= st.dcols);
-    if (env.any(interior && (len_flags | shr_flags))) {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-        for (int n = MAX_PERIOD; n >= 1; n--) {
-            const int dI = st.dI[n];
-            // LEN from X = (i-n, j): band column c + (n - dI)
+    for (int g = 0; g < NG; g++) {
+        const int c = in[g].c;
+        const int i = st.ins_l + st.r - c;   // local a_row
+        const int j = st.del_l - st.r + c;   // local a_col
+        ii[g] = i;
+        jj[g] = j;
+        // ---- INS, src/aln.pyx:525-543
+        if (i == 0) {
+            insv[g] = (float)(100 * (j + 1));
+            insrun[g] = j;
+        } else {
+            const float v1 = in[g].topM + st.indel_start;
+            const float v2 = in[g].topI + st.indel_extend;
+            if (v2 < v1) { insv[g] = v2; insrun[g] = (i == 1) ? 1 : in[g].topIrun + 1; }
+            else { insv[g] = v1; insrun[g] = 1; }
+        }
+        // ---- DEL, src/aln.pyx:547-565
+        if (j == 0) {
+            delv[g] = (float)(100 * (i + 1));
+            delrun[g] = i;
+        } else {
+            const float v1 = in[g].leftM + st.indel_start;
+            const float v2 = in[g].leftD + st.indel_extend;
+            if (v2 < v1) { delv[g] = v2; delrun[g] = (j == 1) ? 1 : in[g].leftDrun + 1; }
+            else { delv[g] = v1; delrun[g] = 1; }
+        }
+        lenv[g] = shrv[g] = init;
+        lenstart[g] = shrstart[g] = 0.0f;
+        lenrun[g] = shrrun[g] = 0;
+        // candidate periods: LEN needs "ref position j starts an n-polymer" and
+        // "read position i-n inside one"; SHR needs "ref position j-n inside one"
+        const bool interior = (c >= 1) && (c <= r2 - 1) && (i >= 0) && (j >= 0) && (i <= st.drows) && (j <= st.dcols);
+        lm[g] = interior ? ((in[g].refx >> 18) & (in[g].seqw >> 18) & 63u) : 0u;
+        sm[g] = interior ? (in[g].refy & 63u) : 0u;
+        pend |= lm[g] | sm[g];
+    }
+
+    // ---- LEN / SHR candidates (pull form of src/aln.pyx:601-633, 642-667)
+    // slot 2g: LEN of cell g, from X = (i-n, j) at band column c + (n - dI);
+    // slot 2g+1: SHR of cell g, from X = (i, j-n) at band column c - dI.
+    constexpr int K = 2 * NG;
+    const int clampv = env.clamp();
+    while (env.any(pend != 0u)) {
+        pend = 0u;
+        int nidx[K], ta[K], tb_[K], crun[K];
+        bool ok[K], inval[K];
+        float cstart[K], score[K];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int g = 0; g < NG; g++) {
+            const int c = in[g].c;
+            const int csafe = c < r2 ? c : r2;
             {
+                const int k = 2 * g;
+                const int nb = top_bit(lm[g]);
+                const int n = nb ? nb : 1;
+                lm[g] &= ~(1u << (n - 1));
+                const int dI = popc32(st.hist6 & ((1u << n) - 1u));
                 const int cx = c + (n - dI);
-                bool ok = interior && ((len_flags >> (n - 1)) & 1u) && (i - n >= 0) && (cx <= 2 * st.r - 1);
-                if (ok) {
-                    const uint32_t smer = ((in.seqw & 0x3FFFFu) >> (3 * (MAX_PERIOD - n)));
-                    const uint32_t rmer = in.refx & ((1u << (3 * n)) - 1u);
-                    ok = (smer == rmer);                 // match(), src/aln.pyx:606-607
-                }
-                if (env.any(ok)) {
-                    if (ok) {
-                        const int L = env.refl(j, n - 1);
-                        float cand, cstart;
-                        int crun;
-                        bool have = true;
-                        if ((in.seqw >> (24 + n - 1)) & 1u) {          // start insertion :613-619
-                            cstart = env.h_mat(n, cx);
-                            cand = cstart + np_score(env, n, L, 1);
-                            crun = n;
-                        } else {                                         // continue :621-633
-                            const int run = (int)(env.h_runs(n, cx) & 0xFFFFu);
-                            have = run > 0;
-                            cstart = env.h_lens(n, cx);
-                            cand = cstart + np_score(env, n, L, run / n + 1);
-                            crun = run + n;
-                        }
-                        if (have && cand < lenv) { lenv = cand; lenrun = crun; lenstart = cstart; }
-                    }
-                }
+                const uint32_t smer = (in[g].seqw & 0x3FFFFu) >> (3 * (MAX_PERIOD - n));
+                const uint32_t rmer = in[g].refx & ((1u << (3 * n)) - 1u);
+                const bool good = (nb != 0) && (ii[g] - n >= 0) && (cx <= r2 - 1) && (smer == rmer);  // match(), :606-607
+                const int cxs = good ? cx : csafe;                        // keep the (unused) reads in range
+                const bool start = ((in[g].seqw >> (24 + n - 1)) & 1u) != 0u;
+                const int L = env.refl(good ? jj[g] : 0, n - 1);
+                cstart[k] = env.h_val(start ? 0 : 1, n, cxs);             // :614 / :628
+                const int run = start ? 0 : (int)(env.h_runs(n, cxs) & 0xFFFFu);
+                const int indel = start ? 1 : div_small(run, n) + 1;     // :615 / :629
+                inval[k] = np_score_index(clampv, L, indel, ta[k], tb_[k]);
+                nidx[k] = n - 1;
+                crun[k] = run + n;                                        // :619 / :633
+                ok[k] = good && (start || run > 0);
             }
-            // SHR from X = (i, j-n): band column c - dI
             {
+                const int k = 2 * g + 1;
+                const int nb = top_bit(sm[g]);
+                const int n = nb ? nb : 1;
+                sm[g] &= ~(1u << (n - 1));
+                const int dI = popc32(st.hist6 & ((1u << n) - 1u));
                 const int cx = c - dI;
-                const bool ok = interior && ((shr_flags >> (n - 1)) & 1u) && (j - n >= 0) && (cx >= 1);
-                if (env.any(ok)) {
-                    if (ok) {
-                        const int L = env.refl(j - n, n - 1);
-                        float cand, cstart;
-                        int crun;
-                        bool have = true;
-                        if ((in.refy >> (6 + n - 1)) & 1u) {           // start deletion :648-654
-                            cstart = env.h_mat(n, cx);
-                            cand = cstart + np_score(env, n, L, -1);
-                            crun = n;
-                        } else {                                         // continue :656-667
-                            const int run = (int)(env.h_runs(n, cx) >> 16);
-                            have = run > 0;
-                            cstart = env.h_shrs(n, cx);
-                            cand = cstart + np_score(env, n, L, -(run / n) - 1);
-                            crun = run + n;
-                        }
-                        if (have && cand < shrv) { shrv = cand; shrrun = crun; shrstart = cstart; }
-                    }
-                }
+                const bool good = (nb != 0) && (jj[g] - n >= 0) && (cx >= 1);
+                const int cxs = good ? cx : csafe;
+                const bool start = ((in[g].refy >> (6 + n - 1)) & 1u) != 0u;
+                const int L = env.refl(good ? jj[g] - n : 0, n - 1);
+                cstart[k] = env.h_val(start ? 0 : 2, n, cxs);             // :649 / :662
+                const int run = start ? 0 : (int)(env.h_runs(n, cxs) >> 16);
+                const int indel = start ? -1 : -div_small(run, n) - 1;   // :650 / :663
+                inval[k] = np_score_index(clampv, L, indel, ta[k], tb_[k]);
+                nidx[k] = n - 1;
+                crun[k] = run + n;                                        // :654 / :667
+                ok[k] = good && (start || run > 0);
+            }
+            pend |= lm[g] | sm[g];
+        }
+        env.template np_many<K>(nidx, ta, tb_, ok, score);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int g = 0; g < NG; g++) {
+            {
+                const int k = 2 * g;
+                const float cand = cstart[k] + (inval[k] ? 100.0f : score[k]);
+                if (ok[k] && cand < lenv[g]) { lenv[g] = cand; lenrun[g] = crun[k]; lenstart[g] = cstart[k]; }
+            }
+            {
+                const int k = 2 * g + 1;
+                const float cand = cstart[k] + (inval[k] ? 100.0f : score[k]);
+                if (ok[k] && cand < shrv[g]) { shrv[g] = cand; shrrun[g] = crun[k]; shrstart[g] = cstart[k]; }
             }
         }
     }
 
-    // ---- MAT, src/aln.pyx:569-592
-    float v;
-    int typ, run;
-    if (i > 0 && j > 0) {
-        run = in.diagMrun + 1;
-        v = in.diagM + env.sub((in.seqw >> 15) & 7u, (in.refx >> 24) & 7u);
-        typ = T_MAT;
-    } else {
-        v = delv + 100.0f;   // "ensure val1 isn't chosen"
-        typ = T_MAT;
-        run = 0;
-    }
-    if (insv < v) { v = insv; typ = T_INS; run = insrun; }
-    if (lenv < v) { v = lenv; typ = T_LEN; run = lenrun; }
-    if (delv < v) { v = delv; typ = T_DEL; run = delrun; }
-    if (shrv < v) { v = shrv; typ = T_SHR; run = shrrun; }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int g = 0; g < NG; g++) {
+        const int c = in[g].c, i = ii[g], j = jj[g];
+        // ---- MAT, src/aln.pyx:569-592
+        float v;
+        int typ = T_MAT, run;
+        if (i > 0 && j > 0) {
+            run = in[g].diagMrun + 1;
+            v = in[g].diagM + env.sub((in[g].seqw >> 15) & 7u, (in[g].refx >> 24) & 7u);
+        } else {
+            v = delv[g] + 100.0f;   // "ensure val1 isn't chosen"
+            run = 0;
+        }
+        if (insv[g] < v) { v = insv[g]; typ = T_INS; run = insrun[g]; }
+        if (lenv[g] < v) { v = lenv[g]; typ = T_LEN; run = lenrun[g]; }
+        if (delv[g] < v) { v = delv[g]; typ = T_DEL; run = delrun[g]; }
+        if (shrv[g] < v) { v = shrv[g]; typ = T_SHR; run = shrrun[g]; }
 
-    o.matv = v;
-    o.insv = insv;
-    o.delv = delv;
-    o.matrun = (typ == T_MAT) ? run : 0;
-    o.insrun = insrun;
-    o.delrun = delrun;
-    o.lenstart = lenstart;
-    o.shrstart = shrstart;
-    o.lenrun_h = first_row ? 0 : lenrun;   // src/aln.pyx:596-599 leaves RUN = j, never usable
-    o.shrrun_h = first_col ? 0 : shrrun;   // src/aln.pyx:637-640 likewise
-    o.tb = (uint32_t)typ | ((uint32_t)run << 3);
-
-    // ---- band edge, src/aln.pyx:502-507 (all five states, TYP = MAT, RUN = 0)
-    if (c == 0 || c == 2 * st.r) {
-        const float e = (float)(100 * (st.b_local + 1));
-        o.matv = e; o.insv = e; o.delv = e;
-        o.matrun = 0; o.insrun = 0; o.delrun = 0;
-        o.lenrun_h = 0; o.shrrun_h = 0;
-        o.tb = 0;
+        CellOut &q = o[g];
+        q.matv = v;
+        q.insv = insv[g];
+        q.delv = delv[g];
+        q.matrun = (typ == T_MAT) ? run : 0;
+        q.insrun = insrun[g];
+        q.delrun = delrun[g];
+        q.lenstart = lenstart[g];
+        q.shrstart = shrstart[g];
+        q.lenrun_h = (i == 0) ? 0 : lenrun[g];   // src/aln.pyx:596-599 leaves RUN = j, never usable
+        q.shrrun_h = (j == 0) ? 0 : shrrun[g];   // src/aln.pyx:637-640 likewise
+        q.tb = (uint32_t)typ | ((uint32_t)run << 3);
+        // ---- band edge, src/aln.pyx:502-507 (all five states, TYP = MAT, RUN = 0)
+        if (c == 0 || c == r2) {
+            const float e = (float)(100 * (st.b_local + 1));
+            q.matv = e; q.insv = e; q.delv = e;
+            q.matrun = 0; q.insrun = 0; q.delrun = 0;
+            q.lenrun_h = 0; q.shrrun_h = 0;
+            q.tb = 0;
+        }
+        // cells outside the chunk rectangle are never read by cells inside it
+        if (!((i >= 0) && (j >= 0) && (i <= st.drows) && (j <= st.dcols))) q.tb = 0;
     }
-    // cells outside the chunk rectangle are never read by cells inside it
-    if (!((i >= 0) && (j >= 0) && (i <= st.drows) && (j <= st.dcols))) o.tb = 0;
 }
 
 }  // namespace npore

@@ -27,11 +27,14 @@
 
 namespace npore {
 
-constexpr int NS = 8;  // history ring rows (>= MAX_PERIOD + 1)
+constexpr int NS = 6;     // history ring rows: row b overwrites row b-6 after this wave has read it
+constexpr int NP_LT = 32;  // LDS copy of np_scores covers ref length < NP_LT ...
+constexpr int NP_CT = 48;  // ... and call length < NP_CT; anything else is read from global memory
 
 struct KParams {
     const ChunkDesc *descs;
-    const int32_t *sched;   // block -> chunk index (largest chunks first)
+    const int32_t *sched;   // wave slot -> chunk index (largest chunks first)
+    int n_chunks;
     const uint8_t *steps;
     const int32_t *inss;
     const uint32_t *seqw;
@@ -40,11 +43,19 @@ struct KParams {
     uint32_t *tb;
     const float *sub_scores;  // [5][5]
     const float *np_scores;   // [max_n][max_l+1][max_l+1]
-    int max_l;
+    int max_n, max_l;
     int r;
     int tbstride;
+    int lstr;               // history row stride per column group: ceil((2r+1)/NG)
+    int rwin;               // reference-L window entries (power of two)
     float indel_start, indel_extend;
 };
+
+// LDS floats needed by one workgroup of `waves` waves
+static inline size_t fill_lds_floats(int ng, int waves, int lstr, int rwin)
+{
+    return (size_t)MAX_PERIOD * NP_LT * NP_CT + 64 + (size_t)waves * ((size_t)4 * NS * ng * lstr + 2 * (size_t)rwin);
+}
 
 // value of the previous / next lane (lane 0 / 63 keep their own)
 __device__ __forceinline__ uint32_t lane_prev(uint32_t v)
@@ -60,63 +71,95 @@ __device__ __forceinline__ float lane_next(float v) { return __uint_as_float(lan
 
 template <int NG>
 struct DevEnv {
-    static constexpr int WP = 64 * NG;
     const float *lds_sub;     // [8][8] padded copy of sub_scores
-    const float *np_scores;
-    const uint8_t *refl_p;    // this chunk's refl bytes
-    float *hist;              // LDS: [4][NS][WP]  (matv, lenstart, shrstart, runs)
-    int np_dim, clampv, slot;
+    const float *lds_np;      // [6][NP_LT][NP_CT]
+    const float *g_np;        // full table in global memory
+    const uint8_t *win;       // LDS window of reference L bytes, 8 per position
+    float *hist;              // LDS: [4][NS][hw]  (MAT.VAL, lenstart, shrstart, runs)
+    int np_dim, clampv, slot, lstr, hw, wmask;
 
-    __device__ __forceinline__ static int colidx(int col)
+    __device__ __forceinline__ int colidx(int col) const
     {
         if constexpr (NG == 1) return col;
-        else return (col % NG) * 64 + col / NG;
+        else return (col % NG) * lstr + col / NG;
     }
     __device__ __forceinline__ int at(int arr, int n, int col) const
     {
-        return (arr * NS + ((slot - n) & (NS - 1))) * WP + colidx(col);
+        int s = slot - n;
+        s += (s < 0) ? NS : 0;
+        return (arr * NS + s) * hw + colidx(col);
     }
     __device__ __forceinline__ float sub(uint32_t s, uint32_t r) const { return lds_sub[s * 8 + r]; }
-    __device__ __forceinline__ float np(int n_idx, int a, int b) const
-    {
-        return np_scores[((size_t)n_idx * np_dim + a) * np_dim + b];
-    }
     __device__ __forceinline__ int clamp() const { return clampv; }
-    __device__ __forceinline__ int refl(int j, int n_idx) const { return refl_p[(size_t)j * 8 + n_idx]; }
-    __device__ __forceinline__ float h_mat(int n, int col) const { return hist[at(0, n, col)]; }
-    __device__ __forceinline__ float h_lens(int n, int col) const { return hist[at(1, n, col)]; }
-    __device__ __forceinline__ float h_shrs(int n, int col) const { return hist[at(2, n, col)]; }
+    __device__ __forceinline__ int refl(int j, int n_idx) const { return win[(j & wmask) * 8 + n_idx]; }
+    __device__ __forceinline__ float h_val(int arr, int n, int col) const { return hist[at(arr, n, col)]; }
     __device__ __forceinline__ uint32_t h_runs(int n, int col) const { return __float_as_uint(hist[at(3, n, col)]); }
     __device__ __forceinline__ bool any(bool x) const { return __builtin_amdgcn_ballot_w64(x) != 0ull; }
+    template <int K>
+    __device__ __forceinline__ void np_many(const int (&n_idx)[K], const int (&a)[K], const int (&b)[K],
+                                            const bool (&active)[K], float (&out)[K]) const
+    {
+        bool oot = false;
+#pragma unroll
+        for (int k = 0; k < K; k++) oot |= active[k] && ((a[k] >= NP_LT) || (b[k] >= NP_CT));
+        if (!any(oot)) {
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const int aa = a[k] < NP_LT ? a[k] : NP_LT - 1, bb = b[k] < NP_CT ? b[k] : NP_CT - 1;
+                out[k] = lds_np[(n_idx[k] * NP_LT + aa) * NP_CT + bb];
+            }
+        } else {   // rare: an n-polymer longer than the LDS table covers
+#pragma unroll
+            for (int k = 0; k < K; k++) out[k] = g_np[((size_t)n_idx[k] * np_dim + a[k]) * np_dim + b[k]];
+        }
+    }
 };
 
-template <int NG>
-__global__ __launch_bounds__(64) void fill_kernel(KParams p)
+template <int NG, int MAXT>
+__global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
 {
     constexpr int WP = 64 * NG;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *lds_sub = lds;        // 64 floats
-    float *hist = lds + 64;      // 4 * NS * WP floats
+    float *lds_np = lds;
+    float *lds_sub = lds + MAX_PERIOD * NP_LT * NP_CT;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int hw = NG * p.lstr;
+    float *wave_lds = lds_sub + 64 + (size_t)wave * (4 * NS * hw + 2 * p.rwin);
+    float *hist = wave_lds;
+    uint2 *win = reinterpret_cast<uint2 *>(wave_lds + 4 * NS * hw);
 
-    const int lane = threadIdx.x;
-    const ChunkDesc d = p.descs[p.sched[blockIdx.x]];
-    const int r = p.r;
-    const int W = 2 * r + 1;
-
-    lds_sub[lane] = ((lane >> 3) < 5 && (lane & 7) < 5) ? p.sub_scores[(lane >> 3) * 5 + (lane & 7)] : 0.0f;
+    // workgroup-shared tables
+    const int np_dim = p.max_l + 1;
+    for (int idx = threadIdx.x; idx < MAX_PERIOD * NP_LT * NP_CT; idx += blockDim.x) {
+        const int n = idx / (NP_LT * NP_CT), a = (idx / NP_CT) % NP_LT, b = idx % NP_CT;
+        lds_np[idx] = (n < p.max_n && a < np_dim && b < np_dim) ? p.np_scores[((size_t)n * np_dim + a) * np_dim + b] : 0.0f;
+    }
+    if (threadIdx.x < 64)
+        lds_sub[threadIdx.x] = ((threadIdx.x >> 3) < 5 && (threadIdx.x & 7) < 5)
+                                   ? p.sub_scores[(threadIdx.x >> 3) * 5 + (threadIdx.x & 7)] : 0.0f;
     __syncthreads();
+
+    const int slot_id = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (slot_id >= p.n_chunks) return;     // waves are independent from here on
+    const ChunkDesc d = p.descs[p.sched[slot_id]];
+    const int r = p.r;
 
     DevEnv<NG> env;
     env.lds_sub = lds_sub;
-    env.np_scores = p.np_scores;
-    env.refl_p = reinterpret_cast<const uint8_t *>(p.refl + d.refw_off);
+    env.lds_np = lds_np;
+    env.g_np = p.np_scores;
+    env.win = reinterpret_cast<const uint8_t *>(win);
     env.hist = hist;
-    env.np_dim = p.max_l + 1;
+    env.np_dim = np_dim;
     env.clampv = p.max_l - 1;
     env.slot = 0;
+    env.lstr = p.lstr;
+    env.hw = hw;
+    env.wmask = p.rwin - 1;
 
     const uint32_t *seqw_g = p.seqw + d.seqw_off;
     const uint2 *refw_g = p.refw + d.refw_off;
+    const uint2 *refl_g = p.refl + d.refw_off;
     const uint8_t *steps_g = p.steps + d.steps_off + d.brk;   // steps_g[k] = step from local row k to k+1
     uint32_t *tb_g = p.tb + d.tb_off;
 
@@ -147,6 +190,13 @@ __global__ __launch_bounds__(64) void fill_kernel(KParams p)
         refx_q = rw.x;
         refy_q = rw.y;
     }
+    // reference-L window: positions [0, wfill) are resident (modulo rwin)
+    int wfill = 0;
+    while (r + 32 >= wfill) {
+        const int j = wfill + lane;
+        win[j & env.wmask] = (j <= d.dcols) ? refl_g[j] : make_uint2(0u, 0u);
+        wfill += 64;
+    }
 
     StepInfo st;
     st.r = r;
@@ -156,14 +206,18 @@ __global__ __launch_bounds__(64) void fill_kernel(KParams p)
     st.indel_extend = p.indel_extend;
     int ins_l = 0;
     uint32_t hist6 = 0;
-    unsigned long long stepmask = 0ull;
+    // input-path steps, 64 per coalesced load, one block prefetched (the buffer is padded)
+    unsigned long long stepmask = __builtin_amdgcn_ballot_w64(steps_g[lane] != 0);
+    unsigned long long nextmask = __builtin_amdgcn_ballot_w64(steps_g[64 + lane] != 0);
 
     for (int bl = 0; bl < d.nrows; bl++) {
         int I = 0;
         if (bl > 0) {
             const int k = bl - 1;              // step k leads from local row k to k+1
-            if ((k & 63) == 0)                 // 64 steps per (coalesced) load; buffer is padded
-                stepmask = __builtin_amdgcn_ballot_w64(steps_g[k + lane] != 0);
+            if ((k & 63) == 0 && k > 0) {
+                stepmask = nextmask;
+                nextmask = __builtin_amdgcn_ballot_w64(steps_g[k + 64 + lane] != 0);
+            }
             I = (int)((stepmask >> (k & 63)) & 1ull);
             ins_l += I;
             hist6 = ((hist6 << 1) | (uint32_t)I) & 63u;
@@ -171,9 +225,8 @@ __global__ __launch_bounds__(64) void fill_kernel(KParams p)
         st.b_local = bl;
         st.ins_l = ins_l;
         st.del_l = bl - ins_l;
-#pragma unroll
-        for (int n = 1; n <= MAX_PERIOD; n++) st.dI[n] = __builtin_popcount(hist6 & ((1u << n) - 1u));
-        env.slot = bl & (NS - 1);
+        st.hist6 = hist6;
+        env.slot = bl % NS;
 
         CellIn in[NG];
         if (bl > 0 && I) {
@@ -212,6 +265,11 @@ __global__ __launch_bounds__(64) void fill_kernel(KParams p)
                 refx_q = rw.x;
                 refy_q = rw.y;
             }
+            if (del_l + r + 32 >= wfill) {   // keep the L window ahead of the band
+                const int j = wfill + lane;
+                win[j & env.wmask] = (j <= d.dcols) ? refl_g[j] : make_uint2(0u, 0u);
+                wfill += 64;
+            }
             const int ql = (del_l + WP - 1 - r - rq_base) & 63;
             const uint32_t inx = (uint32_t)__builtin_amdgcn_readlane((int)refx_q, ql);
             const uint32_t iny = (uint32_t)__builtin_amdgcn_readlane((int)refy_q, ql);
@@ -239,16 +297,18 @@ __global__ __launch_bounds__(64) void fill_kernel(KParams p)
                 in[g].topIrun = in[g].leftDrun = in[g].diagMrun = 0;
             }
         }
-
-        CellOut o[NG];
 #pragma unroll
         for (int g = 0; g < NG; g++) {
             in[g].c = lane * NG + g;
             in[g].seqw = seqw[g];
             in[g].refx = refx[g];
             in[g].refy = refy[g];
-            cell_update(env, st, in[g], o[g]);
         }
+
+        CellOut o[NG];
+        cells_update<NG>(env, st, in, o);
+
+        uint32_t tbw[NG];
 #pragma unroll
         for (int g = 0; g < NG; g++) {
             LMv[g] = in[g].leftM;
@@ -258,13 +318,28 @@ __global__ __launch_bounds__(64) void fill_kernel(KParams p)
             delv[g] = o[g].delv;
             R1[g] = (uint32_t)o[g].matrun | ((uint32_t)o[g].insrun << 16);
             R2[g] = (uint32_t)o[g].matrun | ((uint32_t)o[g].delrun << 16);
-            const int hi = env.slot * WP + DevEnv<NG>::colidx(lane * NG + g);
-            hist[0 * NS * WP + hi] = o[g].matv;
-            hist[1 * NS * WP + hi] = o[g].lenstart;
-            hist[2 * NS * WP + hi] = o[g].shrstart;
-            hist[3 * NS * WP + hi] = __uint_as_float((uint32_t)o[g].lenrun_h | ((uint32_t)o[g].shrrun_h << 16));
-            const int col = lane * NG + g;
-            if (col < W) tb_g[(size_t)bl * p.tbstride + col] = o[g].tb;
+            tbw[g] = o[g].tb;
+            if (lane < p.lstr) {   // columns beyond the band are never read back
+                const int hi = env.slot * hw + g * p.lstr + lane;
+                hist[0 * NS * hw + hi] = o[g].matv;
+                hist[1 * NS * hw + hi] = o[g].lenstart;
+                hist[2 * NS * hw + hi] = o[g].shrstart;
+                hist[3 * NS * hw + hi] = __uint_as_float((uint32_t)o[g].lenrun_h | ((uint32_t)o[g].shrrun_h << 16));
+            }
+        }
+        // one traceback word per cell, NG consecutive words per lane (tbstride is a multiple of 4)
+        uint32_t *trow = tb_g + (size_t)bl * p.tbstride;
+        if constexpr (NG == 1) {
+            if (lane < p.tbstride) trow[lane] = tbw[0];
+        } else if constexpr (NG == 2) {
+            if (lane * 2 < p.tbstride) *reinterpret_cast<uint2 *>(trow + lane * 2) = make_uint2(tbw[0], tbw[1]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NG / 4; q++) {
+                const int col = lane * NG + 4 * q;
+                if (col < p.tbstride)
+                    *reinterpret_cast<uint4 *>(trow + col) = make_uint4(tbw[4 * q], tbw[4 * q + 1], tbw[4 * q + 2], tbw[4 * q + 3]);
+            }
         }
     }
 }

@@ -100,6 +100,7 @@ struct npore_ctx {
     // tunables
     int64_t tb_budget_mb = 0;   // 0 = auto
     int force_ng = 0;
+    int force_waves = 0;
     int host_threads = 0;
     // device buffers
     DevBuf refs, seqs, steps, inss, seqw, refw, refl, descs, sched, rfc, rstat, tb, cout_, clen, cstat;
@@ -119,16 +120,32 @@ int pick_ng(int r, int force)
     return 0;
 }
 
-template <int NG>
-hipError_t launch_fill(const KParams &kp, int n_chunks, hipStream_t s)
+int pow2_at_least(int x)
 {
-    const size_t lds = (64 + 4 * (size_t)NS * 64 * NG) * sizeof(float);
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fill_kernel<NG>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(fill_kernel<NG>, dim3(n_chunks), dim3(64), lds, s, kp);
+    int p = 64;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+// One wave per chunk, `waves` chunks per workgroup (they share the LDS score table).
+template <int NG, int MAXT>
+hipError_t launch_fill(KParams kp, int n_chunks, int force_waves, hipStream_t s)
+{
+    const int W = 2 * kp.r + 1;
+    kp.lstr = (W + NG - 1) / NG;
+    kp.rwin = pow2_at_least(2 * kp.r + 101);
+    kp.n_chunks = n_chunks;
+    const size_t lds_cap = 160 * 1024 / sizeof(float);
+    int waves_max = 1;
+    while (waves_max < MAXT / 64 && fill_lds_floats(NG, waves_max + 1, kp.lstr, kp.rwin) <= lds_cap) waves_max++;
+    if (fill_lds_floats(NG, 1, kp.lstr, kp.rwin) > lds_cap) return hipErrorInvalidValue;
+    int waves = std::min(waves_max, std::max(1, (n_chunks + 255) / 256));
+    if (force_waves > 0) waves = std::min(waves_max, force_waves);
+    const size_t lds = fill_lds_floats(NG, waves, kp.lstr, kp.rwin) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fill_kernel<NG, MAXT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((fill_kernel<NG, MAXT>), dim3((n_chunks + waves - 1) / waves), dim3(64 * waves), lds, s, kp);
     return hipGetLastError();
 }
 
@@ -245,7 +262,7 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, std::v
     // ---- staging layout (one pinned block)
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_steps = 0;
-    const size_t o_inss = al(o_steps + steps_tot + 128);
+    const size_t o_inss = al(o_steps + steps_tot + 256);
     const size_t o_seqw = al(o_inss + inss_tot * 4);
     const size_t o_refw = al(o_seqw + seqw_tot * 4);
     const size_t o_refl = al(o_refw + refw_tot * 8);
@@ -256,7 +273,7 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, std::v
     const size_t stage_bytes = al(o_rstat + nr * 4);
     if (int rc = ctx->h_stage.ensure(stage_bytes)) return rc;
     uint8_t *hs = ctx->h_stage.as<uint8_t>();
-    std::memset(hs + o_steps + steps_tot, 0, 128);
+    std::memset(hs + o_steps + steps_tot, 0, 256);
     std::memcpy(hs + o_desc, descs.data(), n_chunks * sizeof(ChunkDesc));
     std::memcpy(hs + o_sched, sched.data(), n_chunks * 4);
     std::memcpy(hs + o_rfc, rfc.data(), (nr + 1) * 4);
@@ -319,6 +336,7 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, std::v
         kp.tb = ctx->tb.as<uint32_t>();
         kp.sub_scores = ctx->d_sub;
         kp.np_scores = ctx->d_np;
+        kp.max_n = ctx->max_n;
         kp.max_l = ctx->max_l;
         kp.r = r;
         kp.tbstride = tbs;
@@ -326,10 +344,10 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, std::v
         kp.indel_extend = a.indel_extend;
         hipError_t e = hipSuccess;
         switch (ng) {
-            case 1: e = launch_fill<1>(kp, (int)n_chunks, s); break;
-            case 2: e = launch_fill<2>(kp, (int)n_chunks, s); break;
-            case 4: e = launch_fill<4>(kp, (int)n_chunks, s); break;
-            case 8: e = launch_fill<8>(kp, (int)n_chunks, s); break;
+            case 1: e = launch_fill<1, 1024>(kp, (int)n_chunks, ctx->force_waves, s); break;
+            case 2: e = launch_fill<2, 512>(kp, (int)n_chunks, ctx->force_waves, s); break;
+            case 4: e = launch_fill<4, 256>(kp, (int)n_chunks, ctx->force_waves, s); break;
+            case 8: e = launch_fill<8, 128>(kp, (int)n_chunks, ctx->force_waves, s); break;
             default: return fail(NPORE_E_UNSUPPORTED, "unsupported columns-per-lane");
         }
         if (e != hipSuccess) return fail(NPORE_E_HIP, std::string("fill launch: ") + hipGetErrorString(e));
@@ -605,6 +623,7 @@ int npore_ctx_set(npore_ctx *ctx, const char *key, int64_t value)
     const std::string k(key);
     if (k == "tb_budget_mb") ctx->tb_budget_mb = value;
     else if (k == "force_ng") ctx->force_ng = (int)value;
+    else if (k == "force_waves") ctx->force_waves = (int)value;
     else if (k == "host_threads") ctx->host_threads = (int)value;
     else return fail(NPORE_E_INVALID, "unknown key " + k);
     return NPORE_OK;

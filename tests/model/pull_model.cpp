@@ -17,23 +17,27 @@
 using namespace npore;
 
 namespace {
-constexpr int NS = 8;
+constexpr int NS = 6;   // as in the kernel: row b overwrites row b-6 after it was read
 
 struct ModelEnv {
     const float *sub_scores, *np_scores;
     int max_l;
     const uint8_t *refl_p;
-    const float *hm, *hl, *hs;
+    const float *hv[3];
     const uint32_t *hr;
     int W, slot;   // slot of the current row; row b-n is (slot - n) mod NS
     float sub(uint32_t s, uint32_t r) const { return sub_scores[s * 5 + r]; }
-    float np(int n_idx, int a, int b) const { return np_scores[((size_t)n_idx * (max_l + 1) + a) * (max_l + 1) + b]; }
+    template <int K>
+    void np_many(const int (&n_idx)[K], const int (&a)[K], const int (&b)[K], const bool (&active)[K],
+                 float (&out)[K]) const
+    {
+        for (int k = 0; k < K; k++)
+            out[k] = active[k] ? np_scores[((size_t)n_idx[k] * (max_l + 1) + a[k]) * (max_l + 1) + b[k]] : 0.0f;
+    }
     int clamp() const { return max_l - 1; }
     int refl(int j, int n_idx) const { return refl_p[(size_t)j * 8 + n_idx]; }
     size_t at(int n, int col) const { return (size_t)((slot - n + NS) % NS) * W + col; }
-    float h_mat(int n, int col) const { return hm[at(n, col)]; }
-    float h_lens(int n, int col) const { return hl[at(n, col)]; }
-    float h_shrs(int n, int col) const { return hs[at(n, col)]; }
+    float h_val(int arr, int n, int col) const { return hv[arr][at(n, col)]; }
     uint32_t h_runs(int n, int col) const { return hr[at(n, col)]; }
     bool any(bool x) const { return x; }
 };
@@ -74,7 +78,7 @@ extern "C" int64_t pull_model_align(const uint8_t *full_ref, int64_t ref_len, co
         std::vector<uint32_t> tb((size_t)nrows * W, 0u);
         std::vector<CellOut> cur(W);
 
-        ModelEnv env{sub_scores, np_scores, max_l, refl.data(), hm.data(), hl.data(), hs.data(), hr.data(), W, 0};
+        ModelEnv env{sub_scores, np_scores, max_l, refl.data(), {hm.data(), hl.data(), hs.data()}, hr.data(), W, 0};
         for (int bl = 0; bl < nrows; bl++) {
             const int64_t b = brk + bl;
             StepInfo st;
@@ -86,23 +90,27 @@ extern "C" int64_t pull_model_align(const uint8_t *full_ref, int64_t ref_len, co
             st.dcols = dcols;
             st.indel_start = indel_start;
             st.indel_extend = indel_extend;
-            for (int n = 1; n <= MAX_PERIOD; n++) st.dI[n] = (b - n >= brk) ? path.inss[b] - path.inss[b - n] : 0;
+            st.hist6 = 0;
+            for (int k = 0; k < MAX_PERIOD; k++)
+                if (b - 1 - k >= brk && path.steps[b - 1 - k]) st.hist6 |= 1u << k;
             const int I = (bl > 0) ? path.steps[b - 1] : 0;
             env.slot = bl % NS;
             for (int c = 0; c < W; c++) {
-                CellIn in;
-                std::memset(&in, 0, sizeof in);
-                in.c = c;
+                CellIn in[1];
+                std::memset(&in[0], 0, sizeof in);
+                in[0].c = c;
                 const int tc = I ? c : c + 1, lc = I ? c - 1 : c;
-                if (tc >= 0 && tc < W) { in.topM = matv[tc]; in.topI = insv[tc]; in.topIrun = insrun[tc]; }
-                if (lc >= 0 && lc < W) { in.leftM = matv[lc]; in.leftD = delv[lc]; in.leftDrun = delrun[lc]; }
-                in.diagM = I ? LMv[c] : TMv[c];
-                in.diagMrun = I ? LMrun[c] : TMrun[c];
+                if (tc >= 0 && tc < W) { in[0].topM = matv[tc]; in[0].topI = insv[tc]; in[0].topIrun = insrun[tc]; }
+                if (lc >= 0 && lc < W) { in[0].leftM = matv[lc]; in[0].leftD = delv[lc]; in[0].leftDrun = delrun[lc]; }
+                in[0].diagM = I ? LMv[c] : TMv[c];
+                in[0].diagMrun = I ? LMrun[c] : TMrun[c];
                 const int i = st.ins_l + r - c, j = st.del_l - r + c;
-                in.seqw = (i >= 0 && i <= drows) ? seqw[i] : SEQW_SENTINEL;
-                in.refx = (j >= 0 && j <= dcols) ? refw[2 * (size_t)j] : REFW_SENTINEL;
-                in.refy = (j >= 0 && j <= dcols) ? refw[2 * (size_t)j + 1] : 0u;
-                cell_update(env, st, in, cur[c]);
+                in[0].seqw = (i >= 0 && i <= drows) ? seqw[i] : SEQW_SENTINEL;
+                in[0].refx = (j >= 0 && j <= dcols) ? refw[2 * (size_t)j] : REFW_SENTINEL;
+                in[0].refy = (j >= 0 && j <= dcols) ? refw[2 * (size_t)j + 1] : 0u;
+                CellOut out1[1];
+                cells_update<1>(env, st, in, out1);
+                cur[c] = out1[0];
             }
             // commit the row: neighbour-of-neighbour values for the next diagonal, history, traceback
             std::vector<float> nLMv(W), nTMv(W);
