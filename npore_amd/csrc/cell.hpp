@@ -74,6 +74,14 @@ struct CellOut {
     uint32_t tb;               // MAT.TYP | MAT.RUN << 3
 };
 
+// What later LEN/SHR "start"/"continue" moves need from a finished cell.
+struct alignas(16) HistCell {
+    float matv;       // MAT.VAL
+    float lenstart;   // MAT.VAL at the start of its LEN run
+    float shrstart;   // MAT.VAL at the start of its SHR run
+    uint32_t runs;    // LEN.RUN | SHR.RUN << 16 (0 where a continue must not happen)
+};
+
 NPORE_HD int popc32(uint32_t x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -108,9 +116,8 @@ NPORE_HD int div_small(int run, int n)
 //                                     out[k] = np_scores[n_idx][a][b] (a, b already clamped)
 //   int   clamp()                                              max_l - 1 (see np_score_index below)
 //   int   refl(int j, int n_idx)                               L of local ref position j
-//   float h_val(int arr, int n, int col)   arr 0: MAT.VAL, 1: lenstart, 2: shrstart
-//   uint32_t h_runs(int n, int col)        LEN.RUN | SHR.RUN << 16
-//                                          of anti-diagonal b-n at band column col
+//   HistCell h_cell(int n, int col)        what the cell at band column col of
+//                                          anti-diagonal b-n left behind
 //   bool  any(bool)                        wave-level "any lane" (identity on the host)
 
 // np_score, reference src/aln.pyx:257-274, split into index formation and lookup.
@@ -178,77 +185,106 @@ NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in
     }
 
     // ---- LEN / SHR candidates (pull form of src/aln.pyx:601-633, 642-667)
-    // slot 2g: LEN of cell g, from X = (i-n, j) at band column c + (n - dI);
-    // slot 2g+1: SHR of cell g, from X = (i, j-n) at band column c - dI.
-    constexpr int K = 2 * NG;
+    // SHR of cell g comes from X = (i, j-n) at band column c - dI; LEN from
+    // X = (i-n, j) at band column c + (n - dI), dI = inss[b] - inss[b-n].
+    // SHR candidates are dense inside reference n-polymers, LEN candidates are rare
+    // (they also need the read to repeat the same unit), so each has its own loop.
     const int clampv = env.clamp();
-    while (env.any(pend != 0u)) {
-        pend = 0u;
-        int nidx[K], ta[K], tb_[K], crun[K];
-        bool ok[K], inval[K];
-        float cstart[K], score[K];
+    if (env.any(pend != 0u)) {
+        uint32_t pendS = 0u, pendL = 0u;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-        for (int g = 0; g < NG; g++) {
-            const int c = in[g].c;
-            const int csafe = c < r2 ? c : r2;
-            {
-                const int k = 2 * g;
+        for (int g = 0; g < NG; g++) { pendS |= sm[g]; pendL |= lm[g]; }
+
+        while (env.any(pendS != 0u)) {
+            pendS = 0u;
+            int nidx[NG], ta[NG], tb_[NG], crun[NG];
+            bool ok[NG], inval[NG];
+            float cstart[NG], score[NG];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (int g = 0; g < NG; g++) {
+                const int c = in[g].c;
+                const int nb = top_bit(sm[g]);
+                const int n = nb ? nb : 1;
+                sm[g] &= ~(1u << (n - 1));
+                pendS |= sm[g];
+                const int dI = popc32(st.hist6 & ((1u << n) - 1u));
+                const int cx = c - dI;
+                const bool good = (nb != 0) && (jj[g] - n >= 0) && (cx >= 1);
+                const int cxs = good ? cx : (c < r2 ? c : r2);           // keep the (unused) read in range
+                const bool start = ((in[g].refy >> (6 + n - 1)) & 1u) != 0u;
+                const int L = env.refl(good ? jj[g] - n : 0, n - 1);
+                const HistCell h = env.h_cell(n, cxs);
+                cstart[g] = start ? h.matv : h.shrstart;                  // :649 / :662
+                const int run = start ? 0 : (int)(h.runs >> 16);
+                const int indel = start ? -1 : -div_small(run, n) - 1;   // :650 / :663
+                inval[g] = np_score_index(clampv, L, indel, ta[g], tb_[g]);
+                nidx[g] = n - 1;
+                crun[g] = run + n;                                        // :654 / :667
+                ok[g] = good && (start || run > 0);
+            }
+            env.template np_many<NG>(nidx, ta, tb_, ok, score);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (int g = 0; g < NG; g++) {
+                const float cand = cstart[g] + (inval[g] ? 100.0f : score[g]);
+                if (ok[g] && cand < shrv[g]) { shrv[g] = cand; shrrun[g] = crun[g]; shrstart[g] = cstart[g]; }
+            }
+        }
+
+        while (env.any(pendL != 0u)) {
+            pendL = 0u;
+            int nn[NG], cxx[NG];
+            bool good[NG], anygood = false;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (int g = 0; g < NG; g++) {
+                const int c = in[g].c;
                 const int nb = top_bit(lm[g]);
                 const int n = nb ? nb : 1;
                 lm[g] &= ~(1u << (n - 1));
+                pendL |= lm[g];
                 const int dI = popc32(st.hist6 & ((1u << n) - 1u));
                 const int cx = c + (n - dI);
                 const uint32_t smer = (in[g].seqw & 0x3FFFFu) >> (3 * (MAX_PERIOD - n));
                 const uint32_t rmer = in[g].refx & ((1u << (3 * n)) - 1u);
-                const bool good = (nb != 0) && (ii[g] - n >= 0) && (cx <= r2 - 1) && (smer == rmer);  // match(), :606-607
-                const int cxs = good ? cx : csafe;                        // keep the (unused) reads in range
-                const bool start = ((in[g].seqw >> (24 + n - 1)) & 1u) != 0u;
-                const int L = env.refl(good ? jj[g] : 0, n - 1);
-                cstart[k] = env.h_val(start ? 0 : 1, n, cxs);             // :614 / :628
-                const int run = start ? 0 : (int)(env.h_runs(n, cxs) & 0xFFFFu);
-                const int indel = start ? 1 : div_small(run, n) + 1;     // :615 / :629
-                inval[k] = np_score_index(clampv, L, indel, ta[k], tb_[k]);
-                nidx[k] = n - 1;
-                crun[k] = run + n;                                        // :619 / :633
-                ok[k] = good && (start || run > 0);
+                good[g] = (nb != 0) && (ii[g] - n >= 0) && (cx <= r2 - 1) && (smer == rmer);   // match(), :606-607
+                nn[g] = n;
+                cxx[g] = good[g] ? cx : (c < r2 ? c : r2);
+                anygood |= good[g];
             }
-            {
-                const int k = 2 * g + 1;
-                const int nb = top_bit(sm[g]);
-                const int n = nb ? nb : 1;
-                sm[g] &= ~(1u << (n - 1));
-                const int dI = popc32(st.hist6 & ((1u << n) - 1u));
-                const int cx = c - dI;
-                const bool good = (nb != 0) && (jj[g] - n >= 0) && (cx >= 1);
-                const int cxs = good ? cx : csafe;
-                const bool start = ((in[g].refy >> (6 + n - 1)) & 1u) != 0u;
-                const int L = env.refl(good ? jj[g] - n : 0, n - 1);
-                cstart[k] = env.h_val(start ? 0 : 2, n, cxs);             // :649 / :662
-                const int run = start ? 0 : (int)(env.h_runs(n, cxs) >> 16);
-                const int indel = start ? -1 : -div_small(run, n) - 1;   // :650 / :663
-                inval[k] = np_score_index(clampv, L, indel, ta[k], tb_[k]);
-                nidx[k] = n - 1;
-                crun[k] = run + n;                                        // :654 / :667
-                ok[k] = good && (start || run > 0);
-            }
-            pend |= lm[g] | sm[g];
-        }
-        env.template np_many<K>(nidx, ta, tb_, ok, score);
+            if (!env.any(anygood)) continue;
+            int nidx[NG], ta[NG], tb_[NG], crun[NG];
+            bool ok[NG], inval[NG];
+            float cstart[NG], score[NG];
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-        for (int g = 0; g < NG; g++) {
-            {
-                const int k = 2 * g;
-                const float cand = cstart[k] + (inval[k] ? 100.0f : score[k]);
-                if (ok[k] && cand < lenv[g]) { lenv[g] = cand; lenrun[g] = crun[k]; lenstart[g] = cstart[k]; }
+            for (int g = 0; g < NG; g++) {
+                const int n = nn[g];
+                const bool start = ((in[g].seqw >> (24 + n - 1)) & 1u) != 0u;
+                const int L = env.refl(good[g] ? jj[g] : 0, n - 1);
+                const HistCell h = env.h_cell(n, cxx[g]);
+                cstart[g] = start ? h.matv : h.lenstart;                  // :614 / :628
+                const int run = start ? 0 : (int)(h.runs & 0xFFFFu);
+                const int indel = start ? 1 : div_small(run, n) + 1;     // :615 / :629
+                inval[g] = np_score_index(clampv, L, indel, ta[g], tb_[g]);
+                nidx[g] = n - 1;
+                crun[g] = run + n;                                        // :619 / :633
+                ok[g] = good[g] && (start || run > 0);
             }
-            {
-                const int k = 2 * g + 1;
-                const float cand = cstart[k] + (inval[k] ? 100.0f : score[k]);
-                if (ok[k] && cand < shrv[g]) { shrv[g] = cand; shrrun[g] = crun[k]; shrstart[g] = cstart[k]; }
+            env.template np_many<NG>(nidx, ta, tb_, ok, score);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (int g = 0; g < NG; g++) {
+                const float cand = cstart[g] + (inval[g] ? 100.0f : score[g]);
+                if (ok[g] && cand < lenv[g]) { lenv[g] = cand; lenrun[g] = crun[g]; lenstart[g] = cstart[g]; }
             }
         }
     }

@@ -75,7 +75,7 @@ struct DevEnv {
     const float *lds_np;      // [6][NP_LT][NP_CT]
     const float *g_np;        // full table in global memory
     const uint8_t *win;       // LDS window of reference L bytes, 8 per position
-    float *hist;              // LDS: [4][NS][hw]  (MAT.VAL, lenstart, shrstart, runs)
+    const HistCell *hist;     // LDS: [NS][hw] 16-byte records
     int np_dim, clampv, slot, lstr, hw, wmask;
 
     __device__ __forceinline__ int colidx(int col) const
@@ -83,17 +83,15 @@ struct DevEnv {
         if constexpr (NG == 1) return col;
         else return (col % NG) * lstr + col / NG;
     }
-    __device__ __forceinline__ int at(int arr, int n, int col) const
+    __device__ __forceinline__ HistCell h_cell(int n, int col) const
     {
         int s = slot - n;
         s += (s < 0) ? NS : 0;
-        return (arr * NS + s) * hw + colidx(col);
+        return hist[s * hw + colidx(col)];
     }
     __device__ __forceinline__ float sub(uint32_t s, uint32_t r) const { return lds_sub[s * 8 + r]; }
     __device__ __forceinline__ int clamp() const { return clampv; }
     __device__ __forceinline__ int refl(int j, int n_idx) const { return win[(j & wmask) * 8 + n_idx]; }
-    __device__ __forceinline__ float h_val(int arr, int n, int col) const { return hist[at(arr, n, col)]; }
-    __device__ __forceinline__ uint32_t h_runs(int n, int col) const { return __float_as_uint(hist[at(3, n, col)]); }
     __device__ __forceinline__ bool any(bool x) const { return __builtin_amdgcn_ballot_w64(x) != 0ull; }
     template <int K>
     __device__ __forceinline__ void np_many(const int (&n_idx)[K], const int (&a)[K], const int (&b)[K],
@@ -125,7 +123,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int hw = NG * p.lstr;
     float *wave_lds = lds_sub + 64 + (size_t)wave * (4 * NS * hw + 2 * p.rwin);
-    float *hist = wave_lds;
+    HistCell *hist = reinterpret_cast<HistCell *>(wave_lds);
     uint2 *win = reinterpret_cast<uint2 *>(wave_lds + 4 * NS * hw);
 
     // workgroup-shared tables
@@ -319,13 +317,10 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
             R1[g] = (uint32_t)o[g].matrun | ((uint32_t)o[g].insrun << 16);
             R2[g] = (uint32_t)o[g].matrun | ((uint32_t)o[g].delrun << 16);
             tbw[g] = o[g].tb;
-            if (lane < p.lstr) {   // columns beyond the band are never read back
-                const int hi = env.slot * hw + g * p.lstr + lane;
-                hist[0 * NS * hw + hi] = o[g].matv;
-                hist[1 * NS * hw + hi] = o[g].lenstart;
-                hist[2 * NS * hw + hi] = o[g].shrstart;
-                hist[3 * NS * hw + hi] = __uint_as_float((uint32_t)o[g].lenrun_h | ((uint32_t)o[g].shrrun_h << 16));
-            }
+            if (lane < p.lstr)     // columns beyond the band are never read back
+                hist[env.slot * hw + g * p.lstr + lane] =
+                    HistCell{o[g].matv, o[g].lenstart, o[g].shrstart,
+                             (uint32_t)o[g].lenrun_h | ((uint32_t)o[g].shrrun_h << 16)};
         }
         // one traceback word per cell, NG consecutive words per lane (tbstride is a multiple of 4)
         uint32_t *trow = tb_g + (size_t)bl * p.tbstride;

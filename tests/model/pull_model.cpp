@@ -37,8 +37,11 @@ struct ModelEnv {
     int clamp() const { return max_l - 1; }
     int refl(int j, int n_idx) const { return refl_p[(size_t)j * 8 + n_idx]; }
     size_t at(int n, int col) const { return (size_t)((slot - n + NS) % NS) * W + col; }
-    float h_val(int arr, int n, int col) const { return hv[arr][at(n, col)]; }
-    uint32_t h_runs(int n, int col) const { return hr[at(n, col)]; }
+    HistCell h_cell(int n, int col) const
+    {
+        const size_t k = at(n, col);
+        return HistCell{hv[0][k], hv[1][k], hv[2][k], hr[k]};
+    }
     bool any(bool x) const { return x; }
 };
 }  // namespace
