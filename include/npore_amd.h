@@ -121,13 +121,18 @@ int npore_get_np_info(npore_ctx *ctx, const uint8_t *seq, int64_t len, int32_t *
  */
 int npore_last_timing(npore_ctx *ctx, double *ms, int n);
 
-/* Tunables: key in {"tb_budget_mb","force_ng","force_waves","host_threads"}. */
+/* Tunables: key in {"tb_budget_mb","force_nw","force_ng","force_chunks","host_threads"}
+ * (waves per chunk, band columns per lane, chunks per workgroup; 0 = automatic). */
 int npore_ctx_set(npore_ctx *ctx, const char *key, int64_t value);
 
 /* Debug self-test: out128[l] = value lane l receives from lane l-1 (l>0),
  * out128[64+l] = value from lane l+1 (l<63); checks the DPP wave-shift
  * directions the fill kernel relies on. */
 int npore_debug_dpp(uint32_t *out128);
+
+/* Debug self-test: exhaustive check of the kernels' small-divisor division
+ * (run / n, 0 <= run < 65536, 1 <= n <= 6); *mismatches must come back 0. */
+int npore_debug_divcheck(int64_t *mismatches);
 
 #ifdef __cplusplus
 }

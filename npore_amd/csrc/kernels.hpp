@@ -27,13 +27,19 @@
 
 namespace npore {
 
-constexpr int NS = 6;     // history ring rows: row b overwrites row b-6 after this wave has read it
 constexpr int NP_LT = 32;  // LDS copy of np_scores covers ref length < NP_LT ...
 constexpr int NP_CT = 48;  // ... and call length < NP_CT; anything else is read from global memory
+constexpr int XCH_WORDS = 12;   // per wave, per parity: boundary cells handed to the neighbour waves
+
+// history ring rows.  One wave per chunk: row b overwrites row b-6 after this wave
+// has read it (LDS ops of a wave are in order).  Several waves per chunk with one
+// barrier per anti-diagonal: row b must not land on a row (b-1..b-6) another wave
+// may still be reading in the same step, so 7 rows.
+__host__ __device__ constexpr int ring_rows(int nw) { return nw > 1 ? 7 : 6; }
 
 struct KParams {
     const ChunkDesc *descs;
-    const int32_t *sched;   // wave slot -> chunk index (largest chunks first)
+    const int32_t *sched;   // chunk slot -> chunk index (largest chunks first)
     int n_chunks;
     const uint8_t *steps;
     const int32_t *inss;
@@ -51,10 +57,14 @@ struct KParams {
     float indel_start, indel_extend;
 };
 
-// LDS floats needed by one workgroup of `waves` waves
-static inline size_t fill_lds_floats(int ng, int waves, int lstr, int rwin)
+// LDS floats: shared score tables + per chunk (history ring, reference-L window, exchange)
+static inline size_t chunk_lds_floats(int nw, int ng, int lstr, int rwin)
 {
-    return (size_t)MAX_PERIOD * NP_LT * NP_CT + 64 + (size_t)waves * ((size_t)4 * NS * ng * lstr + 2 * (size_t)rwin);
+    return (size_t)4 * ring_rows(nw) * ng * lstr + 2 * (size_t)rwin + (nw > 1 ? 2 * nw * XCH_WORDS : 0);
+}
+static inline size_t fill_lds_floats(int nw, int ng, int chunks, int lstr, int rwin)
+{
+    return (size_t)MAX_PERIOD * NP_LT * NP_CT + 64 + (size_t)chunks * chunk_lds_floats(nw, ng, lstr, rwin);
 }
 
 // value of the previous / next lane (lane 0 / 63 keep their own)
@@ -69,13 +79,13 @@ __device__ __forceinline__ uint32_t lane_next(uint32_t v)
 __device__ __forceinline__ float lane_prev(float v) { return __uint_as_float(lane_prev(__float_as_uint(v))); }
 __device__ __forceinline__ float lane_next(float v) { return __uint_as_float(lane_next(__float_as_uint(v))); }
 
-template <int NG>
+template <int NG, int NSR>
 struct DevEnv {
     const float *lds_sub;     // [8][8] padded copy of sub_scores
     const float *lds_np;      // [6][NP_LT][NP_CT]
     const float *g_np;        // full table in global memory
     const uint8_t *win;       // LDS window of reference L bytes, 8 per position
-    const HistCell *hist;     // LDS: [NS][hw] 16-byte records
+    const HistCell *hist;     // LDS: [NSR][hw] 16-byte records
     int np_dim, clampv, slot, lstr, hw, wmask;
 
     __device__ __forceinline__ int colidx(int col) const
@@ -86,7 +96,7 @@ struct DevEnv {
     __device__ __forceinline__ HistCell h_cell(int n, int col) const
     {
         int s = slot - n;
-        s += (s < 0) ? NS : 0;
+        s += (s < 0) ? NSR : 0;
         return hist[s * hw + colidx(col)];
     }
     __device__ __forceinline__ float sub(uint32_t s, uint32_t r) const { return lds_sub[s * 8 + r]; }
@@ -113,18 +123,24 @@ struct DevEnv {
     }
 };
 
-template <int NG, int MAXT>
+// NW waves per chunk (each owns 64*NG consecutive band columns), NG columns per lane.
+template <int NW, int NG, int MAXT>
 __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
 {
-    constexpr int WP = 64 * NG;
+    constexpr int NSR = ring_rows(NW);
+    constexpr int WPW = 64 * NG;          // columns per wave
+    constexpr int WPT = NW * WPW;         // physical columns per chunk
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *lds_np = lds;
     float *lds_sub = lds + MAX_PERIOD * NP_LT * NP_CT;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int cw = wave % NW;             // wave within the chunk
+    const int cg = wave / NW;             // chunk within the workgroup
     const int hw = NG * p.lstr;
-    float *wave_lds = lds_sub + 64 + (size_t)wave * (4 * NS * hw + 2 * p.rwin);
-    HistCell *hist = reinterpret_cast<HistCell *>(wave_lds);
-    uint2 *win = reinterpret_cast<uint2 *>(wave_lds + 4 * NS * hw);
+    float *chunk_lds = lds_sub + 64 + (size_t)cg * (4 * NSR * hw + 2 * p.rwin + (NW > 1 ? 2 * NW * XCH_WORDS : 0));
+    HistCell *hist = reinterpret_cast<HistCell *>(chunk_lds);
+    uint2 *win = reinterpret_cast<uint2 *>(chunk_lds + 4 * NSR * hw);
+    uint32_t *xchg = reinterpret_cast<uint32_t *>(chunk_lds + 4 * NSR * hw + 2 * p.rwin);   // [2][NW][XCH_WORDS]
 
     // workgroup-shared tables
     const int np_dim = p.max_l + 1;
@@ -137,12 +153,12 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
                                    ? p.sub_scores[(threadIdx.x >> 3) * 5 + (threadIdx.x & 7)] : 0.0f;
     __syncthreads();
 
-    const int slot_id = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (slot_id >= p.n_chunks) return;     // waves are independent from here on
+    const int slot_id = blockIdx.x * ((blockDim.x >> 6) / NW) + cg;
+    if (slot_id >= p.n_chunks) return;     // hardware barriers only count waves that are still alive
     const ChunkDesc d = p.descs[p.sched[slot_id]];
     const int r = p.r;
 
-    DevEnv<NG> env;
+    DevEnv<NG, NSR> env;
     env.lds_sub = lds_sub;
     env.lds_np = lds_np;
     env.g_np = p.np_scores;
@@ -160,6 +176,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     const uint2 *refl_g = p.refl + d.refw_off;
     const uint8_t *steps_g = p.steps + d.steps_off + d.brk;   // steps_g[k] = step from local row k to k+1
     uint32_t *tb_g = p.tb + d.tb_off;
+    const int col0w = cw * WPW;           // first column of this wave
 
     // per-cell state of the previous anti-diagonal
     float matv[NG], insv[NG], delv[NG], LMv[NG], TMv[NG];
@@ -169,32 +186,37 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     for (int g = 0; g < NG; g++) {
         matv[g] = insv[g] = delv[g] = LMv[g] = TMv[g] = 0.0f;
         R1[g] = R2[g] = LT[g] = 0u;
-        const int col = lane * NG + g;
+        const int col = col0w + lane * NG + g;
         const int i = r - col, j = col - r;
         seqw[g] = (i >= 0 && i <= d.drows) ? seqw_g[i] : SEQW_SENTINEL;
         uint2 rw = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint2(REFW_SENTINEL, 0u);
         refx[g] = rw.x;
         refy[g] = rw.y;
     }
-    // queues of words that will enter at column 0 (read) / column WP-1 (reference)
+    // queues of words that will enter at column 0 (read; first wave) / column WPT-1 (reference; last wave)
     int sq_base = r + 1;              // next read index entering at column 0 is ins_l + r
-    int rq_base = WP - r;             // next reference index entering at column WP-1 is del_l + WP-1 - r
-    uint32_t seq_q, refx_q, refy_q;
-    {
+    int rq_base = WPT - r;            // next reference index entering at column WPT-1 is del_l + WPT-1 - r
+    uint32_t seq_q = SEQW_SENTINEL, refx_q = REFW_SENTINEL, refy_q = 0u;
+    if (cw == 0) {
         const int i = sq_base + lane;
         seq_q = (i <= d.drows) ? seqw_g[i] : SEQW_SENTINEL;
+    }
+    // reference-L window: positions [0, wfill) are resident (modulo rwin); kept by the last wave
+    int wfill = 0;
+    if (cw == NW - 1) {
         const int j = rq_base + lane;
         uint2 rw = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint2(REFW_SENTINEL, 0u);
         refx_q = rw.x;
         refy_q = rw.y;
     }
-    // reference-L window: positions [0, wfill) are resident (modulo rwin)
-    int wfill = 0;
     while (r + 32 >= wfill) {
-        const int j = wfill + lane;
-        win[j & env.wmask] = (j <= d.dcols) ? refl_g[j] : make_uint2(0u, 0u);
+        if (cw == NW - 1) {
+            const int j = wfill + lane;
+            win[j & env.wmask] = (j <= d.dcols) ? refl_g[j] : make_uint2(0u, 0u);
+        }
         wfill += 64;
     }
+    if constexpr (NW > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     StepInfo st;
     st.r = r;
@@ -224,22 +246,29 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
         st.ins_l = ins_l;
         st.del_l = bl - ins_l;
         st.hist6 = hist6;
-        env.slot = bl % NS;
+        env.slot = bl % NSR;
+        // boundary cells written by the neighbour waves at the end of the previous step
+        const uint32_t *xin = xchg + ((bl + 1) & 1) * (NW * XCH_WORDS);
 
         CellIn in[NG];
         if (bl > 0 && I) {
             // read words move one column up; word for row ins_l + r enters at column 0
-            const int qi = ins_l + r - sq_base;
-            if (qi >= 64) {   // uniform
-                sq_base += 64;
-                const int i = sq_base + lane;
-                seq_q = (i <= d.drows) ? seqw_g[i] : SEQW_SENTINEL;
-            }
-            const uint32_t incoming = (uint32_t)__builtin_amdgcn_readlane((int)seq_q, (ins_l + r - sq_base) & 63);
-            const float pm = lane_prev(matv[NG - 1]), pd = lane_prev(delv[NG - 1]);
-            const uint32_t pr = lane_prev(R2[NG - 1]);
+            float pm = lane_prev(matv[NG - 1]), pd = lane_prev(delv[NG - 1]);
+            uint32_t pr = lane_prev(R2[NG - 1]);
             uint32_t ps = lane_prev(seqw[NG - 1]);
-            if (lane == 0) ps = incoming;
+            if (cw == 0) {
+                const int qi = ins_l + r - sq_base;
+                if (qi >= 64) {   // uniform
+                    sq_base += 64;
+                    const int i = sq_base + lane;
+                    seq_q = (i <= d.drows) ? seqw_g[i] : SEQW_SENTINEL;
+                }
+                const uint32_t incoming = (uint32_t)__builtin_amdgcn_readlane((int)seq_q, (ins_l + r - sq_base) & 63);
+                if (lane == 0) ps = incoming;
+            } else if constexpr (NW > 1) {
+                const uint32_t *xl = xin + (cw - 1) * XCH_WORDS;   // last cell of the wave below
+                if (lane == 0) { pm = __uint_as_float(xl[0]); pd = __uint_as_float(xl[1]); pr = xl[2]; ps = xl[3]; }
+            }
 #pragma unroll
             for (int g = NG - 1; g >= 0; g--) {
                 in[g].topM = matv[g]; in[g].topI = insv[g]; in[g].topIrun = (int)(R1[g] >> 16);
@@ -253,28 +282,35 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
                 seqw[g] = g ? seqw[g - 1] : ps;
             }
         } else if (bl > 0) {
-            // reference words move one column down; word for col del_l + WP-1 - r enters at column WP-1
+            // reference words move one column down; word for col del_l + WPT-1 - r enters at column WPT-1
             const int del_l = bl - ins_l;
-            const int qj = del_l + WP - 1 - r - rq_base;
-            if (qj >= 64) {
-                rq_base += 64;
-                const int j = rq_base + lane;
-                uint2 rw = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint2(REFW_SENTINEL, 0u);
-                refx_q = rw.x;
-                refy_q = rw.y;
+            float nm = lane_next(matv[0]), ni = lane_next(insv[0]);
+            uint32_t nr = lane_next(R1[0]);
+            uint32_t nx = lane_next(refx[0]), ny = lane_next(refy[0]);
+            if (cw == NW - 1) {
+                const int qj = del_l + WPT - 1 - r - rq_base;
+                if (qj >= 64) {
+                    rq_base += 64;
+                    const int j = rq_base + lane;
+                    uint2 rw = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint2(REFW_SENTINEL, 0u);
+                    refx_q = rw.x;
+                    refy_q = rw.y;
+                }
+                const int ql = (del_l + WPT - 1 - r - rq_base) & 63;
+                const uint32_t inx = (uint32_t)__builtin_amdgcn_readlane((int)refx_q, ql);
+                const uint32_t iny = (uint32_t)__builtin_amdgcn_readlane((int)refy_q, ql);
+                if (lane == 63) { nx = inx; ny = iny; }
+            } else if constexpr (NW > 1) {
+                const uint32_t *xf = xin + (cw + 1) * XCH_WORDS + 4;   // first cell of the wave above
+                if (lane == 63) { nm = __uint_as_float(xf[0]); ni = __uint_as_float(xf[1]); nr = xf[2]; nx = xf[3]; ny = xf[4]; }
             }
-            if (del_l + r + 32 >= wfill) {   // keep the L window ahead of the band
-                const int j = wfill + lane;
-                win[j & env.wmask] = (j <= d.dcols) ? refl_g[j] : make_uint2(0u, 0u);
+            if (del_l + r + 32 >= wfill) {   // keep the L window ahead of the band (32 positions of slack)
+                if (cw == NW - 1) {
+                    const int j = wfill + lane;
+                    win[j & env.wmask] = (j <= d.dcols) ? refl_g[j] : make_uint2(0u, 0u);
+                }
                 wfill += 64;
             }
-            const int ql = (del_l + WP - 1 - r - rq_base) & 63;
-            const uint32_t inx = (uint32_t)__builtin_amdgcn_readlane((int)refx_q, ql);
-            const uint32_t iny = (uint32_t)__builtin_amdgcn_readlane((int)refy_q, ql);
-            const float nm = lane_next(matv[0]), ni = lane_next(insv[0]);
-            const uint32_t nr = lane_next(R1[0]);
-            uint32_t nx = lane_next(refx[0]), ny = lane_next(refy[0]);
-            if (lane == 63) { nx = inx; ny = iny; }
 #pragma unroll
             for (int g = 0; g < NG; g++) {
                 in[g].leftM = matv[g]; in[g].leftD = delv[g]; in[g].leftDrun = (int)(R2[g] >> 16);
@@ -297,7 +333,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
         }
 #pragma unroll
         for (int g = 0; g < NG; g++) {
-            in[g].c = lane * NG + g;
+            in[g].c = col0w + lane * NG + g;
             in[g].seqw = seqw[g];
             in[g].refx = refx[g];
             in[g].refy = refy[g];
@@ -307,6 +343,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
         cells_update<NG>(env, st, in, o);
 
         uint32_t tbw[NG];
+        const int lpos = cw * 64 + lane;      // lane position across the chunk's waves
 #pragma unroll
         for (int g = 0; g < NG; g++) {
             LMv[g] = in[g].leftM;
@@ -317,25 +354,40 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
             R1[g] = (uint32_t)o[g].matrun | ((uint32_t)o[g].insrun << 16);
             R2[g] = (uint32_t)o[g].matrun | ((uint32_t)o[g].delrun << 16);
             tbw[g] = o[g].tb;
-            if (lane < p.lstr)     // columns beyond the band are never read back
-                hist[env.slot * hw + g * p.lstr + lane] =
+            if (lpos < p.lstr)     // columns beyond the band are never read back
+                hist[env.slot * hw + g * p.lstr + lpos] =
                     HistCell{o[g].matv, o[g].lenstart, o[g].shrstart,
                              (uint32_t)o[g].lenrun_h | ((uint32_t)o[g].shrrun_h << 16)};
         }
+        if constexpr (NW > 1) {
+            uint32_t *xout = xchg + (bl & 1) * (NW * XCH_WORDS) + cw * XCH_WORDS;
+            if (lane == 63) {
+                xout[0] = __float_as_uint(matv[NG - 1]); xout[1] = __float_as_uint(delv[NG - 1]);
+                xout[2] = R2[NG - 1]; xout[3] = seqw[NG - 1];
+            }
+            if (lane == 0) {
+                xout[4] = __float_as_uint(matv[0]); xout[5] = __float_as_uint(insv[0]);
+                xout[6] = R1[0]; xout[7] = refx[0]; xout[8] = refy[0];
+            }
+        }
         // one traceback word per cell, NG consecutive words per lane (tbstride is a multiple of 4)
         uint32_t *trow = tb_g + (size_t)bl * p.tbstride;
+        const int tcol = col0w + lane * NG;
         if constexpr (NG == 1) {
-            if (lane < p.tbstride) trow[lane] = tbw[0];
+            if (tcol < p.tbstride) trow[tcol] = tbw[0];
         } else if constexpr (NG == 2) {
-            if (lane * 2 < p.tbstride) *reinterpret_cast<uint2 *>(trow + lane * 2) = make_uint2(tbw[0], tbw[1]);
+            if (tcol < p.tbstride) *reinterpret_cast<uint2 *>(trow + tcol) = make_uint2(tbw[0], tbw[1]);
         } else {
 #pragma unroll
             for (int q = 0; q < NG / 4; q++) {
-                const int col = lane * NG + 4 * q;
+                const int col = tcol + 4 * q;
                 if (col < p.tbstride)
                     *reinterpret_cast<uint4 *>(trow + col) = make_uint4(tbw[4 * q], tbw[4 * q + 1], tbw[4 * q + 2], tbw[4 * q + 3]);
             }
         }
+        // LDS writes of this step visible to the chunk's other waves before they start the next one.
+        // (lgkmcnt only: the traceback stores above must not be waited for.)
+        if constexpr (NW > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
 
@@ -431,6 +483,15 @@ __global__ __launch_bounds__(256) void gather_kernel(GParams p)
         for (int q = threadIdx.x; q < len; q += blockDim.x) dst[w + q] = src[q];
         w += len;
     }
+}
+
+// exhaustive check of div_small on its domain: counts mismatches
+__global__ void divcheck_kernel(unsigned long long *bad)
+{
+    const int run = blockIdx.x * blockDim.x + threadIdx.x;   // 0..65535
+    unsigned long long b = 0;
+    for (int n = 1; n <= MAX_PERIOD; n++) b += (div_small(run, n) != run / n);
+    if (b) atomicAdd(bad, b);
 }
 
 // DPP direction self-test: out[l] = lane_prev(l), out[64+l] = lane_next(l)

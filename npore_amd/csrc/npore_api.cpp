@@ -100,7 +100,8 @@ struct npore_ctx {
     // tunables
     int64_t tb_budget_mb = 0;   // 0 = auto
     int force_ng = 0;
-    int force_waves = 0;
+    int force_chunks = 0;
+    int force_nw = 0;
     int host_threads = 0;
     // device buffers
     DevBuf refs, seqs, steps, inss, seqw, refw, refl, descs, sched, rfc, rstat, tb, cout_, clen, cstat;
@@ -111,12 +112,17 @@ struct npore_ctx {
 
 namespace {
 
-int pick_ng(int r, int force)
+// (waves per chunk) * (columns per lane) * 64 must cover the band; returns nw*16 + ng, 0 if impossible
+int pick_shape(int r, int force_nw, int force_ng)
 {
     const int W = 2 * r + 1;
-    if (force) return (64 * force >= W) ? force : 0;
-    for (int ng : {1, 2, 4, 8})
-        if (64 * ng >= W) return ng;
+    for (int cover : {1, 2, 4, 8}) {
+        if (64 * cover < W) continue;
+        int nw = cover, ng = 1;                 // default: one column per lane, more waves per chunk
+        if (force_ng > 0 && cover % force_ng == 0) { ng = force_ng; nw = cover / ng; }
+        if (force_nw > 0 && cover % force_nw == 0) { nw = force_nw; ng = cover / nw; }
+        return nw * 16 + ng;
+    }
     return 0;
 }
 
@@ -127,25 +133,27 @@ int pow2_at_least(int x)
     return p;
 }
 
-// One wave per chunk, `waves` chunks per workgroup (they share the LDS score table).
-template <int NG, int MAXT>
-hipError_t launch_fill(KParams kp, int n_chunks, int force_waves, hipStream_t s)
+// NW waves per chunk, `chunks` chunks per workgroup (they share the LDS score table).
+template <int NW, int NG, int MAXT>
+hipError_t launch_fill(KParams kp, int n_chunks, int force_chunks, hipStream_t s)
 {
     const int W = 2 * kp.r + 1;
     kp.lstr = (W + NG - 1) / NG;
     kp.rwin = pow2_at_least(2 * kp.r + 101);
     kp.n_chunks = n_chunks;
     const size_t lds_cap = 160 * 1024 / sizeof(float);
-    int waves_max = 1;
-    while (waves_max < MAXT / 64 && fill_lds_floats(NG, waves_max + 1, kp.lstr, kp.rwin) <= lds_cap) waves_max++;
-    if (fill_lds_floats(NG, 1, kp.lstr, kp.rwin) > lds_cap) return hipErrorInvalidValue;
-    int waves = std::min(waves_max, std::max(1, (n_chunks + 255) / 256));
-    if (force_waves > 0) waves = std::min(waves_max, force_waves);
-    const size_t lds = fill_lds_floats(NG, waves, kp.lstr, kp.rwin) * sizeof(float);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fill_kernel<NG, MAXT>),
+    if (fill_lds_floats(NW, NG, 1, kp.lstr, kp.rwin) > lds_cap) return hipErrorInvalidValue;
+    int cmax = 1;
+    while ((cmax + 1) * NW * 64 <= MAXT && fill_lds_floats(NW, NG, cmax + 1, kp.lstr, kp.rwin) <= lds_cap) cmax++;
+    // few chunks: spread them over the CUs; many: pack workgroups so that the table is amortised
+    int chunks = std::min(cmax, std::max(1, (n_chunks + 255) / 256));
+    if (force_chunks > 0) chunks = std::min(cmax, force_chunks);
+    const size_t lds = fill_lds_floats(NW, NG, chunks, kp.lstr, kp.rwin) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fill_kernel<NW, NG, MAXT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((fill_kernel<NG, MAXT>), dim3((n_chunks + waves - 1) / waves), dim3(64 * waves), lds, s, kp);
+    hipLaunchKernelGGL((fill_kernel<NW, NG, MAXT>), dim3((n_chunks + chunks - 1) / chunks), dim3(64 * NW * chunks),
+                       lds, s, kp);
     return hipGetLastError();
 }
 
@@ -344,11 +352,17 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, std::v
         kp.indel_extend = a.indel_extend;
         hipError_t e = hipSuccess;
         switch (ng) {
-            case 1: e = launch_fill<1, 1024>(kp, (int)n_chunks, ctx->force_waves, s); break;
-            case 2: e = launch_fill<2, 512>(kp, (int)n_chunks, ctx->force_waves, s); break;
-            case 4: e = launch_fill<4, 256>(kp, (int)n_chunks, ctx->force_waves, s); break;
-            case 8: e = launch_fill<8, 128>(kp, (int)n_chunks, ctx->force_waves, s); break;
-            default: return fail(NPORE_E_UNSUPPORTED, "unsupported columns-per-lane");
+            case 1 * 16 + 1: e = launch_fill<1, 1, 1024>(kp, (int)n_chunks, ctx->force_chunks, s); break;
+            case 1 * 16 + 2: e = launch_fill<1, 2, 512>(kp, (int)n_chunks, ctx->force_chunks, s); break;
+            case 1 * 16 + 4: e = launch_fill<1, 4, 256>(kp, (int)n_chunks, ctx->force_chunks, s); break;
+            case 1 * 16 + 8: e = launch_fill<1, 8, 128>(kp, (int)n_chunks, ctx->force_chunks, s); break;
+            case 2 * 16 + 1: e = launch_fill<2, 1, 1024>(kp, (int)n_chunks, ctx->force_chunks, s); break;
+            case 2 * 16 + 2: e = launch_fill<2, 2, 512>(kp, (int)n_chunks, ctx->force_chunks, s); break;
+            case 2 * 16 + 4: e = launch_fill<2, 4, 256>(kp, (int)n_chunks, ctx->force_chunks, s); break;
+            case 4 * 16 + 1: e = launch_fill<4, 1, 1024>(kp, (int)n_chunks, ctx->force_chunks, s); break;
+            case 4 * 16 + 2: e = launch_fill<4, 2, 512>(kp, (int)n_chunks, ctx->force_chunks, s); break;
+            case 8 * 16 + 1: e = launch_fill<8, 1, 1024>(kp, (int)n_chunks, ctx->force_chunks, s); break;
+            default: return fail(NPORE_E_UNSUPPORTED, "unsupported waves-per-chunk / columns-per-lane combination");
         }
         if (e != hipSuccess) return fail(NPORE_E_HIP, std::string("fill launch: ") + hipGetErrorString(e));
         HIP_TRY(hipEventRecord(ctx->ev[2], s));
@@ -406,8 +420,8 @@ int run_core(npore_ctx *ctx, const AlignArgs &a, const OutTarget &ot, hipStream_
     if (a.max_b_rows < 2) return fail(NPORE_E_INVALID, "max_b_rows must be >= 2");
     if (a.max_b_rows > 60000)
         return fail(NPORE_E_UNSUPPORTED, "max_b_rows > 60000: run lengths are kept in 16 bits");
-    const int ng = pick_ng(a.r, ctx->force_ng);
-    if (!ng) return fail(NPORE_E_UNSUPPORTED, "band half-width r > 255 (or force_ng too small)");
+    const int ng = pick_shape(a.r, ctx->force_nw, ctx->force_ng);
+    if (!ng) return fail(NPORE_E_UNSUPPORTED, "band half-width r > 255");
     std::fill(ctx->timing, ctx->timing + 8, 0.0);
     if (a.n_reads == 0) return NPORE_OK;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -623,7 +637,8 @@ int npore_ctx_set(npore_ctx *ctx, const char *key, int64_t value)
     const std::string k(key);
     if (k == "tb_budget_mb") ctx->tb_budget_mb = value;
     else if (k == "force_ng") ctx->force_ng = (int)value;
-    else if (k == "force_waves") ctx->force_waves = (int)value;
+    else if (k == "force_chunks") ctx->force_chunks = (int)value;
+    else if (k == "force_nw") ctx->force_nw = (int)value;
     else if (k == "host_threads") ctx->host_threads = (int)value;
     else return fail(NPORE_E_INVALID, "unknown key " + k);
     return NPORE_OK;
@@ -638,6 +653,19 @@ int npore_debug_dpp(uint32_t *out128)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out128, d, 128 * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipFree(d));
+    return NPORE_OK;
+}
+
+int npore_debug_divcheck(int64_t *mismatches)
+{
+    unsigned long long *d = nullptr, h = 0;
+    HIP_TRY(hipMalloc((void **)&d, 8));
+    HIP_TRY(hipMemset(d, 0, 8));
+    hipLaunchKernelGGL(divcheck_kernel, dim3(256), dim3(256), 0, 0, d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(d));
+    *mismatches = (int64_t)h;
     return NPORE_OK;
 }
 
