@@ -115,9 +115,9 @@ int npore_get_np_info(npore_ctx *ctx, const uint8_t *seq, int64_t len, int32_t *
 /*
  * Timing of the stages of the last npore_align_batch* call on this context,
  * measured with HIP events on the stream the kernels ran on (milliseconds):
- *   ms[0] device prep, ms[1] fill kernel(s), ms[2] traceback kernel(s),
- *   ms[3] H2D, ms[4] D2H, ms[5] host prep, ms[6] cells processed (count),
- *   ms[7] fill-kernel launches.
+ *   ms[0] device prep kernels, ms[1] fill kernel(s), ms[2] traceback + gather,
+ *   ms[3] H2D, ms[4] D2H (host-buffer entry point only), ms[5] unused (0),
+ *   ms[6] cells processed (count), ms[7] fill-kernel launches.
  */
 int npore_last_timing(npore_ctx *ctx, double *ms, int n);
 
@@ -133,6 +133,11 @@ int npore_debug_dpp(uint32_t *out128);
 /* Debug self-test: exhaustive check of the kernels' small-divisor division
  * (run / n, 0 <= run < 65536, 1 <= n <= 6); *mismatches must come back 0. */
 int npore_debug_divcheck(int64_t *mismatches);
+
+/* Debug: copy a device-prepared array of the last group of the last align call
+ * to the host (what: 0 steps, 1 inss, 2 chunk descriptors, 3 seqw, 4 refw,
+ * 5 refl, 6 schedule, 7 counters); the GPU tests compare them with the host twin. */
+int npore_debug_fetch(npore_ctx *ctx, int what, void *dst, int64_t bytes);
 
 #ifdef __cplusplus
 }

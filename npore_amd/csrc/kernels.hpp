@@ -40,7 +40,7 @@ __host__ __device__ constexpr int ring_rows(int nw) { return nw > 1 ? 7 : 6; }
 struct KParams {
     const ChunkDesc *descs;
     const int32_t *sched;   // chunk slot -> chunk index (largest chunks first)
-    int n_chunks;
+    const int32_t *n_chunks;   // device-side count (kernels are launched over an upper bound)
     const uint8_t *steps;
     const int32_t *inss;
     const uint32_t *seqw;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     __syncthreads();
 
     const int slot_id = blockIdx.x * ((blockDim.x >> 6) / NW) + cg;
-    if (slot_id >= p.n_chunks) return;     // hardware barriers only count waves that are still alive
+    if (slot_id >= *p.n_chunks) return;    // hardware barriers only count waves that are still alive
     const ChunkDesc d = p.descs[p.sched[slot_id]];
     const int r = p.r;
 
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
 // ---------------------------------------------------------------------------
 struct TParams {
     const ChunkDesc *descs;
-    int n_chunks;
+    const int32_t *n_chunks;
     const int32_t *inss;
     const uint32_t *tb;
     const uint8_t *seqs, *refs;
@@ -408,7 +408,7 @@ struct TParams {
 __global__ __launch_bounds__(64) void traceback_kernel(TParams p)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= p.n_chunks) return;
+    if (k >= *p.n_chunks) return;
     const ChunkDesc d = p.descs[k];
     const int32_t *inss = p.inss + d.inss_off;
     const uint32_t *tb = p.tb + d.tb_off;
@@ -454,6 +454,7 @@ struct GParams {
     const uint8_t *chunk_out;
     const int32_t *chunk_len, *chunk_status;
     const int32_t *read_status_in;     // prep status per read (bad input)
+    const int32_t *counters;
     uint8_t *out;
     const int64_t *out_off;            // [n_reads+1] in the caller's buffer
     int64_t *out_len;

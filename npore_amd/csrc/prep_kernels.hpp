@@ -1,0 +1,378 @@
+// prep_kernels.hpp -- device-side preparation of a batch, so that the whole path
+// runs from the raw (ref, read, CIGAR) bytes resident in HBM without a host
+// round trip:
+//   cigar_scan      per read: converted path length, validity, number of chunks
+//                   (reference src/aln.pyx:386, 391-392, 344-345)
+//   read_scan       exclusive scans over reads (path offsets, first chunk)
+//   expand_path     per read: step bytes and insertion prefix counts
+//                   (src/aln.pyx:279-292; dels[b] = b - inss[b])
+//   make_chunks     per chunk: break points incl. the "don't split DI" shift
+//                   (src/aln.pyx:349-357), rectangle, sizes, size histogram
+//   chunk_scan      offsets of every chunk's arrays; schedule positions
+//   sched_scatter   chunk order for the fill kernel, largest first
+//   annotate        per chunk and sequence: n-polymer annotation
+//                   (get_np_info, src/aln.pyx:179-251, on the chunk slices of
+//                   src/aln.pyx:453-456) and word packing (layout.hpp)
+// All launches are sized from host-known upper bounds and read the actual counts
+// from device memory, so no host synchronisation is needed in between.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "layout.hpp"
+
+namespace npore {
+
+struct PrepParams {
+    int64_t n_reads;
+    const uint8_t *refs;
+    const int64_t *ref_off;
+    const uint8_t *seqs;
+    const int64_t *seq_off;
+    const char *cigs;
+    const int64_t *cig_off;
+    int max_b_rows, r, tbstride, max_n, max_l;
+    int max_chunks;            // capacity of the chunk arrays
+    // per read
+    int32_t *rd_nsteps;        // [n]
+    int32_t *rd_nchunks;       // [n]
+    int32_t *rd_status;        // [n]  NPORE_ST_BAD_INPUT or 0
+    int64_t *rd_steps_off;     // [n+1] exclusive scan of nsteps
+    int32_t *rd_chunk_first;   // [n+1]
+    // path
+    uint8_t *steps;            // [sum nsteps + pad]
+    int32_t *inss;             // [sum (nsteps+1)]  read k starts at rd_steps_off[k] + k
+    // chunks
+    ChunkDesc *descs;
+    int32_t *sched;
+    int32_t *hist;             // [max_b_rows + 2] counting sort by rows, then running positions
+    int32_t *counters;         // [0] number of chunks, [1] overflow flag
+    // annotation
+    uint32_t *seqw;
+    uint2 *refw;
+    uint2 *refl;               // per reference position: bytes 0-5 L for n=1..6, byte 6 L_IDX==0 mask
+    uint2 *seql;               // same for read positions (scratch)
+};
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cigar_scan_kernel(PrepParams p)
+{
+    const int64_t rd = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (rd >= p.n_reads) return;
+    const char *cig = p.cigs + p.cig_off[rd];
+    const int64_t clen = p.cig_off[rd + 1] - p.cig_off[rd];
+    const int64_t S = p.seq_off[rd + 1] - p.seq_off[rd], R = p.ref_off[rd + 1] - p.ref_off[rd];
+    int64_t nM = 0, nI = 0, nD = 0, nBad = 0;
+    for (int64_t k = lane; k - lane < clen; k += 64) {
+        const char c = (k < clen) ? cig[k] : 'I';
+        const bool v = k < clen;
+        const bool m = v && (c == 'X' || c == '=' || c == 'M');
+        const bool i = v && c == 'I';
+        const bool d = v && c == 'D';
+        nM += __popcll(__builtin_amdgcn_ballot_w64(m));
+        nI += __popcll(__builtin_amdgcn_ballot_w64(i));
+        nD += __popcll(__builtin_amdgcn_ballot_w64(d));
+        nBad += __popcll(__builtin_amdgcn_ballot_w64(v && !m && !i && !d));
+    }
+    const uint8_t *sq = p.seqs + p.seq_off[rd], *rf = p.refs + p.ref_off[rd];
+    for (int64_t k = lane; k - lane < S; k += 64) nBad += __popcll(__builtin_amdgcn_ballot_w64(k < S && sq[k] > 4));
+    for (int64_t k = lane; k - lane < R; k += 64) nBad += __popcll(__builtin_amdgcn_ballot_w64(k < R && rf[k] > 4));
+    const int64_t nsteps = 2 * nM + nI + nD;
+    const bool ok = nBad == 0 && nM + nI == S && nM + nD == R && nsteps < (1ll << 30);
+    if (lane == 0) {
+        const int64_t cm1 = (int64_t)p.max_b_rows - 1;
+        p.rd_nsteps[rd] = ok ? (int32_t)nsteps : 0;
+        p.rd_nchunks[rd] = (ok && nsteps > 0) ? (int32_t)((nsteps + cm1 - 1) / cm1) : 0;   // src/aln.pyx:345
+        p.rd_status[rd] = ok ? 0 : 32 /* NPORE_ST_BAD_INPUT */;
+    }
+}
+
+// single workgroup: exclusive scans over reads
+__global__ __launch_bounds__(1024) void read_scan_kernel(PrepParams p)
+{
+    __shared__ int64_t s_steps[1024];
+    __shared__ int64_t s_chunks[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (p.n_reads + 1023) / 1024;
+    const int64_t a = (int64_t)t * per, b = (a + per < p.n_reads) ? a + per : p.n_reads;
+    int64_t ls = 0, lc = 0;
+    for (int64_t k = a; k < b; k++) { ls += p.rd_nsteps[k]; lc += p.rd_nchunks[k]; }
+    s_steps[t] = ls;
+    s_chunks[t] = lc;
+    __syncthreads();
+    if (t == 0) {
+        int64_t as = 0, ac = 0;
+        for (int k = 0; k < 1024; k++) {
+            const int64_t vs = s_steps[k], vc = s_chunks[k];
+            s_steps[k] = as; s_chunks[k] = ac;
+            as += vs; ac += vc;
+        }
+        p.rd_steps_off[p.n_reads] = as;
+        p.rd_chunk_first[p.n_reads] = (int32_t)(ac > p.max_chunks ? p.max_chunks : ac);
+        p.counters[0] = (int32_t)(ac > p.max_chunks ? p.max_chunks : ac);
+        p.counters[1] = ac > p.max_chunks;
+    }
+    __syncthreads();
+    int64_t as = s_steps[t], ac = s_chunks[t];
+    for (int64_t k = a; k < b; k++) {
+        p.rd_steps_off[k] = as;
+        p.rd_chunk_first[k] = (int32_t)ac;
+        as += p.rd_nsteps[k];
+        ac += p.rd_nchunks[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void expand_path_kernel(PrepParams p)
+{
+    const int64_t rd = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (rd >= p.n_reads || p.rd_status[rd] != 0) return;
+    const char *cig = p.cigs + p.cig_off[rd];
+    const int64_t clen = p.cig_off[rd + 1] - p.cig_off[rd];
+    uint8_t *steps = p.steps + p.rd_steps_off[rd];
+    int32_t *inss = p.inss + p.rd_steps_off[rd] + rd;
+    if (lane == 0) inss[0] = 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int64_t base = 0;      // steps emitted so far
+    int32_t baseI = 0;     // 'I' steps emitted so far
+    for (int64_t k0 = 0; k0 < clen; k0 += 64) {
+        const int64_t k = k0 + lane;
+        const bool v = k < clen;
+        const char c = v ? cig[k] : 'D';
+        const bool m = v && (c == 'X' || c == '=' || c == 'M');
+        const bool i = v && c == 'I';
+        const unsigned long long mv = __builtin_amdgcn_ballot_w64(v), mm = __builtin_amdgcn_ballot_w64(m),
+                                 mi = __builtin_amdgcn_ballot_w64(i);
+        const int64_t off = base + __popcll(mv & lt) + __popcll(mm & lt);
+        const int32_t pI = baseI + __popcll((mi | mm) & lt);
+        if (v) {
+            if (m) {            // X,=,M -> "DI"
+                steps[off] = 0; inss[off + 1] = pI;
+                steps[off + 1] = 1; inss[off + 2] = pI + 1;
+            } else if (i) {
+                steps[off] = 1; inss[off + 1] = pI + 1;
+            } else {
+                steps[off] = 0; inss[off + 1] = pI;
+            }
+        }
+        base += __popcll(mv) + __popcll(mm);
+        baseI += __popcll(mi | mm);
+    }
+}
+
+__global__ __launch_bounds__(256) void make_chunks_kernel(PrepParams p)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= p.counters[0]) return;
+    // read owning chunk k: last rd with rd_chunk_first[rd] <= k
+    int64_t lo = 0, hi = p.n_reads;   // invariant: first[lo] <= k < first[hi]
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (p.rd_chunk_first[mid] <= k) lo = mid; else hi = mid;
+    }
+    const int64_t rd = lo;
+    const int ci = k - p.rd_chunk_first[rd];
+    const int nch = p.rd_nchunks[rd];
+    const int32_t nsteps = p.rd_nsteps[rd];
+    const uint8_t *steps = p.steps + p.rd_steps_off[rd];
+    const int32_t *inss = p.inss + p.rd_steps_off[rd] + rd;
+    const int cm1 = p.max_b_rows - 1;
+    auto brk_at = [&](int i) -> int {
+        if (i >= nch) return nsteps;                                   // src/aln.pyx:357
+        int bk = i * cm1;
+        if (i > 0 && steps[bk] == 1 && steps[bk - 1] == 0) bk -= 1;     // src/aln.pyx:353-355
+        return bk;
+    };
+    const int brk = brk_at(ci), nxt = brk_at(ci + 1);
+    ChunkDesc d;
+    d.read_id = (int32_t)rd;
+    d.brk = brk;
+    d.nrows = nxt - brk + 1;
+    d.row0 = inss[brk];
+    d.col0 = brk - inss[brk];
+    d.drows = inss[nxt] - d.row0;
+    d.dcols = (nxt - inss[nxt]) - d.col0;
+    d.out_cap = d.drows + d.dcols;
+    d.steps_off = p.rd_steps_off[rd];
+    d.inss_off = p.rd_steps_off[rd] + rd;
+    d.seqw_off = d.drows + 1;                       // sizes for now; chunk_scan turns them into offsets
+    d.refw_off = d.dcols + 1;
+    d.tb_off = (int64_t)d.nrows * p.tbstride;
+    d.out_off = d.out_cap;
+    d.seq_off = p.seq_off[rd];
+    d.ref_off = p.ref_off[rd];
+    p.descs[k] = d;
+    int key = p.max_b_rows + 1 - d.nrows;           // larger chunks first
+    key = key < 0 ? 0 : key;
+    atomicAdd(&p.hist[key], 1);
+}
+
+// single workgroup: size -> offset for the four per-chunk arrays; histogram -> start positions
+__global__ __launch_bounds__(1024) void chunk_scan_kernel(PrepParams p)
+{
+    __shared__ int64_t s[4][1024];
+    const int t = threadIdx.x;
+    const int n = p.counters[0];
+    const int per = (n + 1023) / 1024;
+    const int a = t * per, b = (a + per < n) ? a + per : n;
+    int64_t l[4] = {0, 0, 0, 0};
+    for (int k = a; k < b; k++) {
+        const ChunkDesc &d = p.descs[k];
+        l[0] += d.seqw_off; l[1] += d.refw_off; l[2] += d.tb_off; l[3] += d.out_off;
+    }
+    for (int q = 0; q < 4; q++) s[q][t] = l[q];
+    __syncthreads();
+    if (t < 4) {
+        int64_t acc = 0;
+        for (int k = 0; k < 1024; k++) { const int64_t v = s[t][k]; s[t][k] = acc; acc += v; }
+    }
+    __syncthreads();
+    int64_t acc[4] = {s[0][t], s[1][t], s[2][t], s[3][t]};
+    for (int k = a; k < b; k++) {
+        ChunkDesc &d = p.descs[k];
+        const int64_t v0 = d.seqw_off, v1 = d.refw_off, v2 = d.tb_off, v3 = d.out_off;
+        d.seqw_off = acc[0]; d.refw_off = acc[1]; d.tb_off = acc[2]; d.out_off = acc[3];
+        acc[0] += v0; acc[1] += v1; acc[2] += v2; acc[3] += v3;
+    }
+    // histogram (max_b_rows + 2 bins) -> exclusive start positions
+    __shared__ int32_t hs[1024];
+    const int nb = p.max_b_rows + 2;
+    const int hper = (nb + 1023) / 1024;
+    const int ha = t * hper, hb = (ha + hper < nb) ? ha + hper : nb;
+    int32_t hl = 0;
+    for (int k = ha; k < hb; k++) hl += p.hist[k];
+    hs[t] = hl;
+    __syncthreads();
+    if (t == 0) {
+        int32_t acc2 = 0;
+        for (int k = 0; k < 1024; k++) { const int32_t v = hs[k]; hs[k] = acc2; acc2 += v; }
+    }
+    __syncthreads();
+    int32_t hacc = hs[t];
+    for (int k = ha; k < hb; k++) { const int32_t v = p.hist[k]; p.hist[k] = hacc; hacc += v; }
+}
+
+__global__ __launch_bounds__(256) void sched_scatter_kernel(PrepParams p)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= p.counters[0]) return;
+    int key = p.max_b_rows + 1 - p.descs[k].nrows;
+    key = key < 0 ? 0 : key;
+    p.sched[atomicAdd(&p.hist[key], 1)] = k;
+}
+
+// ---------------------------------------------------------------------------
+// n-polymer annotation of one sequence by one workgroup, one position per thread
+// at a time.  Restatement of get_np_info (src/aln.pyx:179-251) in which every
+// (position, period) result is a function of run lengths of the periodicity
+// indicator e_n[p] = (seq[p] == seq[p+n]) and of the final results of shorter
+// periods (see prep.hpp / DESIGN.md for the derivation; the CPU tests check this
+// formulation against the oracle's literal loop).
+// ent[p]: bytes 0..5 = L for n = 1..6, byte 6 = mask of periods with L_IDX == 0.
+// Optional int32 outputs Lout/Iout [len][max_n] for the get_np_info() API.
+__device__ void annotate_sequence(const uint8_t *seq, int len, int max_n, int max_l, uint8_t *ent,
+                                  int32_t *Lout, int32_t *Iout)
+{
+    for (int p = threadIdx.x; p < len; p += blockDim.x) {
+        reinterpret_cast<uint2 *>(ent)[p] = make_uint2(0u, 0u);
+    }
+    __syncthreads();
+    for (int n = 1; n <= max_n; n++) {
+        for (int pos = threadIdx.x; pos < len; pos += blockDim.x) {
+            int kf = 0;   // run of e_n starting at pos
+            while (pos + kf + n < len && seq[pos + kf] == seq[pos + kf + n]) kf++;
+            int kb = 0;   // run of e_n ending at pos-1
+            while (pos - 1 - kb >= 0 && pos - 1 - kb + n < len && seq[pos - 1 - kb] == seq[pos - 1 - kb + n]) kb++;
+            const int q = kf / n, J = kb / n;
+            int stored = 0, idx = 0;
+            for (int j = J; j >= 0; j--) {
+                const int l = (j == 0) ? (q >= 1 ? q + 1 : 0) : j + q + 1;
+                if (stored && l <= max_l) break;
+                if (l < 3) continue;
+                const int s = pos - j * n;
+                if (!seq[s]) continue;
+                bool longest = true;
+                for (int n2 = 1; n2 < n; n2++)
+                    if ((long long)l * n <= (long long)ent[(size_t)s * 8 + (n2 - 1)] * n2) longest = false;
+                if (!longest) continue;
+                if (l > stored) { stored = max_l < l ? max_l : l; idx = j; }
+            }
+            if (stored) {
+                ent[(size_t)pos * 8 + (n - 1)] = (uint8_t)stored;
+                if (idx == 0) ent[(size_t)pos * 8 + 6] |= (uint8_t)(1u << (n - 1));
+            }
+            if (Lout) { Lout[(size_t)pos * max_n + (n - 1)] = stored; Iout[(size_t)pos * max_n + (n - 1)] = idx; }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void annotate_kernel(PrepParams p)
+{
+    const int k = blockIdx.x >> 1;
+    const bool is_ref = blockIdx.x & 1;
+    if (k >= p.counters[0]) return;
+    const ChunkDesc d = p.descs[k];
+    const int64_t rd = d.read_id;
+    if (!is_ref) {
+        const int64_t S = p.seq_off[rd + 1] - p.seq_off[rd];
+        const int slen = (int)(((int64_t)d.row0 + d.drows + 1 < S ? (int64_t)d.row0 + d.drows + 1 : S) - d.row0);
+        const uint8_t *seq = p.seqs + p.seq_off[rd] + d.row0;
+        uint8_t *ent = reinterpret_cast<uint8_t *>(p.seql + d.seqw_off);
+        annotate_sequence(seq, slen, p.max_n, p.max_l, ent, nullptr, nullptr);
+        uint32_t *seqw = p.seqw + d.seqw_off;
+        for (int i = threadIdx.x; i <= d.drows; i += blockDim.x) {
+            uint32_t w = 0;
+            for (int q = 0; q < 6; q++) {
+                const int pp = i - 6 + q;
+                w |= ((pp < 0) ? 7u : (uint32_t)seq[pp]) << (3 * q);
+            }
+            for (int n = 1; n <= p.max_n; n++) {
+                const int pp = i - n;
+                if (pp >= 0 && pp < slen && ent[(size_t)pp * 8 + (n - 1)] != 0) {
+                    w |= 1u << (18 + n - 1);
+                    if ((ent[(size_t)pp * 8 + 6] >> (n - 1)) & 1u) w |= 1u << (24 + n - 1);
+                }
+            }
+            seqw[i] = w;
+        }
+    } else {
+        const int64_t R = p.ref_off[rd + 1] - p.ref_off[rd];
+        const int rlen = (int)(((int64_t)d.col0 + d.dcols + 1 < R ? (int64_t)d.col0 + d.dcols + 1 : R) - d.col0);
+        const uint8_t *ref = p.refs + p.ref_off[rd] + d.col0;
+        uint8_t *ent = reinterpret_cast<uint8_t *>(p.refl + d.refw_off);
+        annotate_sequence(ref, rlen, p.max_n, p.max_l, ent, nullptr, nullptr);
+        if (rlen <= d.dcols && threadIdx.x == 0)     // terminator entry of the last chunk: no n-polymer info
+            reinterpret_cast<uint2 *>(ent)[d.dcols] = make_uint2(0u, 0u);
+        __syncthreads();
+        uint2 *refw = p.refw + d.refw_off;
+        for (int j = threadIdx.x; j <= d.dcols; j += blockDim.x) {
+            uint32_t x = 0, y = 0;
+            for (int q = 0; q < 6; q++) {
+                const int pp = j + q;
+                x |= ((pp >= rlen) ? 6u : (uint32_t)ref[pp]) << (3 * q);
+            }
+            for (int n = 1; n <= p.max_n; n++) {
+                if (j < rlen && ent[(size_t)j * 8 + (n - 1)] != 0 && ((ent[(size_t)j * 8 + 6] >> (n - 1)) & 1u))
+                    x |= 1u << (18 + n - 1);
+                const int pp = j - n;
+                if (pp >= 0 && pp < rlen && ent[(size_t)pp * 8 + (n - 1)] != 0) {
+                    y |= 1u << (n - 1);
+                    if ((ent[(size_t)pp * 8 + 6] >> (n - 1)) & 1u) y |= 1u << (6 + n - 1);
+                }
+            }
+            if (j >= 1) x |= (uint32_t)ref[j - 1] << 24;
+            refw[j] = make_uint2(x, y);
+        }
+    }
+}
+
+// get_np_info() API: one sequence, int32 outputs
+__global__ __launch_bounds__(256) void np_info_kernel(const uint8_t *seq, int len, int max_n, int max_l,
+                                                      uint8_t *ent, int32_t *Lout, int32_t *Iout)
+{
+    annotate_sequence(seq, len, max_n, max_l, ent, Lout, Iout);
+}
+
+}  // namespace npore

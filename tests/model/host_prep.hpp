@@ -1,14 +1,15 @@
-// prep.hpp -- host-side preparation of a batch: CIGAR conversion, insertion
-// prefix counts, chunk boundaries, n-polymer annotation and word packing.
-// Plain C++17, no HIP types.  (Round-1 host implementation; the same arrays are
-// what the device prep kernels produce.)
+// host_prep.hpp -- TEST INFRASTRUCTURE: host twin of npore_amd/csrc/prep_kernels.hpp
+// (CIGAR conversion, insertion prefix counts, chunk boundaries, n-polymer
+// annotation, word packing).  The CPU cell model consumes these arrays, and the
+// GPU tests compare the device-prepared arrays with them word for word.  The
+// product library does not include this file.
 #pragma once
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <vector>
 
-#include "layout.hpp"
+#include "../../npore_amd/csrc/layout.hpp"
 
 namespace npore {
 

@@ -13,7 +13,7 @@ _LIB = None
 def build(force=False):
     so = os.path.join(_HERE, "libpull_model.so")
     deps = [os.path.join(_HERE, "pull_model.cpp")] + [
-        os.path.join(_HERE, "..", "..", "npore_amd", "csrc", f) for f in ("cell.hpp", "prep.hpp", "layout.hpp")]
+        os.path.join(_HERE, "..", "..", "npore_amd", "csrc", f) for f in ("cell.hpp", "layout.hpp")] + [os.path.join(_HERE, "host_prep.hpp")]
     if force or not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared",
                                "-o", so, deps[0]])
@@ -52,6 +52,33 @@ def align(ref, seq, cigar, sub, nps, indel_start=5, indel_extend=1, max_b_rows=2
     if n < 0:
         raise ValueError(f"model align failed status={st.value}")
     return out.raw[:n].decode(), st.value
+
+
+def prep(ref, seq, cigar, max_b_rows=20000, max_n=6, max_l=100):
+    """Host-prepared arrays of one read (dict of numpy arrays)."""
+    lib = load()
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    cig = cigar.encode() if isinstance(cigar, str) else bytes(cigar)
+    cap = 2 * len(cig) + 8
+    nchmax = cap // max(1, max_b_rows - 1) + 4
+    steps = np.zeros(cap, np.uint8); inss = np.zeros(cap + 1, np.int32)
+    geom = np.zeros(7 * nchmax, np.int32)
+    seqw = np.zeros(len(seq) + nchmax + 8, np.uint32)
+    refw = np.zeros(2 * (len(ref) + nchmax + 8), np.uint32)
+    refl = np.zeros(8 * (len(ref) + nchmax + 8), np.uint8)
+    ns, ni, nsw, nrw = (C.c_int64() for _ in range(4))
+    lib.pull_model_prep.restype = C.c_int64
+    lib.pull_model_prep.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_char_p, C.c_int64, C.c_int, C.c_int,
+                                    C.c_int] + [C.c_void_p] * 10
+    nch = lib.pull_model_prep(ref.ctypes.data, len(ref), seq.ctypes.data, len(seq), cig, len(cig), max_n, max_l,
+                              max_b_rows, steps.ctypes.data, C.addressof(ns), inss.ctypes.data, C.addressof(ni),
+                              geom.ctypes.data, seqw.ctypes.data, C.addressof(nsw), refw.ctypes.data,
+                              refl.ctypes.data, C.addressof(nrw))
+    if nch < 0:
+        raise ValueError("bad input")
+    return dict(n_chunks=int(nch), steps=steps[:ns.value], inss=inss[:ni.value], geom=geom[:7 * nch].reshape(-1, 7),
+                seqw=seqw[:nsw.value], refw=refw[:2 * nrw.value].reshape(-1, 2), refl=refl[:8 * nrw.value].reshape(-1, 8))
 
 
 def get_np_info(seq, max_n=6, max_l=100):

@@ -1,6 +1,6 @@
 // tests/model/pull_model.cpp -- TEST INFRASTRUCTURE.
 // Host-side, cell-by-cell execution of the *product's* recurrence (cell.hpp) on
-// the *product's* packed inputs (prep.hpp), sweeping anti-diagonals exactly as
+// the *product's* packed inputs (tests/model/host_prep.hpp, the host twin of prep_kernels.hpp), sweeping anti-diagonals exactly as
 // the gfx950 kernel does (same neighbour selection, same 8-row history ring,
 // same traceback words), but one cell at a time.  The CPU tests compare its
 // output with the oracle: this proves the pull reformulation, the carried
@@ -12,7 +12,7 @@
 #include <vector>
 
 #include "../../npore_amd/csrc/cell.hpp"
-#include "../../npore_amd/csrc/prep.hpp"
+#include "host_prep.hpp"
 
 using namespace npore;
 
@@ -164,6 +164,42 @@ extern "C" int64_t pull_model_align(const uint8_t *full_ref, int64_t ref_len, co
         out_len += (int64_t)aln.size();
     }
     return out_len;
+}
+
+// Host-prepared arrays of one read, chunk after chunk, for word-by-word comparison with
+// the device prep kernels.  Returns the number of chunks (or -1); *_n receive element counts.
+extern "C" int64_t pull_model_prep(const uint8_t *full_ref, int64_t ref_len, const uint8_t *full_seq, int64_t seq_len,
+                                   const char *cigar, int64_t cig_len, int max_n, int max_l, int max_b_rows,
+                                   uint8_t *steps, int64_t *steps_n, int32_t *inss, int64_t *inss_n,
+                                   int32_t *chunk_geom /* 7 per chunk: brk nrows row0 col0 drows dcols out_cap */,
+                                   uint32_t *seqw, int64_t *seqw_n, uint32_t *refw, uint8_t *refl, int64_t *refw_n)
+{
+    ReadPath path;
+    if (!build_path(cigar, cig_len, seq_len, ref_len, max_b_rows, path)) return -1;
+    std::memcpy(steps, path.steps.data(), path.steps.size());
+    *steps_n = (int64_t)path.steps.size();
+    std::memcpy(inss, path.inss.data(), path.inss.size() * 4);
+    *inss_n = (int64_t)path.inss.size();
+    int64_t so = 0, ro = 0;
+    std::vector<int32_t> scratch;
+    int64_t nch = path.steps.empty() ? 0 : (int64_t)path.breaks.size() - 1;
+    for (int64_t k = 0; k < nch; k++) {
+        const int64_t brk = path.breaks[k], nxt = path.breaks[k + 1];
+        const int row0 = path.inss[brk], col0 = (int)(brk - path.inss[brk]);
+        const int drows = path.inss[nxt] - row0, dcols = (int)(nxt - path.inss[nxt]) - col0;
+        const int slen = (int)(std::min<int64_t>((int64_t)row0 + drows + 1, seq_len) - row0);
+        const int rlen = (int)(std::min<int64_t>((int64_t)col0 + dcols + 1, ref_len) - col0);
+        int32_t *g = chunk_geom + 7 * k;
+        g[0] = (int32_t)brk; g[1] = (int32_t)(nxt - brk + 1); g[2] = row0; g[3] = col0; g[4] = drows; g[5] = dcols;
+        g[6] = drows + dcols;
+        pack_chunk_words(full_seq + row0, slen, drows, full_ref + col0, rlen, dcols, max_n, max_l, seqw + so,
+                         refw + 2 * ro, refl + 8 * ro, scratch);
+        so += drows + 1;
+        ro += dcols + 1;
+    }
+    *seqw_n = so;
+    *refw_n = ro;
+    return nch;
 }
 
 extern "C" void pull_model_np_info(const uint8_t *seq, int64_t len, int max_n, int max_l, int32_t *out)

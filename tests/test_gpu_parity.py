@@ -128,6 +128,55 @@ def test_kernel_shapes(tables, r, ng, chunks):
     c.close()
 
 
+def test_device_prep_matches_host_twin(ctx):
+    """Path conversion, breaks, n-polymer annotation and word packing done by the prep
+    kernels, word for word against tests/model/host_prep.hpp (itself checked vs the oracle)."""
+    from model import model
+    lib = _lib.load()
+    rng = np.random.default_rng(4)
+    desc_dt = np.dtype([("read_id", "i4"), ("brk", "i4"), ("nrows", "i4"), ("row0", "i4"), ("col0", "i4"),
+                        ("drows", "i4"), ("dcols", "i4"), ("out_cap", "i4"), ("steps_off", "i8"), ("inss_off", "i8"),
+                        ("seqw_off", "i8"), ("refw_off", "i8"), ("tb_off", "i8"), ("out_off", "i8"), ("seq_off", "i8"),
+                        ("ref_off", "i8")])
+    assert desc_dt.itemsize == 96
+
+    def fetch(what, dtype, count):
+        a = np.zeros(count, dtype)
+        assert lib.npore_debug_fetch(ctx.handle, what, a.ctypes.data, a.nbytes) == 0, _lib.last_error()
+        return a
+
+    for k in range(12):
+        ref, seq, cig = synth.make_pair(900, k, int(rng.integers(50, 3000)), float(rng.choice([0.0, 0.1, 0.4])), 0.5)
+        if k % 3 == 0:
+            ref = ref.copy(); ref[rng.integers(0, len(ref), size=3)] = 0
+        mbr = int(rng.choice([40, 333, 20000]))
+        ctx.align_batch([ref], [seq], [cig], r=10, max_b_rows=mbr)
+        want = model.prep(ref, seq, cig, max_b_rows=mbr)
+        nch = int(fetch(7, np.int32, 2)[0])
+        assert nch == want["n_chunks"]
+        assert np.array_equal(fetch(0, np.uint8, len(want["steps"])), want["steps"])
+        assert np.array_equal(fetch(1, np.int32, len(want["inss"])), want["inss"])
+        d = fetch(2, desc_dt, nch)
+        geom = np.stack([d[f] for f in ("brk", "nrows", "row0", "col0", "drows", "dcols", "out_cap")], axis=1)
+        assert np.array_equal(geom, want["geom"])
+        assert np.array_equal(fetch(3, np.uint32, len(want["seqw"])), want["seqw"])
+        assert np.array_equal(fetch(4, np.uint32, want["refw"].size).reshape(-1, 2), want["refw"])
+        got_l = fetch(5, np.uint8, want["refl"].size).reshape(-1, 8)
+        assert np.array_equal(got_l[:, :6], want["refl"][:, :6])
+        sched = fetch(6, np.int32, nch)
+        assert sorted(sched.tolist()) == list(range(nch))
+        assert all(d["nrows"][sched[i]] >= d["nrows"][sched[i + 1]] for i in range(nch - 1))
+
+
+def test_get_np_info_device(ctx):
+    seqs = [enc(s) for s in load_json("np_info_seqs.json") if len(s)]
+    rng = np.random.default_rng(8)
+    for k in range(20):
+        seqs.append(rng.choice(rng.integers(0, 5, size=int(rng.integers(1, 4))), size=int(rng.integers(1, 3000))).astype(np.uint8))
+    for s in seqs:
+        assert np.array_equal(ctx.get_np_info(s), oracle.get_np_info(s))
+
+
 def test_div_small_domain():
     """The device's float-reciprocal division is exact on its whole domain."""
     lib = _lib.load()
