@@ -371,8 +371,12 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
             }
         }
         // one traceback word per cell, NG consecutive words per lane (tbstride is a multiple of 4)
+        // (the row's spare last word carries inss[b] for the traceback)
         uint32_t *trow = tb_g + (size_t)bl * p.tbstride;
         const int tcol = col0w + lane * NG;
+#pragma unroll
+        for (int g = 0; g < NG; g++)
+            if (tcol + g == p.tbstride - 1) tbw[g] = (uint32_t)(d.row0 + ins_l);
         if constexpr (NG == 1) {
             if (tcol < p.tbstride) trow[tcol] = tbw[0];
         } else if constexpr (NG == 2) {
@@ -395,7 +399,6 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
 struct TParams {
     const ChunkDesc *descs;
     const int32_t *n_chunks;
-    const int32_t *inss;
     const uint32_t *tb;
     const uint8_t *seqs, *refs;
     uint8_t *chunk_out;        // per-chunk slots, ops right-aligned
@@ -405,46 +408,82 @@ struct TParams {
     int tbstride;
 };
 
+// One wavefront per chunk.  Every hop of the traceback needs the cell's word and the
+// band position of its anti-diagonal (inss[b]); the fill kernel stores the latter in
+// the row's spare last word, so ONE coalesced load of the whole row (16 bytes per
+// lane) serves the hop, and the next row is requested before the ops of the current
+// run are emitted (lane-parallel), so emission overlaps the load latency.
+template <int NL>   // uint4 loads per lane covering a row: tbstride <= 256 * NL
 __global__ __launch_bounds__(64) void traceback_kernel(TParams p)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.x;
     if (k >= *p.n_chunks) return;
+    const int lane = threadIdx.x;
     const ChunkDesc d = p.descs[k];
-    const int32_t *inss = p.inss + d.inss_off;
     const uint32_t *tb = p.tb + d.tb_off;
     const uint8_t *seq = p.seqs + d.seq_off, *ref = p.refs + d.ref_off;
     uint8_t *out = p.chunk_out + d.out_off;
-    const int W = 2 * p.r + 1;
+    const int W = 2 * p.r + 1, stride = p.tbstride;
     int a_row = d.row0 + d.drows, a_col = d.col0 + d.dcols;
-    int pos = d.out_cap;   // write backwards
+    int pos = d.out_cap;   // ops are written backwards
     int status = 0;
+
+    uint4 row[NL];
+    auto load_row = [&](int bl) {
+#pragma unroll
+        for (int q = 0; q < NL; q++) {
+            const int idx = (q * 64 + lane) * 4;
+            row[q] = (idx < stride) ? *reinterpret_cast<const uint4 *>(tb + (size_t)bl * stride + idx)
+                                    : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto word = [&](int col) -> uint32_t {   // col is wave-uniform
+        uint4 v = row[0];
+        if constexpr (NL > 1) { if ((col >> 8) & 1) v = row[NL - 1]; }
+        const int comp = col & 3;
+        const uint32_t sel = comp == 0 ? v.x : comp == 1 ? v.y : comp == 2 ? v.z : v.w;
+        return (uint32_t)__builtin_amdgcn_readlane((int)sel, (col & 255) >> 2);
+    };
+    auto in_chunk = [&](int ar, int ac) {
+        const int bl = ar + ac - d.brk;
+        return ar >= d.row0 && ac >= d.col0 && bl >= 0 && bl < d.nrows;
+    };
+
+    if ((a_row > d.row0 || a_col > d.col0) && in_chunk(a_row, a_col)) load_row(a_row + a_col - d.brk);
     while (a_row > d.row0 || a_col > d.col0) {
-        const int bl = a_row + a_col - d.brk;
-        if (a_row < d.row0 || a_col < d.col0 || bl < 0 || bl >= d.nrows) { status |= 16; break; }
-        const int bc = inss[a_row + a_col] - a_row + p.r;
+        if (!in_chunk(a_row, a_col)) { status |= 16; break; }
+        const int bc = (int)word(stride - 1) - a_row + p.r;     // inss[b] - a_row + r, src/aln.pyx:322-326
         if (bc < 0 || bc >= W) { status |= 16; break; }
-        const uint32_t w = tb[(size_t)bl * p.tbstride + bc];
-        const int typ = (int)(w & 7u), run = (int)(w >> 3);
+        const uint32_t w = word(bc);
+        const int typ = (int)(w & 7u), run = (int)(w >> 3);     // src/aln.pyx:684-685
         if (run < 1) { status |= 4; break; }
         if (run > pos) { status |= 16; break; }
-        if (typ == T_LEN || typ == T_INS) {
-            for (int q = 0; q < run; q++) out[--pos] = 'I';
-            a_row -= run;
-        } else if (typ == T_SHR || typ == T_DEL) {
-            for (int q = 0; q < run; q++) out[--pos] = 'D';
-            a_col -= run;
-        } else if (typ == T_MAT) {
-            bool bad = false;
-            for (int q = 0; q < run; q++) {
-                a_row--; a_col--;
-                if (a_row < d.row0 || a_col < d.col0) { bad = true; break; }
-                out[--pos] = (ref[a_col] == seq[a_row]) ? '=' : 'X';
-            }
-            if (bad) { status |= 16; break; }
+        int n_row = a_row, n_col = a_col, emit = run;
+        uint8_t ch = 0;
+        if (typ == T_LEN || typ == T_INS) { ch = 'I'; n_row -= run; }
+        else if (typ == T_SHR || typ == T_DEL) { ch = 'D'; n_col -= run; }
+        else if (typ == T_MAT) {
+            const int lim = min(a_row - d.row0, a_col - d.col0);
+            emit = run < lim ? run : lim;                          // diagonal steps that stay in the chunk
+            n_row -= emit; n_col -= emit;
         } else { status |= 8; break; }
+        // request the next row now; the emission below overlaps its latency
+        if ((n_row > d.row0 || n_col > d.col0) && in_chunk(n_row, n_col)) load_row(n_row + n_col - d.brk);
+        if (ch) {
+            for (int q = lane; q < emit; q += 64) out[pos - 1 - q] = ch;
+        } else {
+            for (int q = lane; q < emit; q += 64)
+                out[pos - 1 - q] = (ref[a_col - 1 - q] == seq[a_row - 1 - q]) ? '=' : 'X';   // src/aln.pyx:732-735
+        }
+        pos -= emit;
+        if (emit < run) { status |= 16; break; }
+        a_row = n_row;
+        a_col = n_col;
     }
-    p.chunk_len[k] = d.out_cap - pos;
-    p.chunk_status[k] = status;
+    if (lane == 0) {
+        p.chunk_len[k] = d.out_cap - pos;
+        p.chunk_status[k] = status;
+    }
 }
 
 // ---------------------------------------------------------------------------

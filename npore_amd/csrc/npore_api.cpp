@@ -292,7 +292,6 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     TParams tp;
     tp.descs = pp.descs;
     tp.n_chunks = pp.counters;
-    tp.inss = pp.inss;
     tp.tb = kp.tb;
     tp.seqs = a.d_seqs;
     tp.refs = a.d_refs;
@@ -301,7 +300,8 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     tp.chunk_status = ctx->cstat.as<int32_t>();
     tp.r = r;
     tp.tbstride = tbs;
-    hipLaunchKernelGGL(traceback_kernel, dim3((unsigned)((max_chunks + 63) / 64)), dim3(64), 0, s, tp);
+    if (tbs <= 256) hipLaunchKernelGGL(traceback_kernel<1>, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
+    else hipLaunchKernelGGL(traceback_kernel<2>, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
     HIP_TRY(hipGetLastError());
 
     GParams gp;
