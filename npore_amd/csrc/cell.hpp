@@ -103,7 +103,7 @@ NPORE_HD int top_bit(uint32_t m)   // 1-based index of the highest set bit, 0 if
 NPORE_HD int div_small(int run, int n)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return (int)((float)run * __frcp_rn((float)n) + 0.03f);
+    return (int)((float)run * __builtin_amdgcn_rcpf((float)n) + 0.03f);   // v_rcp_f32: 1 ulp
 #else
     return run / n;
 #endif
@@ -153,25 +153,27 @@ NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in
         const int j = st.del_l - st.r + c;   // local a_col
         ii[g] = i;
         jj[g] = j;
-        // ---- INS, src/aln.pyx:525-543
-        if (i == 0) {
-            insv[g] = (float)(100 * (j + 1));
-            insrun[g] = j;
-        } else {
+        // ---- INS, src/aln.pyx:525-543 (branch-free: selects only)
+        {
             const float v1 = in[g].topM + st.indel_start;
             const float v2 = in[g].topI + st.indel_extend;
-            if (v2 < v1) { insv[g] = v2; insrun[g] = (i == 1) ? 1 : in[g].topIrun + 1; }
-            else { insv[g] = v1; insrun[g] = 1; }
+            const bool ext = v2 < v1;
+            const int erun = (i == 1) ? 1 : in[g].topIrun + 1;
+            const float v = ext ? v2 : v1;
+            const int rr = ext ? erun : 1;
+            insv[g] = (i == 0) ? (float)(100 * (j + 1)) : v;
+            insrun[g] = (i == 0) ? j : rr;
         }
         // ---- DEL, src/aln.pyx:547-565
-        if (j == 0) {
-            delv[g] = (float)(100 * (i + 1));
-            delrun[g] = i;
-        } else {
+        {
             const float v1 = in[g].leftM + st.indel_start;
             const float v2 = in[g].leftD + st.indel_extend;
-            if (v2 < v1) { delv[g] = v2; delrun[g] = (j == 1) ? 1 : in[g].leftDrun + 1; }
-            else { delv[g] = v1; delrun[g] = 1; }
+            const bool ext = v2 < v1;
+            const int erun = (j == 1) ? 1 : in[g].leftDrun + 1;
+            const float v = ext ? v2 : v1;
+            const int rr = ext ? erun : 1;
+            delv[g] = (j == 0) ? (float)(100 * (i + 1)) : v;
+            delrun[g] = (j == 0) ? i : rr;
         }
         lenv[g] = shrv[g] = init;
         lenstart[g] = shrstart[g] = 0.0f;
@@ -232,7 +234,10 @@ NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in
 #endif
             for (int g = 0; g < NG; g++) {
                 const float cand = cstart[g] + (inval[g] ? 100.0f : score[g]);
-                if (ok[g] && cand < shrv[g]) { shrv[g] = cand; shrrun[g] = crun[g]; shrstart[g] = cstart[g]; }
+                const bool take = ok[g] && cand < shrv[g];
+                shrv[g] = take ? cand : shrv[g];
+                shrrun[g] = take ? crun[g] : shrrun[g];
+                shrstart[g] = take ? cstart[g] : shrstart[g];
             }
         }
 
@@ -284,7 +289,10 @@ NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in
 #endif
             for (int g = 0; g < NG; g++) {
                 const float cand = cstart[g] + (inval[g] ? 100.0f : score[g]);
-                if (ok[g] && cand < lenv[g]) { lenv[g] = cand; lenrun[g] = crun[g]; lenstart[g] = cstart[g]; }
+                const bool take = ok[g] && cand < lenv[g];
+                lenv[g] = take ? cand : lenv[g];
+                lenrun[g] = take ? crun[g] : lenrun[g];
+                lenstart[g] = take ? cstart[g] : lenstart[g];
             }
         }
     }
@@ -294,43 +302,42 @@ NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in
 #endif
     for (int g = 0; g < NG; g++) {
         const int c = in[g].c, i = ii[g], j = jj[g];
-        // ---- MAT, src/aln.pyx:569-592
-        float v;
-        int typ = T_MAT, run;
-        if (i > 0 && j > 0) {
-            run = in[g].diagMrun + 1;
-            v = in[g].diagM + env.sub((in[g].seqw >> 15) & 7u, (in[g].refx >> 24) & 7u);
-        } else {
-            v = delv[g] + 100.0f;   // "ensure val1 isn't chosen"
-            run = 0;
+        // ---- MAT, src/aln.pyx:569-592 (selects; candidate order INS, LEN, DEL, SHR, strict '<')
+        const bool diag_ok = (i > 0) && (j > 0);
+        const float vdiag = in[g].diagM + env.sub((in[g].seqw >> 15) & 7u, (in[g].refx >> 24) & 7u);
+        float v = diag_ok ? vdiag : delv[g] + 100.0f;     // else-branch: "ensure val1 isn't chosen"
+        uint32_t tr = diag_ok ? ((uint32_t)T_MAT | ((uint32_t)(in[g].diagMrun + 1) << 3)) : (uint32_t)T_MAT;  // typ | run<<3
+        {
+            const bool t1 = insv[g] < v;
+            v = t1 ? insv[g] : v;
+            tr = t1 ? ((uint32_t)T_INS | ((uint32_t)insrun[g] << 3)) : tr;
+            const bool t2 = lenv[g] < v;
+            v = t2 ? lenv[g] : v;
+            tr = t2 ? ((uint32_t)T_LEN | ((uint32_t)lenrun[g] << 3)) : tr;
+            const bool t3 = delv[g] < v;
+            v = t3 ? delv[g] : v;
+            tr = t3 ? ((uint32_t)T_DEL | ((uint32_t)delrun[g] << 3)) : tr;
+            const bool t4 = shrv[g] < v;
+            v = t4 ? shrv[g] : v;
+            tr = t4 ? ((uint32_t)T_SHR | ((uint32_t)shrrun[g] << 3)) : tr;
         }
-        if (insv[g] < v) { v = insv[g]; typ = T_INS; run = insrun[g]; }
-        if (lenv[g] < v) { v = lenv[g]; typ = T_LEN; run = lenrun[g]; }
-        if (delv[g] < v) { v = delv[g]; typ = T_DEL; run = delrun[g]; }
-        if (shrv[g] < v) { v = shrv[g]; typ = T_SHR; run = shrrun[g]; }
-
+        // band edge, src/aln.pyx:502-507: all five states = 100*(b_row+1), TYP = MAT, RUN = 0
+        const bool edge = (c == 0) || (c == r2);
+        const bool inrect = (i >= 0) && (j >= 0) && (i <= st.drows) && (j <= st.dcols);
+        const float e = (float)(100 * (st.b_local + 1));
         CellOut &q = o[g];
-        q.matv = v;
-        q.insv = insv[g];
-        q.delv = delv[g];
-        q.matrun = (typ == T_MAT) ? run : 0;
-        q.insrun = insrun[g];
-        q.delrun = delrun[g];
+        q.matv = edge ? e : v;
+        q.insv = edge ? e : insv[g];
+        q.delv = edge ? e : delv[g];
+        q.matrun = (edge || (tr & 7u) != (uint32_t)T_MAT) ? 0 : (int)(tr >> 3);
+        q.insrun = edge ? 0 : insrun[g];
+        q.delrun = edge ? 0 : delrun[g];
         q.lenstart = lenstart[g];
         q.shrstart = shrstart[g];
-        q.lenrun_h = (i == 0) ? 0 : lenrun[g];   // src/aln.pyx:596-599 leaves RUN = j, never usable
-        q.shrrun_h = (j == 0) ? 0 : shrrun[g];   // src/aln.pyx:637-640 likewise
-        q.tb = (uint32_t)typ | ((uint32_t)run << 3);
-        // ---- band edge, src/aln.pyx:502-507 (all five states, TYP = MAT, RUN = 0)
-        if (c == 0 || c == r2) {
-            const float e = (float)(100 * (st.b_local + 1));
-            q.matv = e; q.insv = e; q.delv = e;
-            q.matrun = 0; q.insrun = 0; q.delrun = 0;
-            q.lenrun_h = 0; q.shrrun_h = 0;
-            q.tb = 0;
-        }
+        q.lenrun_h = (edge || i == 0) ? 0 : lenrun[g];   // src/aln.pyx:596-599 leaves RUN = j, never usable
+        q.shrrun_h = (edge || j == 0) ? 0 : shrrun[g];   // src/aln.pyx:637-640 likewise
         // cells outside the chunk rectangle are never read by cells inside it
-        if (!((i >= 0) && (j >= 0) && (i <= st.drows) && (j <= st.dcols))) q.tb = 0;
+        q.tb = (edge || !inrect) ? 0u : tr;
     }
 }
 

@@ -107,18 +107,23 @@ struct DevEnv {
     __device__ __forceinline__ void np_many(const int (&n_idx)[K], const int (&a)[K], const int (&b)[K],
                                             const bool (&active)[K], float (&out)[K]) const
     {
-        bool oot = false;
+        // Always an LDS read (ds_read); lengths beyond the LDS copy are rare and patched
+        // from global memory under a wave-uniform branch.  (Selecting between an LDS and a
+        // global *pointer* would turn every lookup into a flat load, whose completion
+        // wait also drains the outstanding traceback stores.)
+        bool oot[K], anyoot = false;
 #pragma unroll
-        for (int k = 0; k < K; k++) oot |= active[k] && ((a[k] >= NP_LT) || (b[k] >= NP_CT));
-        if (!any(oot)) {
+        for (int k = 0; k < K; k++) {
+            oot[k] = active[k] && ((a[k] >= NP_LT) || (b[k] >= NP_CT));
+            anyoot |= oot[k];
+            const int aa = a[k] < NP_LT ? a[k] : NP_LT - 1, bb = b[k] < NP_CT ? b[k] : NP_CT - 1;
+            out[k] = lds_np[(n_idx[k] * NP_LT + aa) * NP_CT + bb];
+            asm volatile("" : "+v"(out[k]));   // keep this a ds_read: do not fold it with the global load below
+        }
+        if (any(anyoot)) {
 #pragma unroll
-            for (int k = 0; k < K; k++) {
-                const int aa = a[k] < NP_LT ? a[k] : NP_LT - 1, bb = b[k] < NP_CT ? b[k] : NP_CT - 1;
-                out[k] = lds_np[(n_idx[k] * NP_LT + aa) * NP_CT + bb];
-            }
-        } else {   // rare: an n-polymer longer than the LDS table covers
-#pragma unroll
-            for (int k = 0; k < K; k++) out[k] = g_np[((size_t)n_idx[k] * np_dim + a[k]) * np_dim + b[k]];
+            for (int k = 0; k < K; k++)
+                if (oot[k]) out[k] = g_np[((size_t)n_idx[k] * np_dim + a[k]) * np_dim + b[k]];
         }
     }
 };
