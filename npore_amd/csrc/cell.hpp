@@ -134,7 +134,18 @@ NPORE_HD bool np_score_index(int clampv, int ref_np_len, int indel_len, int &a, 
     return invalid;
 }
 
-template <int NG, class Env>
+// True when every band cell of this anti-diagonal is an ordinary one: inside the chunk
+// rectangle, not on its first two rows / columns, and with all of its <= 6-back
+// LEN/SHR source cells inside the rectangle too.  That is the case for all but the
+// first and last ~2r anti-diagonals of a chunk, and lets the wave run the FAST
+// instantiation below, which drops the first-row / first-column / rectangle selects.
+NPORE_HD bool step_is_plain(const StepInfo &st)
+{
+    return (st.ins_l - st.r >= MAX_PERIOD) && (st.del_l - st.r >= MAX_PERIOD) &&
+           (st.ins_l + st.r <= st.drows) && (st.del_l + st.r <= st.dcols);
+}
+
+template <int NG, bool FAST, class Env>
 NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in)[NG], CellOut (&o)[NG])
 {
     const int r2 = 2 * st.r;
@@ -158,29 +169,30 @@ NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in
             const float v1 = in[g].topM + st.indel_start;
             const float v2 = in[g].topI + st.indel_extend;
             const bool ext = v2 < v1;
-            const int erun = (i == 1) ? 1 : in[g].topIrun + 1;
+            const int erun = (!FAST && i == 1) ? 1 : in[g].topIrun + 1;
             const float v = ext ? v2 : v1;
             const int rr = ext ? erun : 1;
-            insv[g] = (i == 0) ? (float)(100 * (j + 1)) : v;
-            insrun[g] = (i == 0) ? j : rr;
+            insv[g] = (!FAST && i == 0) ? (float)(100 * (j + 1)) : v;
+            insrun[g] = (!FAST && i == 0) ? j : rr;
         }
         // ---- DEL, src/aln.pyx:547-565
         {
             const float v1 = in[g].leftM + st.indel_start;
             const float v2 = in[g].leftD + st.indel_extend;
             const bool ext = v2 < v1;
-            const int erun = (j == 1) ? 1 : in[g].leftDrun + 1;
+            const int erun = (!FAST && j == 1) ? 1 : in[g].leftDrun + 1;
             const float v = ext ? v2 : v1;
             const int rr = ext ? erun : 1;
-            delv[g] = (j == 0) ? (float)(100 * (i + 1)) : v;
-            delrun[g] = (j == 0) ? i : rr;
+            delv[g] = (!FAST && j == 0) ? (float)(100 * (i + 1)) : v;
+            delrun[g] = (!FAST && j == 0) ? i : rr;
         }
         lenv[g] = shrv[g] = init;
         lenstart[g] = shrstart[g] = 0.0f;
         lenrun[g] = shrrun[g] = 0;
         // candidate periods: LEN needs "ref position j starts an n-polymer" and
         // "read position i-n inside one"; SHR needs "ref position j-n inside one"
-        const bool interior = (c >= 1) && (c <= r2 - 1) && (i >= 0) && (j >= 0) && (i <= st.drows) && (j <= st.dcols);
+        const bool interior = (c >= 1) && (c <= r2 - 1) &&
+                              (FAST || ((i >= 0) && (j >= 0) && (i <= st.drows) && (j <= st.dcols)));
         lm[g] = interior ? ((in[g].refx >> 18) & (in[g].seqw >> 18) & 63u) : 0u;
         sm[g] = interior ? (in[g].refy & 63u) : 0u;
         pend |= lm[g] | sm[g];
@@ -215,11 +227,11 @@ NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in
                 pendS |= sm[g];
                 const int dI = popc32(st.hist6 & ((1u << n) - 1u));
                 const int cx = c - dI;
-                const bool good = (nb != 0) && (jj[g] - n >= 0) && (cx >= 1);
-                const int cxs = good ? cx : (c < r2 ? c : r2);           // keep the (unused) read in range
+                const bool good = (nb != 0) && (FAST || jj[g] - n >= 0) && (cx >= 1);
+                // (lanes that are not `good` read some in-LDS garbage below and ignore it)
                 const bool start = ((in[g].refy >> (6 + n - 1)) & 1u) != 0u;
-                const int L = env.refl(good ? jj[g] - n : 0, n - 1);
-                const HistCell h = env.h_cell(n, cxs);
+                const int L = env.refl(jj[g] - n, n - 1);
+                const HistCell h = env.h_cell(n, cx);
                 cstart[g] = start ? h.matv : h.shrstart;                  // :649 / :662
                 const int run = start ? 0 : (int)(h.runs >> 16);
                 const int indel = start ? -1 : -div_small(run, n) - 1;   // :650 / :663
@@ -258,9 +270,9 @@ NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in
                 const int cx = c + (n - dI);
                 const uint32_t smer = (in[g].seqw & 0x3FFFFu) >> (3 * (MAX_PERIOD - n));
                 const uint32_t rmer = in[g].refx & ((1u << (3 * n)) - 1u);
-                good[g] = (nb != 0) && (ii[g] - n >= 0) && (cx <= r2 - 1) && (smer == rmer);   // match(), :606-607
+                good[g] = (nb != 0) && (FAST || ii[g] - n >= 0) && (cx <= r2 - 1) && (smer == rmer);   // match(), :606-607
                 nn[g] = n;
-                cxx[g] = good[g] ? cx : (c < r2 ? c : r2);
+                cxx[g] = cx;
                 anygood |= good[g];
             }
             if (!env.any(anygood)) continue;
@@ -273,7 +285,7 @@ NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in
             for (int g = 0; g < NG; g++) {
                 const int n = nn[g];
                 const bool start = ((in[g].seqw >> (24 + n - 1)) & 1u) != 0u;
-                const int L = env.refl(good[g] ? jj[g] : 0, n - 1);
+                const int L = env.refl(jj[g], n - 1);
                 const HistCell h = env.h_cell(n, cxx[g]);
                 cstart[g] = start ? h.matv : h.lenstart;                  // :614 / :628
                 const int run = start ? 0 : (int)(h.runs & 0xFFFFu);
@@ -303,7 +315,7 @@ NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in
     for (int g = 0; g < NG; g++) {
         const int c = in[g].c, i = ii[g], j = jj[g];
         // ---- MAT, src/aln.pyx:569-592 (selects; candidate order INS, LEN, DEL, SHR, strict '<')
-        const bool diag_ok = (i > 0) && (j > 0);
+        const bool diag_ok = FAST || ((i > 0) && (j > 0));
         const float vdiag = in[g].diagM + env.sub((in[g].seqw >> 15) & 7u, (in[g].refx >> 24) & 7u);
         float v = diag_ok ? vdiag : delv[g] + 100.0f;     // else-branch: "ensure val1 isn't chosen"
         uint32_t tr = diag_ok ? ((uint32_t)T_MAT | ((uint32_t)(in[g].diagMrun + 1) << 3)) : (uint32_t)T_MAT;  // typ | run<<3
@@ -323,7 +335,7 @@ NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in
         }
         // band edge, src/aln.pyx:502-507: all five states = 100*(b_row+1), TYP = MAT, RUN = 0
         const bool edge = (c == 0) || (c == r2);
-        const bool inrect = (i >= 0) && (j >= 0) && (i <= st.drows) && (j <= st.dcols);
+        const bool inrect = FAST || ((i >= 0) && (j >= 0) && (i <= st.drows) && (j <= st.dcols));
         const float e = (float)(100 * (st.b_local + 1));
         CellOut &q = o[g];
         q.matv = edge ? e : v;
@@ -334,8 +346,8 @@ NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in
         q.delrun = edge ? 0 : delrun[g];
         q.lenstart = lenstart[g];
         q.shrstart = shrstart[g];
-        q.lenrun_h = (edge || i == 0) ? 0 : lenrun[g];   // src/aln.pyx:596-599 leaves RUN = j, never usable
-        q.shrrun_h = (edge || j == 0) ? 0 : shrrun[g];   // src/aln.pyx:637-640 likewise
+        q.lenrun_h = (edge || (!FAST && i == 0)) ? 0 : lenrun[g];   // src/aln.pyx:596-599 leaves RUN = j, never usable
+        q.shrrun_h = (edge || (!FAST && j == 0)) ? 0 : shrrun[g];   // src/aln.pyx:637-640 likewise
         // cells outside the chunk rectangle are never read by cells inside it
         q.tb = (edge || !inrect) ? 0u : tr;
     }

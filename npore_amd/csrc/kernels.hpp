@@ -67,14 +67,14 @@ static inline size_t fill_lds_floats(int nw, int ng, int chunks, int lstr, int r
     return (size_t)MAX_PERIOD * NP_LT * NP_CT + 64 + (size_t)chunks * chunk_lds_floats(nw, ng, lstr, rwin);
 }
 
-// value of the previous / next lane (lane 0 / 63 keep their own)
+// value of the previous / next lane (lane 0 / 63 get 0)
 __device__ __forceinline__ uint32_t lane_prev(uint32_t v)
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
 }
 __device__ __forceinline__ uint32_t lane_next(uint32_t v)
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
 }
 __device__ __forceinline__ float lane_prev(float v) { return __uint_as_float(lane_prev(__float_as_uint(v))); }
 __device__ __forceinline__ float lane_next(float v) { return __uint_as_float(lane_next(__float_as_uint(v))); }
@@ -345,7 +345,8 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
         }
 
         CellOut o[NG];
-        cells_update<NG>(env, st, in, o);
+        if (step_is_plain(st)) cells_update<NG, true>(env, st, in, o);    // wave-uniform: all but ~4r steps per chunk
+        else cells_update<NG, false>(env, st, in, o);
 
         uint32_t tbw[NG];
         const int lpos = cw * 64 + lane;      // lane position across the chunk's waves

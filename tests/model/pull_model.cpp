@@ -35,10 +35,12 @@ struct ModelEnv {
             out[k] = active[k] ? np_scores[((size_t)n_idx[k] * (max_l + 1) + a[k]) * (max_l + 1) + b[k]] : 0.0f;
     }
     int clamp() const { return max_l - 1; }
-    int refl(int j, int n_idx) const { return refl_p[(size_t)j * 8 + n_idx]; }
+    int refl_n;   // entries in refl_p
+    int refl(int j, int n_idx) const { return (j >= 0 && j < refl_n) ? refl_p[(size_t)j * 8 + n_idx] : 0; }
     size_t at(int n, int col) const { return (size_t)((slot - n + NS) % NS) * W + col; }
     HistCell h_cell(int n, int col) const
     {
+        if (col < 0 || col >= W) return HistCell{0.f, 0.f, 0.f, 0u};   // ignored by callers (lane not `good`)
         const size_t k = at(n, col);
         return HistCell{hv[0][k], hv[1][k], hv[2][k], hr[k]};
     }
@@ -81,7 +83,7 @@ extern "C" int64_t pull_model_align(const uint8_t *full_ref, int64_t ref_len, co
         std::vector<uint32_t> tb((size_t)nrows * W, 0u);
         std::vector<CellOut> cur(W);
 
-        ModelEnv env{sub_scores, np_scores, max_l, refl.data(), {hm.data(), hl.data(), hs.data()}, hr.data(), W, 0};
+        ModelEnv env{sub_scores, np_scores, max_l, refl.data(), {hm.data(), hl.data(), hs.data()}, hr.data(), W, 0, dcols + 1};
         for (int bl = 0; bl < nrows; bl++) {
             const int64_t b = brk + bl;
             StepInfo st;
@@ -112,7 +114,8 @@ extern "C" int64_t pull_model_align(const uint8_t *full_ref, int64_t ref_len, co
                 in[0].refx = (j >= 0 && j <= dcols) ? refw[2 * (size_t)j] : REFW_SENTINEL;
                 in[0].refy = (j >= 0 && j <= dcols) ? refw[2 * (size_t)j + 1] : 0u;
                 CellOut out1[1];
-                cells_update<1>(env, st, in, out1);
+                if (step_is_plain(st)) cells_update<1, true>(env, st, in, out1);   // same dispatch as the kernel
+                else cells_update<1, false>(env, st, in, out1);
                 cur[c] = out1[0];
             }
             // commit the row: neighbour-of-neighbour values for the next diagonal, history, traceback

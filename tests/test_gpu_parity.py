@@ -37,7 +37,7 @@ def test_dpp_directions():
     assert lib.npore_debug_dpp(out) == 0
     prev, nxt = list(out[:64]), list(out[64:])
     assert prev[1:] == list(range(0, 63)) and prev[0] == 0
-    assert nxt[:63] == list(range(1, 64)) and nxt[63] == 63
+    assert nxt[:63] == list(range(1, 64)) and nxt[63] == 0
 
 
 def test_unit_aligns(ctx):
