@@ -208,7 +208,11 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     if (int rc = ctx->hist.ensure((size_t)(a.max_b_rows + 2) * 4)) return rc;
     if (int rc = ctx->counters.ensure(64)) return rc;
     if (int rc = ctx->seqw.ensure((size_t)(S_tot + max_chunks + 16) * 4)) return rc;
-    if (int rc = ctx->seql.ensure((size_t)(S_tot + max_chunks + 16) * 8)) return rc;
+    {
+        const size_t pstride = ((size_t)a.max_b_rows + 1 + 15) & ~(size_t)15;
+        const size_t need = (8 * pstride <= 160 * 1024) ? 64 : (size_t)2 * max_chunks * 7 * pstride;
+        if (int rc = ctx->seql.ensure(need)) return rc;
+    }
     if (int rc = ctx->refw.ensure((size_t)(R_tot + max_chunks + 16) * 8)) return rc;
     if (int rc = ctx->refl.ensure((size_t)(R_tot + max_chunks + 16) * 8)) return rc;
     if (int rc = ctx->tb.ensure((size_t)tb_words * 4 + 64)) return rc;
@@ -249,7 +253,15 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     hipLaunchKernelGGL(make_chunks_kernel, dim3(ch_blocks), dim3(256), 0, s, pp);
     hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, s, pp);
     hipLaunchKernelGGL(sched_scatter_kernel, dim3(ch_blocks), dim3(256), 0, s, pp);
-    hipLaunchKernelGGL(annotate_kernel, dim3((unsigned)(2 * max_chunks)), dim3(256), 0, s, pp);
+    {
+        // slice bytes + 7 byte planes per position in LDS when that fits (it does for the default max_b_rows)
+        const size_t pstride = ((size_t)a.max_b_rows + 1 + 15) & ~(size_t)15;
+        const int planes_in_lds = 8 * pstride <= 160 * 1024;
+        const size_t alds = planes_in_lds ? 8 * pstride : pstride;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&annotate_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
+        hipLaunchKernelGGL(annotate_kernel, dim3((unsigned)(2 * max_chunks)), dim3(1024), alds, s, pp, planes_in_lds);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev[1], s));
 
@@ -535,8 +547,9 @@ int npore_get_np_info(npore_ctx *ctx, const uint8_t *seq, int64_t len, int32_t *
     HIP_TRY(hipSetDevice(ctx->device));
     const int mn = ctx->max_n;
     DevBuf dseq, dent, dL, dI;
+    const int pstride = (int)((len + 15) & ~(int64_t)15);
     int rc = dseq.ensure(len + 16);
-    if (!rc) rc = dent.ensure((size_t)len * 8 + 16);
+    if (!rc) rc = dent.ensure((size_t)pstride * 7 + 16);
     if (!rc) rc = dL.ensure((size_t)len * mn * 4);
     if (!rc) rc = dI.ensure((size_t)len * mn * 4);
     std::vector<int32_t> L((size_t)len * mn), I((size_t)len * mn);
@@ -544,8 +557,8 @@ int npore_get_np_info(npore_ctx *ctx, const uint8_t *seq, int64_t len, int32_t *
     if (!rc) {
         e = hipMemcpy(dseq.p, seq, len, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(np_info_kernel, dim3(1), dim3(256), 0, ctx->stream, dseq.as<uint8_t>(), (int)len, mn,
-                               ctx->max_l, dent.as<uint8_t>(), dL.as<int32_t>(), dI.as<int32_t>());
+            hipLaunchKernelGGL(np_info_kernel, dim3(1), dim3(1024), 0, ctx->stream, dseq.as<uint8_t>(), (int)len, mn,
+                               ctx->max_l, dent.as<uint8_t>(), pstride, dL.as<int32_t>(), dI.as<int32_t>());
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

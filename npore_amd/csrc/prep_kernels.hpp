@@ -262,117 +262,156 @@ __global__ __launch_bounds__(256) void sched_scatter_kernel(PrepParams p)
 }
 
 // ---------------------------------------------------------------------------
-// n-polymer annotation of one sequence by one workgroup, one position per thread
-// at a time.  Restatement of get_np_info (src/aln.pyx:179-251) in which every
-// (position, period) result is a function of run lengths of the periodicity
-// indicator e_n[p] = (seq[p] == seq[p+n]) and of the final results of shorter
-// periods (see prep.hpp / DESIGN.md for the derivation; the CPU tests check this
-// formulation against the oracle's literal loop).
-// ent[p]: bytes 0..5 = L for n = 1..6, byte 6 = mask of periods with L_IDX == 0.
-// Optional int32 outputs Lout/Iout [len][max_n] for the get_np_info() API.
-__device__ void annotate_sequence(const uint8_t *seq, int len, int max_n, int max_l, uint8_t *ent,
-                                  int32_t *Lout, int32_t *Iout)
+// n-polymer annotation of one sequence by one workgroup.  Restatement of get_np_info
+// (src/aln.pyx:179-251) in which every (position, period) result is a function of
+// run lengths of the periodicity indicator e_n[p] = (seq[p] == seq[p+n]) and of the
+// final results of shorter periods (derivation: DESIGN.md; the CPU tests check the
+// host twin of this formulation against the oracle's literal loop):
+//   kf = run of e_n starting at pos, kb = run ending at pos-1;  a start s = pos - j*n
+//   covers pos iff j <= kb/n and then has l = j + kf/n + 1 repeats (0 if < 1 full one).
+//   Starts are visited in ascending order and overwrite when l exceeds the stored
+//   (capped) value, so the earliest eligible start wins, except that while l > max_l
+//   later eligible starts keep overwriting L_IDX.  Eligible: base != N, l > 2, and
+//   l*n > L[s][n2]*n2 for every shorter period n2 (already final).
+// Each wave handles windows of 64 consecutive positions; the run lengths come from
+// ballots of e_n over whole windows (count trailing / leading ones), so a long run
+// costs one step per 64 positions instead of one per position.
+// planes: byte planes [7][pstride]: 0..5 = L for n = 1..6, 6 = mask of periods with
+// L_IDX == 0 (LDS when the slice fits, else global scratch).  Optional int32 outputs
+// Lout/Iout [len][max_n] for the get_np_info() API.
+__device__ __forceinline__ void annotate_sequence(const uint8_t *seq, int len, int max_n, int max_l,
+                                                  uint8_t *planes, int pstride, int32_t *Lout, int32_t *Iout)
 {
-    for (int p = threadIdx.x; p < len; p += blockDim.x) {
-        reinterpret_cast<uint2 *>(ent)[p] = make_uint2(0u, 0u);
-    }
-    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (int p = threadIdx.x; p < len; p += blockDim.x) planes[6 * pstride + p] = 0;
     for (int n = 1; n <= max_n; n++) {
-        for (int pos = threadIdx.x; pos < len; pos += blockDim.x) {
-            int kf = 0;   // run of e_n starting at pos
-            while (pos + kf + n < len && seq[pos + kf] == seq[pos + kf + n]) kf++;
-            int kb = 0;   // run of e_n ending at pos-1
-            while (pos - 1 - kb >= 0 && pos - 1 - kb + n < len && seq[pos - 1 - kb] == seq[pos - 1 - kb + n]) kb++;
-            const int q = kf / n, J = kb / n;
-            int stored = 0, idx = 0;
-            for (int j = J; j >= 0; j--) {
-                const int l = (j == 0) ? (q >= 1 ? q + 1 : 0) : j + q + 1;
-                if (stored && l <= max_l) break;
-                if (l < 3) continue;
-                const int s = pos - j * n;
-                if (!seq[s]) continue;
-                bool longest = true;
-                for (int n2 = 1; n2 < n; n2++)
-                    if ((long long)l * n <= (long long)ent[(size_t)s * 8 + (n2 - 1)] * n2) longest = false;
-                if (!longest) continue;
-                if (l > stored) { stored = max_l < l ? max_l : l; idx = j; }
+        uint8_t *Ln = planes + (size_t)(n - 1) * pstride;
+        for (int base = wave * 64; base < len; base += nwaves * 64) {
+            const int pos = base + lane;
+            auto e_at = [&](int q) { return q >= 0 && q + n < len && seq[q] == seq[q + n]; };
+            const unsigned long long M0 = __builtin_amdgcn_ballot_w64(e_at(pos));
+            // forward run from pos
+            int kf;
+            {
+                const unsigned long long inv = ~(M0 >> lane);   // bits >= 64-lane of the shifted mask are 0 -> 1 here
+                kf = inv ? __builtin_ctzll(inv) : 64;
             }
-            if (stored) {
-                ent[(size_t)pos * 8 + (n - 1)] = (uint8_t)stored;
-                if (idx == 0) ent[(size_t)pos * 8 + 6] |= (uint8_t)(1u << (n - 1));
+            bool cont = (kf == 64 - lane);
+            for (int k = base + 64; k < len && __builtin_amdgcn_ballot_w64(cont) != 0ull; k += 64) {
+                const unsigned long long Mk = __builtin_amdgcn_ballot_w64(e_at(k + lane));
+                const int t = (~Mk) ? __builtin_ctzll(~Mk) : 64;
+                if (cont) { kf += t; cont = (t == 64); }
             }
-            if (Lout) { Lout[(size_t)pos * max_n + (n - 1)] = stored; Iout[(size_t)pos * max_n + (n - 1)] = idx; }
+            // backward run ending at pos-1
+            int kb = 0;
+            if (lane > 0) {
+                const unsigned long long inv = ~(M0 << (64 - lane));   // bits below are 0 after the shift -> 1 here
+                kb = __builtin_clzll(inv);                              // inv != 0 because lane > 0
+            }
+            bool contb = (kb == lane);
+            for (int k = base - 64; k >= 0 && __builtin_amdgcn_ballot_w64(contb) != 0ull; k -= 64) {
+                const unsigned long long Mk = __builtin_amdgcn_ballot_w64(e_at(k + lane));
+                const int t = (~Mk) ? __builtin_clzll(~Mk) : 64;
+                if (contb) { kb += t; contb = (t == 64); }
+            }
+            if (pos < len) {
+                const int q = kf / n, J = kb / n;
+                int stored = 0, idx = 0;
+                for (int j = J; j >= 0; j--) {
+                    const int l = (j == 0) ? (q >= 1 ? q + 1 : 0) : j + q + 1;
+                    if (stored && l <= max_l) break;
+                    if (l < 3) continue;
+                    const int s = pos - j * n;
+                    if (!seq[s]) continue;
+                    bool longest = true;
+                    for (int n2 = 1; n2 < n; n2++)
+                        if (l * n <= (int)planes[(size_t)(n2 - 1) * pstride + s] * n2) longest = false;
+                    if (!longest) continue;
+                    if (l > stored) { stored = max_l < l ? max_l : l; idx = j; }
+                }
+                Ln[pos] = (uint8_t)stored;
+                if (stored && idx == 0) planes[6 * pstride + pos] |= (uint8_t)(1u << (n - 1));
+                if (Lout) { Lout[(size_t)pos * max_n + (n - 1)] = stored; Iout[(size_t)pos * max_n + (n - 1)] = idx; }
+            }
         }
         __threadfence_block();
         __syncthreads();
     }
 }
 
-__global__ __launch_bounds__(256) void annotate_kernel(PrepParams p)
+// One workgroup per (chunk, sequence).  The slice and the L planes are staged in LDS
+// (8 bytes per position) when they fit; otherwise the planes live in global scratch.
+__global__ __launch_bounds__(1024) void annotate_kernel(PrepParams p, int planes_in_lds)
 {
+    extern __shared__ __attribute__((aligned(16))) uint8_t sbuf[];
     const int k = blockIdx.x >> 1;
     const bool is_ref = blockIdx.x & 1;
     if (k >= p.counters[0]) return;
     const ChunkDesc d = p.descs[k];
     const int64_t rd = d.read_id;
+    const int64_t T = is_ref ? p.ref_off[rd + 1] - p.ref_off[rd] : p.seq_off[rd + 1] - p.seq_off[rd];
+    const int start = is_ref ? d.col0 : d.row0, span = is_ref ? d.dcols : d.drows;
+    const int len = (int)(((int64_t)start + span + 1 < T ? (int64_t)start + span + 1 : T) - start);   // src/aln.pyx:453-454
+    const uint8_t *g = (is_ref ? p.refs + p.ref_off[rd] : p.seqs + p.seq_off[rd]) + start;
+    const int pstride = (p.max_b_rows + 1 + 15) & ~15;
+    uint8_t *sseq = sbuf;
+    uint8_t *planes = planes_in_lds ? sbuf + pstride
+                                    : reinterpret_cast<uint8_t *>(p.seql) + ((size_t)blockIdx.x * 7) * pstride;
+    for (int q = threadIdx.x; q < len; q += blockDim.x) sseq[q] = g[q];
+    __syncthreads();
+    annotate_sequence(sseq, len, p.max_n, p.max_l, planes, pstride, nullptr, nullptr);
+    auto Lat = [&](int pos, int n) -> uint32_t { return planes[(size_t)(n - 1) * pstride + pos]; };
+    auto idx0 = [&](int pos, int n) -> bool { return (planes[(size_t)6 * pstride + pos] >> (n - 1)) & 1u; };
     if (!is_ref) {
-        const int64_t S = p.seq_off[rd + 1] - p.seq_off[rd];
-        const int slen = (int)(((int64_t)d.row0 + d.drows + 1 < S ? (int64_t)d.row0 + d.drows + 1 : S) - d.row0);
-        const uint8_t *seq = p.seqs + p.seq_off[rd] + d.row0;
-        uint8_t *ent = reinterpret_cast<uint8_t *>(p.seql + d.seqw_off);
-        annotate_sequence(seq, slen, p.max_n, p.max_l, ent, nullptr, nullptr);
         uint32_t *seqw = p.seqw + d.seqw_off;
-        for (int i = threadIdx.x; i <= d.drows; i += blockDim.x) {
+        for (int i = threadIdx.x; i <= span; i += blockDim.x) {
             uint32_t w = 0;
             for (int q = 0; q < 6; q++) {
                 const int pp = i - 6 + q;
-                w |= ((pp < 0) ? 7u : (uint32_t)seq[pp]) << (3 * q);
+                w |= ((pp < 0) ? 7u : (uint32_t)sseq[pp]) << (3 * q);
             }
             for (int n = 1; n <= p.max_n; n++) {
                 const int pp = i - n;
-                if (pp >= 0 && pp < slen && ent[(size_t)pp * 8 + (n - 1)] != 0) {
+                if (pp >= 0 && pp < len && Lat(pp, n) != 0) {
                     w |= 1u << (18 + n - 1);
-                    if ((ent[(size_t)pp * 8 + 6] >> (n - 1)) & 1u) w |= 1u << (24 + n - 1);
+                    if (idx0(pp, n)) w |= 1u << (24 + n - 1);
                 }
             }
             seqw[i] = w;
         }
     } else {
-        const int64_t R = p.ref_off[rd + 1] - p.ref_off[rd];
-        const int rlen = (int)(((int64_t)d.col0 + d.dcols + 1 < R ? (int64_t)d.col0 + d.dcols + 1 : R) - d.col0);
-        const uint8_t *ref = p.refs + p.ref_off[rd] + d.col0;
-        uint8_t *ent = reinterpret_cast<uint8_t *>(p.refl + d.refw_off);
-        annotate_sequence(ref, rlen, p.max_n, p.max_l, ent, nullptr, nullptr);
-        if (rlen <= d.dcols && threadIdx.x == 0)     // terminator entry of the last chunk: no n-polymer info
-            reinterpret_cast<uint2 *>(ent)[d.dcols] = make_uint2(0u, 0u);
-        __syncthreads();
         uint2 *refw = p.refw + d.refw_off;
-        for (int j = threadIdx.x; j <= d.dcols; j += blockDim.x) {
-            uint32_t x = 0, y = 0;
+        uint2 *refl = p.refl + d.refw_off;
+        for (int j = threadIdx.x; j <= span; j += blockDim.x) {
+            uint32_t x = 0, y = 0, l03 = 0, l45 = 0;
             for (int q = 0; q < 6; q++) {
                 const int pp = j + q;
-                x |= ((pp >= rlen) ? 6u : (uint32_t)ref[pp]) << (3 * q);
+                x |= ((pp >= len) ? 6u : (uint32_t)sseq[pp]) << (3 * q);
             }
             for (int n = 1; n <= p.max_n; n++) {
-                if (j < rlen && ent[(size_t)j * 8 + (n - 1)] != 0 && ((ent[(size_t)j * 8 + 6] >> (n - 1)) & 1u))
-                    x |= 1u << (18 + n - 1);
+                if (j < len) {
+                    const uint32_t l = Lat(j, n);
+                    if (n <= 4) l03 |= l << (8 * (n - 1)); else l45 |= l << (8 * (n - 5));
+                    if (l != 0 && idx0(j, n)) x |= 1u << (18 + n - 1);
+                }
                 const int pp = j - n;
-                if (pp >= 0 && pp < rlen && ent[(size_t)pp * 8 + (n - 1)] != 0) {
+                if (pp >= 0 && pp < len && Lat(pp, n) != 0) {
                     y |= 1u << (n - 1);
-                    if ((ent[(size_t)pp * 8 + 6] >> (n - 1)) & 1u) y |= 1u << (6 + n - 1);
+                    if (idx0(pp, n)) y |= 1u << (6 + n - 1);
                 }
             }
-            if (j >= 1) x |= (uint32_t)ref[j - 1] << 24;
+            if (j >= 1) x |= (uint32_t)sseq[j - 1] << 24;
             refw[j] = make_uint2(x, y);
+            refl[j] = make_uint2(l03, l45);     // bytes 0..5 = L for n = 1..6 (0 past the slice)
         }
     }
 }
 
-// get_np_info() API: one sequence, int32 outputs
-__global__ __launch_bounds__(256) void np_info_kernel(const uint8_t *seq, int len, int max_n, int max_l,
-                                                      uint8_t *ent, int32_t *Lout, int32_t *Iout)
+// get_np_info() API: one sequence of any length, planes in global scratch, int32 outputs
+__global__ __launch_bounds__(1024) void np_info_kernel(const uint8_t *seq, int len, int max_n, int max_l,
+                                                       uint8_t *planes, int pstride, int32_t *Lout, int32_t *Iout)
 {
-    annotate_sequence(seq, len, max_n, max_l, ent, Lout, Iout);
+    annotate_sequence(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
 }
 
 }  // namespace npore

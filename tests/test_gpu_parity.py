@@ -177,6 +177,22 @@ def test_get_np_info_device(ctx):
         assert np.array_equal(ctx.get_np_info(s), oracle.get_np_info(s))
 
 
+def test_large_max_b_rows(ctx, tables):
+    """max_b_rows above the default: one chunk longer than the LDS-resident annotation
+    planes cover (global-scratch planes), 16-bit run lengths near their range."""
+    sub, nps = tables
+    refs, seqs, cigs = synth.make_batch(77, 2, ref_len=16_000)
+    for mbr in (40000, 60000, 25000):
+        got, st = ctx.align_batch(refs, seqs, cigs, r=30, max_b_rows=mbr, return_status=True)
+        assert not st.any()
+        for k in range(2):
+            assert got[k] == oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=30, max_b_rows=mbr), (mbr, k)
+    with pytest.raises(aln.NporeError):
+        ctx.align_batch(refs, seqs, cigs, r=30, max_b_rows=70000)     # refused loudly, not silently wrong
+    with pytest.raises(aln.NporeError):
+        ctx.align_batch(refs, seqs, cigs, r=300)
+
+
 def test_div_small_domain():
     """The device's float-reciprocal division is exact on its whole domain."""
     lib = _lib.load()
