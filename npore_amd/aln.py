@@ -72,7 +72,7 @@ class Context:
     def timing(self):
         t = (C.c_double * 8)()
         _check(self.lib.npore_last_timing(self.handle, t, 8))
-        keys = ("dev_prep_ms", "fill_ms", "traceback_ms", "h2d_ms", "d2h_ms", "host_prep_ms", "cells", "launches")
+        keys = ("dev_prep_ms", "fill_ms", "traceback_ms", "h2d_ms", "d2h_ms", "reserved", "cells", "launches")
         return dict(zip(keys, list(t)))
 
     def align_batch(self, refs, seqs, cigars, indel_start=5, indel_extend=1, max_b_rows=20000, r=30,

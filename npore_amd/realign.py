@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""realign.py -- BAM in, SAM out, same flags as reference src/realign.py:15-71.
+
+    python -m npore_amd.realign --bam reads.bam --ref ref.fasta --out_prefix out \\
+                                [--stats_dir DIR] [--contig ...] [--max_reads N] ...
+
+The per-read DP runs on an MI355X through libnpore_amd.so; reads are handed to
+it in batches instead of one align() call per pool worker
+(src/realign.py:110-114).  --recalc_cms / --plot need samtools / matplotlib
+pipelines that are out of scope here (the shipped guppy5_stats are loaded).
+"""
+import argparse
+import os
+import sys
+from time import perf_counter
+
+import numpy as np
+
+from . import aln, bam as bam_mod, cfg
+
+
+def argparser():
+    parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    parser.add_argument("--bam", required=True, help="Input BAM to be realigned.")
+    parser.add_argument("--ref", required=True, help="Input reference FASTA.")
+    parser.add_argument("--out_prefix", required=True, help="Output SAM file prefix.")
+    parser.add_argument("--contig", type=str, help="Single contig to realign (with --contig_beg/--contig_end).")
+    parser.add_argument("--contig_beg", type=int, help="Start of realigned region.")
+    parser.add_argument("--contig_end", type=int, help="End of realigned region.")
+    parser.add_argument("--contigs", type=str, help="Comma-separated contigs to realign.")
+    parser.add_argument("--max_reads", type=int, default=0, help="Limit on realigned reads (0 = all).")
+    parser.add_argument("--bed", type=str, help="BED file of regions to realign.")
+    parser.add_argument("--max_n", type=int, default=6, help="Maximum n-polymer period considered.")
+    parser.add_argument("--max_l", type=int, default=100, help="Maximum n-polymer repeat count considered.")
+    parser.add_argument("--chunk_width", type=int, default=100000, help="(confusion-matrix recalculation only)")
+    parser.add_argument("--stats_dir", default=None,
+                        help="Directory with subs/nps/inss/dels _cm.npy (default: the shipped guppy5_stats).")
+    parser.add_argument("--plot", action="store_true", help="(not supported in this build)")
+    parser.add_argument("--recalc_cms", action="store_true", help="(not supported in this build)")
+    parser.add_argument("--recalc_exit", action="store_true", help="(not supported in this build)")
+    # additions
+    parser.add_argument("--batch_reads", type=int, default=4096, help="Reads per GPU batch.")
+    parser.add_argument("--device", type=int, default=int(os.environ.get("LOCAL_RANK", "0")), help="HIP device.")
+    return parser
+
+
+def main():
+    if cfg.args.plot or cfg.args.recalc_cms or cfg.args.recalc_exit:
+        print("\nERROR: --plot / --recalc_cms / --recalc_exit are not available in npore_amd "
+              "(they need samtools mpileup + matplotlib); the confusion matrices in --stats_dir are used as is.")
+        sys.exit(1)
+    print("> reading reference")
+    ref_seqs = bam_mod.read_fasta(cfg.args.ref)
+    print("> selecting BAM regions")
+    bam = bam_mod.BamFile(cfg.args.bam)
+    bam_mod.get_bam_regions(bam, ref_seqs)
+
+    print("> calculating score matrices")
+    cfg.args.sub_scores, cfg.args.np_scores, cfg.args.ins_scores, cfg.args.del_scores = \
+        aln.load_default_tables(cfg.args.stats_dir)
+
+    print("> creating output SAM")
+    out_sam = f"{cfg.args.out_prefix}.sam"
+    bam_mod.create_header(out_sam, bam)
+
+    print("> extracting read data from BAM")
+    read_data = bam_mod.get_read_data(bam, ref_seqs)
+
+    start = perf_counter()
+    print("> computing individual read realignments")
+    ctx = aln.Context(cfg.args.sub_scores, cfg.args.np_scores, device=cfg.args.device)
+    batch, n = [], 0
+    for rd in read_data:
+        batch.append(rd)
+        if len(batch) >= cfg.args.batch_reads:
+            n += bam_mod.realign_reads(ctx, batch, out_sam)
+            batch = []
+    n += bam_mod.realign_reads(ctx, batch, out_sam)
+    ctx.close()
+    print(f"    {n} reads, runtime: {perf_counter() - start:.2f}s")
+
+
+if __name__ == "__main__":
+    cfg.args = argparser().parse_args()
+    try:
+        main()
+    except KeyboardInterrupt:
+        print("\nERROR: Program terminated.")
+        sys.exit(1)

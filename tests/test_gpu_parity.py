@@ -243,3 +243,31 @@ def test_10kb_properties(ctx, tables):
                 j += 1
     for k in (0, 17):
         assert got[k] == oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=100)
+
+
+def test_realign_cli_end_to_end(tmp_path):
+    """BAM in -> SAM out through `python -m npore_amd.realign` == the reference's own golden
+    output test/data/npore_realigned.sam (record by record; the @PG line differs by design)."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    prefix = str(tmp_path / "realigned")
+    subprocess.check_call([sys.executable, "-m", "npore_amd.realign", "--bam", os.path.join(GOLDEN, "data", "reads.bam"),
+                           "--ref", os.path.join(GOLDEN, "data", "ref.fasta"), "--out_prefix", prefix], cwd=REPO)
+
+    def records(path):
+        hdr, recs = [], {}
+        for line in open(path):
+            if line.startswith("@"):
+                hdr.append(line.rstrip("\n"))
+            else:
+                f = line.rstrip("\n").split("\t")
+                recs[f[0]] = f
+        return hdr, recs
+
+    hdr, got = records(prefix + ".sam")
+    ghdr, want = records(os.path.join(GOLDEN, "data", "npore_realigned.sam"))
+    assert hdr[:2] == ghdr[:2] and hdr[2].startswith("@PG\tPN:realigner\tID:realigner\tVN:")
+    assert got.keys() == want.keys() and len(got) == 10
+    for name in want:
+        assert got[name] == want[name], name

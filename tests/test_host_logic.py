@@ -1,0 +1,142 @@
+"""CPU tests of the host side: C-ABI surface, glue, BAM reader, tables, sharding."""
+import argparse
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from npore_amd import _lib, aln, bam, cfg, cig, dist, synth
+from conftest import load_json, GOLDEN, REPO
+
+
+def test_header_symbols_exported_and_bound():
+    """Every function include/npore_amd.h declares is exported by the built library and
+    bound in npore_amd/_lib.py (no compute calls: there is no GPU here)."""
+    hdr = open(os.path.join(REPO, "include", "npore_amd.h")).read()
+    declared = set(re.findall(r"\b(npore_[a-z_0-9]+)\s*\(", hdr)) - {"npore_ctx"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.npore_abi_version() == 1
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (npore_[a-z_0-9]+)", out))
+    assert declared <= exported
+
+
+def test_no_gpu_fails_loudly(tables):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    sub, nps = tables
+    with pytest.raises(aln.NporeError):
+        aln.Context(sub, nps, max_n=6, max_l=100)      # no CPU fallback behind the C ABI
+
+
+def test_product_does_not_touch_oracle():
+    """Nothing under npore_amd/ imports, includes, links or executes oracle/ or tests/model."""
+    py = re.compile(r"^\s*(import|from)\s+(oracle|tests|model)\b|oracle[./]|libnpore_oracle|libpull_model", re.M)
+    cc = re.compile(r"#\s*include\s*[<\"][^>\"]*(oracle|tests/|host_prep|pull_model)")
+    for root, _, files in os.walk(os.path.join(REPO, "npore_amd")):
+        for f in files:
+            txt = open(os.path.join(root, f), errors="replace").read() if f.endswith((".py", ".hpp", ".cpp", ".h")) else ""
+            assert not (py.search(txt) if f.endswith(".py") else cc.search(txt)), f
+
+
+def test_calc_score_matrices_golden(tables):
+    """Row T: tables from the shipped count matrices == the reference's (G1), bit for bit."""
+    sub, nps = tables
+    cfg.args = argparse.Namespace(max_n=6, max_l=100)
+    s, n, ins, dels = aln.load_default_tables()
+    assert s.dtype == np.float32 and n.dtype == np.float32
+    assert np.array_equal(s, sub) and np.array_equal(n, nps)
+    z = np.load(os.path.join(GOLDEN, "tables.npz"))
+    assert np.array_equal(ins, z["ins_scores"]) and np.array_equal(dels, z["del_scores"])
+
+
+def test_cigar_glue_golden():
+    """expand/collapse, bases_to_int and the one-pass standardisation reproduce the final
+    CIGARs of the reference's test/data/npore_realigned.sam from its raw align() strings."""
+    assert cig.expand_cigar("1D3M2I") == "DMMMII" and cig.collapse_cigar("DMMMII") == "1D3M2I"
+    assert cig.bases_to_int("NACGT-").tolist() == [0, 1, 2, 3, 4, 5]
+    fasta = bam.read_fasta(os.path.join(GOLDEN, "data", "ref.fasta"))["ref"]
+    want = {r["name"]: r for r in load_json("reads_e2e.json")}
+    golden = {}
+    for line in open(os.path.join(GOLDEN, "data", "npore_realigned.sam")):
+        if not line.startswith("@"):
+            f = line.split("\t")
+            golden[f[0]] = f[5]
+    for line in open(os.path.join(GOLDEN, "data", "reads.sam")):
+        if line.startswith("@"):
+            continue
+        f = line.rstrip("\n").split("\t")
+        ex = cig.expand_cigar(f[5]).replace("S", "").replace("H", "")
+        start = int(f[3]) - 1
+        rlen = sum(1 for c in ex if c in "XD=M")
+        final = cig.collapse_cigar(cig.standardize(want[f[0]]["raw_align"], cig.bases_to_int(fasta[start:start + rlen]),
+                                                   cig.bases_to_int(f[9].upper())))
+        assert final == want[f[0]]["final_cigar"] == golden[f[0]]
+
+
+def test_bam_reader_equals_sam():
+    """reads.bam decoded with zlib+struct == reads.sam field for field (pysam-free ingest)."""
+    b = bam.BamFile(os.path.join(GOLDEN, "data", "reads.bam"))
+    assert b.references == ["ref"] and b.lengths == [1001]
+    refs = bam.read_fasta(os.path.join(GOLDEN, "data", "ref.fasta"))
+    cfg.args = argparse.Namespace(bam="b", ref="r", contig=None, contigs=None, bed=None, contig_beg=None,
+                                  contig_end=None, max_reads=0, max_n=6, max_l=100)
+    assert bam.get_bam_regions(b, refs) == [("ref", 0, 1000)]
+    rds = list(bam.get_read_data(b, refs))
+    sam = {}
+    for line in open(os.path.join(GOLDEN, "data", "reads.sam")):
+        if not line.startswith("@"):
+            f = line.rstrip("\n").split("\t")
+            sam[f[0]] = f
+    assert len(rds) == 10
+    for rd in rds:
+        f = sam[rd[0]]
+        assert (int(f[1]), int(f[3]) - 1, int(f[4]), f[5], f[9], f[10], f[11]) == \
+               (rd[1], rd[3], rd[4], rd[5], rd[7], rd[8], f"HP:i:{rd[10]}")
+        assert len(rd[9]) == rd[6] - rd[3]
+    cfg.args.max_reads = 3
+    assert len(list(bam.get_read_data(b, refs))) == 3
+
+
+def test_synth_deterministic():
+    a = synth.make_pair(2, 5)
+    b = synth.make_pair(2, 5)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    ops = np.frombuffer(a[2], np.uint8)
+    assert np.isin(ops, [ord("="), ord("X"), ord("I")]).sum() == len(a[1])
+    assert np.isin(ops, [ord("="), ord("X"), ord("D")]).sum() == len(a[0])
+
+
+def _gloo_worker(rank, world_size, port, q):
+    import torch.distributed as tdist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size))
+    tdist.init_process_group("gloo", rank=rank, world_size=world_size)
+    mine = list(dist.shard_indices(1001, rank, world_size))
+    sums, maxes = dist.reduce_counters({"reads": len(mine), "cells": sum(mine)}, {"elapsed": 1.0 + rank})
+    q.put((rank, mine[:3], sums, maxes))
+    tdist.destroy_process_group()
+
+
+def test_sharding_and_reduction_gloo_world2():
+    """N>1 path on CPU: reads dealt round-robin, counters reduced with one sum + one max."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 2, 4] and res[1][1] == [1, 3, 5]
+    for _, _, sums, maxes in res:
+        assert sums["reads"] == 1001 and sums["cells"] == sum(range(1001)) and maxes["elapsed"] == 2.0
