@@ -64,9 +64,10 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ    # launched by torch.distributed.run
+    if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("nccl", device_id=dev)                 # "nccl" is RCCL on ROCm
 
     sub, nps, _, _ = aln.load_default_tables()
     ctx = aln.Context(sub, nps, max_n=6, max_l=100, device=local)
@@ -96,7 +97,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -111,17 +112,14 @@ def main():
         fill_ms.append(tm["fill_ms"]); tb_ms.append(tm["traceback_ms"]); prep_ms.append(tm["dev_prep_ms"])
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed = float(el.item())
-        bad = torch.tensor([int((d_st != 0).sum().item())], dtype=torch.int64, device=dev)
-        dist.all_reduce(bad, op=dist.ReduceOp.SUM)
-        n_bad = int(bad.item())
-    else:
-        n_bad = int((d_st != 0).sum().item())
-
-    total_reads = n * world * args.steps
+    # the only collective of the job: sum of counters, max of the elapsed time
+    from npore_amd.dist import reduce_counters
+    sums, maxes = reduce_counters({"reads": n * args.steps, "bad": int((d_st != 0).sum().item())},
+                                  {"elapsed": elapsed}, device=dev)
+    elapsed = maxes["elapsed"]
+    n_bad = int(sums["bad"])
+    total_reads = int(sums["reads"])
+    assert total_reads == n * world * args.steps
     value = total_reads / elapsed
 
     # ---- roofline of the dominant kernel (fill): algorithmic bytes per launch / measured duration
@@ -169,7 +167,7 @@ def main():
             "bad_reads": n_bad,
         }
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     ctx.close()
 
