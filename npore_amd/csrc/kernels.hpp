@@ -22,6 +22,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "cell.hpp"
 #include "layout.hpp"
 
@@ -29,7 +31,7 @@ namespace npore {
 
 constexpr int NP_LT = 32;  // LDS copy of np_scores covers ref length < NP_LT ...
 constexpr int NP_CT = 48;  // ... and call length < NP_CT; anything else is read from global memory
-constexpr int XCH_WORDS = 12;   // per wave, per parity: boundary cells handed to the neighbour waves
+constexpr int XCH_WORDS = 12;   // 0-4 last cell, 5-9 first cell   // per wave, per parity: boundary cells handed to the neighbour waves
 
 // history ring rows.  One wave per chunk: row b overwrites row b-6 after this wave
 // has read it (LDS ops of a wave are in order).  Several waves per chunk with one
@@ -229,50 +231,47 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     st.dcols = d.dcols;
     st.indel_start = p.indel_start;
     st.indel_extend = p.indel_extend;
-    int ins_l = 0;
-    uint32_t hist6 = 0;
+    st.b_local = 0;
+    st.ins_l = 0;
+    st.del_l = 0;
+    st.hist6 = 0;
     // input-path steps, 64 per coalesced load, one block prefetched (the buffer is padded)
     unsigned long long stepmask = __builtin_amdgcn_ballot_w64(steps_g[lane] != 0);
     unsigned long long nextmask = __builtin_amdgcn_ballot_w64(steps_g[64 + lane] != 0);
+    const int lpos = cw * 64 + lane;          // lane position across the chunk's waves
+    const int tcol = col0w + lane * NG;       // first band column of this lane
+    const bool hist_lane = lpos < p.lstr;     // columns beyond the band are never read back
 
-    for (int bl = 0; bl < d.nrows; bl++) {
-        int I = 0;
-        if (bl > 0) {
-            const int k = bl - 1;              // step k leads from local row k to k+1
-            if ((k & 63) == 0 && k > 0) {
-                stepmask = nextmask;
-                nextmask = __builtin_amdgcn_ballot_w64(steps_g[k + 64 + lane] != 0);
-            }
-            I = (int)((stepmask >> (k & 63)) & 1ull);
-            ins_l += I;
-            hist6 = ((hist6 << 1) | (uint32_t)I) & 63u;
-        }
-        st.b_local = bl;
-        st.ins_l = ins_l;
-        st.del_l = bl - ins_l;
-        st.hist6 = hist6;
-        env.slot = bl % NSR;
+    // One anti-diagonal.  MODE 0: first row of the chunk (no neighbours), 1: the input path
+    // stepped 'I' (read words move one column up, "left" is the previous lane), 2: 'D'
+    // (reference words move one column down, "top" is the next lane).  The whole body is
+    // instantiated per mode so that no register shuffling is needed where the modes meet.
+    auto step = [&](auto mode_tag) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        const int bl = st.b_local;
         // boundary cells written by the neighbour waves at the end of the previous step
         const uint32_t *xin = xchg + ((bl + 1) & 1) * (NW * XCH_WORDS);
-
         CellIn in[NG];
-        if (bl > 0 && I) {
-            // read words move one column up; word for row ins_l + r enters at column 0
+        if constexpr (MODE == 1) {
             float pm = lane_prev(matv[NG - 1]), pd = lane_prev(delv[NG - 1]);
             uint32_t pr = lane_prev(R2[NG - 1]);
             uint32_t ps = lane_prev(seqw[NG - 1]);
             if (cw == 0) {
-                const int qi = ins_l + r - sq_base;
-                if (qi >= 64) {   // uniform
+                // word for row ins_l + r enters at column 0
+                if (st.ins_l + r - sq_base >= 64) {   // uniform
                     sq_base += 64;
                     const int i = sq_base + lane;
                     seq_q = (i <= d.drows) ? seqw_g[i] : SEQW_SENTINEL;
                 }
-                const uint32_t incoming = (uint32_t)__builtin_amdgcn_readlane((int)seq_q, (ins_l + r - sq_base) & 63);
-                if (lane == 0) ps = incoming;
+                const uint32_t incoming = (uint32_t)__builtin_amdgcn_readlane((int)seq_q, (st.ins_l + r - sq_base) & 63);
+                ps = (lane == 0) ? incoming : ps;
             } else if constexpr (NW > 1) {
-                const uint32_t *xl = xin + (cw - 1) * XCH_WORDS;   // last cell of the wave below
-                if (lane == 0) { pm = __uint_as_float(xl[0]); pd = __uint_as_float(xl[1]); pr = xl[2]; ps = xl[3]; }
+                const uint32_t *xl = xin + (cw - 1) * XCH_WORDS;   // last cell of the wave below (broadcast reads)
+                const uint32_t x0 = xl[0], x1 = xl[1], x2 = xl[2], x3 = xl[3];
+                pm = (lane == 0) ? __uint_as_float(x0) : pm;
+                pd = (lane == 0) ? __uint_as_float(x1) : pd;
+                pr = (lane == 0) ? x2 : pr;
+                ps = (lane == 0) ? x3 : ps;
             }
 #pragma unroll
             for (int g = NG - 1; g >= 0; g--) {
@@ -286,30 +285,34 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
                 LT[g] = (lr & 0xFFFFu) | (R1[g] << 16);
                 seqw[g] = g ? seqw[g - 1] : ps;
             }
-        } else if (bl > 0) {
-            // reference words move one column down; word for col del_l + WPT-1 - r enters at column WPT-1
-            const int del_l = bl - ins_l;
+        } else if constexpr (MODE == 2) {
             float nm = lane_next(matv[0]), ni = lane_next(insv[0]);
             uint32_t nr = lane_next(R1[0]);
             uint32_t nx = lane_next(refx[0]), ny = lane_next(refy[0]);
             if (cw == NW - 1) {
-                const int qj = del_l + WPT - 1 - r - rq_base;
-                if (qj >= 64) {
+                // word for col del_l + WPT-1 - r enters at column WPT-1
+                if (st.del_l + WPT - 1 - r - rq_base >= 64) {
                     rq_base += 64;
                     const int j = rq_base + lane;
                     uint2 rw = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint2(REFW_SENTINEL, 0u);
                     refx_q = rw.x;
                     refy_q = rw.y;
                 }
-                const int ql = (del_l + WPT - 1 - r - rq_base) & 63;
+                const int ql = (st.del_l + WPT - 1 - r - rq_base) & 63;
                 const uint32_t inx = (uint32_t)__builtin_amdgcn_readlane((int)refx_q, ql);
                 const uint32_t iny = (uint32_t)__builtin_amdgcn_readlane((int)refy_q, ql);
-                if (lane == 63) { nx = inx; ny = iny; }
+                nx = (lane == 63) ? inx : nx;
+                ny = (lane == 63) ? iny : ny;
             } else if constexpr (NW > 1) {
-                const uint32_t *xf = xin + (cw + 1) * XCH_WORDS + 4;   // first cell of the wave above
-                if (lane == 63) { nm = __uint_as_float(xf[0]); ni = __uint_as_float(xf[1]); nr = xf[2]; nx = xf[3]; ny = xf[4]; }
+                const uint32_t *xf = xin + (cw + 1) * XCH_WORDS + 5;   // first cell of the wave above
+                const uint32_t x0 = xf[0], x1 = xf[1], x2 = xf[2], x3 = xf[3], x4 = xf[4];
+                nm = (lane == 63) ? __uint_as_float(x0) : nm;
+                ni = (lane == 63) ? __uint_as_float(x1) : ni;
+                nr = (lane == 63) ? x2 : nr;
+                nx = (lane == 63) ? x3 : nx;
+                ny = (lane == 63) ? x4 : ny;
             }
-            if (del_l + r + 32 >= wfill) {   // keep the L window ahead of the band (32 positions of slack)
+            if (st.del_l + r + 32 >= wfill) {   // keep the L window ahead of the band (32 positions of slack)
                 if (cw == NW - 1) {
                     const int j = wfill + lane;
                     win[j & env.wmask] = (j <= d.dcols) ? refl_g[j] : make_uint2(0u, 0u);
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
         }
 #pragma unroll
         for (int g = 0; g < NG; g++) {
-            in[g].c = col0w + lane * NG + g;
+            in[g].c = tcol + g;
             in[g].seqw = seqw[g];
             in[g].refx = refx[g];
             in[g].refy = refy[g];
@@ -349,7 +352,6 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
         else cells_update<NG, false>(env, st, in, o);
 
         uint32_t tbw[NG];
-        const int lpos = cw * 64 + lane;      // lane position across the chunk's waves
 #pragma unroll
         for (int g = 0; g < NG; g++) {
             LMv[g] = in[g].leftM;
@@ -359,30 +361,27 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
             delv[g] = o[g].delv;
             R1[g] = (uint32_t)o[g].matrun | ((uint32_t)o[g].insrun << 16);
             R2[g] = (uint32_t)o[g].matrun | ((uint32_t)o[g].delrun << 16);
-            tbw[g] = o[g].tb;
-            if (lpos < p.lstr)     // columns beyond the band are never read back
+            // the row's spare last word carries inss[b] for the traceback
+            tbw[g] = (tcol + g == p.tbstride - 1) ? (uint32_t)(d.row0 + st.ins_l) : o[g].tb;
+            if (hist_lane)
                 hist[env.slot * hw + g * p.lstr + lpos] =
                     HistCell{o[g].matv, o[g].lenstart, o[g].shrstart,
                              (uint32_t)o[g].lenrun_h | ((uint32_t)o[g].shrrun_h << 16)};
         }
         if constexpr (NW > 1) {
-            uint32_t *xout = xchg + (bl & 1) * (NW * XCH_WORDS) + cw * XCH_WORDS;
-            if (lane == 63) {
-                xout[0] = __float_as_uint(matv[NG - 1]); xout[1] = __float_as_uint(delv[NG - 1]);
-                xout[2] = R2[NG - 1]; xout[3] = seqw[NG - 1];
-            }
-            if (lane == 0) {
-                xout[4] = __float_as_uint(matv[0]); xout[5] = __float_as_uint(insv[0]);
-                xout[6] = R1[0]; xout[7] = refx[0]; xout[8] = refy[0];
+            // boundary cells for the neighbour waves: words 0-4 from the last lane, 5-9 from the first
+            if (lane == 0 || lane == 63) {
+                const bool first = (lane == 0);
+                uint32_t *xout = xchg + (bl & 1) * (NW * XCH_WORDS) + cw * XCH_WORDS + (first ? 5 : 0);
+                xout[0] = __float_as_uint(first ? matv[0] : matv[NG - 1]);
+                xout[1] = __float_as_uint(first ? insv[0] : delv[NG - 1]);
+                xout[2] = first ? R1[0] : R2[NG - 1];
+                xout[3] = first ? refx[0] : seqw[NG - 1];
+                xout[4] = refy[0];
             }
         }
         // one traceback word per cell, NG consecutive words per lane (tbstride is a multiple of 4)
-        // (the row's spare last word carries inss[b] for the traceback)
         uint32_t *trow = tb_g + (size_t)bl * p.tbstride;
-        const int tcol = col0w + lane * NG;
-#pragma unroll
-        for (int g = 0; g < NG; g++)
-            if (tcol + g == p.tbstride - 1) tbw[g] = (uint32_t)(d.row0 + ins_l);
         if constexpr (NG == 1) {
             if (tcol < p.tbstride) trow[tcol] = tbw[0];
         } else if constexpr (NG == 2) {
@@ -398,6 +397,23 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
         // LDS writes of this step visible to the chunk's other waves before they start the next one.
         // (lgkmcnt only: the traceback stores above must not be waited for.)
         if constexpr (NW > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+
+    step(std::integral_constant<int, 0>{});
+    for (int bl = 1; bl < d.nrows; bl++) {
+        const int k = bl - 1;              // step k leads from local row k to k+1
+        if ((k & 63) == 0 && k > 0) {
+            stepmask = nextmask;
+            nextmask = __builtin_amdgcn_ballot_w64(steps_g[k + 64 + lane] != 0);
+        }
+        const int I = (int)((stepmask >> (k & 63)) & 1ull);
+        st.b_local = bl;
+        st.ins_l += I;
+        st.del_l = bl - st.ins_l;
+        st.hist6 = ((st.hist6 << 1) | (uint32_t)I) & 63u;
+        env.slot = (env.slot + 1 == NSR) ? 0 : env.slot + 1;
+        if (I) step(std::integral_constant<int, 1>{});
+        else step(std::integral_constant<int, 2>{});
     }
 }
 
