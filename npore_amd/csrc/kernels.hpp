@@ -81,6 +81,16 @@ __device__ __forceinline__ uint32_t lane_next(uint32_t v)
 __device__ __forceinline__ float lane_prev(float v) { return __uint_as_float(lane_prev(__float_as_uint(v))); }
 __device__ __forceinline__ float lane_next(float v) { return __uint_as_float(lane_next(__float_as_uint(v))); }
 
+// tell the compiler a value is wave-uniform (it then lives in SGPRs and conditions on it
+// become scalar branches instead of exec-mask juggling)
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t uni(int64_t v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 template <int NG, int NSR>
 struct DevEnv {
     const float *lds_sub;     // [8][8] padded copy of sub_scores
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *lds_np = lds;
     float *lds_sub = lds + MAX_PERIOD * NP_LT * NP_CT;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = uni((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int cw = wave % NW;             // wave within the chunk
     const int cg = wave / NW;             // chunk within the workgroup
     const int hw = NG * p.lstr;
@@ -162,7 +172,10 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
 
     const int slot_id = blockIdx.x * ((blockDim.x >> 6) / NW) + cg;
     if (slot_id >= *p.n_chunks) return;    // hardware barriers only count waves that are still alive
-    const ChunkDesc d = p.descs[p.sched[slot_id]];
+    ChunkDesc d = p.descs[uni(p.sched[slot_id])];
+    d.brk = uni(d.brk); d.nrows = uni(d.nrows); d.row0 = uni(d.row0); d.col0 = uni(d.col0);
+    d.drows = uni(d.drows); d.dcols = uni(d.dcols);
+    d.steps_off = uni(d.steps_off); d.seqw_off = uni(d.seqw_off); d.refw_off = uni(d.refw_off); d.tb_off = uni(d.tb_off);
     const int r = p.r;
 
     DevEnv<NG, NSR> env;
