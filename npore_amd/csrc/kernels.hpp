@@ -30,7 +30,7 @@
 namespace npore {
 
 constexpr int NP_LT = 32;  // LDS copy of np_scores covers ref length < NP_LT ...
-constexpr int NP_CT = 48;  // ... and call length < NP_CT; anything else is read from global memory
+constexpr int NP_CT = 64;  // ... and call length < NP_CT (powers of two: shifts and masks); else global memory
 constexpr int XCH_WORDS = 12;   // 0-4 last cell, 5-9 first cell   // per wave, per parity: boundary cells handed to the neighbour waves
 
 // history ring rows.  One wave per chunk: row b overwrites row b-6 after this wave
@@ -109,7 +109,7 @@ struct DevEnv {
     {
         int s = slot - n;
         s += (s < 0) ? NSR : 0;
-        return hist[s * hw + colidx(col)];
+        return hist[__umul24((unsigned)s, (unsigned)hw) + colidx(col)];   // 24-bit multiply: full rate
     }
     __device__ __forceinline__ float sub(uint32_t s, uint32_t r) const { return lds_sub[s * 8 + r]; }
     __device__ __forceinline__ int clamp() const { return clampv; }
@@ -126,16 +126,21 @@ struct DevEnv {
         bool oot[K], anyoot = false;
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            oot[k] = active[k] && ((a[k] >= NP_LT) || (b[k] >= NP_CT));
+            oot[k] = active[k] && (((unsigned)a[k] >= (unsigned)NP_LT) || ((unsigned)b[k] >= (unsigned)NP_CT));
             anyoot |= oot[k];
-            const int aa = a[k] < NP_LT ? a[k] : NP_LT - 1, bb = b[k] < NP_CT ? b[k] : NP_CT - 1;
-            out[k] = lds_np[(n_idx[k] * NP_LT + aa) * NP_CT + bb];
+            out[k] = lds_np[((n_idx[k] * NP_LT + (a[k] & (NP_LT - 1))) << 6) + (b[k] & (NP_CT - 1))];
             asm volatile("" : "+v"(out[k]));   // keep this a ds_read: do not fold it with the global load below
         }
-        if (any(anyoot)) {
+        static_assert(NP_CT == 64, "index uses << 6");
+        if (__builtin_amdgcn_ballot_w64(anyoot) != 0ull) {
 #pragma unroll
             for (int k = 0; k < K; k++)
-                if (oot[k]) out[k] = g_np[((size_t)n_idx[k] * np_dim + a[k]) * np_dim + b[k]];
+                if (oot[k]) {
+                    out[k] = g_np[((size_t)n_idx[k] * np_dim + a[k]) * np_dim + b[k]];
+                    // consume the value HERE: otherwise the compiler parks its s_waitcnt vmcnt(0) at the
+                    // join below, where it would run on every pass and drain the traceback stores
+                    asm volatile("" : "+v"(out[k]));
+                }
         }
     }
 };
@@ -275,6 +280,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
                     sq_base += 64;
                     const int i = sq_base + lane;
                     seq_q = (i <= d.drows) ? seqw_g[i] : SEQW_SENTINEL;
+                    asm volatile("" : "+v"(seq_q));   // wait for the reload inside this rare branch (see np_many)
                 }
                 const uint32_t incoming = (uint32_t)__builtin_amdgcn_readlane((int)seq_q, (st.ins_l + r - sq_base) & 63);
                 ps = (lane == 0) ? incoming : ps;
@@ -310,6 +316,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
                     uint2 rw = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint2(REFW_SENTINEL, 0u);
                     refx_q = rw.x;
                     refy_q = rw.y;
+                    asm volatile("" : "+v"(refx_q), "+v"(refy_q));   // wait inside the rare branch
                 }
                 const int ql = (st.del_l + WPT - 1 - r - rq_base) & 63;
                 const uint32_t inx = (uint32_t)__builtin_amdgcn_readlane((int)refx_q, ql);
