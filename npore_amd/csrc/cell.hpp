@@ -62,6 +62,7 @@ struct CellIn {
     int topIrun, leftDrun; // INS.RUN / DEL.RUN of those
     int diagMrun;          // MAT.RUN of the diagonal cell if its MAT.TYP == MAT else 0
     uint32_t seqw, refx, refy;
+    uint32_t sc0, sc1;     // refw.z/.w: pre-decoded SHR candidates of this column (layout.hpp)
     int c;                 // band column 0..2r
 };
 
@@ -145,6 +146,49 @@ NPORE_HD bool step_is_plain(const StepInfo &st)
            (st.ins_l + st.r <= st.drows) && (st.del_l + st.r <= st.dcols);
 }
 
+// One SHR candidate per cell (pull form of src/aln.pyx:642-667): period nn[g] (>= 1),
+// repeat count LL[g] of reference position j-n, start-vs-continue, and whether the cell
+// has such a candidate at all.  X = (i, j-n) sits at band column c - dI of anti-diagonal b-n.
+template <int NG, bool FAST, class Env>
+NPORE_HD void shr_pass(const Env &env, const StepInfo &st, const CellIn (&in)[NG], const int (&jj)[NG],
+                       const int (&nn)[NG], const int (&LL)[NG], const bool (&startf)[NG], const bool (&act)[NG],
+                       float (&shrv)[NG], int (&shrrun)[NG], float (&shrstart)[NG])
+{
+    const int clampv = env.clamp();
+    int nidx[NG], ta[NG], tb_[NG], crun[NG];
+    bool ok[NG], inval[NG];
+    float cstart[NG], score[NG];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int g = 0; g < NG; g++) {
+        const int n = nn[g];
+        const int dI = popc32(st.hist6 & ((1u << n) - 1u));
+        const int cx = in[g].c - dI;
+        const bool good = act[g] && (FAST || jj[g] - n >= 0) && (cx >= 1);
+        // (lanes that are not `good` read some in-LDS garbage below and ignore it)
+        const HistCell h = env.h_cell(n, cx);
+        cstart[g] = startf[g] ? h.matv : h.shrstart;                  // :649 / :662
+        const int run = startf[g] ? 0 : (int)(h.runs >> 16);
+        const int indel = startf[g] ? -1 : -div_small(run, n) - 1;   // :650 / :663
+        inval[g] = np_score_index(clampv, LL[g], indel, ta[g], tb_[g]);
+        nidx[g] = n - 1;
+        crun[g] = run + n;                                            // :654 / :667
+        ok[g] = good && (startf[g] || run > 0);
+    }
+    env.template np_many<NG>(nidx, ta, tb_, ok, score);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int g = 0; g < NG; g++) {
+        const float cand = cstart[g] + (inval[g] ? 100.0f : score[g]);
+        const bool take = ok[g] && cand < shrv[g];
+        shrv[g] = take ? cand : shrv[g];
+        shrrun[g] = take ? crun[g] : shrrun[g];
+        shrstart[g] = take ? cstart[g] : shrstart[g];
+    }
+}
+
 template <int NG, bool FAST, class Env>
 NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in)[NG], CellOut (&o)[NG])
 {
@@ -194,7 +238,7 @@ NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in
         const bool interior = (c >= 1) && (c <= r2 - 1) &&
                               (FAST || ((i >= 0) && (j >= 0) && (i <= st.drows) && (j <= st.dcols)));
         lm[g] = interior ? ((in[g].refx >> 18) & (in[g].seqw >> 18) & 63u) : 0u;
-        sm[g] = interior ? (in[g].refy & 63u) : 0u;
+        sm[g] = interior ? (in[g].sc0 & 7u) : 0u;      // period of the column's first SHR candidate (0 = none)
         pend |= lm[g] | sm[g];
     }
 
@@ -204,6 +248,7 @@ NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in
     // SHR candidates are dense inside reference n-polymers, LEN candidates are rare
     // (they also need the read to repeat the same unit), so each has its own loop.
     const int clampv = env.clamp();
+    (void)clampv;
     if (env.any(pend != 0u)) {
         uint32_t pendS = 0u, pendL = 0u;
 #if defined(__HIPCC__)
@@ -211,45 +256,63 @@ NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in
 #endif
         for (int g = 0; g < NG; g++) { pendS |= sm[g]; pendL |= lm[g]; }
 
-        while (env.any(pendS != 0u)) {
-            pendS = 0u;
-            int nidx[NG], ta[NG], tb_[NG], crun[NG];
-            bool ok[NG], inval[NG];
-            float cstart[NG], score[NG];
+        if (env.any(pendS != 0u)) {
+            // the column's two highest periods come pre-decoded with the reference words
+            // (evaluation order = the reference's: higher period first)
+            int nn[NG], LL[NG];
+            bool startf[NG], act[NG], more = false, second = false;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
             for (int g = 0; g < NG; g++) {
-                const int c = in[g].c;
-                const int nb = top_bit(sm[g]);
-                const int n = nb ? nb : 1;
-                sm[g] &= ~(1u << (n - 1));
-                pendS |= sm[g];
-                const int dI = popc32(st.hist6 & ((1u << n) - 1u));
-                const int cx = c - dI;
-                const bool good = (nb != 0) && (FAST || jj[g] - n >= 0) && (cx >= 1);
-                // (lanes that are not `good` read some in-LDS garbage below and ignore it)
-                const bool start = ((in[g].refy >> (6 + n - 1)) & 1u) != 0u;
-                const int L = env.refl(jj[g] - n, n - 1);
-                const HistCell h = env.h_cell(n, cx);
-                cstart[g] = start ? h.matv : h.shrstart;                  // :649 / :662
-                const int run = start ? 0 : (int)(h.runs >> 16);
-                const int indel = start ? -1 : -div_small(run, n) - 1;   // :650 / :663
-                inval[g] = np_score_index(clampv, L, indel, ta[g], tb_[g]);
-                nidx[g] = n - 1;
-                crun[g] = run + n;                                        // :654 / :667
-                ok[g] = good && (start || run > 0);
+                const uint32_t dsc = in[g].sc0;
+                act[g] = sm[g] != 0u;
+                nn[g] = act[g] ? (int)(dsc & 7u) : 1;
+                startf[g] = (dsc & 8u) != 0u;
+                LL[g] = (int)((dsc >> 4) & 127u);
+                second |= act[g] && (in[g].sc1 & 7u) != 0u;
+                more |= act[g] && (in[g].sc1 & 0x800u) != 0u;
             }
-            env.template np_many<NG>(nidx, ta, tb_, ok, score);
+            shr_pass<NG, FAST>(env, st, in, jj, nn, LL, startf, act, shrv, shrrun, shrstart);
+            if (env.any(second)) {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-            for (int g = 0; g < NG; g++) {
-                const float cand = cstart[g] + (inval[g] ? 100.0f : score[g]);
-                const bool take = ok[g] && cand < shrv[g];
-                shrv[g] = take ? cand : shrv[g];
-                shrrun[g] = take ? crun[g] : shrrun[g];
-                shrstart[g] = take ? cstart[g] : shrstart[g];
+                for (int g = 0; g < NG; g++) {
+                    const uint32_t dsc = in[g].sc1;
+                    act[g] = (sm[g] != 0u) && (dsc & 7u) != 0u;
+                    nn[g] = act[g] ? (int)(dsc & 7u) : 1;
+                    startf[g] = (dsc & 8u) != 0u;
+                    LL[g] = (int)((dsc >> 4) & 127u);
+                }
+                shr_pass<NG, FAST>(env, st, in, jj, nn, LL, startf, act, shrv, shrrun, shrstart);
+            }
+            if (env.any(more)) {     // rare: three or more periods in one column -> decode the rest generically
+                uint32_t rest[NG], pr = 0u;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+                for (int g = 0; g < NG; g++) {
+                    const uint32_t done = (1u << ((in[g].sc0 & 7u) - 1u)) | (1u << ((in[g].sc1 & 7u) - 1u));
+                    rest[g] = (sm[g] != 0u && (in[g].sc1 & 0x800u)) ? (in[g].refy & 63u & ~done) : 0u;
+                    pr |= rest[g];
+                }
+                while (env.any(pr != 0u)) {
+                    pr = 0u;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+                    for (int g = 0; g < NG; g++) {
+                        const int nb = top_bit(rest[g]);
+                        act[g] = nb != 0;
+                        nn[g] = nb ? nb : 1;
+                        rest[g] &= ~(1u << (nn[g] - 1));
+                        pr |= rest[g];
+                        startf[g] = ((in[g].refy >> (6 + nn[g] - 1)) & 1u) != 0u;
+                        LL[g] = env.refl(jj[g] - nn[g], nn[g] - 1);
+                    }
+                    shr_pass<NG, FAST>(env, st, in, jj, nn, LL, startf, act, shrv, shrrun, shrstart);
+                }
             }
         }
 

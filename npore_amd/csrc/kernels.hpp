@@ -31,7 +31,7 @@ namespace npore {
 
 constexpr int NP_LT = 32;  // LDS copy of np_scores covers ref length < NP_LT ...
 constexpr int NP_CT = 64;  // ... and call length < NP_CT (powers of two: shifts and masks); else global memory
-constexpr int XCH_WORDS = 12;   // 0-4 last cell, 5-9 first cell   // per wave, per parity: boundary cells handed to the neighbour waves
+constexpr int XCH_WORDS = 12;   // 0-4 last cell, 5-11 first cell   // per wave, per parity: boundary cells handed to the neighbour waves
 
 // history ring rows.  One wave per chunk: row b overwrites row b-6 after this wave
 // has read it (LDS ops of a wave are in order).  Several waves per chunk with one
@@ -46,7 +46,7 @@ struct KParams {
     const uint8_t *steps;
     const int32_t *inss;
     const uint32_t *seqw;
-    const uint2 *refw;
+    const uint4 *refw;      // x, y and the two pre-decoded SHR candidates (layout.hpp)
     const uint2 *refl;      // 8 bytes per reference position
     uint32_t *tb;
     const float *sub_scores;  // [5][5]
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     env.wmask = p.rwin - 1;
 
     const uint32_t *seqw_g = p.seqw + d.seqw_off;
-    const uint2 *refw_g = p.refw + d.refw_off;
+    const uint4 *refw_g = p.refw + d.refw_off;
     const uint2 *refl_g = p.refl + d.refw_off;
     const uint8_t *steps_g = p.steps + d.steps_off + d.brk;   // steps_g[k] = step from local row k to k+1
     uint32_t *tb_g = p.tb + d.tb_off;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     // per-cell state of the previous anti-diagonal
     float matv[NG], insv[NG], delv[NG], LMv[NG], TMv[NG];
     uint32_t R1[NG], R2[NG], LT[NG];   // matrun|insrun<<16, matrun|delrun<<16, LMrun|TMrun<<16
-    uint32_t seqw[NG], refx[NG], refy[NG];
+    uint32_t seqw[NG], refx[NG], refy[NG], rc0[NG], rc1[NG];
 #pragma unroll
     for (int g = 0; g < NG; g++) {
         matv[g] = insv[g] = delv[g] = LMv[g] = TMv[g] = 0.0f;
@@ -214,14 +214,17 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
         const int col = col0w + lane * NG + g;
         const int i = r - col, j = col - r;
         seqw[g] = (i >= 0 && i <= d.drows) ? seqw_g[i] : SEQW_SENTINEL;
-        uint2 rw = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint2(REFW_SENTINEL, 0u);
+        uint4 rw = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint4(REFW_SENTINEL, 0u, 0u, 0u);
         refx[g] = rw.x;
         refy[g] = rw.y;
+        rc0[g] = rw.z;
+        rc1[g] = rw.w;
     }
     // queues of words that will enter at column 0 (read; first wave) / column WPT-1 (reference; last wave)
     int sq_base = r + 1;              // next read index entering at column 0 is ins_l + r
     int rq_base = WPT - r;            // next reference index entering at column WPT-1 is del_l + WPT-1 - r
-    uint32_t seq_q = SEQW_SENTINEL, refx_q = REFW_SENTINEL, refy_q = 0u;
+    uint32_t seq_q = SEQW_SENTINEL;
+    uint4 ref_q = make_uint4(REFW_SENTINEL, 0u, 0u, 0u);
     if (cw == 0) {
         const int i = sq_base + lane;
         seq_q = (i <= d.drows) ? seqw_g[i] : SEQW_SENTINEL;
@@ -230,9 +233,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     int wfill = 0;
     if (cw == NW - 1) {
         const int j = rq_base + lane;
-        uint2 rw = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint2(REFW_SENTINEL, 0u);
-        refx_q = rw.x;
-        refy_q = rw.y;
+        ref_q = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint4(REFW_SENTINEL, 0u, 0u, 0u);
     }
     while (r + 32 >= wfill) {
         if (cw == NW - 1) {
@@ -308,29 +309,34 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
             float nm = lane_next(matv[0]), ni = lane_next(insv[0]);
             uint32_t nr = lane_next(R1[0]);
             uint32_t nx = lane_next(refx[0]), ny = lane_next(refy[0]);
+            uint32_t nc0 = lane_next(rc0[0]), nc1 = lane_next(rc1[0]);
             if (cw == NW - 1) {
                 // word for col del_l + WPT-1 - r enters at column WPT-1
                 if (st.del_l + WPT - 1 - r - rq_base >= 64) {
                     rq_base += 64;
                     const int j = rq_base + lane;
-                    uint2 rw = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint2(REFW_SENTINEL, 0u);
-                    refx_q = rw.x;
-                    refy_q = rw.y;
-                    asm volatile("" : "+v"(refx_q), "+v"(refy_q));   // wait inside the rare branch
+                    ref_q = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint4(REFW_SENTINEL, 0u, 0u, 0u);
+                    asm volatile("" : "+v"(ref_q.x), "+v"(ref_q.y), "+v"(ref_q.z), "+v"(ref_q.w));   // wait inside the rare branch
                 }
                 const int ql = (st.del_l + WPT - 1 - r - rq_base) & 63;
-                const uint32_t inx = (uint32_t)__builtin_amdgcn_readlane((int)refx_q, ql);
-                const uint32_t iny = (uint32_t)__builtin_amdgcn_readlane((int)refy_q, ql);
+                const uint32_t inx = (uint32_t)__builtin_amdgcn_readlane((int)ref_q.x, ql);
+                const uint32_t iny = (uint32_t)__builtin_amdgcn_readlane((int)ref_q.y, ql);
+                const uint32_t inz = (uint32_t)__builtin_amdgcn_readlane((int)ref_q.z, ql);
+                const uint32_t inw = (uint32_t)__builtin_amdgcn_readlane((int)ref_q.w, ql);
                 nx = (lane == 63) ? inx : nx;
                 ny = (lane == 63) ? iny : ny;
+                nc0 = (lane == 63) ? inz : nc0;
+                nc1 = (lane == 63) ? inw : nc1;
             } else if constexpr (NW > 1) {
                 const uint32_t *xf = xin + (cw + 1) * XCH_WORDS + 5;   // first cell of the wave above
-                const uint32_t x0 = xf[0], x1 = xf[1], x2 = xf[2], x3 = xf[3], x4 = xf[4];
+                const uint32_t x0 = xf[0], x1 = xf[1], x2 = xf[2], x3 = xf[3], x4 = xf[4], x5 = xf[5], x6 = xf[6];
                 nm = (lane == 63) ? __uint_as_float(x0) : nm;
                 ni = (lane == 63) ? __uint_as_float(x1) : ni;
                 nr = (lane == 63) ? x2 : nr;
                 nx = (lane == 63) ? x3 : nx;
                 ny = (lane == 63) ? x4 : ny;
+                nc0 = (lane == 63) ? x5 : nc0;
+                nc1 = (lane == 63) ? x6 : nc1;
             }
             if (st.del_l + r + 32 >= wfill) {   // keep the L window ahead of the band (32 positions of slack)
                 if (cw == NW - 1) {
@@ -351,6 +357,8 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
                 LT[g] = (R2[g] & 0xFFFFu) | (tr << 16);
                 refx[g] = (g < NG - 1) ? refx[g + 1] : nx;
                 refy[g] = (g < NG - 1) ? refy[g + 1] : ny;
+                rc0[g] = (g < NG - 1) ? rc0[g + 1] : nc0;
+                rc1[g] = (g < NG - 1) ? rc1[g + 1] : nc1;
             }
         } else {
 #pragma unroll
@@ -365,6 +373,8 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
             in[g].seqw = seqw[g];
             in[g].refx = refx[g];
             in[g].refy = refy[g];
+            in[g].sc0 = rc0[g];
+            in[g].sc1 = rc1[g];
         }
 
         CellOut o[NG];
@@ -398,6 +408,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
                 xout[2] = first ? R1[0] : R2[NG - 1];
                 xout[3] = first ? refx[0] : seqw[NG - 1];
                 xout[4] = refy[0];
+                if (first) { xout[5] = rc0[0]; xout[6] = rc1[0]; }
             }
         }
         // one traceback word per cell, NG consecutive words per lane (tbstride is a multiple of 4)

@@ -24,6 +24,11 @@
 //   refw[j].y
 //     bits  0-5   bit n-1: reference position j-n lies in an n-polymer (L != 0)
 //     bits  6-11  bit n-1: ... and is its first copy                  (L_IDX == 0)
+//   refw[j].z/.w  the column's two highest-period SHR candidates, pre-decoded:
+//     bits 0-2 period n (0 = none), bit 3 "first copy" (start a deletion rather than
+//     continue one), bits 4-10 L of reference position j-n for that period;
+//     bit 11 of .w: the column has more than two candidate periods (rare; the rest is
+//     decoded from .y and the L window)
 //   refl[j]  8 bytes: byte n-1 = L of reference position j for period n (0..max_l)
 //
 // n-polymer annotation follows get_np_info (reference src/aln.pyx:179-251) on the

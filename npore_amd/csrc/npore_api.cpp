@@ -213,7 +213,7 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
         const size_t need = (8 * pstride <= 160 * 1024) ? 64 : (size_t)2 * max_chunks * 7 * pstride;
         if (int rc = ctx->seql.ensure(need)) return rc;
     }
-    if (int rc = ctx->refw.ensure((size_t)(R_tot + max_chunks + 16) * 8)) return rc;
+    if (int rc = ctx->refw.ensure((size_t)(R_tot + max_chunks + 16) * 16)) return rc;
     if (int rc = ctx->refl.ensure((size_t)(R_tot + max_chunks + 16) * 8)) return rc;
     if (int rc = ctx->tb.ensure((size_t)tb_words * 4 + 64)) return rc;
     if (int rc = ctx->cout_.ensure((size_t)(S_tot + R_tot) + 64)) return rc;
@@ -240,7 +240,7 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     pp.hist = ctx->hist.as<int32_t>();
     pp.counters = ctx->counters.as<int32_t>();
     pp.seqw = ctx->seqw.as<uint32_t>();
-    pp.refw = ctx->refw.as<uint2>();
+    pp.refw = ctx->refw.as<uint4>();
     pp.refl = ctx->refl.as<uint2>();
     pp.seql = ctx->seql.as<uint2>();
 

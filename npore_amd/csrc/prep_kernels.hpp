@@ -48,7 +48,7 @@ struct PrepParams {
     int32_t *counters;         // [0] number of chunks, [1] overflow flag
     // annotation
     uint32_t *seqw;
-    uint2 *refw;
+    uint4 *refw;
     uint2 *refl;               // per reference position: bytes 0-5 L for n=1..6, byte 6 L_IDX==0 mask
     uint2 *seql;               // same for read positions (scratch)
 };
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(1024) void annotate_kernel(PrepParams p, int planes
             seqw[i] = w;
         }
     } else {
-        uint2 *refw = p.refw + d.refw_off;
+        uint4 *refw = p.refw + d.refw_off;
         uint2 *refl = p.refl + d.refw_off;
         for (int j = threadIdx.x; j <= span; j += blockDim.x) {
             uint32_t x = 0, y = 0, l03 = 0, l45 = 0;
@@ -401,7 +401,18 @@ __global__ __launch_bounds__(1024) void annotate_kernel(PrepParams p, int planes
                 }
             }
             if (j >= 1) x |= (uint32_t)sseq[j - 1] << 24;
-            refw[j] = make_uint2(x, y);
+            // pre-decoded SHR candidates: the two highest periods flagged in y (layout.hpp)
+            uint32_t dsc0 = 0u, dsc1 = 0u;
+            int nd = 0;
+            for (int n = p.max_n; n >= 1; n--) {
+                if (!((y >> (n - 1)) & 1u)) continue;
+                const uint32_t v = (uint32_t)n | (((y >> (6 + n - 1)) & 1u) << 3) | (Lat(j - n, n) << 4);
+                if (nd == 0) dsc0 = v;
+                else if (nd == 1) dsc1 = v;
+                else dsc1 |= 0x800u;
+                nd++;
+            }
+            refw[j] = make_uint4(x, y, dsc0, dsc1);
             refl[j] = make_uint2(l03, l45);     // bytes 0..5 = L for n = 1..6 (0 past the slice)
         }
     }

@@ -118,7 +118,7 @@ inline bool build_path(const char *cig, int64_t cig_len, int64_t seq_len, int64_
 // is one, src/aln.pyx:453-454).  Outputs have drows+1 / dcols+1 entries.
 inline void pack_chunk_words(const uint8_t *seq, int slen, int drows,
                              const uint8_t *ref, int rlen, int dcols, int max_n, int max_l,
-                             uint32_t *seqw, uint32_t *refw /* interleaved x,y */, uint8_t *refl /* 8/entry */,
+                             uint32_t *seqw, uint32_t *refw /* interleaved x,y,z,w */, uint8_t *refl /* 8/entry */,
                              std::vector<int32_t> &scratch)
 {
     scratch.resize((size_t)2 * max_n * (size_t)(std::max(slen, rlen) + 1));
@@ -166,8 +166,23 @@ inline void pack_chunk_words(const uint8_t *seq, int slen, int drows,
             }
         }
         if (j >= 1) x |= (uint32_t)ref[j - 1] << 24;
-        refw[2 * j] = x;
-        refw[2 * j + 1] = y;
+        // pre-decoded SHR candidates: the two highest periods with y's "inside an n-polymer" bit
+        uint32_t dsc[2] = {0u, 0u};
+        int nd = 0;
+        for (int n = max_n; n >= 1; n--) {
+            if (!((y >> (n - 1)) & 1u)) continue;
+            if (nd < 2) {
+                const uint32_t l = (uint32_t)L[(size_t)(j - n) * max_n + (n - 1)];
+                dsc[nd] = (uint32_t)n | (((y >> (6 + n - 1)) & 1u) << 3) | (l << 4);
+            } else {
+                dsc[1] |= 0x800u;
+            }
+            nd++;
+        }
+        refw[4 * j] = x;
+        refw[4 * j + 1] = y;
+        refw[4 * j + 2] = dsc[0];
+        refw[4 * j + 3] = dsc[1];
     }
 }
 

@@ -65,7 +65,7 @@ def prep(ref, seq, cigar, max_b_rows=20000, max_n=6, max_l=100):
     steps = np.zeros(cap, np.uint8); inss = np.zeros(cap + 1, np.int32)
     geom = np.zeros(7 * nchmax, np.int32)
     seqw = np.zeros(len(seq) + nchmax + 8, np.uint32)
-    refw = np.zeros(2 * (len(ref) + nchmax + 8), np.uint32)
+    refw = np.zeros(4 * (len(ref) + nchmax + 8), np.uint32)
     refl = np.zeros(8 * (len(ref) + nchmax + 8), np.uint8)
     ns, ni, nsw, nrw = (C.c_int64() for _ in range(4))
     lib.pull_model_prep.restype = C.c_int64
@@ -78,7 +78,7 @@ def prep(ref, seq, cigar, max_b_rows=20000, max_n=6, max_l=100):
     if nch < 0:
         raise ValueError("bad input")
     return dict(n_chunks=int(nch), steps=steps[:ns.value], inss=inss[:ni.value], geom=geom[:7 * nch].reshape(-1, 7),
-                seqw=seqw[:nsw.value], refw=refw[:2 * nrw.value].reshape(-1, 2), refl=refl[:8 * nrw.value].reshape(-1, 8))
+                seqw=seqw[:nsw.value], refw=refw[:4 * nrw.value].reshape(-1, 4), refl=refl[:8 * nrw.value].reshape(-1, 8))
 
 
 def get_np_info(seq, max_n=6, max_l=100):

@@ -71,7 +71,7 @@ extern "C" int64_t pull_model_align(const uint8_t *full_ref, int64_t ref_len, co
         const int drows = rowN - row0, dcols = colN - col0;
         const int slen = (int)(std::min<int64_t>(rowN + 1, seq_len) - row0);
         const int rlen = (int)(std::min<int64_t>(colN + 1, ref_len) - col0);
-        std::vector<uint32_t> seqw(drows + 1), refw(2 * (size_t)(dcols + 1));
+        std::vector<uint32_t> seqw(drows + 1), refw(4 * (size_t)(dcols + 1));
         std::vector<uint8_t> refl(8 * (size_t)(dcols + 1));
         pack_chunk_words(full_seq + row0, slen, drows, full_ref + col0, rlen, dcols, max_n, max_l, seqw.data(),
                          refw.data(), refl.data(), scratch);
@@ -111,8 +111,10 @@ extern "C" int64_t pull_model_align(const uint8_t *full_ref, int64_t ref_len, co
                 in[0].diagMrun = I ? LMrun[c] : TMrun[c];
                 const int i = st.ins_l + r - c, j = st.del_l - r + c;
                 in[0].seqw = (i >= 0 && i <= drows) ? seqw[i] : SEQW_SENTINEL;
-                in[0].refx = (j >= 0 && j <= dcols) ? refw[2 * (size_t)j] : REFW_SENTINEL;
-                in[0].refy = (j >= 0 && j <= dcols) ? refw[2 * (size_t)j + 1] : 0u;
+                in[0].refx = (j >= 0 && j <= dcols) ? refw[4 * (size_t)j] : REFW_SENTINEL;
+                in[0].refy = (j >= 0 && j <= dcols) ? refw[4 * (size_t)j + 1] : 0u;
+                in[0].sc0 = (j >= 0 && j <= dcols) ? refw[4 * (size_t)j + 2] : 0u;
+                in[0].sc1 = (j >= 0 && j <= dcols) ? refw[4 * (size_t)j + 3] : 0u;
                 CellOut out1[1];
                 if (step_is_plain(st)) cells_update<1, true>(env, st, in, out1);   // same dispatch as the kernel
                 else cells_update<1, false>(env, st, in, out1);
@@ -196,7 +198,7 @@ extern "C" int64_t pull_model_prep(const uint8_t *full_ref, int64_t ref_len, con
         g[0] = (int32_t)brk; g[1] = (int32_t)(nxt - brk + 1); g[2] = row0; g[3] = col0; g[4] = drows; g[5] = dcols;
         g[6] = drows + dcols;
         pack_chunk_words(full_seq + row0, slen, drows, full_ref + col0, rlen, dcols, max_n, max_l, seqw + so,
-                         refw + 2 * ro, refl + 8 * ro, scratch);
+                         refw + 4 * ro, refl + 8 * ro, scratch);
         so += drows + 1;
         ro += dcols + 1;
     }

@@ -160,7 +160,7 @@ def test_device_prep_matches_host_twin(ctx):
         geom = np.stack([d[f] for f in ("brk", "nrows", "row0", "col0", "drows", "dcols", "out_cap")], axis=1)
         assert np.array_equal(geom, want["geom"])
         assert np.array_equal(fetch(3, np.uint32, len(want["seqw"])), want["seqw"])
-        assert np.array_equal(fetch(4, np.uint32, want["refw"].size).reshape(-1, 2), want["refw"])
+        assert np.array_equal(fetch(4, np.uint32, want["refw"].size).reshape(-1, 4), want["refw"])
         got_l = fetch(5, np.uint8, want["refl"].size).reshape(-1, 8)
         assert np.array_equal(got_l[:, :6], want["refl"][:, :6])
         sched = fetch(6, np.int32, nch)
