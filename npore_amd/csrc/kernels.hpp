@@ -34,9 +34,9 @@ constexpr int NP_CT = 64;  // ... and call length < NP_CT (powers of two: shifts
 constexpr int XCH_WORDS = 12;   // 0-4 last cell, 5-11 first cell   // per wave, per parity: boundary cells handed to the neighbour waves
 
 // history ring rows.  One wave per chunk: row b overwrites row b-6 after this wave
-// has read it (LDS ops of a wave are in order).  Several waves per chunk with one
-// barrier per anti-diagonal: row b must not land on a row (b-1..b-6) another wave
-// may still be reading in the same step, so 7 rows.
+// has read it (LDS ops of a wave are in order).  Several waves per chunk: a wave may
+// be one anti-diagonal ahead of its neighbours (it starts b+1 once they finished b),
+// so row b+1 must not land on a row (b..b-5) a neighbour may still be reading: 7 rows.
 __host__ __device__ constexpr int ring_rows(int nw) { return nw > 1 ? 7 : 6; }
 
 struct KParams {
@@ -62,7 +62,7 @@ struct KParams {
 // LDS floats: shared score tables + per chunk (history ring, reference-L window, exchange)
 static inline size_t chunk_lds_floats(int nw, int ng, int lstr, int rwin)
 {
-    return (size_t)4 * ring_rows(nw) * ng * lstr + 2 * (size_t)rwin + (nw > 1 ? 2 * nw * XCH_WORDS : 0);
+    return (size_t)4 * ring_rows(nw) * ng * lstr + 2 * (size_t)rwin + (nw > 1 ? 2 * nw * XCH_WORDS + 8 : 0);
 }
 static inline size_t fill_lds_floats(int nw, int ng, int chunks, int lstr, int rwin)
 {
@@ -159,10 +159,11 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     const int cw = wave % NW;             // wave within the chunk
     const int cg = wave / NW;             // chunk within the workgroup
     const int hw = NG * p.lstr;
-    float *chunk_lds = lds_sub + 64 + (size_t)cg * (4 * NSR * hw + 2 * p.rwin + (NW > 1 ? 2 * NW * XCH_WORDS : 0));
+    float *chunk_lds = lds_sub + 64 + (size_t)cg * (4 * NSR * hw + 2 * p.rwin + (NW > 1 ? 2 * NW * XCH_WORDS + 8 : 0));
     HistCell *hist = reinterpret_cast<HistCell *>(chunk_lds);
     uint2 *win = reinterpret_cast<uint2 *>(chunk_lds + 4 * NSR * hw);
     uint32_t *xchg = reinterpret_cast<uint32_t *>(chunk_lds + 4 * NSR * hw + 2 * p.rwin);   // [2][NW][XCH_WORDS]
+    volatile int *prog = reinterpret_cast<volatile int *>(xchg + 2 * NW * XCH_WORDS);          // [NW] anti-diagonals completed
 
     // workgroup-shared tables
     const int np_dim = p.max_l + 1;
@@ -242,7 +243,10 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
         }
         wfill += 64;
     }
-    if constexpr (NW > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (NW > 1) {
+        if (lane == 0) prog[cw] = 0;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
 
     StepInfo st;
     st.r = r;
@@ -268,6 +272,19 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     auto step = [&](auto mode_tag) __attribute__((always_inline)) {
         constexpr int MODE = decltype(mode_tag)::value;
         const int bl = st.b_local;
+        if constexpr (NW > 1 && MODE != 0) {
+            // Per-chunk hand-shake instead of a workgroup barrier: this wave may start anti-diagonal bl
+            // once its two neighbour waves have finished bl-1 (they own the only columns it reads).
+            // LDS requests of a wave are served in order, so a neighbour's progress word becomes
+            // visible after the history / exchange words it wrote before it.
+            for (;;) {
+                const int a = (cw > 0) ? prog[cw - 1] : 0x7fffffff;
+                const int b = (cw < NW - 1) ? prog[cw + 1] : 0x7fffffff;
+                if (uni((a < b ? a : b)) >= bl) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+        }
         // boundary cells written by the neighbour waves at the end of the previous step
         const uint32_t *xin = xchg + ((bl + 1) & 1) * (NW * XCH_WORDS);
         CellIn in[NG];
@@ -425,9 +442,12 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
                     *reinterpret_cast<uint4 *>(trow + col) = make_uint4(tbw[4 * q], tbw[4 * q + 1], tbw[4 * q + 2], tbw[4 * q + 3]);
             }
         }
-        // LDS writes of this step visible to the chunk's other waves before they start the next one.
-        // (lgkmcnt only: the traceback stores above must not be waited for.)
-        if constexpr (NW > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // publish progress after this step's LDS writes (same in-order LDS queue); never vmcnt:
+        // the traceback stores above must stay in flight
+        if constexpr (NW > 1) {
+            asm volatile("" ::: "memory");
+            if (lane == 0) prog[cw] = bl + 1;
+        }
     };
 
     step(std::integral_constant<int, 0>{});
