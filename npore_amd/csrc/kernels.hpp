@@ -163,7 +163,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     HistCell *hist = reinterpret_cast<HistCell *>(chunk_lds);
     uint2 *win = reinterpret_cast<uint2 *>(chunk_lds + 4 * NSR * hw);
     uint32_t *xchg = reinterpret_cast<uint32_t *>(chunk_lds + 4 * NSR * hw + 2 * p.rwin);   // [2][NW][XCH_WORDS]
-    volatile int *prog = reinterpret_cast<volatile int *>(xchg + 2 * NW * XCH_WORDS);          // [NW] anti-diagonals completed
+    int *prog = reinterpret_cast<int *>(xchg + 2 * NW * XCH_WORDS);          // [NW] anti-diagonals completed
 
     // workgroup-shared tables
     const int np_dim = p.max_l + 1;
@@ -278,8 +278,10 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
             // LDS requests of a wave are served in order, so a neighbour's progress word becomes
             // visible after the history / exchange words it wrote before it.
             for (;;) {
-                const int a = (cw > 0) ? prog[cw - 1] : 0x7fffffff;
-                const int b = (cw < NW - 1) ? prog[cw + 1] : 0x7fffffff;
+                // relaxed workgroup-scope atomics keep these plain LDS reads (a volatile access would
+                // become a flat system-scope load with a vmcnt(0) wait)
+                const int a = (cw > 0) ? __hip_atomic_load(&prog[cw - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
+                const int b = (cw < NW - 1) ? __hip_atomic_load(&prog[cw + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
                 if (uni((a < b ? a : b)) >= bl) break;
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
         // the traceback stores above must stay in flight
         if constexpr (NW > 1) {
             asm volatile("" ::: "memory");
-            if (lane == 0) prog[cw] = bl + 1;
+            if (lane == 0) __hip_atomic_store(&prog[cw], bl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
 
