@@ -258,9 +258,15 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
         const size_t pstride = ((size_t)a.max_b_rows + 1 + 15) & ~(size_t)15;
         const int planes_in_lds = 8 * pstride <= 160 * 1024;
         const size_t alds = planes_in_lds ? 8 * pstride : pstride;
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&annotate_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
-        hipLaunchKernelGGL(annotate_kernel, dim3((unsigned)(2 * max_chunks)), dim3(1024), alds, s, pp, planes_in_lds);
+        if (planes_in_lds) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&annotate_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
+            hipLaunchKernelGGL(annotate_kernel<true>, dim3((unsigned)(2 * max_chunks)), dim3(1024), alds, s, pp);
+        } else {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&annotate_kernel<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
+            hipLaunchKernelGGL(annotate_kernel<false>, dim3((unsigned)(2 * max_chunks)), dim3(1024), alds, s, pp);
+        }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev[1], s));

@@ -341,7 +341,8 @@ __device__ __forceinline__ void annotate_sequence(const uint8_t *seq, int len, i
 
 // One workgroup per (chunk, sequence).  The slice and the L planes are staged in LDS
 // (8 bytes per position) when they fit; otherwise the planes live in global scratch.
-__global__ __launch_bounds__(1024) void annotate_kernel(PrepParams p, int planes_in_lds)
+template <bool PLANES_IN_LDS>
+__global__ __launch_bounds__(1024) void annotate_kernel(PrepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sbuf[];
     const int k = blockIdx.x >> 1;
@@ -355,8 +356,9 @@ __global__ __launch_bounds__(1024) void annotate_kernel(PrepParams p, int planes
     const uint8_t *g = (is_ref ? p.refs + p.ref_off[rd] : p.seqs + p.seq_off[rd]) + start;
     const int pstride = (p.max_b_rows + 1 + 15) & ~15;
     uint8_t *sseq = sbuf;
-    uint8_t *planes = planes_in_lds ? sbuf + pstride
-                                    : reinterpret_cast<uint8_t *>(p.seql) + ((size_t)blockIdx.x * 7) * pstride;
+    uint8_t *planes;   // a compile-time choice, so that the LDS case uses ds_* instructions rather than flat ones
+    if constexpr (PLANES_IN_LDS) planes = sbuf + pstride;
+    else planes = reinterpret_cast<uint8_t *>(p.seql) + ((size_t)blockIdx.x * 7) * pstride;
     for (int q = threadIdx.x; q < len; q += blockDim.x) sseq[q] = g[q];
     __syncthreads();
     annotate_sequence(sseq, len, p.max_n, p.max_l, planes, pstride, nullptr, nullptr);
