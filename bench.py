@@ -129,8 +129,15 @@ def main():
                     for s, r_, ol in zip(seqs, refs, out_len))
     fill_avg_ms = float(np.mean(fill_ms))
     achieved = bytes_alg / (fill_avg_ms * 1e-3) / 1e9
+    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same default command
+    # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, KB -> bytes); null for other workloads
+    traffic = None
+    prof = os.path.join(REPO, "profiles", "r01_fill_pmc_summary.json")
+    if (n, args.ref_len, args.r, args.max_b_rows, args.base_seed) == (1000, 10_000, 100, 20000, 2) and os.path.exists(prof):
+        pm = json.load(open(prof))
+        traffic = int((2 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024)
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "kernel": "fill_kernel", "kernel_ms": round(fill_avg_ms, 3),
                 "bytes_alg_per_launch": int(bytes_alg)}
 
