@@ -113,6 +113,19 @@ int npore_align_batch_device(npore_ctx *ctx, int64_t n_reads,
 int npore_get_np_info(npore_ctx *ctx, const uint8_t *seq, int64_t len, int32_t *out);
 
 /*
+ * Host-side glue after align(): what realign_read does with the returned string
+ * (reference src/bam.pyx:65-78 with src/cig.pyx:102-192 and collapse_cigar, src/cig.pyx:13-38):
+ * X,= -> M, one pass of push-D-left / I-through-D / push-I-left / I-through-D, 'ID' -> 'M',
+ * run-length encoding.  alns: concatenated align() strings; out receives the collapsed
+ * CIGAR text of read i in out[out_off[i] .. out_off[i+1]) (2 bytes per op is always enough).
+ * No GPU involved; `threads` <= 0 means all host cores.
+ */
+int npore_standardize_batch(int64_t n_reads, const char *alns, const int64_t *aln_off,
+                            const uint8_t *refs, const int64_t *ref_off,
+                            const uint8_t *seqs, const int64_t *seq_off,
+                            char *out, const int64_t *out_off, int64_t *out_len, int threads);
+
+/*
  * Timing of the stages of the last npore_align_batch* call on this context,
  * measured with HIP events on the stream the kernels ran on (milliseconds):
  *   ms[0] device prep kernels, ms[1] fill kernel(s), ms[2] traceback + gather,

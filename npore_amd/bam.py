@@ -15,7 +15,7 @@ import zlib
 import numpy as np
 
 from . import cfg
-from .cig import bases_to_int, collapse_cigar, expand_cigar, standardize
+from .cig import bases_to_int, expand_cigar, standardize_batch
 
 _SEQ16 = "=ACMGRSVTWYHKDBN"
 _CIGOPS = "MIDNSHP=XB"
@@ -232,15 +232,15 @@ def realign_reads(ctx, read_data, out_sam, r=30, max_b_rows=20000):
         refs.append(bases_to_int(rd[9]))
         seqs.append(bases_to_int(rd[7]))
     alns, status = ctx.align_batch(refs, seqs, cigs, r=r, max_b_rows=max_b_rows, return_status=True)
+    finals = standardize_batch(alns, refs, seqs)          # src/bam.pyx:65-78, C++ glue in the library
     with open(out_sam, "a") as fh:
-        for rd, aln, st, ref, seq in zip(read_data, alns, status, refs, seqs):
+        for rd, final, st in zip(read_data, finals, status):
             read_id, flag, ref_name, start, mapq, _cig, stop, sseq, quals, _ref, hap = rd
             if st & 32:
                 print(f"\nERROR: read '{read_id}': CIGAR does not match sequence lengths; skipped.")
                 continue
             if st:
                 print(f"\nERROR: inconsistent traceback for read '{read_id}' (status {int(st)})")   # src/aln.pyx:689-716
-            cigar = standardize(aln, ref, seq)
-            fh.write(f"{read_id}\t{flag}\t{ref_name}\t{start + 1}\t{mapq}\t{collapse_cigar(cigar)}\t*\t0\t"
+            fh.write(f"{read_id}\t{flag}\t{ref_name}\t{start + 1}\t{mapq}\t{final}\t*\t0\t"
                      f"{stop - start}\t{sseq}\t{quals}\tHP:i:{hap}\n")
     return len(read_data)

@@ -132,3 +132,38 @@ def standardize(aln, int_ref, int_seq):
     push_indels_left(cig, seq, 1)
     push_inss_thru_dels(cig)
     return "".join("MID"[c] for c in cig).replace("ID", "M")
+
+
+def standardize_batch(alns, int_refs, int_seqs, threads=0):
+    """Collapsed final CIGARs for a batch: `collapse_cigar(standardize(...))` per read, done by
+    the library's C++ glue (npore_standardize_batch) on all host cores."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    n = len(alns)
+    if n == 0:
+        return []
+    ab = [a.encode() for a in alns]
+    refs = [np.ascontiguousarray(x, dtype=np.uint8) for x in int_refs]
+    seqs = [np.ascontiguousarray(x, dtype=np.uint8) for x in int_seqs]
+
+    def pack(parts, lens):
+        off = np.zeros(n + 1, np.int64)
+        np.cumsum(lens, out=off[1:])
+        return off
+
+    ao = pack(ab, [len(a) for a in ab])
+    ro = pack(refs, [len(x) for x in refs])
+    so = pack(seqs, [len(x) for x in seqs])
+    oo = pack(ab, [2 * len(a) + 16 for a in ab])
+    abuf = np.frombuffer(b"".join(ab) + b"\0", dtype=np.uint8)
+    rbuf = np.concatenate(refs + [np.zeros(1, np.uint8)])
+    sbuf = np.concatenate(seqs + [np.zeros(1, np.uint8)])
+    out = np.zeros(int(oo[-1]) + 1, np.uint8)
+    olen = np.zeros(n, np.int64)
+    rc = lib.npore_standardize_batch(n, abuf.ctypes.data, ao.ctypes.data, rbuf.ctypes.data, ro.ctypes.data,
+                                     sbuf.ctypes.data, so.ctypes.data, out.ctypes.data, oo.ctypes.data,
+                                     olen.ctypes.data, threads)
+    if rc != 0:
+        raise RuntimeError(f"npore_standardize_batch: {rc} {_lib.last_error()}")
+    return [out[oo[i]:oo[i] + olen[i]].tobytes().decode() for i in range(n)]

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/npore_amd.h"
+#include "glue.hpp"
 #include "kernels.hpp"
 #include "prep_kernels.hpp"
 
@@ -600,6 +601,36 @@ int npore_ctx_set(npore_ctx *ctx, const char *key, int64_t value)
     else if (k == "host_threads") { /* accepted for compatibility: there is no host-side preparation any more */ }
     else return fail(NPORE_E_INVALID, "unknown key " + k);
     return NPORE_OK;
+}
+
+int npore_standardize_batch(int64_t n_reads, const char *alns, const int64_t *aln_off, const uint8_t *refs,
+                            const int64_t *ref_off, const uint8_t *seqs, const int64_t *seq_off, char *out,
+                            const int64_t *out_off, int64_t *out_len, int threads)
+{
+    if (n_reads < 0 || (n_reads > 0 && (!alns || !aln_off || !ref_off || !seq_off || !out || !out_off || !out_len)))
+        return fail(NPORE_E_INVALID, "null argument");
+    const int nt = threads > 0 ? threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    std::atomic<int64_t> next{0};
+    std::atomic<int> bad{0};
+    auto work = [&] {
+        for (;;) {
+            const int64_t i = next.fetch_add(1);
+            if (i >= n_reads) break;
+            const std::string c = standardize_collapsed(alns + aln_off[i], aln_off[i + 1] - aln_off[i],
+                                                        refs + ref_off[i], ref_off[i + 1] - ref_off[i],
+                                                        seqs + seq_off[i], seq_off[i + 1] - seq_off[i]);
+            if ((int64_t)c.size() > out_off[i + 1] - out_off[i]) { out_len[i] = -1; bad++; continue; }
+            std::memcpy(out + out_off[i], c.data(), c.size());
+            out_len[i] = (int64_t)c.size();
+        }
+    };
+    if (nt <= 1 || n_reads <= 1) work();
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < std::min<int64_t>(nt, n_reads); t++) pool.emplace_back(work);
+        for (auto &t : pool) t.join();
+    }
+    return bad ? fail(NPORE_E_INVALID, "output slot too small") : NPORE_OK;
 }
 
 // debug / self-test entries (used by tests -m gpu)

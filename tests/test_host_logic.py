@@ -81,6 +81,23 @@ def test_cigar_glue_golden():
         assert final == want[f[0]]["final_cigar"] == golden[f[0]]
 
 
+def test_cpp_glue_equals_python_glue(tables):
+    """npore_standardize_batch (C++) == cig.standardize + collapse_cigar (Python restatement) on the
+    golden reads and on oracle alignments of random reads (indels next to repeats)."""
+    import oracle
+    sub, nps = tables
+    alns, refs, seqs = [], [], []
+    for k in range(60):
+        ref, seq, c = synth.make_pair(31, k, 200 + 13 * k, 0.15, 0.6)
+        alns.append(oracle.align(ref, seq, c, sub, nps, r=10)); refs.append(ref); seqs.append(seq)
+    alns += ["", "IIII", "DDDD", "=" * 7]
+    refs += [np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.array([1, 1, 1, 1], np.uint8), np.array([1, 2, 3, 4, 1, 2, 3], np.uint8)]
+    seqs += [np.zeros(0, np.uint8), np.array([2, 2, 2, 2], np.uint8), np.zeros(0, np.uint8), np.array([1, 2, 3, 4, 1, 2, 3], np.uint8)]
+    want = [cig.collapse_cigar(cig.standardize(a, r_, s_)) for a, r_, s_ in zip(alns, refs, seqs)]
+    assert cig.standardize_batch(alns, refs, seqs) == want
+    assert cig.standardize_batch(alns, refs, seqs, threads=1) == want
+
+
 def test_bam_reader_equals_sam():
     """reads.bam decoded with zlib+struct == reads.sam field for field (pysam-free ingest)."""
     b = bam.BamFile(os.path.join(GOLDEN, "data", "reads.bam"))
