@@ -115,6 +115,7 @@ NPORE_HD int div_small(int run, int n)
 //   template<int K> void np_many(const int (&n_idx)[K], const int (&a)[K], const int (&b)[K],
 //                                const bool (&active)[K], float (&out)[K])
 //                                     out[k] = np_scores[n_idx][a][b] (a, b already clamped)
+//   float np_lds(int row, int call)       np_scores[row / 32][row % 32][call], row < 6*32, call < 64
 //   int   clamp()                                              max_l - 1 (see np_score_index below)
 //   int   refl(int j, int n_idx)                               L of local ref position j
 //   HistCell h_cell(int n, int col)        what the cell at band column col of
@@ -144,6 +145,39 @@ NPORE_HD bool step_is_plain(const StepInfo &st)
 {
     return (st.ins_l - st.r >= MAX_PERIOD) && (st.del_l - st.r >= MAX_PERIOD) &&
            (st.ins_l + st.r <= st.drows) && (st.del_l + st.r <= st.dcols);
+}
+
+// SHR candidate straight from a column descriptor whose repeat count is < 32 (all lanes;
+// wave-uniform precondition): then the score row is in the LDS table, the call length
+// L - k - 1 is < 32 too, and none of np_score's clamps can trigger -- only "call < 0 -> 100".
+template <int NG, bool FAST, class Env>
+NPORE_HD void shr_pass_small(const Env &env, const StepInfo &st, const CellIn (&in)[NG], const int (&jj)[NG],
+                             const uint32_t (&dsc)[NG], const bool (&act)[NG],
+                             float (&shrv)[NG], int (&shrrun)[NG], float (&shrstart)[NG])
+{
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int g = 0; g < NG; g++) {
+        const int nb = (int)(dsc[g] & 7u);
+        const int n = nb ? nb : 1;
+        const int dI = popc32(st.hist6 & ((1u << n) - 1u));
+        const int cx = in[g].c - dI;
+        const bool good = act[g] && (FAST || jj[g] - n >= 0) && (cx >= 1);
+        const bool start = (dsc[g] & 8u) != 0u;
+        const int L = (int)((dsc[g] >> 4) & 127u);
+        const HistCell h = env.h_cell(n, cx);
+        const float cstart = start ? h.matv : h.shrstart;             // :649 / :662
+        const int run = start ? 0 : (int)(h.runs >> 16);
+        const int call = L - (start ? 1 : div_small(run, n) + 1);     // L + indel, :650 / :663
+        const int row = (int)((dsc[g] >> 12) & 255u);                 // (n-1)*32 + L
+        const float score = env.np_lds(row, call < 0 ? 0 : call);
+        const float cand = cstart + (call < 0 ? 100.0f : score);
+        const bool take = good && (start || run > 0) && cand < shrv[g];
+        shrv[g] = take ? cand : shrv[g];
+        shrrun[g] = take ? run + n : shrrun[g];                        // :654 / :667
+        shrstart[g] = take ? cstart : shrstart[g];
+    }
 }
 
 // One SHR candidate per cell (pull form of src/aln.pyx:642-667): period nn[g] (>= 1),
@@ -260,32 +294,41 @@ NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in
             // the column's two highest periods come pre-decoded with the reference words
             // (evaluation order = the reference's: higher period first)
             int nn[NG], LL[NG];
-            bool startf[NG], act[NG], more = false, second = false;
+            uint32_t dsc[NG];
+            bool startf[NG], act[NG], more = false, second = false, bigL = false;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
             for (int g = 0; g < NG; g++) {
-                const uint32_t dsc = in[g].sc0;
                 act[g] = sm[g] != 0u;
-                nn[g] = act[g] ? (int)(dsc & 7u) : 1;
-                startf[g] = (dsc & 8u) != 0u;
-                LL[g] = (int)((dsc >> 4) & 127u);
+                dsc[g] = in[g].sc0;
                 second |= act[g] && (in[g].sc1 & 7u) != 0u;
                 more |= act[g] && (in[g].sc1 & 0x800u) != 0u;
+                bigL |= act[g] && (((in[g].sc0 | in[g].sc1) >> 20) & 1u) != 0u;
             }
-            shr_pass<NG, FAST>(env, st, in, jj, nn, LL, startf, act, shrv, shrrun, shrstart);
+            const bool small_l = !env.any(bigL);     // wave-uniform: every live descriptor has L < 32
+            auto decode = [&]() {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+                for (int g = 0; g < NG; g++) {
+                    nn[g] = act[g] ? (int)(dsc[g] & 7u) : 1;
+                    startf[g] = (dsc[g] & 8u) != 0u;
+                    LL[g] = (int)((dsc[g] >> 4) & 127u);
+                }
+            };
+            if (small_l) shr_pass_small<NG, FAST>(env, st, in, jj, dsc, act, shrv, shrrun, shrstart);
+            else { decode(); shr_pass<NG, FAST>(env, st, in, jj, nn, LL, startf, act, shrv, shrrun, shrstart); }
             if (env.any(second)) {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
                 for (int g = 0; g < NG; g++) {
-                    const uint32_t dsc = in[g].sc1;
-                    act[g] = (sm[g] != 0u) && (dsc & 7u) != 0u;
-                    nn[g] = act[g] ? (int)(dsc & 7u) : 1;
-                    startf[g] = (dsc & 8u) != 0u;
-                    LL[g] = (int)((dsc >> 4) & 127u);
+                    dsc[g] = in[g].sc1;
+                    act[g] = (sm[g] != 0u) && (dsc[g] & 7u) != 0u;
                 }
-                shr_pass<NG, FAST>(env, st, in, jj, nn, LL, startf, act, shrv, shrrun, shrstart);
+                if (small_l) shr_pass_small<NG, FAST>(env, st, in, jj, dsc, act, shrv, shrrun, shrstart);
+                else { decode(); shr_pass<NG, FAST>(env, st, in, jj, nn, LL, startf, act, shrv, shrrun, shrstart); }
             }
             if (env.any(more)) {     // rare: three or more periods in one column -> decode the rest generically
                 uint32_t rest[NG], pr = 0u;

@@ -112,6 +112,7 @@ struct DevEnv {
         return hist[__umul24((unsigned)s, (unsigned)hw) + colidx(col)];   // 24-bit multiply: full rate
     }
     __device__ __forceinline__ float sub(uint32_t s, uint32_t r) const { return lds_sub[s * 8 + r]; }
+    __device__ __forceinline__ float np_lds(int row, int call) const { return lds_np[(row << 6) + call]; }
     __device__ __forceinline__ int clamp() const { return clampv; }
     __device__ __forceinline__ int refl(int j, int n_idx) const { return win[(j & wmask) * 8 + n_idx]; }
     __device__ __forceinline__ bool any(bool x) const { return __builtin_amdgcn_ballot_w64(x) != 0ull; }

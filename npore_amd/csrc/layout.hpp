@@ -28,7 +28,8 @@
 //     bits 0-2 period n (0 = none), bit 3 "first copy" (start a deletion rather than
 //     continue one), bits 4-10 L of reference position j-n for that period;
 //     bit 11 of .w: the column has more than two candidate periods (rare; the rest is
-//     decoded from .y and the L window)
+//     decoded from .y and the L window);
+//     bits 12-19 (n-1)*32 + min(L,31): row of the LDS score table; bit 20: L >= 32 (row not in LDS)
 //   refl[j]  8 bytes: byte n-1 = L of reference position j for period n (0..max_l)
 //
 // n-polymer annotation follows get_np_info (reference src/aln.pyx:179-251) on the

@@ -34,6 +34,10 @@ struct ModelEnv {
         for (int k = 0; k < K; k++)
             out[k] = active[k] ? np_scores[((size_t)n_idx[k] * (max_l + 1) + a[k]) * (max_l + 1) + b[k]] : 0.0f;
     }
+    float np_lds(int row, int call) const
+    {
+        return np_scores[((size_t)(row / 32) * (max_l + 1) + row % 32) * (max_l + 1) + call];
+    }
     int clamp() const { return max_l - 1; }
     int refl_n;   // entries in refl_p
     int refl(int j, int n_idx) const { return (j >= 0 && j < refl_n) ? refl_p[(size_t)j * 8 + n_idx] : 0; }
