@@ -181,7 +181,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     if (slot_id >= *p.n_chunks) return;    // hardware barriers only count waves that are still alive
     ChunkDesc d = p.descs[uni(p.sched[slot_id])];
     d.brk = uni(d.brk); d.nrows = uni(d.nrows); d.row0 = uni(d.row0); d.col0 = uni(d.col0);
-    d.drows = uni(d.drows); d.dcols = uni(d.dcols);
+    d.drows = uni(d.drows); d.dcols = uni(d.dcols); d.plain_lo = uni(d.plain_lo); d.plain_hi = uni(d.plain_hi);
     d.steps_off = uni(d.steps_off); d.seqw_off = uni(d.seqw_off); d.refw_off = uni(d.refw_off); d.tb_off = uni(d.tb_off);
     const int r = p.r;
 
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
         }
 
         CellOut o[NG];
-        if (step_is_plain(st)) cells_update<NG, true>(env, st, in, o);    // wave-uniform: all but ~4r steps per chunk
+        if (bl >= d.plain_lo && bl < d.plain_hi) cells_update<NG, true>(env, st, in, o);    // == step_is_plain(st); all but ~4r steps
         else cells_update<NG, false>(env, st, in, o);
 
         uint32_t tbw[NG];
@@ -454,13 +454,16 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     };
 
     step(std::integral_constant<int, 0>{});
+    int left = 64;                         // steps left in stepmask
     for (int bl = 1; bl < d.nrows; bl++) {
-        const int k = bl - 1;              // step k leads from local row k to k+1
-        if ((k & 63) == 0 && k > 0) {
+        if (left == 0) {                   // step bl-1 leads from local row bl-1 to bl
             stepmask = nextmask;
-            nextmask = __builtin_amdgcn_ballot_w64(steps_g[k + 64 + lane] != 0);
+            nextmask = __builtin_amdgcn_ballot_w64(steps_g[bl - 1 + 64 + lane] != 0);
+            left = 64;
         }
-        const int I = (int)((stepmask >> (k & 63)) & 1ull);
+        const int I = (int)(stepmask & 1ull);
+        stepmask >>= 1;
+        left--;
         st.b_local = bl;
         st.ins_l += I;
         st.del_l = bl - st.ins_l;

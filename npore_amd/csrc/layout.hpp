@@ -67,6 +67,9 @@ struct alignas(16) ChunkDesc {
     int64_t out_off;    // byte offset of this chunk's output slot
     int64_t seq_off;    // byte offset of the READ's first base in the seqs buffer (for '='/'X')
     int64_t ref_off;    // byte offset of the READ's first reference base in the refs buffer
+    int32_t plain_lo;   // anti-diagonals [plain_lo, plain_hi) of the chunk are "plain" (cell.hpp,
+    int32_t plain_hi;   // step_is_plain): both conditions are monotone along the input path
+    int32_t pad_[2];
 };
 
 // traceback row stride (uint32 words) for band half-width r: 2r+1 rounded up to 4

@@ -201,6 +201,26 @@ __global__ __launch_bounds__(256) void make_chunks_kernel(PrepParams p)
     d.out_off = d.out_cap;
     d.seq_off = p.seq_off[rd];
     d.ref_off = p.ref_off[rd];
+    // plain range (cell.hpp step_is_plain): ins_l, del_l are non-decreasing in the local row b, so
+    //   ins_l - r >= 6 && del_l - r >= 6        holds from some row on,
+    //   ins_l + r <= drows && del_l + r <= dcols holds up to some row.
+    {
+        auto first_ge = [&](bool use_del, int target) {   // smallest b in [0,nrows] with value(b) >= target
+            int lo2 = 0, hi2 = d.nrows;
+            while (lo2 < hi2) {
+                const int mid = (lo2 + hi2) >> 1;
+                const int ins_l = inss[brk + mid] - d.row0;
+                const int v = use_del ? mid - ins_l : ins_l;
+                if (v >= target) hi2 = mid; else lo2 = mid + 1;
+            }
+            return lo2;
+        };
+        const int a1 = first_ge(false, p.r + 6), a2 = first_ge(true, p.r + 6);
+        const int b1 = first_ge(false, d.drows - p.r + 1), b2 = first_ge(true, d.dcols - p.r + 1);   // first row violating
+        d.plain_lo = a1 > a2 ? a1 : a2;
+        d.plain_hi = b1 < b2 ? b1 : b2;
+        d.pad_[0] = d.pad_[1] = 0;
+    }
     p.descs[k] = d;
     int key = p.max_b_rows + 1 - d.nrows;           // larger chunks first
     key = key < 0 ? 0 : key;

@@ -137,8 +137,8 @@ def test_device_prep_matches_host_twin(ctx):
     desc_dt = np.dtype([("read_id", "i4"), ("brk", "i4"), ("nrows", "i4"), ("row0", "i4"), ("col0", "i4"),
                         ("drows", "i4"), ("dcols", "i4"), ("out_cap", "i4"), ("steps_off", "i8"), ("inss_off", "i8"),
                         ("seqw_off", "i8"), ("refw_off", "i8"), ("tb_off", "i8"), ("out_off", "i8"), ("seq_off", "i8"),
-                        ("ref_off", "i8")])
-    assert desc_dt.itemsize == 96
+                        ("ref_off", "i8"), ("plain_lo", "i4"), ("plain_hi", "i4"), ("pad", "i4", 2)])
+    assert desc_dt.itemsize == 112
 
     def fetch(what, dtype, count):
         a = np.zeros(count, dtype)
@@ -159,6 +159,16 @@ def test_device_prep_matches_host_twin(ctx):
         d = fetch(2, desc_dt, nch)
         geom = np.stack([d[f] for f in ("brk", "nrows", "row0", "col0", "drows", "dcols", "out_cap")], axis=1)
         assert np.array_equal(geom, want["geom"])
+        # plain range == the per-step predicate of cell.hpp (step_is_plain), evaluated row by row
+        for q in range(nch):
+            ins = want["inss"][d["brk"][q]:d["brk"][q] + d["nrows"][q]] - d["row0"][q]
+            dl = np.arange(d["nrows"][q]) - ins
+            plain = (ins - 10 >= 6) & (dl - 10 >= 6) & (ins + 10 <= d["drows"][q]) & (dl + 10 <= d["dcols"][q])
+            idx = np.nonzero(plain)[0]
+            if len(idx):
+                assert (d["plain_lo"][q], d["plain_hi"][q]) == (idx[0], idx[-1] + 1) and plain[idx[0]:idx[-1] + 1].all()
+            else:
+                assert d["plain_lo"][q] >= d["plain_hi"][q]
         assert np.array_equal(fetch(3, np.uint32, len(want["seqw"])), want["seqw"])
         assert np.array_equal(fetch(4, np.uint32, want["refw"].size).reshape(-1, 4), want["refw"])
         got_l = fetch(5, np.uint8, want["refl"].size).reshape(-1, 8)
