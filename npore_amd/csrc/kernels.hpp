@@ -270,8 +270,12 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     // stepped 'I' (read words move one column up, "left" is the previous lane), 2: 'D'
     // (reference words move one column down, "top" is the next lane).  The whole body is
     // instantiated per mode so that no register shuffling is needed where the modes meet.
-    auto step = [&](auto mode_tag) __attribute__((always_inline)) {
+    auto step = [&](auto mode_tag, auto role_tag) __attribute__((always_inline)) {
         constexpr int MODE = decltype(mode_tag)::value;
+        // ROLE: 0 = only wave of the chunk, 1 = first, 2 = middle, 3 = last (compile-time so that the
+        // per-role code needs no joins inside the loop)
+        constexpr int ROLE = decltype(role_tag)::value;
+        constexpr bool IS_FIRST = (ROLE == 0 || ROLE == 1), IS_LAST = (ROLE == 0 || ROLE == 3);
         const int bl = st.b_local;
         if constexpr (NW > 1 && MODE != 0) {
             // Per-chunk hand-shake instead of a workgroup barrier: this wave may start anti-diagonal bl
@@ -281,8 +285,8 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
             for (;;) {
                 // relaxed workgroup-scope atomics keep these plain LDS reads (a volatile access would
                 // become a flat system-scope load with a vmcnt(0) wait)
-                const int a = (cw > 0) ? __hip_atomic_load(&prog[cw - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
-                const int b = (cw < NW - 1) ? __hip_atomic_load(&prog[cw + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
+                const int a = !IS_FIRST ? __hip_atomic_load(&prog[cw - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
+                const int b = !IS_LAST ? __hip_atomic_load(&prog[cw + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
                 if (uni((a < b ? a : b)) >= bl) break;
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
             float pm = lane_prev(matv[NG - 1]), pd = lane_prev(delv[NG - 1]);
             uint32_t pr = lane_prev(R2[NG - 1]);
             uint32_t ps = lane_prev(seqw[NG - 1]);
-            if (cw == 0) {
+            if constexpr (IS_FIRST) {
                 // word for row ins_l + r enters at column 0
                 if (st.ins_l + r - sq_base >= 64) {   // uniform
                     sq_base += 64;
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
                 }
                 const uint32_t incoming = (uint32_t)__builtin_amdgcn_readlane((int)seq_q, (st.ins_l + r - sq_base) & 63);
                 ps = (lane == 0) ? incoming : ps;
-            } else if constexpr (NW > 1) {
+            } else {
                 const uint32_t *xl = xin + (cw - 1) * XCH_WORDS;   // last cell of the wave below (broadcast reads)
                 const uint32_t x0 = xl[0], x1 = xl[1], x2 = xl[2], x3 = xl[3];
                 pm = (lane == 0) ? __uint_as_float(x0) : pm;
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
             uint32_t nr = lane_next(R1[0]);
             uint32_t nx = lane_next(refx[0]), ny = lane_next(refy[0]);
             uint32_t nc0 = lane_next(rc0[0]), nc1 = lane_next(rc1[0]);
-            if (cw == NW - 1) {
+            if constexpr (IS_LAST) {
                 // word for col del_l + WPT-1 - r enters at column WPT-1
                 if (st.del_l + WPT - 1 - r - rq_base >= 64) {
                     rq_base += 64;
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
                 ny = (lane == 63) ? iny : ny;
                 nc0 = (lane == 63) ? inz : nc0;
                 nc1 = (lane == 63) ? inw : nc1;
-            } else if constexpr (NW > 1) {
+            } else {
                 const uint32_t *xf = xin + (cw + 1) * XCH_WORDS + 5;   // first cell of the wave above
                 const uint32_t x0 = xf[0], x1 = xf[1], x2 = xf[2], x3 = xf[3], x4 = xf[4], x5 = xf[5], x6 = xf[6];
                 nm = (lane == 63) ? __uint_as_float(x0) : nm;
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
                 nc1 = (lane == 63) ? x6 : nc1;
             }
             if (st.del_l + r + 32 >= wfill) {   // keep the L window ahead of the band (32 positions of slack)
-                if (cw == NW - 1) {
+                if constexpr (IS_LAST) {
                     const int j = wfill + lane;
                     win[j & env.wmask] = (j <= d.dcols) ? refl_g[j] : make_uint2(0u, 0u);
                 }
@@ -453,25 +457,32 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
         }
     };
 
-    step(std::integral_constant<int, 0>{});
-    int left = 64;                         // steps left in stepmask
-    for (int bl = 1; bl < d.nrows; bl++) {
-        if (left == 0) {                   // step bl-1 leads from local row bl-1 to bl
-            stepmask = nextmask;
-            nextmask = __builtin_amdgcn_ballot_w64(steps_g[bl - 1 + 64 + lane] != 0);
-            left = 64;
+    auto run = [&](auto role_tag) __attribute__((always_inline)) {
+        step(std::integral_constant<int, 0>{}, role_tag);
+        int left = 64;                         // steps left in stepmask
+        for (int bl = 1; bl < d.nrows; bl++) {
+            if (left == 0) {                   // step bl-1 leads from local row bl-1 to bl
+                stepmask = nextmask;
+                nextmask = __builtin_amdgcn_ballot_w64(steps_g[bl - 1 + 64 + lane] != 0);
+                left = 64;
+            }
+            const int I = (int)(stepmask & 1ull);
+            stepmask >>= 1;
+            left--;
+            st.b_local = bl;
+            st.ins_l += I;
+            st.del_l = bl - st.ins_l;
+            st.hist6 = ((st.hist6 << 1) | (uint32_t)I) & 63u;
+            env.slot = (env.slot + 1 == NSR) ? 0 : env.slot + 1;
+            if (I) step(std::integral_constant<int, 1>{}, role_tag);
+            else step(std::integral_constant<int, 2>{}, role_tag);
         }
-        const int I = (int)(stepmask & 1ull);
-        stepmask >>= 1;
-        left--;
-        st.b_local = bl;
-        st.ins_l += I;
-        st.del_l = bl - st.ins_l;
-        st.hist6 = ((st.hist6 << 1) | (uint32_t)I) & 63u;
-        env.slot = (env.slot + 1 == NSR) ? 0 : env.slot + 1;
-        if (I) step(std::integral_constant<int, 1>{});
-        else step(std::integral_constant<int, 2>{});
-    }
+    };
+    // the wave's role within its chunk decides where annotation words and boundary cells come from
+    if constexpr (NW == 1) run(std::integral_constant<int, 0>{});
+    else if (cw == 0) run(std::integral_constant<int, 1>{});
+    else if (cw == NW - 1) run(std::integral_constant<int, 3>{});
+    else run(std::integral_constant<int, 2>{});
 }
 
 // ---------------------------------------------------------------------------
