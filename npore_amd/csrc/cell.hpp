@@ -223,7 +223,9 @@ NPORE_HD void shr_pass(const Env &env, const StepInfo &st, const CellIn (&in)[NG
     }
 }
 
-template <int NG, bool FAST, class Env>
+// EDGES = false: the caller patches the two band-edge cells itself (kernels.hpp patches only the
+// three values their one in-band neighbour reads).
+template <int NG, bool FAST, bool EDGES = true, class Env>
 NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in)[NG], CellOut (&o)[NG])
 {
     const int r2 = 2 * st.r;
@@ -440,7 +442,7 @@ NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in
             tr = t4 ? ((uint32_t)T_SHR | ((uint32_t)shrrun[g] << 3)) : tr;
         }
         // band edge, src/aln.pyx:502-507: all five states = 100*(b_row+1), TYP = MAT, RUN = 0
-        const bool edge = (c == 0) || (c == r2);
+        const bool edge = EDGES && ((c == 0) || (c == r2));
         const bool inrect = FAST || ((i >= 0) && (j >= 0) && (i <= st.drows) && (j <= st.dcols));
         const float e = (float)(100 * (st.b_local + 1));
         CellOut &q = o[g];

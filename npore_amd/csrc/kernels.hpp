@@ -265,6 +265,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     const int lpos = cw * 64 + lane;          // lane position across the chunk's waves
     const int tcol = col0w + lane * NG;       // first band column of this lane
     const bool hist_lane = lpos < p.lstr;     // columns beyond the band are never read back
+    const bool has_hi_edge = (2 * r >= col0w) && (2 * r < col0w + WPW);
 
     // One anti-diagonal.  MODE 0: first row of the chunk (no neighbours), 1: the input path
     // stepped 'I' (read words move one column up, "left" is the previous lane), 2: 'D'
@@ -402,8 +403,12 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
         }
 
         CellOut o[NG];
-        if (bl >= d.plain_lo && bl < d.plain_hi) cells_update<NG, true>(env, st, in, o);    // == step_is_plain(st); all but ~4r steps
-        else cells_update<NG, false>(env, st, in, o);
+        // band-edge cells (columns 0 and 2r; reference src/aln.pyx:502-507: every state = 100*(b_row+1),
+        // TYP = MAT, RUN = 0).  With one column per lane only three values of an edge cell are ever read
+        // (by its one in-band neighbour), so only those are patched below; the traceback kernel treats edge columns as "run 0" itself.
+        constexpr bool EDGE_PATCH = (NG == 1);
+        if (bl >= d.plain_lo && bl < d.plain_hi) cells_update<NG, true, !EDGE_PATCH>(env, st, in, o);    // == step_is_plain(st)
+        else cells_update<NG, false, !EDGE_PATCH>(env, st, in, o);
 
         uint32_t tbw[NG];
 #pragma unroll
@@ -415,6 +420,20 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
             delv[g] = o[g].delv;
             R1[g] = (uint32_t)o[g].matrun | ((uint32_t)o[g].insrun << 16);
             R2[g] = (uint32_t)o[g].matrun | ((uint32_t)o[g].delrun << 16);
+            if constexpr (EDGE_PATCH) {
+                const float e = (float)(100 * (bl + 1));
+                if constexpr (IS_FIRST) {      // column 0 is lane 0 of the first wave; read as a LEFT neighbour
+                    matv[0] = (lane == 0) ? e : matv[0];
+                    delv[0] = (lane == 0) ? e : delv[0];
+                    R2[0] = (lane == 0) ? 0u : R2[0];
+                }
+                if (has_hi_edge) {             // the wave holding column 2r (wave-uniform); read as a TOP neighbour
+                    const bool is_edge = (tcol == 2 * r);
+                    matv[0] = is_edge ? e : matv[0];
+                    insv[0] = is_edge ? e : insv[0];
+                    R1[0] = is_edge ? 0u : R1[0];
+                }
+            }
             // the row's spare last word carries inss[b] for the traceback
             tbw[g] = (tcol + g == p.tbstride - 1) ? (uint32_t)(d.row0 + st.ins_l) : o[g].tb;
             if (hist_lane)
@@ -544,7 +563,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(TParams p)
         if (!in_chunk(a_row, a_col)) { status |= 16; break; }
         const int bc = (int)word(stride - 1) - a_row + p.r;     // inss[b] - a_row + r, src/aln.pyx:322-326
         if (bc < 0 || bc >= W) { status |= 16; break; }
-        const uint32_t w = word(bc);
+        const uint32_t w = (bc == 0 || bc == W - 1) ? 0u : word(bc);   // band edge: TYP = MAT, RUN = 0 (src/aln.pyx:502-507)
         const int typ = (int)(w & 7u), run = (int)(w >> 3);     // src/aln.pyx:684-685
         if (run < 1) { status |= 4; break; }
         if (run > pos) { status |= 16; break; }
