@@ -273,8 +273,9 @@ NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in
         // "read position i-n inside one"; SHR needs "ref position j-n inside one"
         const bool interior = (c >= 1) && (c <= r2 - 1) &&
                               (FAST || ((i >= 0) && (j >= 0) && (i <= st.drows) && (j <= st.dcols)));
-        lm[g] = interior ? ((in[g].refx >> 18) & (in[g].seqw >> 18) & 63u) : 0u;
-        sm[g] = interior ? (in[g].sc0 & 7u) : 0u;      // period of the column's first SHR candidate (0 = none)
+        const uint32_t imask = interior ? 0xFFFFFFFFu : 0u;    // loop-invariant in the plain case
+        lm[g] = ((in[g].refx & in[g].seqw & imask) >> 18) & 63u;
+        sm[g] = in[g].sc0 & imask & 7u;                 // period of the column's first SHR candidate (0 = none)
         pend |= lm[g] | sm[g];
     }
 
@@ -427,6 +428,7 @@ NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in
         const float vdiag = in[g].diagM + env.sub((in[g].seqw >> 15) & 7u, (in[g].refx >> 24) & 7u);
         float v = diag_ok ? vdiag : delv[g] + 100.0f;     // else-branch: "ensure val1 isn't chosen"
         uint32_t tr = diag_ok ? ((uint32_t)T_MAT | ((uint32_t)(in[g].diagMrun + 1) << 3)) : (uint32_t)T_MAT;  // typ | run<<3
+        bool any_taken;
         {
             const bool t1 = insv[g] < v;
             v = t1 ? insv[g] : v;
@@ -440,6 +442,7 @@ NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in
             const bool t4 = shrv[g] < v;
             v = t4 ? shrv[g] : v;
             tr = t4 ? ((uint32_t)T_SHR | ((uint32_t)shrrun[g] << 3)) : tr;
+            any_taken = t1 || t2 || t3 || t4;
         }
         // band edge, src/aln.pyx:502-507: all five states = 100*(b_row+1), TYP = MAT, RUN = 0
         const bool edge = EDGES && ((c == 0) || (c == r2));
@@ -449,7 +452,8 @@ NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in
         q.matv = edge ? e : v;
         q.insv = edge ? e : insv[g];
         q.delv = edge ? e : delv[g];
-        q.matrun = (edge || (tr & 7u) != (uint32_t)T_MAT) ? 0 : (int)(tr >> 3);
+        // MAT.RUN while MAT.TYP == MAT (no INDEL state won), else 0 -- from the compare masks, not from tr
+        q.matrun = (edge || any_taken || !diag_ok) ? 0 : in[g].diagMrun + 1;
         q.insrun = edge ? 0 : insrun[g];
         q.delrun = edge ? 0 : delrun[g];
         q.lenstart = lenstart[g];
