@@ -203,6 +203,31 @@ def test_large_max_b_rows(ctx, tables):
         ctx.align_batch(refs, seqs, cigs, r=300)
 
 
+def test_groups_under_small_traceback_budget(tables):
+    """A batch whose traceback does not fit the budget is processed in several groups of reads
+    (work buffers reused); results and order are unchanged."""
+    sub, nps = tables
+    c = aln.Context(sub, nps, max_n=6, max_l=100, device=0)
+    refs, seqs, cigs = synth.make_batch(55, 40, ref_len=2500)
+    want = c.align_batch(refs, seqs, cigs, r=30)
+    c.set("tb_budget_mb", 8)            # ~ 5 reads of 2.5 kb at r=30 per group
+    got, st = c.align_batch(refs, seqs, cigs, r=30, return_status=True)
+    assert not st.any() and got == want
+    assert c.timing()["launches"] >= 4
+    for k in (0, 39):
+        assert got[k] == oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=30)
+    c.close()
+
+
+def test_widest_band(ctx, tables):
+    sub, nps = tables
+    refs, seqs, cigs = synth.make_batch(66, 3, ref_len=1200, p_np=0.1)
+    got, st = ctx.align_batch(refs, seqs, cigs, r=255, return_status=True)
+    assert not st.any()
+    for k in range(3):
+        assert got[k] == oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=255)
+
+
 def test_div_small_domain():
     """The device's float-reciprocal division is exact on its whole domain."""
     lib = _lib.load()
