@@ -15,6 +15,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Build what the tests load (the in-tree gfx950 library, the oracle, the cell model) when a
+    compiler is around; on the GPU box the prebuilt files travel with the snapshot."""
+    import shutil
+    if shutil.which("hipcc"):
+        from npore_amd import _lib
+        try:
+            _lib.build()
+        except Exception as e:          # the tests that need it will fail loudly themselves
+            print(f"conftest: building libnpore_amd.so failed: {e}", file=sys.stderr)
+    if shutil.which("gcc"):
+        import oracle
+        oracle.build()
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        from model import model
+        model.build()
+
+
 @pytest.fixture(scope="session")
 def tables():
     """G1: score tables as produced by the reference's calc_score_matrices."""
