@@ -157,8 +157,13 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     float *lds_np = lds;
     float *lds_sub = lds + MAX_PERIOD * NP_LT * NP_CT;
     const int wave = uni((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int cw = wave % NW;             // wave within the chunk
-    const int cg = wave / NW;             // chunk within the workgroup
+    // Role-major numbering: consecutive waves (which the hardware deals round-robin over the CU's four
+    // SIMDs) belong to DIFFERENT chunks, so that each SIMD hosts a mix of roles -- the last wave of a
+    // chunk usually has few live columns (r=100: 9 of 64) and would otherwise leave one SIMD idle
+    // while the other three carry all the full waves.
+    const int cpg = (int)(blockDim.x >> 6) / NW;   // chunks per workgroup
+    const int cw = wave / cpg;            // wave within the chunk
+    const int cg = wave % cpg;            // chunk within the workgroup
     const int hw = NG * p.lstr;
     float *chunk_lds = lds_sub + 64 + (size_t)cg * (4 * NSR * hw + 2 * p.rwin + (NW > 1 ? 2 * NW * XCH_WORDS + 8 : 0));
     HistCell *hist = reinterpret_cast<HistCell *>(chunk_lds);
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
                                    ? p.sub_scores[(threadIdx.x >> 3) * 5 + (threadIdx.x & 7)] : 0.0f;
     __syncthreads();
 
-    const int slot_id = blockIdx.x * ((blockDim.x >> 6) / NW) + cg;
+    const int slot_id = blockIdx.x * cpg + cg;
     if (slot_id >= *p.n_chunks) return;    // hardware barriers only count waves that are still alive
     ChunkDesc d = p.descs[uni(p.sched[slot_id])];
     d.brk = uni(d.brk); d.nrows = uni(d.nrows); d.row0 = uni(d.row0); d.col0 = uni(d.col0);
