@@ -21,11 +21,18 @@
 //
 // SIMT shape.  A lane rarely has more than one or two live candidates, but which
 // period n is live differs from lane to lane, so instead of twelve
-// (n, LEN/SHR) blocks the candidates are consumed by a loop in which every lane
-// takes its own highest remaining n (per-lane n), for LEN and SHR and for all NG
-// cells of the lane at once, branch-free inside the loop so that the LDS reads
-// of the 2*NG evaluations overlap.  The loop runs max-over-lanes(#candidates)
-// times (wave-uniform `any`).
+// (n, LEN/SHR) blocks the candidates are consumed in passes in which every lane
+// takes its own highest remaining n (per-lane n); a pass is skipped when no lane
+// of the wave has a candidate left (wave-uniform `any`).  Everything that depends
+// only on (n, anti-diagonal) -- where the source row sits in the history ring and
+// how far the band moved -- is a per-step table indexed by the lane's n
+// (Env::step_tables; one ds_bpermute per use on the device).
+//
+// History convention.  "No candidate can come from here" is stored in the history
+// itself instead of being tested per candidate: records outside band columns
+// 1..2r-1 (the band edges and HIST_PAD pad records either side of a row) are
+// never written and hold MAT.VAL = +inf, and a cell that is not inside a LEN (SHR)
+// run stores lenstart (shrstart) = +inf; an infinite candidate never wins a strict '<'.
 //
 // Arithmetic is IEEE fp32: one add per candidate, strict '<' compares, in the
 // reference's order.  No FMA contraction is possible (adds only).
@@ -33,12 +40,6 @@
 #include <stdint.h>
 
 #include "layout.hpp"
-
-#if defined(__HIPCC__)
-#define NPORE_HD __host__ __device__ __forceinline__
-#else
-#define NPORE_HD inline
-#endif
 
 namespace npore {
 
@@ -61,14 +62,14 @@ struct CellIn {
     float diagM;           // MAT.VAL of (a_row-1, a_col-1)
     int topIrun, leftDrun; // INS.RUN / DEL.RUN of those
     int diagMrun;          // MAT.RUN of the diagonal cell if its MAT.TYP == MAT else 0
-    uint32_t seqw, refx, refy;
+    uint32_t seqw, refx;
     uint32_t sc0, sc1;     // refw.z/.w: pre-decoded SHR candidates of this column (layout.hpp)
     int c;                 // band column 0..2r
 };
 
 struct CellOut {
     float matv, insv, delv;
-    float lenstart, shrstart;  // MAT.VAL at the start of the current LEN / SHR run
+    float lenstart, shrstart;  // MAT.VAL at the start of the current LEN / SHR run (+inf outside a run)
     int matrun;                // MAT.RUN if MAT.TYP == MAT else 0
     int insrun, delrun;
     int lenrun_h, shrrun_h;    // LEN.RUN / SHR.RUN as later "continue" moves may use them
@@ -78,10 +79,13 @@ struct CellOut {
 // What later LEN/SHR "start"/"continue" moves need from a finished cell.
 struct alignas(16) HistCell {
     float matv;       // MAT.VAL
-    float lenstart;   // MAT.VAL at the start of its LEN run
-    float shrstart;   // MAT.VAL at the start of its SHR run
-    uint32_t runs;    // LEN.RUN | SHR.RUN << 16 (0 where a continue must not happen)
+    float lenstart;   // MAT.VAL at the start of its LEN run, +inf if it is in none
+    float shrstart;   // MAT.VAL at the start of its SHR run, +inf if it is in none
+    uint32_t runs;    // LEN.RUN | SHR.RUN << 16
 };
+
+NPORE_HD float huge_f() { return __builtin_inff(); }
+NPORE_HD HistCell hist_none() { return HistCell{huge_f(), huge_f(), huge_f(), 0u}; }
 
 NPORE_HD int popc32(uint32_t x)
 {
@@ -91,36 +95,60 @@ NPORE_HD int popc32(uint32_t x)
     return __builtin_popcount(x);
 #endif
 }
-NPORE_HD int top_bit(uint32_t m)   // 1-based index of the highest set bit, 0 if none
+// 0-based index of the highest set bit; 32 if m == 0 (v_ffbh_u32 returns -1 for 0, and the
+// plain instruction is wanted here, not a clz with a zero fix-up)
+NPORE_HD int top_index(uint32_t m)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return 32 - __clz((int)m);
+    int lead;
+    asm("v_ffbh_u32 %0, %1" : "=v"(lead) : "v"(m));
+    return 31 - lead;
 #else
-    return m ? 32 - __builtin_clz(m) : 0;
+    return m ? 31 - __builtin_clz(m) : 32;
 #endif
 }
-// run / n for 0 <= run < 65536, 1 <= n <= 6.  On the device a float reciprocal
-// plus a bias is exact on that domain (checked exhaustively by the GPU tests).
-NPORE_HD int div_small(int run, int n)
+// keep the low `width & 31` bits (v_bfe_u32)
+NPORE_HD uint32_t low_bits(uint32_t x, int width)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return (int)((float)run * __builtin_amdgcn_rcpf((float)n) + 0.03f);   // v_rcp_f32: 1 ulp
+    return __builtin_amdgcn_ubfe(x, 0u, (uint32_t)width);
 #else
-    return run / n;
+    return x & ((1u << (width & 31)) - 1u);
+#endif
+}
+
+// run / n by a 16.16 reciprocal (RECIP16[n] = ceil(65536 / n)): exact for run < 13107; beyond
+// that the estimate is q or q + 1 with q >= 2184, far above every length clamp of np_score, so
+// the two are indistinguishable to the recurrence (checked exhaustively by the GPU tests).
+NPORE_HD uint32_t recip16(int n) { return n ? (65536u + (uint32_t)n - 1u) / (uint32_t)n : 0u; }
+NPORE_HD int div_recip(int run, uint32_t m)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)((uint32_t)__umul24((unsigned)run, m) >> 16);   // run < 2^16, m <= 2^16: fits 32 bits
+#else
+    return (int)(((uint64_t)(uint32_t)run * m) >> 16);
 #endif
 }
 
 // Env supplies (all const, all inlined):
 //   float sub(uint32_t seq_base, uint32_t ref_base)            sub_scores[s][r]
-//   template<int K> void np_many(const int (&n_idx)[K], const int (&a)[K], const int (&b)[K],
-//                                const bool (&active)[K], float (&out)[K])
-//                                     out[k] = np_scores[n_idx][a][b] (a, b already clamped)
-//   float np_lds(int row, int call)       np_scores[row / 32][row % 32][call], row < 6*32, call < 64
+//   float np_full(int n_idx, int a, int b, bool active)        np_scores[n_idx][a][b] (a, b already clamped)
+//   float np_small(uint32_t dsc, int q)     np_score(L, -(q+1)) for a descriptor with L < NP_LT:
+//                                           np_scores[n-1][L][L-1-q], or INF_F if that call length is < 0
 //   int   clamp()                                              max_l - 1 (see np_score_index below)
 //   int   refl(int j, int n_idx)                               L of local ref position j
-//   HistCell h_cell(int n, int col)        what the cell at band column col of
-//                                          anti-diagonal b-n left behind
-//   bool  any(bool)                        wave-level "any lane" (identity on the host)
+//   uint32_t refy(int j)                                       refw[j].y, 0 outside the chunk's columns
+//   Tab   step_tables(const StepInfo &)     whatever the lookups below need per anti-diagonal
+//   HistCell h_shr(Tab, uint32_t n4, int c) what the cell (i, j-n) left behind: band column
+//                                           c - (inss[b]-inss[b-n]) of anti-diagonal b-n   (n4 = 4n)
+//   HistCell h_len(Tab, uint32_t n4, int c) likewise (i-n, j): column c + n - (inss[b]-inss[b-n])
+//   uint32_t recip(Tab, uint32_t n4)        RECIP16[n]
+//   int   mer_shift(Tab, uint32_t n4)       3*(MAX_PERIOD-n)
+//   uint32_t mer_mask(Tab, uint32_t n4)     (1 << 3n) - 1
+//   bool  any(bool), any2(bool a, bool b)   wave-level "any lane" of x / of a && b (identity on the host)
+// Lanes without a candidate call these with n4 = 0 (or, in the LEN filter, 4*33) and ignore the result.
+// The table lookups are cross-lane reads on the device: call them where all lanes are active
+// (never behind a per-lane `&&` / `?:`).
 
 // np_score, reference src/aln.pyx:257-274, split into index formation and lookup.
 // Callers pass max_l where the signature says max_n, so lengths clamp to max_l-1
@@ -147,322 +175,205 @@ NPORE_HD bool step_is_plain(const StepInfo &st)
            (st.ins_l + st.r <= st.drows) && (st.del_l + st.r <= st.dcols);
 }
 
-// SHR candidate straight from a column descriptor whose repeat count is < 32 (all lanes;
-// wave-uniform precondition): then the score row is in the LDS table, the call length
-// L - k - 1 is < 32 too, and none of np_score's clamps can trigger -- only "call < 0 -> 100".
-template <int NG, bool FAST, class Env>
-NPORE_HD void shr_pass_small(const Env &env, const StepInfo &st, const CellIn (&in)[NG], const int (&jj)[NG],
-                             const uint32_t (&dsc)[NG], const bool (&act)[NG],
-                             float (&shrv)[NG], int (&shrrun)[NG], float (&shrstart)[NG])
+// SHR candidate straight from a column descriptor whose repeat count is < NP_LT (all lanes;
+// wave-uniform precondition): the score comes from the LDS table at an address the
+// descriptor already holds, minus the number of copies deleted so far (src/aln.pyx:642-667).
+template <bool FAST, class Env, class Tab>
+NPORE_HD void shr_small(const Env &env, const Tab &tab, const CellIn &in, int j, uint32_t dsc, bool act,
+                        float &shrv, int &shrrun, float &shrstart)
 {
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-    for (int g = 0; g < NG; g++) {
-        const int nb = (int)(dsc[g] & 7u);
-        const int n = nb ? nb : 1;
-        const int dI = popc32(st.hist6 & ((1u << n) - 1u));
-        const int cx = in[g].c - dI;
-        const bool good = act[g] && (FAST || jj[g] - n >= 0) && (cx >= 1);
-        const bool start = (dsc[g] & 8u) != 0u;
-        const int L = (int)((dsc[g] >> 4) & 127u);
-        const HistCell h = env.h_cell(n, cx);
-        const float cstart = start ? h.matv : h.shrstart;             // :649 / :662
-        const int run = start ? 0 : (int)(h.runs >> 16);
-        const int call = L - (start ? 1 : div_small(run, n) + 1);     // L + indel, :650 / :663
-        const int row = (int)((dsc[g] >> 12) & 255u);                 // (n-1)*32 + L
-        const float score = env.np_lds(row, call < 0 ? 0 : call);
-        const float cand = cstart + (call < 0 ? 100.0f : score);
-        const bool take = good && (start || run > 0) && cand < shrv[g];
-        shrv[g] = take ? cand : shrv[g];
-        shrrun[g] = take ? run + n : shrrun[g];                        // :654 / :667
-        shrstart[g] = take ? cstart : shrstart[g];
-    }
+    const uint32_t n4 = dsc & DSC_N4;
+    const int n = (int)(n4 >> 2);
+    const HistCell h = env.h_shr(tab, n4, in.c);
+    const bool start = (dsc & DSC_START) != 0u;
+    const float cstart = start ? h.matv : h.shrstart;                 // :649 / :662
+    const int run = start ? 0 : (int)(h.runs >> 16);
+    const int q = div_recip(run, env.recip(tab, n4));                 // indel = -(q + 1), :650 / :663
+    const float cand = cstart + env.np_small(dsc, q);
+    const bool take = act && (FAST || j - n >= 0) && cand < shrv;
+    shrv = take ? cand : shrv;
+    shrrun = take ? run + n : shrrun;                                  // :654 / :667
+    shrstart = take ? cstart : shrstart;
 }
 
-// One SHR candidate per cell (pull form of src/aln.pyx:642-667): period nn[g] (>= 1),
-// repeat count LL[g] of reference position j-n, start-vs-continue, and whether the cell
-// has such a candidate at all.  X = (i, j-n) sits at band column c - dI of anti-diagonal b-n.
-template <int NG, bool FAST, class Env>
-NPORE_HD void shr_pass(const Env &env, const StepInfo &st, const CellIn (&in)[NG], const int (&jj)[NG],
-                       const int (&nn)[NG], const int (&LL)[NG], const bool (&startf)[NG], const bool (&act)[NG],
-                       float (&shrv)[NG], int (&shrrun)[NG], float (&shrstart)[NG])
+// One SHR candidate of period n (n4 = 4n; 0 = this cell has none), repeat count L of reference
+// position j-n, any L (pull form of src/aln.pyx:642-667).
+template <bool FAST, class Env, class Tab>
+NPORE_HD void shr_generic(const Env &env, const Tab &tab, const CellIn &in, int j, uint32_t n4, int L, bool start,
+                          bool act, float &shrv, int &shrrun, float &shrstart)
 {
-    const int clampv = env.clamp();
-    int nidx[NG], ta[NG], tb_[NG], crun[NG];
-    bool ok[NG], inval[NG];
-    float cstart[NG], score[NG];
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-    for (int g = 0; g < NG; g++) {
-        const int n = nn[g];
-        const int dI = popc32(st.hist6 & ((1u << n) - 1u));
-        const int cx = in[g].c - dI;
-        const bool good = act[g] && (FAST || jj[g] - n >= 0) && (cx >= 1);
-        // (lanes that are not `good` read some in-LDS garbage below and ignore it)
-        const HistCell h = env.h_cell(n, cx);
-        cstart[g] = startf[g] ? h.matv : h.shrstart;                  // :649 / :662
-        const int run = startf[g] ? 0 : (int)(h.runs >> 16);
-        const int indel = startf[g] ? -1 : -div_small(run, n) - 1;   // :650 / :663
-        inval[g] = np_score_index(clampv, LL[g], indel, ta[g], tb_[g]);
-        nidx[g] = n - 1;
-        crun[g] = run + n;                                            // :654 / :667
-        ok[g] = good && (startf[g] || run > 0);
-    }
-    env.template np_many<NG>(nidx, ta, tb_, ok, score);
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-    for (int g = 0; g < NG; g++) {
-        const float cand = cstart[g] + (inval[g] ? 100.0f : score[g]);
-        const bool take = ok[g] && cand < shrv[g];
-        shrv[g] = take ? cand : shrv[g];
-        shrrun[g] = take ? crun[g] : shrrun[g];
-        shrstart[g] = take ? cstart[g] : shrstart[g];
-    }
+    const int n = (int)(n4 >> 2);
+    const HistCell h = env.h_shr(tab, n4, in.c);
+    const float cstart = start ? h.matv : h.shrstart;
+    const int run = start ? 0 : (int)(h.runs >> 16);
+    const int indel = -div_recip(run, env.recip(tab, n4)) - 1;
+    int a, call;
+    const bool inval = np_score_index(env.clamp(), L, indel, a, call);
+    const bool ok = act && (FAST || j - n >= 0);
+    const float score = env.np_full(n ? n - 1 : 0, a, call, ok);
+    const float cand = cstart + (inval ? INF_F : score);
+    const bool take = ok && cand < shrv;
+    shrv = take ? cand : shrv;
+    shrrun = take ? run + n : shrrun;
+    shrstart = take ? cstart : shrstart;
 }
 
 // EDGES = false: the caller patches the two band-edge cells itself (kernels.hpp patches only the
 // three values their one in-band neighbour reads).
-template <int NG, bool FAST, bool EDGES = true, class Env>
-NPORE_HD void cells_update(const Env &env, const StepInfo &st, const CellIn (&in)[NG], CellOut (&o)[NG])
+template <bool FAST, bool EDGES = true, class Env>
+NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, CellOut &q)
 {
     const int r2 = 2 * st.r;
-    float insv[NG], delv[NG], lenv[NG], shrv[NG], lenstart[NG], shrstart[NG];
-    int insrun[NG], delrun[NG], lenrun[NG], shrrun[NG], ii[NG], jj[NG];
-    uint32_t lm[NG], sm[NG];
+    const int c = in.c;
+    const int i = st.ins_l + st.r - c;   // local a_row
+    const int j = st.del_l - st.r + c;   // local a_col
     const float init = (float)(100 * st.b_local);    // src/aln.pyx:473,476
-    uint32_t pend = 0;
-
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-    for (int g = 0; g < NG; g++) {
-        const int c = in[g].c;
-        const int i = st.ins_l + st.r - c;   // local a_row
-        const int j = st.del_l - st.r + c;   // local a_col
-        ii[g] = i;
-        jj[g] = j;
-        // ---- INS, src/aln.pyx:525-543 (branch-free: selects only)
-        {
-            const float v1 = in[g].topM + st.indel_start;
-            const float v2 = in[g].topI + st.indel_extend;
-            const bool ext = v2 < v1;
-            const int erun = (!FAST && i == 1) ? 1 : in[g].topIrun + 1;
-            const float v = ext ? v2 : v1;
-            const int rr = ext ? erun : 1;
-            insv[g] = (!FAST && i == 0) ? (float)(100 * (j + 1)) : v;
-            insrun[g] = (!FAST && i == 0) ? j : rr;
-        }
-        // ---- DEL, src/aln.pyx:547-565
-        {
-            const float v1 = in[g].leftM + st.indel_start;
-            const float v2 = in[g].leftD + st.indel_extend;
-            const bool ext = v2 < v1;
-            const int erun = (!FAST && j == 1) ? 1 : in[g].leftDrun + 1;
-            const float v = ext ? v2 : v1;
-            const int rr = ext ? erun : 1;
-            delv[g] = (!FAST && j == 0) ? (float)(100 * (i + 1)) : v;
-            delrun[g] = (!FAST && j == 0) ? i : rr;
-        }
-        lenv[g] = shrv[g] = init;
-        lenstart[g] = shrstart[g] = 0.0f;
-        lenrun[g] = shrrun[g] = 0;
-        // candidate periods: LEN needs "ref position j starts an n-polymer" and
-        // "read position i-n inside one"; SHR needs "ref position j-n inside one"
-        const bool interior = (c >= 1) && (c <= r2 - 1) &&
-                              (FAST || ((i >= 0) && (j >= 0) && (i <= st.drows) && (j <= st.dcols)));
-        const uint32_t imask = interior ? 0xFFFFFFFFu : 0u;    // loop-invariant in the plain case
-        lm[g] = ((in[g].refx & in[g].seqw & imask) >> 18) & 63u;
-        sm[g] = in[g].sc0 & imask & 7u;                 // period of the column's first SHR candidate (0 = none)
-        pend |= lm[g] | sm[g];
+    float insv, delv;
+    int insrun, delrun;
+    // ---- INS, src/aln.pyx:525-543 (branch-free: selects only)
+    {
+        const float v1 = in.topM + st.indel_start;
+        const float v2 = in.topI + st.indel_extend;
+        const bool ext = v2 < v1;
+        const int erun = (!FAST && i == 1) ? 1 : in.topIrun + 1;
+        const float v = ext ? v2 : v1;
+        const int rr = ext ? erun : 1;
+        insv = (!FAST && i == 0) ? (float)(100 * (j + 1)) : v;
+        insrun = (!FAST && i == 0) ? j : rr;
     }
+    // ---- DEL, src/aln.pyx:547-565
+    {
+        const float v1 = in.leftM + st.indel_start;
+        const float v2 = in.leftD + st.indel_extend;
+        const bool ext = v2 < v1;
+        const int erun = (!FAST && j == 1) ? 1 : in.leftDrun + 1;
+        const float v = ext ? v2 : v1;
+        const int rr = ext ? erun : 1;
+        delv = (!FAST && j == 0) ? (float)(100 * (i + 1)) : v;
+        delrun = (!FAST && j == 0) ? i : rr;
+    }
+    float lenv = init, shrv = init, lenstart = huge_f(), shrstart = huge_f();
+    int lenrun = 0, shrrun = 0;
+    // candidate periods: LEN needs "ref position j starts an n-polymer" and
+    // "read position i-n inside one"; SHR needs "ref position j-n inside one"
+    const bool interior = (c >= 1) && (c <= r2 - 1) &&
+                          (FAST || ((i >= 0) && (j >= 0) && (i <= st.drows) && (j <= st.dcols)));
+    const uint32_t imask = interior ? 0xFFFFFFFFu : 0u;    // loop-invariant in the plain case
+    uint32_t lm = ((in.refx & in.seqw & imask) >> 18) & 63u;
+    const uint32_t sm = in.sc0 & imask & DSC_N4;            // 4 * period of the column's first SHR candidate
 
     // ---- LEN / SHR candidates (pull form of src/aln.pyx:601-633, 642-667)
-    // SHR of cell g comes from X = (i, j-n) at band column c - dI; LEN from
+    // SHR of a cell comes from X = (i, j-n) at band column c - dI; LEN from
     // X = (i-n, j) at band column c + (n - dI), dI = inss[b] - inss[b-n].
     // SHR candidates are dense inside reference n-polymers, LEN candidates are rare
     // (they also need the read to repeat the same unit), so each has its own loop.
-    const int clampv = env.clamp();
-    (void)clampv;
-    if (env.any(pend != 0u)) {
-        uint32_t pendS = 0u, pendL = 0u;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-        for (int g = 0; g < NG; g++) { pendS |= sm[g]; pendL |= lm[g]; }
-
-        if (env.any(pendS != 0u)) {
+    if (env.any((lm | sm) != 0u)) {
+        const auto tab = env.step_tables(st);
+        if (env.any(sm != 0u)) {
             // the column's two highest periods come pre-decoded with the reference words
             // (evaluation order = the reference's: higher period first)
-            int nn[NG], LL[NG];
-            uint32_t dsc[NG];
-            bool startf[NG], act[NG], more = false, second = false, bigL = false;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-            for (int g = 0; g < NG; g++) {
-                act[g] = sm[g] != 0u;
-                dsc[g] = in[g].sc0;
-                second |= act[g] && (in[g].sc1 & 7u) != 0u;
-                more |= act[g] && (in[g].sc1 & 0x800u) != 0u;
-                bigL |= act[g] && (((in[g].sc0 | in[g].sc1) >> 20) & 1u) != 0u;
-            }
-            const bool small_l = !env.any(bigL);     // wave-uniform: every live descriptor has L < 32
-            auto decode = [&]() {
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-                for (int g = 0; g < NG; g++) {
-                    nn[g] = act[g] ? (int)(dsc[g] & 7u) : 1;
-                    startf[g] = (dsc[g] & 8u) != 0u;
-                    LL[g] = (int)((dsc[g] >> 4) & 127u);
+            // (any2(a, b) = any(a && b) from two separate lane masks: a ballot of a compound condition
+            // would first be rebuilt as a 0/1 vector and compared again)
+            const bool act = sm != 0u;
+            const bool has2 = (in.sc1 & DSC_N4) != 0u, act2 = act && has2;
+            const bool rare1 = ((in.sc0 | in.sc1) & (DSC_BIGL | DSC_MORE)) != 0u;
+            if (!env.any2(act, rare1)) {
+                shr_small<FAST>(env, tab, in, j, in.sc0, act, shrv, shrrun, shrstart);
+                if (env.any2(act, has2)) shr_small<FAST>(env, tab, in, j, in.sc1, act2, shrv, shrrun, shrstart);
+            } else {
+                // a long n-polymer (L >= NP_LT) or three or more periods in one column somewhere in the wave
+                shr_generic<FAST>(env, tab, in, j, in.sc0 & DSC_N4, (int)((in.sc0 >> 8) & 127u),
+                                  (in.sc0 & DSC_START) != 0u, act, shrv, shrrun, shrstart);
+                if (env.any2(act, has2))
+                    shr_generic<FAST>(env, tab, in, j, in.sc1 & DSC_N4, (int)((in.sc1 >> 8) & 127u),
+                                      (in.sc1 & DSC_START) != 0u, act2, shrv, shrrun, shrstart);
+                const bool more = act2 && (in.sc1 & DSC_MORE) != 0u;
+                if (env.any(more)) {
+                const uint32_t ry = env.refy(j);      // refw[j].y (layout.hpp); not carried through the lanes
+                const uint32_t done = (1u << ((in.sc0 >> 2) & 7u)) | (1u << ((in.sc1 >> 2) & 7u));   // bit n
+                uint32_t rest = more ? ((ry & 63u) << 1) & ~done : 0u;                                // bit n
+                while (env.any(rest != 0u)) {
+                    const bool a3 = rest != 0u;
+                    const int n = a3 ? top_index(rest) : 0;
+                    rest &= ~(1u << n);
+                    const bool startf = ((ry >> ((6 + n - 1) & 31)) & 1u) != 0u;
+                    const int L = env.refl(j - n, n ? n - 1 : 0);
+                    shr_generic<FAST>(env, tab, in, j, (uint32_t)n << 2, L, startf, a3, shrv, shrrun, shrstart);
                 }
-            };
-            if (small_l) shr_pass_small<NG, FAST>(env, st, in, jj, dsc, act, shrv, shrrun, shrstart);
-            else { decode(); shr_pass<NG, FAST>(env, st, in, jj, nn, LL, startf, act, shrv, shrrun, shrstart); }
-            if (env.any(second)) {
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-                for (int g = 0; g < NG; g++) {
-                    dsc[g] = in[g].sc1;
-                    act[g] = (sm[g] != 0u) && (dsc[g] & 7u) != 0u;
-                }
-                if (small_l) shr_pass_small<NG, FAST>(env, st, in, jj, dsc, act, shrv, shrrun, shrstart);
-                else { decode(); shr_pass<NG, FAST>(env, st, in, jj, nn, LL, startf, act, shrv, shrrun, shrstart); }
-            }
-            if (env.any(more)) {     // rare: three or more periods in one column -> decode the rest generically
-                uint32_t rest[NG], pr = 0u;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-                for (int g = 0; g < NG; g++) {
-                    const uint32_t done = (1u << ((in[g].sc0 & 7u) - 1u)) | (1u << ((in[g].sc1 & 7u) - 1u));
-                    rest[g] = (sm[g] != 0u && (in[g].sc1 & 0x800u)) ? (in[g].refy & 63u & ~done) : 0u;
-                    pr |= rest[g];
-                }
-                while (env.any(pr != 0u)) {
-                    pr = 0u;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-                    for (int g = 0; g < NG; g++) {
-                        const int nb = top_bit(rest[g]);
-                        act[g] = nb != 0;
-                        nn[g] = nb ? nb : 1;
-                        rest[g] &= ~(1u << (nn[g] - 1));
-                        pr |= rest[g];
-                        startf[g] = ((in[g].refy >> (6 + nn[g] - 1)) & 1u) != 0u;
-                        LL[g] = env.refl(jj[g] - nn[g], nn[g] - 1);
-                    }
-                    shr_pass<NG, FAST>(env, st, in, jj, nn, LL, startf, act, shrv, shrrun, shrstart);
                 }
             }
         }
 
-        while (env.any(pendL != 0u)) {
-            pendL = 0u;
-            int nn[NG], cxx[NG];
-            bool good[NG], anygood = false;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-            for (int g = 0; g < NG; g++) {
-                const int c = in[g].c;
-                const int nb = top_bit(lm[g]);
-                const int n = nb ? nb : 1;
-                lm[g] &= ~(1u << (n - 1));
-                pendL |= lm[g];
-                const int dI = popc32(st.hist6 & ((1u << n) - 1u));
-                const int cx = c + (n - dI);
-                const uint32_t smer = (in[g].seqw & 0x3FFFFu) >> (3 * (MAX_PERIOD - n));
-                const uint32_t rmer = in[g].refx & ((1u << (3 * n)) - 1u);
-                good[g] = (nb != 0) && (FAST || ii[g] - n >= 0) && (cx <= r2 - 1) && (smer == rmer);   // match(), :606-607
-                nn[g] = n;
-                cxx[g] = cx;
-                anygood |= good[g];
-            }
-            if (!env.any(anygood)) continue;
-            int nidx[NG], ta[NG], tb_[NG], crun[NG];
-            bool ok[NG], inval[NG];
-            float cstart[NG], score[NG];
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-            for (int g = 0; g < NG; g++) {
-                const int n = nn[g];
-                const bool start = ((in[g].seqw >> (24 + n - 1)) & 1u) != 0u;
-                const int L = env.refl(jj[g], n - 1);
-                const HistCell h = env.h_cell(n, cxx[g]);
-                cstart[g] = start ? h.matv : h.lenstart;                  // :614 / :628
-                const int run = start ? 0 : (int)(h.runs & 0xFFFFu);
-                const int indel = start ? 1 : div_small(run, n) + 1;     // :615 / :629
-                inval[g] = np_score_index(clampv, L, indel, ta[g], tb_[g]);
-                nidx[g] = n - 1;
-                crun[g] = run + n;                                        // :619 / :633
-                ok[g] = good[g] && (start || run > 0);
-            }
-            env.template np_many<NG>(nidx, ta, tb_, ok, score);
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-            for (int g = 0; g < NG; g++) {
-                const float cand = cstart[g] + (inval[g] ? 100.0f : score[g]);
-                const bool take = ok[g] && cand < lenv[g];
-                lenv[g] = take ? cand : lenv[g];
-                lenrun[g] = take ? crun[g] : lenrun[g];
-                lenstart[g] = take ? cstart[g] : lenstart[g];
-            }
+        const uint32_t s18 = in.seqw & 0x3FFFFu;
+        while (env.any(lm != 0u)) {
+            const bool valid = lm != 0u;
+            const int nm1 = top_index(lm);                 // period - 1 (32 if this lane has none left)
+            lm = low_bits(lm, nm1);
+            const uint32_t n4 = (uint32_t)(nm1 + 1) << 2;  // (4*33 where none: tables are 8-periodic)
+            // both lookups BEFORE any per-lane condition: on the device they read other lanes' registers,
+            // which only works while every lane of the wave is executing
+            const uint32_t smer = s18 >> env.mer_shift(tab, n4);
+            const uint32_t mmask = env.mer_mask(tab, n4);
+            const bool match = ((smer ^ in.refx) & mmask) == 0u;                                  // match(), :606-607
+            const bool inside = FAST || i - (nm1 + 1) >= 0;
+            const bool good = valid && inside && match;
+            if (!(FAST ? env.any2(valid, match) : env.any(good))) continue;
+            const int n = nm1 + 1;
+            const bool start = ((in.seqw >> ((24 + nm1) & 31)) & 1u) != 0u;
+            const int L = env.refl(j, nm1 & 7);
+            const HistCell h = env.h_len(tab, n4, c);
+            const float cstart = start ? h.matv : h.lenstart;                  // :614 / :628
+            const int run = start ? 0 : (int)(h.runs & 0xFFFFu);
+            const int indel = div_recip(run, env.recip(tab, n4)) + 1;          // :615 / :629
+            int a, call;
+            const bool inval = np_score_index(env.clamp(), L, indel, a, call);
+            const float score = env.np_full(nm1 & 7, a, call, good);
+            const float cand = cstart + (inval ? INF_F : score);
+            const bool take = good && cand < lenv;
+            lenv = take ? cand : lenv;
+            lenrun = take ? run + n : lenrun;                                  // :619 / :633
+            lenstart = take ? cstart : lenstart;
         }
     }
 
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-    for (int g = 0; g < NG; g++) {
-        const int c = in[g].c, i = ii[g], j = jj[g];
-        // ---- MAT, src/aln.pyx:569-592 (selects; candidate order INS, LEN, DEL, SHR, strict '<')
-        const bool diag_ok = FAST || ((i > 0) && (j > 0));
-        const float vdiag = in[g].diagM + env.sub((in[g].seqw >> 15) & 7u, (in[g].refx >> 24) & 7u);
-        float v = diag_ok ? vdiag : delv[g] + 100.0f;     // else-branch: "ensure val1 isn't chosen"
-        uint32_t tr = diag_ok ? ((uint32_t)T_MAT | ((uint32_t)(in[g].diagMrun + 1) << 3)) : (uint32_t)T_MAT;  // typ | run<<3
-        bool any_taken;
-        {
-            const bool t1 = insv[g] < v;
-            v = t1 ? insv[g] : v;
-            tr = t1 ? ((uint32_t)T_INS | ((uint32_t)insrun[g] << 3)) : tr;
-            const bool t2 = lenv[g] < v;
-            v = t2 ? lenv[g] : v;
-            tr = t2 ? ((uint32_t)T_LEN | ((uint32_t)lenrun[g] << 3)) : tr;
-            const bool t3 = delv[g] < v;
-            v = t3 ? delv[g] : v;
-            tr = t3 ? ((uint32_t)T_DEL | ((uint32_t)delrun[g] << 3)) : tr;
-            const bool t4 = shrv[g] < v;
-            v = t4 ? shrv[g] : v;
-            tr = t4 ? ((uint32_t)T_SHR | ((uint32_t)shrrun[g] << 3)) : tr;
-            any_taken = t1 || t2 || t3 || t4;
-        }
-        // band edge, src/aln.pyx:502-507: all five states = 100*(b_row+1), TYP = MAT, RUN = 0
-        const bool edge = EDGES && ((c == 0) || (c == r2));
-        const bool inrect = FAST || ((i >= 0) && (j >= 0) && (i <= st.drows) && (j <= st.dcols));
-        const float e = (float)(100 * (st.b_local + 1));
-        CellOut &q = o[g];
-        q.matv = edge ? e : v;
-        q.insv = edge ? e : insv[g];
-        q.delv = edge ? e : delv[g];
-        // MAT.RUN while MAT.TYP == MAT (no INDEL state won), else 0 -- from the compare masks, not from tr
-        q.matrun = (edge || any_taken || !diag_ok) ? 0 : in[g].diagMrun + 1;
-        q.insrun = edge ? 0 : insrun[g];
-        q.delrun = edge ? 0 : delrun[g];
-        q.lenstart = lenstart[g];
-        q.shrstart = shrstart[g];
-        q.lenrun_h = (edge || (!FAST && i == 0)) ? 0 : lenrun[g];   // src/aln.pyx:596-599 leaves RUN = j, never usable
-        q.shrrun_h = (edge || (!FAST && j == 0)) ? 0 : shrrun[g];   // src/aln.pyx:637-640 likewise
-        // cells outside the chunk rectangle are never read by cells inside it
-        q.tb = (edge || !inrect) ? 0u : tr;
-    }
+    // ---- MAT, src/aln.pyx:569-592 (selects; candidate order INS, LEN, DEL, SHR, strict '<')
+    const bool diag_ok = FAST || ((i > 0) && (j > 0));
+    const float vdiag = in.diagM + env.sub((in.seqw >> 15) & 7u, (in.refx >> 24) & 7u);
+    float v = diag_ok ? vdiag : delv + 100.0f;     // else-branch: "ensure val1 isn't chosen"
+    uint32_t tr = diag_ok ? ((uint32_t)T_MAT | ((uint32_t)(in.diagMrun + 1) << 3)) : (uint32_t)T_MAT;  // typ | run<<3
+    const bool t1 = insv < v;
+    v = t1 ? insv : v;
+    tr = t1 ? ((uint32_t)T_INS | ((uint32_t)insrun << 3)) : tr;
+    const bool t2 = lenv < v;
+    v = t2 ? lenv : v;
+    tr = t2 ? ((uint32_t)T_LEN | ((uint32_t)lenrun << 3)) : tr;
+    const bool t3 = delv < v;
+    v = t3 ? delv : v;
+    tr = t3 ? ((uint32_t)T_DEL | ((uint32_t)delrun << 3)) : tr;
+    const bool t4 = shrv < v;
+    v = t4 ? shrv : v;
+    tr = t4 ? ((uint32_t)T_SHR | ((uint32_t)shrrun << 3)) : tr;
+    const bool any_taken = t1 || t2 || t3 || t4;
+    // band edge, src/aln.pyx:502-507: all five states = 100*(b_row+1), TYP = MAT, RUN = 0
+    const bool edge = EDGES && ((c == 0) || (c == r2));
+    const bool inrect = FAST || ((i >= 0) && (j >= 0) && (i <= st.drows) && (j <= st.dcols));
+    const float e = (float)(100 * (st.b_local + 1));
+    q.matv = edge ? e : v;
+    q.insv = edge ? e : insv;
+    q.delv = edge ? e : delv;
+    // MAT.RUN while MAT.TYP == MAT (no INDEL state won), else 0 -- from the compare masks, not from tr
+    q.matrun = (edge || any_taken || !diag_ok) ? 0 : in.diagMrun + 1;
+    q.insrun = edge ? 0 : insrun;
+    q.delrun = edge ? 0 : delrun;
+    // src/aln.pyx:596-599 / :637-640 leave RUN = j / i on the first row / column, which no continue
+    // move can use: such a cell is "in no run" for its successors
+    const bool no_len = !FAST && i == 0, no_shr = !FAST && j == 0;
+    q.lenstart = no_len ? huge_f() : lenstart;
+    q.shrstart = no_shr ? huge_f() : shrstart;
+    q.lenrun_h = no_len ? 0 : lenrun;
+    q.shrrun_h = no_shr ? 0 : shrrun;
+    // cells outside the chunk rectangle are never read by cells inside it
+    q.tb = (edge || !inrect) ? 0u : tr;
 }
 
 }  // namespace npore

@@ -1,20 +1,19 @@
 // kernels.hpp -- gfx950 (CDNA4, wave64) kernels of the realignment path.
 //
-//   fill_kernel<NG>   one wavefront per chunk.  Band column c of the current
-//                     anti-diagonal lives in lane c / NG, register slot c % NG
-//                     (NG consecutive columns per lane), so "column +-1" is a
-//                     register rename inside a lane and one DPP wave shift at the
-//                     lane boundary.  Per step (anti-diagonal) each cell needs its
+//   fill_kernel<NW>   NW wavefronts per chunk, band column c of the current
+//                     anti-diagonal in lane c % 64 of wave c / 64, so "column +-1"
+//                     is one DPP wave shift (and one LDS exchange record where two
+//                     waves meet).  Per step (anti-diagonal) each cell needs its
 //                     top / left / diagonal neighbours (previous two
 //                     anti-diagonals: registers) and, for the n-polymer LEN/SHR
 //                     states, values from up to 6 anti-diagonals back (LDS ring of
-//                     NS rows).  The read/reference annotation words travel
+//                     NSR rows).  The read/reference annotation words travel
 //                     through the lanes systolically: an 'I' step of the input
 //                     path shifts the read words one column up, a 'D' step shifts
 //                     the reference words one column down; the word entering at
 //                     the band edge comes from a 64-entry per-wave queue register.
 //                     The only per-cell HBM traffic is one 32-bit traceback word.
-//   traceback_kernel  one lane per chunk: follows MAT.TYP/MAT.RUN words
+//   traceback_kernel  one wavefront per chunk: follows MAT.TYP/MAT.RUN words
 //                     (reference src/aln.pyx:670-742), writes ops right-aligned
 //                     into the chunk's output slot.
 //   gather_kernel     one workgroup per read: concatenates its chunks' op
@@ -29,9 +28,9 @@
 
 namespace npore {
 
-constexpr int NP_LT = 32;  // LDS copy of np_scores covers ref length < NP_LT ...
-constexpr int NP_CT = 64;  // ... and call length < NP_CT (powers of two: shifts and masks); else global memory
-constexpr int XCH_WORDS = 12;   // 0-4 last cell, 5-11 first cell   // per wave, per parity: boundary cells handed to the neighbour waves
+static_assert(NP_LT == NP_CT - NP_C0 && (NP_LT & (NP_LT - 1)) == 0, "np_full's range test");
+constexpr int XCH_WORDS = 12;   // per wave, per parity: boundary cells handed to the neighbour waves
+                                // (words 0-3 last cell, 5-10 first cell)
 
 // history ring rows.  One wave per chunk: row b overwrites row b-6 after this wave
 // has read it (LDS ops of a wave are in order).  Several waves per chunk: a wave may
@@ -54,19 +53,19 @@ struct KParams {
     int max_n, max_l;
     int r;
     int tbstride;
-    int lstr;               // history row stride per column group: ceil((2r+1)/NG)
+    int hw;                 // history records per ring row: 2r+1 columns + HIST_PAD
     int rwin;               // reference-L window entries (power of two)
     float indel_start, indel_extend;
 };
 
 // LDS floats: shared score tables + per chunk (history ring, reference-L window, exchange)
-static inline size_t chunk_lds_floats(int nw, int ng, int lstr, int rwin)
+static inline size_t chunk_lds_floats(int nw, int hw, int rwin)
 {
-    return (size_t)4 * ring_rows(nw) * ng * lstr + 2 * (size_t)rwin + (nw > 1 ? 2 * nw * XCH_WORDS + 8 : 0);
+    return (size_t)4 * (ring_rows(nw) * hw + HIST_PAD) + 2 * (size_t)rwin + (nw > 1 ? 2 * nw * XCH_WORDS + 8 : 0);
 }
-static inline size_t fill_lds_floats(int nw, int ng, int chunks, int lstr, int rwin)
+static inline size_t fill_lds_floats(int nw, int chunks, int hw, int rwin)
 {
-    return (size_t)MAX_PERIOD * NP_LT * NP_CT + 64 + (size_t)chunks * chunk_lds_floats(nw, ng, lstr, rwin);
+    return (size_t)MAX_PERIOD * NP_LT * NP_CT + 64 + (size_t)chunks * chunk_lds_floats(nw, hw, rwin);
 }
 
 // value of the previous / next lane (lane 0 / 63 get 0)
@@ -90,69 +89,94 @@ __device__ __forceinline__ int64_t uni(int64_t v)
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
+// per-lane lookup in a table spread over the lanes of a register: lane l reads tab[lane addr4/4]
+__device__ __forceinline__ uint32_t lane_table(uint32_t addr4, uint32_t tab)
+{
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)addr4, (int)tab);
+}
 
-template <int NG, int NSR>
+template <int NSR>
 struct DevEnv {
     const float *lds_sub;     // [8][8] padded copy of sub_scores
-    const float *lds_np;      // [6][NP_LT][NP_CT]
+    const char *lds_np;       // [6][NP_LT][NP_CT] floats (layout.hpp)
     const float *g_np;        // full table in global memory
     const uint8_t *win;       // LDS window of reference L bytes, 8 per position
-    const HistCell *hist;     // LDS: [NSR][hw] 16-byte records
-    int np_dim, clampv, slot, lstr, hw, wmask;
+    const char *hist_c;       // LDS: this lane's own band column in ring row 0
+    const uint4 *refw_g;      // the chunk's reference words (rare re-reads)
+    int np_dim, clampv, slot, hw16, wmask, dcols;
+    // tables over n, spread over the lanes: lane l holds the entry of n = l & 7
+    uint32_t t_n, t_low, t_recip, t_msh, t_mmask;
 
-    __device__ __forceinline__ int colidx(int col) const
+    struct Tab { uint32_t e; };   // lane l: byte offset from "own column, ring row 0" to column c - dI of row b-n, n = l & 7
+    __device__ __forceinline__ Tab step_tables(const StepInfo &st) const
     {
-        if constexpr (NG == 1) return col;
-        else return (col % NG) * lstr + col / NG;
+        const uint32_t dI = (uint32_t)__popc(st.hist6 & t_low);
+        const uint32_t t = (uint32_t)slot - t_n;            // row of anti-diagonal b-n in the ring
+        const uint32_t row = min(t, t + (uint32_t)NSR);     // (slot - n) mod NSR for slot - n >= -NSR
+        return Tab{__umul24(row, (uint32_t)hw16) - (dI << 4)};
     }
-    __device__ __forceinline__ HistCell h_cell(int n, int col) const
+    __device__ __forceinline__ HistCell h_shr(const Tab &tab, uint32_t n4, int) const
     {
-        int s = slot - n;
-        s += (s < 0) ? NSR : 0;
-        return hist[__umul24((unsigned)s, (unsigned)hw) + colidx(col)];   // 24-bit multiply: full rate
+        return *reinterpret_cast<const HistCell *>(hist_c + (int)lane_table(n4, tab.e));
     }
+    __device__ __forceinline__ HistCell h_len(const Tab &tab, uint32_t n4, int) const
+    {
+        return *reinterpret_cast<const HistCell *>(hist_c + (int)(lane_table(n4, tab.e) + (n4 << 2)));
+    }
+    __device__ __forceinline__ uint32_t recip(const Tab &, uint32_t n4) const { return lane_table(n4, t_recip); }
+    __device__ __forceinline__ int mer_shift(const Tab &, uint32_t n4) const { return (int)lane_table(n4, t_msh); }
+    __device__ __forceinline__ uint32_t mer_mask(const Tab &, uint32_t n4) const { return lane_table(n4, t_mmask); }
     __device__ __forceinline__ float sub(uint32_t s, uint32_t r) const { return lds_sub[s * 8 + r]; }
-    __device__ __forceinline__ float np_lds(int row, int call) const { return lds_np[(row << 6) + call]; }
+    __device__ __forceinline__ float np_small(uint32_t dsc, int q) const
+    {
+        const uint32_t a = (dsc >> 15) & 0xFFFFu;
+        return *reinterpret_cast<const float *>(lds_np + (a - 4u * (uint32_t)min(q, NP_C0)));
+    }
     __device__ __forceinline__ int clamp() const { return clampv; }
     __device__ __forceinline__ int refl(int j, int n_idx) const { return win[(j & wmask) * 8 + n_idx]; }
+    __device__ __forceinline__ uint32_t refy(int j) const
+    {
+        uint32_t y = 0u;
+        if (j >= 0 && j <= dcols) {
+            y = refw_g[j].y;
+            asm volatile("" : "+v"(y));   // wait for it inside this rare branch (see np_full)
+        }
+        return y;
+    }
     __device__ __forceinline__ bool any(bool x) const { return __builtin_amdgcn_ballot_w64(x) != 0ull; }
-    template <int K>
-    __device__ __forceinline__ void np_many(const int (&n_idx)[K], const int (&a)[K], const int (&b)[K],
-                                            const bool (&active)[K], float (&out)[K]) const
+    __device__ __forceinline__ bool any2(bool a, bool b) const
+    {
+        return (__builtin_amdgcn_ballot_w64(a) & __builtin_amdgcn_ballot_w64(b)) != 0ull;
+    }
+    __device__ __forceinline__ float np_full(int n_idx, int a, int b, bool active) const
     {
         // Always an LDS read (ds_read); lengths beyond the LDS copy are rare and patched
         // from global memory under a wave-uniform branch.  (Selecting between an LDS and a
         // global *pointer* would turn every lookup into a flat load, whose completion
         // wait also drains the outstanding traceback stores.)
-        bool oot[K], anyoot = false;
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            oot[k] = active[k] && (((unsigned)a[k] >= (unsigned)NP_LT) || ((unsigned)b[k] >= (unsigned)NP_CT));
-            anyoot |= oot[k];
-            out[k] = lds_np[((n_idx[k] * NP_LT + (a[k] & (NP_LT - 1))) << 6) + (b[k] & (NP_CT - 1))];
-            asm volatile("" : "+v"(out[k]));   // keep this a ds_read: do not fold it with the global load below
+        const bool big = (unsigned)(a | b) >= (unsigned)NP_LT;     // a, b >= 0 and NP_LT == NP_CT - NP_C0 is a power of two
+        const bool oot = active && big;
+        float out = reinterpret_cast<const float *>(lds_np)[((n_idx * NP_LT + (a & (NP_LT - 1))) * NP_CT) + NP_C0 +
+                                                            (b & (NP_CT - NP_C0 - 1))];
+        asm volatile("" : "+v"(out));   // keep this a ds_read: do not fold it with the global load below
+        if (any2(active, big)) {
+            if (oot) {
+                out = g_np[((size_t)n_idx * np_dim + a) * np_dim + b];
+                // consume the value HERE: otherwise the compiler parks its s_waitcnt vmcnt(0) at the
+                // join below, where it would run on every pass and drain the traceback stores
+                asm volatile("" : "+v"(out));
+            }
         }
-        static_assert(NP_CT == 64, "index uses << 6");
-        if (__builtin_amdgcn_ballot_w64(anyoot) != 0ull) {
-#pragma unroll
-            for (int k = 0; k < K; k++)
-                if (oot[k]) {
-                    out[k] = g_np[((size_t)n_idx[k] * np_dim + a[k]) * np_dim + b[k]];
-                    // consume the value HERE: otherwise the compiler parks its s_waitcnt vmcnt(0) at the
-                    // join below, where it would run on every pass and drain the traceback stores
-                    asm volatile("" : "+v"(out[k]));
-                }
-        }
+        return out;
     }
 };
 
-// NW waves per chunk (each owns 64*NG consecutive band columns), NG columns per lane.
-template <int NW, int NG, int MAXT>
+// NW waves per chunk, each owning 64 consecutive band columns.
+template <int NW, int MAXT>
 __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
 {
     constexpr int NSR = ring_rows(NW);
-    constexpr int WPW = 64 * NG;          // columns per wave
-    constexpr int WPT = NW * WPW;         // physical columns per chunk
+    constexpr int WPT = NW * 64;          // physical columns per chunk
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *lds_np = lds;
     float *lds_sub = lds + MAX_PERIOD * NP_LT * NP_CT;
@@ -164,18 +188,19 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     const int cpg = (int)(blockDim.x >> 6) / NW;   // chunks per workgroup
     const int cw = wave / cpg;            // wave within the chunk
     const int cg = wave % cpg;            // chunk within the workgroup
-    const int hw = NG * p.lstr;
-    float *chunk_lds = lds_sub + 64 + (size_t)cg * (4 * NSR * hw + 2 * p.rwin + (NW > 1 ? 2 * NW * XCH_WORDS + 8 : 0));
-    HistCell *hist = reinterpret_cast<HistCell *>(chunk_lds);
-    uint2 *win = reinterpret_cast<uint2 *>(chunk_lds + 4 * NSR * hw);
-    uint32_t *xchg = reinterpret_cast<uint32_t *>(chunk_lds + 4 * NSR * hw + 2 * p.rwin);   // [2][NW][XCH_WORDS]
+    const int hw = p.hw;
+    float *chunk_lds = lds_sub + 64 + (size_t)cg * (4 * (NSR * hw + HIST_PAD) + 2 * p.rwin + (NW > 1 ? 2 * NW * XCH_WORDS + 8 : 0));
+    HistCell *hist = reinterpret_cast<HistCell *>(chunk_lds) + HIST_PAD;     // row 0, column 0
+    uint2 *win = reinterpret_cast<uint2 *>(chunk_lds + 4 * (NSR * hw + HIST_PAD));
+    uint32_t *xchg = reinterpret_cast<uint32_t *>(chunk_lds + 4 * (NSR * hw + HIST_PAD) + 2 * p.rwin);   // [2][NW][XCH_WORDS]
     int *prog = reinterpret_cast<int *>(xchg + 2 * NW * XCH_WORDS);          // [NW] anti-diagonals completed
 
     // workgroup-shared tables
     const int np_dim = p.max_l + 1;
     for (int idx = threadIdx.x; idx < MAX_PERIOD * NP_LT * NP_CT; idx += blockDim.x) {
-        const int n = idx / (NP_LT * NP_CT), a = (idx / NP_CT) % NP_LT, b = idx % NP_CT;
-        lds_np[idx] = (n < p.max_n && a < np_dim && b < np_dim) ? p.np_scores[((size_t)n * np_dim + a) * np_dim + b] : 0.0f;
+        const int n = idx / (NP_LT * NP_CT), a = (idx / NP_CT) % NP_LT, b = idx % NP_CT - NP_C0;
+        lds_np[idx] = b < 0 ? INF_F
+                            : (n < p.max_n && a < np_dim && b < np_dim) ? p.np_scores[((size_t)n * np_dim + a) * np_dim + b] : 0.0f;
     }
     if (threadIdx.x < 64)
         lds_sub[threadIdx.x] = ((threadIdx.x >> 3) < 5 && (threadIdx.x & 7) < 5)
@@ -189,43 +214,49 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     d.drows = uni(d.drows); d.dcols = uni(d.dcols); d.plain_lo = uni(d.plain_lo); d.plain_hi = uni(d.plain_hi);
     d.steps_off = uni(d.steps_off); d.seqw_off = uni(d.seqw_off); d.refw_off = uni(d.refw_off); d.tb_off = uni(d.tb_off);
     const int r = p.r;
-
-    DevEnv<NG, NSR> env;
-    env.lds_sub = lds_sub;
-    env.lds_np = lds_np;
-    env.g_np = p.np_scores;
-    env.win = reinterpret_cast<const uint8_t *>(win);
-    env.hist = hist;
-    env.np_dim = np_dim;
-    env.clampv = p.max_l - 1;
-    env.slot = 0;
-    env.lstr = p.lstr;
-    env.hw = hw;
-    env.wmask = p.rwin - 1;
+    const int lpos = cw * 64 + lane;          // band column of this lane
+    const int tcol = lpos;
 
     const uint32_t *seqw_g = p.seqw + d.seqw_off;
     const uint4 *refw_g = p.refw + d.refw_off;
     const uint2 *refl_g = p.refl + d.refw_off;
     const uint8_t *steps_g = p.steps + d.steps_off + d.brk;   // steps_g[k] = step from local row k to k+1
     uint32_t *tb_g = p.tb + d.tb_off;
-    const int col0w = cw * WPW;           // first column of this wave
+
+    DevEnv<NSR> env;
+    env.lds_sub = lds_sub;
+    env.lds_np = reinterpret_cast<const char *>(lds_np);
+    env.g_np = p.np_scores;
+    env.win = reinterpret_cast<const uint8_t *>(win);
+    env.hist_c = reinterpret_cast<const char *>(hist + tcol);
+    env.refw_g = refw_g;
+    env.np_dim = np_dim;
+    env.clampv = p.max_l - 1;
+    env.slot = 0;
+    env.hw16 = hw * 16;
+    env.wmask = p.rwin - 1;
+    env.dcols = d.dcols;
+    {
+        const int nl = lane & 7;
+        env.t_n = (uint32_t)nl;
+        env.t_low = (1u << nl) - 1u;
+        env.t_recip = recip16(nl);
+        env.t_msh = nl <= MAX_PERIOD ? 3u * (uint32_t)(MAX_PERIOD - nl) : 0u;
+        env.t_mmask = (1u << (3 * nl)) - 1u;
+    }
 
     // per-cell state of the previous anti-diagonal
-    float matv[NG], insv[NG], delv[NG], LMv[NG], TMv[NG];
-    uint32_t R1[NG], R2[NG], LT[NG];   // matrun|insrun<<16, matrun|delrun<<16, LMrun|TMrun<<16
-    uint32_t seqw[NG], refx[NG], refy[NG], rc0[NG], rc1[NG];
-#pragma unroll
-    for (int g = 0; g < NG; g++) {
-        matv[g] = insv[g] = delv[g] = LMv[g] = TMv[g] = 0.0f;
-        R1[g] = R2[g] = LT[g] = 0u;
-        const int col = col0w + lane * NG + g;
-        const int i = r - col, j = col - r;
-        seqw[g] = (i >= 0 && i <= d.drows) ? seqw_g[i] : SEQW_SENTINEL;
+    float matv = 0.0f, insv = 0.0f, delv = 0.0f, LMv = 0.0f, TMv = 0.0f;
+    uint32_t R1 = 0u, R2 = 0u;      // matrun|insrun<<16, matrun|delrun<<16
+    uint32_t LMr = 0u, TMr = 0u;    // low half: MAT.RUN of the left / top neighbour of the previous step
+    uint32_t seqw, refx, rc0, rc1;
+    {
+        const int i = r - tcol, j = tcol - r;
+        seqw = (i >= 0 && i <= d.drows) ? seqw_g[i] : SEQW_SENTINEL;
         uint4 rw = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint4(REFW_SENTINEL, 0u, 0u, 0u);
-        refx[g] = rw.x;
-        refy[g] = rw.y;
-        rc0[g] = rw.z;
-        rc1[g] = rw.w;
+        refx = rw.x;
+        rc0 = rw.z;
+        rc1 = rw.w;
     }
     // queues of words that will enter at column 0 (read; first wave) / column WPT-1 (reference; last wave)
     int sq_base = r + 1;              // next read index entering at column 0 is ins_l + r
@@ -249,6 +280,9 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
         }
         wfill += 64;
     }
+    // history: every record starts as "no candidate can come from here" (cell.hpp); the band edges and
+    // the pad records either side of a row stay that way
+    for (int k = lpos - HIST_PAD; k < NSR * hw; k += WPT) hist[k] = hist_none();
     if constexpr (NW > 1) {
         if (lane == 0) prog[cw] = 0;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -267,10 +301,9 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     // input-path steps, 64 per coalesced load, one block prefetched (the buffer is padded)
     unsigned long long stepmask = __builtin_amdgcn_ballot_w64(steps_g[lane] != 0);
     unsigned long long nextmask = __builtin_amdgcn_ballot_w64(steps_g[64 + lane] != 0);
-    const int lpos = cw * 64 + lane;          // lane position across the chunk's waves
-    const int tcol = col0w + lane * NG;       // first band column of this lane
-    const bool hist_lane = lpos < p.lstr;     // columns beyond the band are never read back
-    const bool has_hi_edge = (2 * r >= col0w) && (2 * r < col0w + WPW);
+    const bool hist_lane = (tcol >= 1) && (tcol <= 2 * r - 1);     // band-interior columns leave history
+    const bool tb_lane = tcol <= 2 * r;
+    const uint32_t tcol4 = (uint32_t)tcol * 4u;
 
     // One anti-diagonal.  MODE 0: first row of the chunk (no neighbours), 1: the input path
     // stepped 'I' (read words move one column up, "left" is the previous lane), 2: 'D'
@@ -299,74 +332,74 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
             asm volatile("" ::: "memory");
         }
         // boundary cells written by the neighbour waves at the end of the previous step
-        const uint32_t *xin = xchg + ((bl + 1) & 1) * (NW * XCH_WORDS);
-        CellIn in[NG];
+        // (the record addresses are wave-uniform; pinning each in ONE vector register lets every word
+        // use an immediate offset instead of its own scalar-to-vector move)
+        const int xin = ((bl + 1) & 1) * (NW * XCH_WORDS);
+        CellIn in;
         if constexpr (MODE == 1) {
-            float pm = lane_prev(matv[NG - 1]), pd = lane_prev(delv[NG - 1]);
-            uint32_t pr = lane_prev(R2[NG - 1]);
-            uint32_t ps = lane_prev(seqw[NG - 1]);
+            float pm = lane_prev(matv), pd = lane_prev(delv);
+            uint32_t pr = lane_prev(R2);
+            uint32_t ps = lane_prev(seqw);
             if constexpr (IS_FIRST) {
                 // word for row ins_l + r enters at column 0
                 if (st.ins_l + r - sq_base >= 64) {   // uniform
                     sq_base += 64;
                     const int i = sq_base + lane;
                     seq_q = (i <= d.drows) ? seqw_g[i] : SEQW_SENTINEL;
-                    asm volatile("" : "+v"(seq_q));   // wait for the reload inside this rare branch (see np_many)
+                    asm volatile("" : "+v"(seq_q));   // wait for the reload inside this rare branch (see np_full)
                 }
                 const uint32_t incoming = (uint32_t)__builtin_amdgcn_readlane((int)seq_q, (st.ins_l + r - sq_base) & 63);
                 ps = (lane == 0) ? incoming : ps;
             } else {
-                const uint32_t *xl = xin + (cw - 1) * XCH_WORDS;   // last cell of the wave below (broadcast reads)
+                int xi = xin + (cw - 1) * XCH_WORDS;               // last cell of the wave below (broadcast reads)
+                asm volatile("" : "+v"(xi));
+                const uint32_t *xl = xchg + xi;
                 const uint32_t x0 = xl[0], x1 = xl[1], x2 = xl[2], x3 = xl[3];
                 pm = (lane == 0) ? __uint_as_float(x0) : pm;
                 pd = (lane == 0) ? __uint_as_float(x1) : pd;
                 pr = (lane == 0) ? x2 : pr;
                 ps = (lane == 0) ? x3 : ps;
             }
-#pragma unroll
-            for (int g = NG - 1; g >= 0; g--) {
-                in[g].topM = matv[g]; in[g].topI = insv[g]; in[g].topIrun = (int)(R1[g] >> 16);
-                in[g].leftM = g ? matv[g - 1] : pm;
-                in[g].leftD = g ? delv[g - 1] : pd;
-                const uint32_t lr = g ? R2[g - 1] : pr;
-                in[g].leftDrun = (int)(lr >> 16);
-                in[g].diagM = LMv[g];
-                in[g].diagMrun = (int)(LT[g] & 0xFFFFu);
-                LT[g] = (lr & 0xFFFFu) | (R1[g] << 16);
-                seqw[g] = g ? seqw[g - 1] : ps;
-            }
+            in.topM = matv; in.topI = insv; in.topIrun = (int)(R1 >> 16);
+            in.leftM = pm;
+            in.leftD = pd;
+            in.leftDrun = (int)(pr >> 16);
+            in.diagM = LMv;
+            in.diagMrun = (int)(LMr & 0xFFFFu);
+            LMr = pr;
+            TMr = R1;
+            seqw = ps;
         } else if constexpr (MODE == 2) {
-            float nm = lane_next(matv[0]), ni = lane_next(insv[0]);
-            uint32_t nr = lane_next(R1[0]);
-            uint32_t nx = lane_next(refx[0]), ny = lane_next(refy[0]);
-            uint32_t nc0 = lane_next(rc0[0]), nc1 = lane_next(rc1[0]);
+            float nm = lane_next(matv), ni = lane_next(insv);
+            uint32_t nr = lane_next(R1);
+            uint32_t nx = lane_next(refx);
+            uint32_t nc0 = lane_next(rc0), nc1 = lane_next(rc1);
             if constexpr (IS_LAST) {
                 // word for col del_l + WPT-1 - r enters at column WPT-1
                 if (st.del_l + WPT - 1 - r - rq_base >= 64) {
                     rq_base += 64;
                     const int j = rq_base + lane;
                     ref_q = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint4(REFW_SENTINEL, 0u, 0u, 0u);
-                    asm volatile("" : "+v"(ref_q.x), "+v"(ref_q.y), "+v"(ref_q.z), "+v"(ref_q.w));   // wait inside the rare branch
+                    asm volatile("" : "+v"(ref_q.x), "+v"(ref_q.z), "+v"(ref_q.w));   // wait inside the rare branch
                 }
                 const int ql = (st.del_l + WPT - 1 - r - rq_base) & 63;
                 const uint32_t inx = (uint32_t)__builtin_amdgcn_readlane((int)ref_q.x, ql);
-                const uint32_t iny = (uint32_t)__builtin_amdgcn_readlane((int)ref_q.y, ql);
                 const uint32_t inz = (uint32_t)__builtin_amdgcn_readlane((int)ref_q.z, ql);
                 const uint32_t inw = (uint32_t)__builtin_amdgcn_readlane((int)ref_q.w, ql);
                 nx = (lane == 63) ? inx : nx;
-                ny = (lane == 63) ? iny : ny;
                 nc0 = (lane == 63) ? inz : nc0;
                 nc1 = (lane == 63) ? inw : nc1;
             } else {
-                const uint32_t *xf = xin + (cw + 1) * XCH_WORDS + 5;   // first cell of the wave above
-                const uint32_t x0 = xf[0], x1 = xf[1], x2 = xf[2], x3 = xf[3], x4 = xf[4], x5 = xf[5], x6 = xf[6];
+                int xi = xin + (cw + 1) * XCH_WORDS + 5;           // first cell of the wave above
+                asm volatile("" : "+v"(xi));
+                const uint32_t *xf = xchg + xi;
+                const uint32_t x0 = xf[0], x1 = xf[1], x2 = xf[2], x3 = xf[3], x4 = xf[4], x5 = xf[5];
                 nm = (lane == 63) ? __uint_as_float(x0) : nm;
                 ni = (lane == 63) ? __uint_as_float(x1) : ni;
                 nr = (lane == 63) ? x2 : nr;
                 nx = (lane == 63) ? x3 : nx;
-                ny = (lane == 63) ? x4 : ny;
-                nc0 = (lane == 63) ? x5 : nc0;
-                nc1 = (lane == 63) ? x6 : nc1;
+                nc0 = (lane == 63) ? x4 : nc0;
+                nc1 = (lane == 63) ? x5 : nc1;
             }
             if (st.del_l + r + 32 >= wfill) {   // keep the L window ahead of the band (32 positions of slack)
                 if constexpr (IS_LAST) {
@@ -375,103 +408,89 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
                 }
                 wfill += 64;
             }
-#pragma unroll
-            for (int g = 0; g < NG; g++) {
-                in[g].leftM = matv[g]; in[g].leftD = delv[g]; in[g].leftDrun = (int)(R2[g] >> 16);
-                in[g].topM = (g < NG - 1) ? matv[g + 1] : nm;
-                in[g].topI = (g < NG - 1) ? insv[g + 1] : ni;
-                const uint32_t tr = (g < NG - 1) ? R1[g + 1] : nr;
-                in[g].topIrun = (int)(tr >> 16);
-                in[g].diagM = TMv[g];
-                in[g].diagMrun = (int)(LT[g] >> 16);
-                LT[g] = (R2[g] & 0xFFFFu) | (tr << 16);
-                refx[g] = (g < NG - 1) ? refx[g + 1] : nx;
-                refy[g] = (g < NG - 1) ? refy[g + 1] : ny;
-                rc0[g] = (g < NG - 1) ? rc0[g + 1] : nc0;
-                rc1[g] = (g < NG - 1) ? rc1[g + 1] : nc1;
-            }
+            in.leftM = matv; in.leftD = delv; in.leftDrun = (int)(R2 >> 16);
+            in.topM = nm;
+            in.topI = ni;
+            in.topIrun = (int)(nr >> 16);
+            in.diagM = TMv;
+            in.diagMrun = (int)(TMr & 0xFFFFu);
+            LMr = R2;
+            TMr = nr;
+            refx = nx;
+            rc0 = nc0;
+            rc1 = nc1;
         } else {
-#pragma unroll
-            for (int g = 0; g < NG; g++) {
-                in[g].topM = in[g].topI = in[g].leftM = in[g].leftD = in[g].diagM = 0.0f;
-                in[g].topIrun = in[g].leftDrun = in[g].diagMrun = 0;
-            }
+            in.topM = in.topI = in.leftM = in.leftD = in.diagM = 0.0f;
+            in.topIrun = in.leftDrun = in.diagMrun = 0;
         }
-#pragma unroll
-        for (int g = 0; g < NG; g++) {
-            in[g].c = tcol + g;
-            in[g].seqw = seqw[g];
-            in[g].refx = refx[g];
-            in[g].refy = refy[g];
-            in[g].sc0 = rc0[g];
-            in[g].sc1 = rc1[g];
-        }
+        in.c = tcol;
+        in.seqw = seqw;
+        in.refx = refx;
+        in.sc0 = rc0;
+        in.sc1 = rc1;
 
-        CellOut o[NG];
+        CellOut o;
         // band-edge cells (columns 0 and 2r; reference src/aln.pyx:502-507: every state = 100*(b_row+1),
-        // TYP = MAT, RUN = 0).  With one column per lane only three values of an edge cell are ever read
-        // (by its one in-band neighbour), so only those are patched below; the traceback kernel treats edge columns as "run 0" itself.
-        constexpr bool EDGE_PATCH = (NG == 1);
-        if (bl >= d.plain_lo && bl < d.plain_hi) cells_update<NG, true, !EDGE_PATCH>(env, st, in, o);    // == step_is_plain(st)
-        else cells_update<NG, false, !EDGE_PATCH>(env, st, in, o);
+        // TYP = MAT, RUN = 0).  Only three values of an edge cell are ever read (by its one in-band
+        // neighbour), so only those are patched below; edge columns leave no history and the traceback
+        // kernel treats them as "run 0" itself.
+        if (bl >= d.plain_lo && bl < d.plain_hi) cell_update<true, false>(env, st, in, o);    // == step_is_plain(st)
+        else cell_update<false, false>(env, st, in, o);
 
-        uint32_t tbw[NG];
-#pragma unroll
-        for (int g = 0; g < NG; g++) {
-            LMv[g] = in[g].leftM;
-            TMv[g] = in[g].topM;
-            matv[g] = o[g].matv;
-            insv[g] = o[g].insv;
-            delv[g] = o[g].delv;
-            R1[g] = (uint32_t)o[g].matrun | ((uint32_t)o[g].insrun << 16);
-            R2[g] = (uint32_t)o[g].matrun | ((uint32_t)o[g].delrun << 16);
-            if constexpr (EDGE_PATCH) {
-                const float e = (float)(100 * (bl + 1));
-                if constexpr (IS_FIRST) {      // column 0 is lane 0 of the first wave; read as a LEFT neighbour
-                    matv[0] = (lane == 0) ? e : matv[0];
-                    delv[0] = (lane == 0) ? e : delv[0];
-                    R2[0] = (lane == 0) ? 0u : R2[0];
-                }
-                if (has_hi_edge) {             // the wave holding column 2r (wave-uniform); read as a TOP neighbour
-                    const bool is_edge = (tcol == 2 * r);
-                    matv[0] = is_edge ? e : matv[0];
-                    insv[0] = is_edge ? e : insv[0];
-                    R1[0] = is_edge ? 0u : R1[0];
-                }
+        LMv = in.leftM;
+        TMv = in.topM;
+        matv = o.matv;
+        insv = o.insv;
+        delv = o.delv;
+        R1 = (uint32_t)o.matrun | ((uint32_t)o.insrun << 16);
+        R2 = (uint32_t)o.matrun | ((uint32_t)o.delrun << 16);
+        {
+            const float e = (float)(100 * (bl + 1));
+            if constexpr (IS_FIRST) {      // column 0 is lane 0 of the first wave; read as a LEFT neighbour
+                matv = (lane == 0) ? e : matv;
+                delv = (lane == 0) ? e : delv;
+                R2 = (lane == 0) ? 0u : R2;
             }
-            // the row's spare last word carries inss[b] for the traceback
-            tbw[g] = (tcol + g == p.tbstride - 1) ? (uint32_t)(d.row0 + st.ins_l) : o[g].tb;
-            if (hist_lane)
-                hist[env.slot * hw + g * p.lstr + lpos] =
-                    HistCell{o[g].matv, o[g].lenstart, o[g].shrstart,
-                             (uint32_t)o[g].lenrun_h | ((uint32_t)o[g].shrrun_h << 16)};
+            if constexpr (IS_LAST) {       // column 2r lies in the last wave (NW = ceil((2r+1)/64)); read as a TOP neighbour
+                const bool is_edge = (tcol == 2 * r);
+                matv = is_edge ? e : matv;
+                insv = is_edge ? e : insv;
+                R1 = is_edge ? 0u : R1;
+            }
         }
+        if (hist_lane)
+            hist[env.slot * hw + tcol] =
+                HistCell{o.matv, o.lenstart, o.shrstart, (uint32_t)o.lenrun_h | ((uint32_t)o.shrrun_h << 16)};
         if constexpr (NW > 1) {
-            // boundary cells for the neighbour waves: words 0-4 from the last lane, 5-9 from the first
-            if (lane == 0 || lane == 63) {
-                const bool first = (lane == 0);
-                uint32_t *xout = xchg + (bl & 1) * (NW * XCH_WORDS) + cw * XCH_WORDS + (first ? 5 : 0);
-                xout[0] = __float_as_uint(first ? matv[0] : matv[NG - 1]);
-                xout[1] = __float_as_uint(first ? insv[0] : delv[NG - 1]);
-                xout[2] = first ? R1[0] : R2[NG - 1];
-                xout[3] = first ? refx[0] : seqw[NG - 1];
-                xout[4] = refy[0];
-                if (first) { xout[5] = rc0[0]; xout[6] = rc1[0]; }
+            // boundary cells for the neighbour waves: the last lane's cell for the wave above (it reads
+            // it as a LEFT neighbour), the first lane's for the wave below (TOP neighbour + reference words)
+            int xo = (bl & 1) * (NW * XCH_WORDS) + cw * XCH_WORDS;
+            asm volatile("" : "+v"(xo));
+            uint32_t *xout = xchg + xo;
+            if constexpr (!IS_LAST) {
+                if (lane == 63) {
+                    xout[0] = __float_as_uint(matv);
+                    xout[1] = __float_as_uint(delv);
+                    xout[2] = R2;
+                    xout[3] = seqw;
+                }
+            }
+            if constexpr (!IS_FIRST) {
+                if (lane == 0) {
+                    xout[5] = __float_as_uint(matv);
+                    xout[6] = __float_as_uint(insv);
+                    xout[7] = R1;
+                    xout[8] = refx;
+                    xout[9] = rc0;
+                    xout[10] = rc1;
+                }
             }
         }
-        // one traceback word per cell, NG consecutive words per lane (tbstride is a multiple of 4)
-        uint32_t *trow = tb_g + (size_t)bl * p.tbstride;
-        if constexpr (NG == 1) {
-            if (tcol < p.tbstride) trow[tcol] = tbw[0];
-        } else if constexpr (NG == 2) {
-            if (tcol < p.tbstride) *reinterpret_cast<uint2 *>(trow + tcol) = make_uint2(tbw[0], tbw[1]);
-        } else {
-#pragma unroll
-            for (int q = 0; q < NG / 4; q++) {
-                const int col = tcol + 4 * q;
-                if (col < p.tbstride)
-                    *reinterpret_cast<uint4 *>(trow + col) = make_uint4(tbw[4 * q], tbw[4 * q + 1], tbw[4 * q + 2], tbw[4 * q + 3]);
-            }
+        // one traceback word per cell: uniform row base in SGPRs + per-lane byte offset, so the store
+        // costs no address arithmetic (the compiler would otherwise carry a 64-bit per-lane pointer)
+        if (tb_lane) {
+            const uint32_t *trow = tb_g + (size_t)bl * p.tbstride;
+            asm volatile("global_store_dword %0, %1, %2" : : "v"(tcol4), "v"(o.tb), "s"(trow) : "memory");
         }
         // publish progress after this step's LDS writes (same in-order LDS queue); never vmcnt:
         // the traceback stores above must stay in flight
@@ -514,6 +533,7 @@ struct TParams {
     const ChunkDesc *descs;
     const int32_t *n_chunks;
     const uint32_t *tb;
+    const int32_t *inss;       // per read: inss[b] for every anti-diagonal of its input path
     const uint8_t *seqs, *refs;
     uint8_t *chunk_out;        // per-chunk slots, ops right-aligned
     int32_t *chunk_len;        // ops emitted
@@ -523,10 +543,9 @@ struct TParams {
 };
 
 // One wavefront per chunk.  Every hop of the traceback needs the cell's word and the
-// band position of its anti-diagonal (inss[b]); the fill kernel stores the latter in
-// the row's spare last word, so ONE coalesced load of the whole row (16 bytes per
-// lane) serves the hop, and the next row is requested before the ops of the current
-// run are emitted (lane-parallel), so emission overlaps the load latency.
+// band position of its anti-diagonal (inss[b]): ONE coalesced load of the whole row
+// (16 bytes per lane) plus one scalar-like load of inss[b], both requested before the
+// ops of the current run are emitted (lane-parallel), so emission overlaps their latency.
 template <int NL>   // uint4 loads per lane covering a row: tbstride <= 256 * NL
 __global__ __launch_bounds__(64) void traceback_kernel(TParams p)
 {
@@ -542,8 +561,11 @@ __global__ __launch_bounds__(64) void traceback_kernel(TParams p)
     int pos = d.out_cap;   // ops are written backwards
     int status = 0;
 
+    const int32_t *inss = p.inss + d.inss_off + d.brk;
     uint4 row[NL];
+    int row_ins = 0;
     auto load_row = [&](int bl) {
+        row_ins = inss[bl];
 #pragma unroll
         for (int q = 0; q < NL; q++) {
             const int idx = (q * 64 + lane) * 4;
@@ -566,7 +588,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(TParams p)
     if ((a_row > d.row0 || a_col > d.col0) && in_chunk(a_row, a_col)) load_row(a_row + a_col - d.brk);
     while (a_row > d.row0 || a_col > d.col0) {
         if (!in_chunk(a_row, a_col)) { status |= 16; break; }
-        const int bc = (int)word(stride - 1) - a_row + p.r;     // inss[b] - a_row + r, src/aln.pyx:322-326
+        const int bc = row_ins - a_row + p.r;     // inss[b] - a_row + r, src/aln.pyx:322-326
         if (bc < 0 || bc >= W) { status |= 16; break; }
         const uint32_t w = (bc == 0 || bc == W - 1) ? 0u : word(bc);   // band edge: TYP = MAT, RUN = 0 (src/aln.pyx:502-507)
         const int typ = (int)(w & 7u), run = (int)(w >> 3);     // src/aln.pyx:684-685
@@ -639,12 +661,15 @@ __global__ __launch_bounds__(256) void gather_kernel(GParams p)
     }
 }
 
-// exhaustive check of div_small on its domain: counts mismatches
+// exhaustive check of div_recip on its domain: counts violations of its contract
 __global__ void divcheck_kernel(unsigned long long *bad)
 {
     const int run = blockIdx.x * blockDim.x + threadIdx.x;   // 0..65535
     unsigned long long b = 0;
-    for (int n = 1; n <= MAX_PERIOD; n++) b += (div_small(run, n) != run / n);
+    for (int n = 1; n <= MAX_PERIOD; n++) {
+        const int q = div_recip(run, recip16(n)), t = run / n;
+        b += !(q == t || (run >= 13107 && q == t + 1));   // cell.hpp: exact where it matters
+    }
     if (b) atomicAdd(bad, b);
 }
 

@@ -24,12 +24,15 @@
 //   refw[j].y
 //     bits  0-5   bit n-1: reference position j-n lies in an n-polymer (L != 0)
 //     bits  6-11  bit n-1: ... and is its first copy                  (L_IDX == 0)
-//   refw[j].z/.w  the column's two highest-period SHR candidates, pre-decoded:
-//     bits 0-2 period n (0 = none), bit 3 "first copy" (start a deletion rather than
-//     continue one), bits 4-10 L of reference position j-n for that period;
-//     bit 11 of .w: the column has more than two candidate periods (rare; the rest is
-//     decoded from .y and the L window);
-//     bits 12-19 (n-1)*32 + min(L,31): row of the LDS score table; bit 20: L >= 32 (row not in LDS)
+//   refw[j].z/.w  the column's two highest-period SHR candidates, pre-decoded (make_shr_desc):
+//     bits 2-4   period n (0 = none), so that word & 0x1C = 4n (a ds_bpermute lane address)
+//     bit  6     L >= 32: the score row is not in the LDS table
+//     bit  7     (.w only) the column has more than two candidate periods (rare; the rest is
+//                decoded from .y and the L window)
+//     bits 8-14  L of reference position j-n for that period
+//     bits 15-30 byte address, inside the LDS score table, of the entry for "call length L-1":
+//                ((n-1)*32 + L)*256 + (32 + L-1)*4; a deletion of q more copies reads 4q bytes lower
+//     bit  31    "first copy": start a deletion rather than continue one
 //   refl[j]  8 bytes: byte n-1 = L of reference position j for period n (0..max_l)
 //
 // n-polymer annotation follows get_np_info (reference src/aln.pyx:179-251) on the
@@ -41,6 +44,12 @@
 #pragma once
 #include <stdint.h>
 
+#if defined(__HIPCC__)
+#define NPORE_HD __host__ __device__ __forceinline__
+#else
+#define NPORE_HD inline
+#endif
+
 namespace npore {
 
 enum : int { T_MAT = 0, T_INS = 1, T_LEN = 2, T_DEL = 3, T_SHR = 4 };
@@ -49,6 +58,17 @@ constexpr uint32_t SEQW_SENTINEL = 0x3FFFFu;  // six code-7 bases, no flags
 constexpr uint32_t REFW_SENTINEL = 0x36DB6u;  // six code-6 bases, no flags
 constexpr int MAX_PERIOD = 6;                  // kernels are specialised for max_n <= 6
 constexpr float INF_F = 100.0f;                // reference src/aln.pyx:428
+constexpr int HIST_PAD = 6;                    // never-written history records either side of a row (cell.hpp)
+
+constexpr uint32_t DSC_N4 = 0x1Cu, DSC_BIGL = 1u << 6, DSC_MORE = 1u << 7, DSC_START = 1u << 31;
+// LDS score table: [MAX_PERIOD][NP_LT][NP_CT] floats, entry NP_C0 + call for call in [-NP_C0, NP_CT - NP_C0)
+// holding np_scores[n][L][call], and INF_F where call < 0 (np_score's "call < 0 -> 100")
+constexpr int NP_LT = 32, NP_CT = 64, NP_C0 = 32;
+NPORE_HD uint32_t make_shr_desc(int n, bool start, uint32_t L)
+{
+    const uint32_t addr = L < (uint32_t)NP_LT ? (((uint32_t)(n - 1) * NP_LT + L) * NP_CT + NP_C0 + L - 1u) * 4u : 0u;
+    return ((uint32_t)n << 2) | (L >= (uint32_t)NP_LT ? DSC_BIGL : 0u) | (L << 8) | (addr << 15) | (start ? DSC_START : 0u);
+}
 
 struct alignas(16) ChunkDesc {
     int32_t read_id;

@@ -99,9 +99,7 @@ struct npore_ctx {
     float *d_sub = nullptr, *d_np = nullptr;
     // tunables
     int64_t tb_budget_mb = 0;   // 0 = auto
-    int force_ng = 0;
     int force_chunks = 0;
-    int force_nw = 0;
     // device buffers (grow-only, reused across calls)
     DevBuf in_refs, in_seqs, in_cigs, in_off;                       // raw inputs (host-buffer entry point)
     DevBuf rd_i32, rd_i64, steps, inss, descs, sched, hist, counters; // path + chunks
@@ -113,18 +111,12 @@ struct npore_ctx {
 
 namespace {
 
-// (waves per chunk) * (columns per lane) * 64 must cover the band; returns nw*16 + ng, 0 if impossible
-int pick_shape(int r, int force_nw, int force_ng)
+// waves per chunk: the smallest count whose 64 * nw lanes cover the band (the kernel relies on band
+// column 2r lying in the last wave); 0 if the band is too wide
+int pick_shape(int r)
 {
-    const int W = 2 * r + 1;
-    for (int cover : {1, 2, 4, 8}) {
-        if (64 * cover < W) continue;
-        int nw = cover, ng = 1;                 // default: one column per lane, more waves per chunk
-        if (force_ng > 0 && cover % force_ng == 0) { ng = force_ng; nw = cover / ng; }
-        if (force_nw > 0 && cover % force_nw == 0) { nw = force_nw; ng = cover / nw; }
-        return nw * 16 + ng;
-    }
-    return 0;
+    const int nw = (2 * r + 1 + 63) / 64;
+    return nw <= 8 ? nw : 0;
 }
 
 int pow2_at_least(int x)
@@ -135,24 +127,25 @@ int pow2_at_least(int x)
 }
 
 // NW waves per chunk, `chunks` chunks per workgroup (they share the LDS score table).
-template <int NW, int NG, int MAXT>
+template <int NW>
 hipError_t launch_fill(KParams kp, int max_chunks, int force_chunks, hipStream_t s)
 {
+    constexpr int MAXT = 1024;
     const int W = 2 * kp.r + 1;
-    kp.lstr = (W + NG - 1) / NG;
+    kp.hw = W + HIST_PAD;
     kp.rwin = pow2_at_least(2 * kp.r + 101);
     const size_t lds_cap = 160 * 1024 / sizeof(float);
-    if (fill_lds_floats(NW, NG, 1, kp.lstr, kp.rwin) > lds_cap) return hipErrorInvalidValue;
+    if (fill_lds_floats(NW, 1, kp.hw, kp.rwin) > lds_cap) return hipErrorInvalidValue;
     int cmax = 1;
-    while ((cmax + 1) * NW * 64 <= MAXT && fill_lds_floats(NW, NG, cmax + 1, kp.lstr, kp.rwin) <= lds_cap) cmax++;
+    while ((cmax + 1) * NW * 64 <= MAXT && fill_lds_floats(NW, cmax + 1, kp.hw, kp.rwin) <= lds_cap) cmax++;
     // few chunks: spread them over the CUs; many: pack workgroups so that the table is amortised
     int chunks = std::min(cmax, std::max(1, (max_chunks + 255) / 256));
     if (force_chunks > 0) chunks = std::min(cmax, force_chunks);
-    const size_t lds = fill_lds_floats(NW, NG, chunks, kp.lstr, kp.rwin) * sizeof(float);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fill_kernel<NW, NG, MAXT>),
+    const size_t lds = fill_lds_floats(NW, chunks, kp.hw, kp.rwin) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fill_kernel<NW, MAXT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((fill_kernel<NW, NG, MAXT>), dim3((max_chunks + chunks - 1) / chunks), dim3(64 * NW * chunks),
+    hipLaunchKernelGGL((fill_kernel<NW, MAXT>), dim3((max_chunks + chunks - 1) / chunks), dim3(64 * NW * chunks),
                        lds, s, kp);
     return hipGetLastError();
 }
@@ -293,17 +286,15 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     hipError_t e = hipSuccess;
     const int mc = (int)max_chunks;
     switch (shape) {
-        case 1 * 16 + 1: e = launch_fill<1, 1, 1024>(kp, mc, ctx->force_chunks, s); break;
-        case 1 * 16 + 2: e = launch_fill<1, 2, 512>(kp, mc, ctx->force_chunks, s); break;
-        case 1 * 16 + 4: e = launch_fill<1, 4, 256>(kp, mc, ctx->force_chunks, s); break;
-        case 1 * 16 + 8: e = launch_fill<1, 8, 128>(kp, mc, ctx->force_chunks, s); break;
-        case 2 * 16 + 1: e = launch_fill<2, 1, 1024>(kp, mc, ctx->force_chunks, s); break;
-        case 2 * 16 + 2: e = launch_fill<2, 2, 512>(kp, mc, ctx->force_chunks, s); break;
-        case 2 * 16 + 4: e = launch_fill<2, 4, 256>(kp, mc, ctx->force_chunks, s); break;
-        case 4 * 16 + 1: e = launch_fill<4, 1, 1024>(kp, mc, ctx->force_chunks, s); break;
-        case 4 * 16 + 2: e = launch_fill<4, 2, 512>(kp, mc, ctx->force_chunks, s); break;
-        case 8 * 16 + 1: e = launch_fill<8, 1, 1024>(kp, mc, ctx->force_chunks, s); break;
-        default: return fail(NPORE_E_UNSUPPORTED, "unsupported waves-per-chunk / columns-per-lane combination");
+        case 1: e = launch_fill<1>(kp, mc, ctx->force_chunks, s); break;
+        case 2: e = launch_fill<2>(kp, mc, ctx->force_chunks, s); break;
+        case 3: e = launch_fill<3>(kp, mc, ctx->force_chunks, s); break;
+        case 4: e = launch_fill<4>(kp, mc, ctx->force_chunks, s); break;
+        case 5: e = launch_fill<5>(kp, mc, ctx->force_chunks, s); break;
+        case 6: e = launch_fill<6>(kp, mc, ctx->force_chunks, s); break;
+        case 7: e = launch_fill<7>(kp, mc, ctx->force_chunks, s); break;
+        case 8: e = launch_fill<8>(kp, mc, ctx->force_chunks, s); break;
+        default: return fail(NPORE_E_UNSUPPORTED, "unsupported waves-per-chunk count");
     }
     if (e != hipSuccess) return fail(NPORE_E_HIP, std::string("fill launch: ") + hipGetErrorString(e));
     HIP_TRY(hipEventRecord(ctx->ev[2], s));
@@ -312,6 +303,7 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     tp.descs = pp.descs;
     tp.n_chunks = pp.counters;
     tp.tb = kp.tb;
+    tp.inss = pp.inss;
     tp.seqs = a.d_seqs;
     tp.refs = a.d_refs;
     tp.chunk_out = ctx->cout_.as<uint8_t>();
@@ -360,7 +352,7 @@ int run_core(npore_ctx *ctx, const AlignArgs &a, const OutTarget &ot, hipStream_
     if (a.max_b_rows < 2) return fail(NPORE_E_INVALID, "max_b_rows must be >= 2");
     if (a.max_b_rows > 60000)
         return fail(NPORE_E_UNSUPPORTED, "max_b_rows > 60000: run lengths are kept in 16 bits");
-    const int shape = pick_shape(a.r, ctx->force_nw, ctx->force_ng);
+    const int shape = pick_shape(a.r);
     if (!shape) return fail(NPORE_E_UNSUPPORTED, "band half-width r > 255");
     std::fill(ctx->timing, ctx->timing + 8, 0.0);
     if (a.n_reads == 0) return NPORE_OK;
@@ -595,9 +587,9 @@ int npore_ctx_set(npore_ctx *ctx, const char *key, int64_t value)
     if (!ctx || !key) return fail(NPORE_E_INVALID, "null argument");
     const std::string k(key);
     if (k == "tb_budget_mb") ctx->tb_budget_mb = value;
-    else if (k == "force_ng") ctx->force_ng = (int)value;
+    else if (k == "force_ng") { if (value > 1) return fail(NPORE_E_UNSUPPORTED, "one band column per lane is the only layout"); }
     else if (k == "force_chunks") ctx->force_chunks = (int)value;
-    else if (k == "force_nw") ctx->force_nw = (int)value;
+    else if (k == "force_nw") { if (value > 0) return fail(NPORE_E_UNSUPPORTED, "waves per chunk follow from the band width"); }
     else if (k == "host_threads") { /* accepted for compatibility: there is no host-side preparation any more */ }
     else return fail(NPORE_E_INVALID, "unknown key " + k);
     return NPORE_OK;

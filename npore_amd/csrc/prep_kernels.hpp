@@ -429,11 +429,10 @@ __global__ __launch_bounds__(1024) void annotate_kernel(PrepParams p)
             for (int n = p.max_n; n >= 1; n--) {
                 if (!((y >> (n - 1)) & 1u)) continue;
                 const uint32_t l = Lat(j - n, n);
-                const uint32_t v = (uint32_t)n | (((y >> (6 + n - 1)) & 1u) << 3) | (l << 4) |
-                                   (((uint32_t)(n - 1) * 32u + (l < 31u ? l : 31u)) << 12) | ((l >= 32u ? 1u : 0u) << 20);
+                const uint32_t v = make_shr_desc(n, ((y >> (6 + n - 1)) & 1u) != 0u, l);
                 if (nd == 0) dsc0 = v;
                 else if (nd == 1) dsc1 = v;
-                else dsc1 |= 0x800u;
+                else dsc1 |= DSC_MORE;
                 nd++;
             }
             refw[j] = make_uint4(x, y, dsc0, dsc1);

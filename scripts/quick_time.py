@@ -7,7 +7,7 @@ rs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [100, 30
 ref_len = int(sys.argv[3]) if len(sys.argv) > 3 else 10000
 sub, nps, _, _ = aln.load_default_tables()
 ctx = aln.Context(sub, nps)
-for k in ('force_ng','force_nw','force_chunks'):
+for k in ('force_chunks',):
     if os.environ.get('NPORE_'+k.upper()): ctx.set(k, int(os.environ['NPORE_'+k.upper()]))
 t = time.time(); refs, seqs, cigs = synth.make_batch(2, n, ref_len=ref_len); print("gen", time.time() - t, flush=True)
 for r in rs:

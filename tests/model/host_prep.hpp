@@ -173,10 +173,9 @@ inline void pack_chunk_words(const uint8_t *seq, int slen, int drows,
             if (!((y >> (n - 1)) & 1u)) continue;
             if (nd < 2) {
                 const uint32_t l = (uint32_t)L[(size_t)(j - n) * max_n + (n - 1)];
-                dsc[nd] = (uint32_t)n | (((y >> (6 + n - 1)) & 1u) << 3) | (l << 4) |
-                          (((uint32_t)(n - 1) * 32u + (l < 31u ? l : 31u)) << 12) | ((l >= 32u ? 1u : 0u) << 20);
+                dsc[nd] = make_shr_desc(n, ((y >> (6 + n - 1)) & 1u) != 0u, l);
             } else {
-                dsc[1] |= 0x800u;
+                dsc[1] |= DSC_MORE;
             }
             nd++;
         }

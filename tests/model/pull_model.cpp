@@ -23,32 +23,51 @@ struct ModelEnv {
     const float *sub_scores, *np_scores;
     int max_l;
     const uint8_t *refl_p;
+    const uint32_t *refw_p;
     const float *hv[3];
     const uint32_t *hr;
     int W, slot;   // slot of the current row; row b-n is (slot - n) mod NS
+    int refl_n;    // entries in refl_p / refw_p
+    struct Tab { uint32_t hist6; };
+    Tab step_tables(const StepInfo &st) const { return Tab{st.hist6}; }
     float sub(uint32_t s, uint32_t r) const { return sub_scores[s * 5 + r]; }
-    template <int K>
-    void np_many(const int (&n_idx)[K], const int (&a)[K], const int (&b)[K], const bool (&active)[K],
-                 float (&out)[K]) const
+    float np_full(int n_idx, int a, int b, bool active) const
     {
-        for (int k = 0; k < K; k++)
-            out[k] = active[k] ? np_scores[((size_t)n_idx[k] * (max_l + 1) + a[k]) * (max_l + 1) + b[k]] : 0.0f;
+        return active ? np_scores[((size_t)n_idx * (max_l + 1) + a) * (max_l + 1) + b] : 0.0f;
     }
-    float np_lds(int row, int call) const
+    float np_small(uint32_t dsc, int q) const
     {
-        return np_scores[((size_t)(row / 32) * (max_l + 1) + row % 32) * (max_l + 1) + call];
+        const int n = (int)((dsc >> 2) & 7u), L = (int)((dsc >> 8) & 127u);
+        const int call = L - 1 - q;
+        if (n == 0 || call < 0) return INF_F;
+        return np_scores[((size_t)(n - 1) * (max_l + 1) + L) * (max_l + 1) + call];
     }
     int clamp() const { return max_l - 1; }
-    int refl_n;   // entries in refl_p
     int refl(int j, int n_idx) const { return (j >= 0 && j < refl_n) ? refl_p[(size_t)j * 8 + n_idx] : 0; }
-    size_t at(int n, int col) const { return (size_t)((slot - n + NS) % NS) * W + col; }
-    HistCell h_cell(int n, int col) const
+    uint32_t refy(int j) const { return (j >= 0 && j < refl_n) ? refw_p[4 * (size_t)j + 1] : 0u; }
+    // history: band edges and everything outside the band hold "no candidate can come from here"
+    HistCell h_at(int n, int col) const
     {
-        if (col < 0 || col >= W) return HistCell{0.f, 0.f, 0.f, 0u};   // ignored by callers (lane not `good`)
-        const size_t k = at(n, col);
+        if (col < 1 || col > W - 2) return hist_none();
+        const size_t k = (size_t)((slot - n + NS) % NS) * W + col;
         return HistCell{hv[0][k], hv[1][k], hv[2][k], hr[k]};
     }
+    static int period(uint32_t n4) { return (int)((n4 >> 2) & 7u); }   // tables are 8-periodic over the lanes
+    HistCell h_shr(const Tab &t, uint32_t n4, int c) const
+    {
+        const int n = period(n4);
+        return h_at(n, c - popc32(t.hist6 & ((1u << n) - 1u)));
+    }
+    HistCell h_len(const Tab &t, uint32_t n4, int c) const
+    {
+        const int n = period(n4);
+        return h_at(n, c + n - popc32(t.hist6 & ((1u << n) - 1u)));
+    }
+    uint32_t recip(const Tab &, uint32_t n4) const { return recip16(period(n4)); }
+    int mer_shift(const Tab &, uint32_t n4) const { const int n = period(n4); return n <= MAX_PERIOD ? 3 * (MAX_PERIOD - n) : 0; }
+    uint32_t mer_mask(const Tab &, uint32_t n4) const { return (1u << (3 * period(n4))) - 1u; }
     bool any(bool x) const { return x; }
+    bool any2(bool a, bool b) const { return a && b; }
 };
 }  // namespace
 
@@ -87,7 +106,7 @@ extern "C" int64_t pull_model_align(const uint8_t *full_ref, int64_t ref_len, co
         std::vector<uint32_t> tb((size_t)nrows * W, 0u);
         std::vector<CellOut> cur(W);
 
-        ModelEnv env{sub_scores, np_scores, max_l, refl.data(), {hm.data(), hl.data(), hs.data()}, hr.data(), W, 0, dcols + 1};
+        ModelEnv env{sub_scores, np_scores, max_l, refl.data(), refw.data(), {hm.data(), hl.data(), hs.data()}, hr.data(), W, 0, dcols + 1};
         for (int bl = 0; bl < nrows; bl++) {
             const int64_t b = brk + bl;
             StepInfo st;
@@ -105,24 +124,21 @@ extern "C" int64_t pull_model_align(const uint8_t *full_ref, int64_t ref_len, co
             const int I = (bl > 0) ? path.steps[b - 1] : 0;
             env.slot = bl % NS;
             for (int c = 0; c < W; c++) {
-                CellIn in[1];
-                std::memset(&in[0], 0, sizeof in);
-                in[0].c = c;
+                CellIn in;
+                std::memset(&in, 0, sizeof in);
+                in.c = c;
                 const int tc = I ? c : c + 1, lc = I ? c - 1 : c;
-                if (tc >= 0 && tc < W) { in[0].topM = matv[tc]; in[0].topI = insv[tc]; in[0].topIrun = insrun[tc]; }
-                if (lc >= 0 && lc < W) { in[0].leftM = matv[lc]; in[0].leftD = delv[lc]; in[0].leftDrun = delrun[lc]; }
-                in[0].diagM = I ? LMv[c] : TMv[c];
-                in[0].diagMrun = I ? LMrun[c] : TMrun[c];
+                if (tc >= 0 && tc < W) { in.topM = matv[tc]; in.topI = insv[tc]; in.topIrun = insrun[tc]; }
+                if (lc >= 0 && lc < W) { in.leftM = matv[lc]; in.leftD = delv[lc]; in.leftDrun = delrun[lc]; }
+                in.diagM = I ? LMv[c] : TMv[c];
+                in.diagMrun = I ? LMrun[c] : TMrun[c];
                 const int i = st.ins_l + r - c, j = st.del_l - r + c;
-                in[0].seqw = (i >= 0 && i <= drows) ? seqw[i] : SEQW_SENTINEL;
-                in[0].refx = (j >= 0 && j <= dcols) ? refw[4 * (size_t)j] : REFW_SENTINEL;
-                in[0].refy = (j >= 0 && j <= dcols) ? refw[4 * (size_t)j + 1] : 0u;
-                in[0].sc0 = (j >= 0 && j <= dcols) ? refw[4 * (size_t)j + 2] : 0u;
-                in[0].sc1 = (j >= 0 && j <= dcols) ? refw[4 * (size_t)j + 3] : 0u;
-                CellOut out1[1];
-                if (step_is_plain(st)) cells_update<1, true>(env, st, in, out1);   // same dispatch as the kernel
-                else cells_update<1, false>(env, st, in, out1);
-                cur[c] = out1[0];
+                in.seqw = (i >= 0 && i <= drows) ? seqw[i] : SEQW_SENTINEL;
+                in.refx = (j >= 0 && j <= dcols) ? refw[4 * (size_t)j] : REFW_SENTINEL;
+                in.sc0 = (j >= 0 && j <= dcols) ? refw[4 * (size_t)j + 2] : 0u;
+                in.sc1 = (j >= 0 && j <= dcols) ? refw[4 * (size_t)j + 3] : 0u;
+                if (step_is_plain(st)) cell_update<true>(env, st, in, cur[c]);   // same dispatch as the kernel
+                else cell_update<false>(env, st, in, cur[c]);
             }
             // commit the row: neighbour-of-neighbour values for the next diagonal, history, traceback
             std::vector<float> nLMv(W), nTMv(W);

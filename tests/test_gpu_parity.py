@@ -107,15 +107,14 @@ def test_fuzz_vs_oracle(ctx, tables, r):
             assert got[k] == want and st[k] == wst, (r, mbr, ist, iex, k)
 
 
-@pytest.mark.parametrize("r,ng,chunks", [(100, 1, 0), (100, 2, 0), (100, 4, 0), (100, 1, 1), (100, 1, 3),
-                                         (40, 1, 0), (40, 2, 0), (200, 1, 0), (200, 2, 0), (200, 4, 0), (200, 8, 0),
-                                         (30, 1, 1), (30, 1, 5)])
-def test_kernel_shapes(tables, r, ng, chunks):
-    """Every (waves per chunk, columns per lane, chunks per workgroup) decomposition
-    of the band gives the same strings as the oracle."""
+@pytest.mark.parametrize("r,chunks", [(100, 0), (100, 1), (100, 3), (100, 2), (30, 1), (30, 5), (30, 0),
+                                      (40, 0), (70, 0), (70, 2), (95, 0), (96, 0), (140, 0), (170, 0), (200, 0),
+                                      (230, 0), (230, 1)])
+def test_kernel_shapes(tables, r, chunks):
+    """Every waves-per-chunk count (1..8, following from r) and several chunks-per-workgroup
+    packings give the same strings as the oracle."""
     sub, nps = tables
     c = aln.Context(sub, nps, max_n=6, max_l=100, device=0)
-    c.set("force_ng", ng)
     c.set("force_chunks", chunks)
     refs, seqs, cigs = synth.make_batch(321, 12, ref_len=900, p_np=0.15)
     refs2, seqs2, cigs2 = synth.make_batch(322, 3, ref_len=2600, p_np=0.05)
@@ -124,7 +123,7 @@ def test_kernel_shapes(tables, r, ng, chunks):
         got, st = c.align_batch(refs, seqs, cigs, r=r, max_b_rows=mbr, return_status=True)
         assert not st.any()
         for k in range(len(refs)):
-            assert got[k] == oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=r, max_b_rows=mbr), (r, ng, chunks, mbr, k)
+            assert got[k] == oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=r, max_b_rows=mbr), (r, chunks, mbr, k)
     c.close()
 
 
