@@ -131,7 +131,7 @@ NPORE_HD int div_recip(int run, uint32_t m)
 }
 
 // Env supplies (all const, all inlined):
-//   float sub(uint32_t seq_base, uint32_t ref_base)            sub_scores[s][r]
+//   float sub(uint32_t seqw, uint32_t refx)                    sub_scores[seq[i-1]][ref[j-1]] from the two words
 //   float np_full(int n_idx, int a, int b, bool active)        np_scores[n_idx][a][b] (a, b already clamped)
 //   float np_small(uint32_t dsc, int q)     np_score(L, -(q+1)) for a descriptor with L < NP_LT:
 //                                           np_scores[n-1][L][L-1-q], or INF_F if that call length is < 0
@@ -143,7 +143,7 @@ NPORE_HD int div_recip(int run, uint32_t m)
 //                                           c - (inss[b]-inss[b-n]) of anti-diagonal b-n   (n4 = 4n)
 //   HistCell h_len(Tab, uint32_t n4, int c) likewise (i-n, j): column c + n - (inss[b]-inss[b-n])
 //   uint32_t recip(Tab, uint32_t n4)        RECIP16[n]
-//   int   mer_shift(Tab, uint32_t n4)       3*(MAX_PERIOD-n)
+//   int   mer_shift(Tab, uint32_t n4)       32 - 3n (0 for n = 0)
 //   uint32_t mer_mask(Tab, uint32_t n4)     (1 << 3n) - 1
 //   bool  any(bool), any2(bool a, bool b)   wave-level "any lane" of x / of a && b (identity on the host)
 // Lanes without a candidate call these with n4 = 0 (or, in the LEN filter, 4*33) and ignore the result.
@@ -182,13 +182,14 @@ template <bool FAST, class Env, class Tab>
 NPORE_HD void shr_small(const Env &env, const Tab &tab, const CellIn &in, int j, uint32_t dsc, bool act,
                         float &shrv, int &shrrun, float &shrstart)
 {
-    const uint32_t n4 = dsc & DSC_N4;
-    const int n = (int)(n4 >> 2);
-    const HistCell h = env.h_shr(tab, n4, in.c);
+    // the descriptor itself serves as the lane-table address: the tables repeat every 8 lanes and only
+    // address bits 2-7 select a lane, so the flag bits above the period do not matter
+    const int n = (int)((dsc >> 2) & 7u);
+    const HistCell h = env.h_shr(tab, dsc, in.c);
     const bool start = (dsc & DSC_START) != 0u;
     const float cstart = start ? h.matv : h.shrstart;                 // :649 / :662
     const int run = start ? 0 : (int)(h.runs >> 16);
-    const int q = div_recip(run, env.recip(tab, n4));                 // indel = -(q + 1), :650 / :663
+    const int q = div_recip(run, env.recip(tab, dsc));                // indel = -(q + 1), :650 / :663
     const float cand = cstart + env.np_small(dsc, q);
     const bool take = act && (FAST || j - n >= 0) && cand < shrv;
     shrv = take ? cand : shrv;
@@ -259,8 +260,8 @@ NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, 
     const bool interior = (c >= 1) && (c <= r2 - 1) &&
                           (FAST || ((i >= 0) && (j >= 0) && (i <= st.drows) && (j <= st.dcols)));
     const uint32_t imask = interior ? 0xFFFFFFFFu : 0u;    // loop-invariant in the plain case
-    uint32_t lm = ((in.refx & in.seqw & imask) >> 18) & 63u;
-    const uint32_t sm = in.sc0 & imask & DSC_N4;            // 4 * period of the column's first SHR candidate
+    uint32_t lm = ((in.refx & in.seqw & imask) >> FLAG_SHIFT) & 63u;
+    const uint32_t sm = in.sc0 & imask & (DSC_N4 | DSC_HAS2 | DSC_RARE);   // period of the column's first SHR candidate + summary bits
 
     // ---- LEN / SHR candidates (pull form of src/aln.pyx:601-633, 642-667)
     // SHR of a cell comes from X = (i, j-n) at band column c - dI; LEN from
@@ -275,16 +276,21 @@ NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, 
             // (any2(a, b) = any(a && b) from two separate lane masks: a ballot of a compound condition
             // would first be rebuilt as a 0/1 vector and compared again)
             const bool act = sm != 0u;
-            const bool has2 = (in.sc1 & DSC_N4) != 0u, act2 = act && has2;
-            const bool rare1 = ((in.sc0 | in.sc1) & (DSC_BIGL | DSC_MORE)) != 0u;
-            if (!env.any2(act, rare1)) {
-                shr_small<FAST>(env, tab, in, j, in.sc0, act, shrv, shrrun, shrstart);
-                if (env.any2(act, has2)) shr_small<FAST>(env, tab, in, j, in.sc1, act2, shrv, shrrun, shrstart);
+            const bool has2 = (sm & DSC_HAS2) != 0u, act2 = has2;
+            if (!env.any(sm >= DSC_RARE)) {
+                if (env.any(has2)) {
+                    // both in one block: the second candidate's history / table reads are independent of
+                    // the first's outcome and overlap with it
+                    shr_small<FAST>(env, tab, in, j, in.sc0, act, shrv, shrrun, shrstart);
+                    shr_small<FAST>(env, tab, in, j, in.sc1, act2, shrv, shrrun, shrstart);
+                } else {
+                    shr_small<FAST>(env, tab, in, j, in.sc0, act, shrv, shrrun, shrstart);
+                }
             } else {
                 // a long n-polymer (L >= NP_LT) or three or more periods in one column somewhere in the wave
                 shr_generic<FAST>(env, tab, in, j, in.sc0 & DSC_N4, (int)((in.sc0 >> 8) & 127u),
                                   (in.sc0 & DSC_START) != 0u, act, shrv, shrrun, shrstart);
-                if (env.any2(act, has2))
+                if (env.any(has2))
                     shr_generic<FAST>(env, tab, in, j, in.sc1 & DSC_N4, (int)((in.sc1 >> 8) & 127u),
                                       (in.sc1 & DSC_START) != 0u, act2, shrv, shrrun, shrstart);
                 const bool more = act2 && (in.sc1 & DSC_MORE) != 0u;
@@ -304,7 +310,7 @@ NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, 
             }
         }
 
-        const uint32_t s18 = in.seqw & 0x3FFFFu;
+        const uint32_t refm = in.refx >> MER_SHIFT;
         while (env.any(lm != 0u)) {
             const bool valid = lm != 0u;
             const int nm1 = top_index(lm);                 // period - 1 (32 if this lane has none left)
@@ -312,14 +318,14 @@ NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, 
             const uint32_t n4 = (uint32_t)(nm1 + 1) << 2;  // (4*33 where none: tables are 8-periodic)
             // both lookups BEFORE any per-lane condition: on the device they read other lanes' registers,
             // which only works while every lane of the wave is executing
-            const uint32_t smer = s18 >> env.mer_shift(tab, n4);
+            const uint32_t smer = in.seqw >> env.mer_shift(tab, n4);      // the n most recent read bases
             const uint32_t mmask = env.mer_mask(tab, n4);
-            const bool match = ((smer ^ in.refx) & mmask) == 0u;                                  // match(), :606-607
+            const bool match = ((smer ^ refm) & mmask) == 0u;                                     // match(), :606-607
             const bool inside = FAST || i - (nm1 + 1) >= 0;
             const bool good = valid && inside && match;
             if (!(FAST ? env.any2(valid, match) : env.any(good))) continue;
             const int n = nm1 + 1;
-            const bool start = ((in.seqw >> ((24 + nm1) & 31)) & 1u) != 0u;
+            const bool start = ((in.seqw >> (nm1 & 31)) & 1u) != 0u;
             const int L = env.refl(j, nm1 & 7);
             const HistCell h = env.h_len(tab, n4, c);
             const float cstart = start ? h.matv : h.lenstart;                  // :614 / :628
@@ -338,7 +344,7 @@ NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, 
 
     // ---- MAT, src/aln.pyx:569-592 (selects; candidate order INS, LEN, DEL, SHR, strict '<')
     const bool diag_ok = FAST || ((i > 0) && (j > 0));
-    const float vdiag = in.diagM + env.sub((in.seqw >> 15) & 7u, (in.refx >> 24) & 7u);
+    const float vdiag = in.diagM + env.sub(in.seqw, in.refx);
     float v = diag_ok ? vdiag : delv + 100.0f;     // else-branch: "ensure val1 isn't chosen"
     uint32_t tr = diag_ok ? ((uint32_t)T_MAT | ((uint32_t)(in.diagMrun + 1) << 3)) : (uint32_t)T_MAT;  // typ | run<<3
     const bool t1 = insv < v;

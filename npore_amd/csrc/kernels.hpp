@@ -65,7 +65,7 @@ static inline size_t chunk_lds_floats(int nw, int hw, int rwin)
 }
 static inline size_t fill_lds_floats(int nw, int chunks, int hw, int rwin)
 {
-    return (size_t)MAX_PERIOD * NP_LT * NP_CT + 64 + (size_t)chunks * chunk_lds_floats(nw, hw, rwin);
+    return (size_t)MAX_PERIOD * NP_LT * NP_CT + SUBT_ENTRIES + (size_t)chunks * chunk_lds_floats(nw, hw, rwin);
 }
 
 // value of the previous / next lane (lane 0 / 63 get 0)
@@ -97,7 +97,7 @@ __device__ __forceinline__ uint32_t lane_table(uint32_t addr4, uint32_t tab)
 
 template <int NSR>
 struct DevEnv {
-    const float *lds_sub;     // [8][8] padded copy of sub_scores
+    const char *lds_sub;      // [ref 8][seq 8][4] copy of sub_scores (layout.hpp SUBT_*)
     const char *lds_np;       // [6][NP_LT][NP_CT] floats (layout.hpp)
     const float *g_np;        // full table in global memory
     const uint8_t *win;       // LDS window of reference L bytes, 8 per position
@@ -126,7 +126,11 @@ struct DevEnv {
     __device__ __forceinline__ uint32_t recip(const Tab &, uint32_t n4) const { return lane_table(n4, t_recip); }
     __device__ __forceinline__ int mer_shift(const Tab &, uint32_t n4) const { return (int)lane_table(n4, t_msh); }
     __device__ __forceinline__ uint32_t mer_mask(const Tab &, uint32_t n4) const { return lane_table(n4, t_mmask); }
-    __device__ __forceinline__ float sub(uint32_t s, uint32_t r) const { return lds_sub[s * 8 + r]; }
+    __device__ __forceinline__ float sub(uint32_t seqw, uint32_t refx) const
+    {
+        // bits 2-9 of {refx, seqw} >> 25: ref[j-1] (3 bits) | seq[i-1] (3 bits) | 2 bits of seq[i-2] (don't care)
+        return *reinterpret_cast<const float *>(lds_sub + (__builtin_amdgcn_alignbit(refx, seqw, 25) & 0x3FCu));
+    }
     __device__ __forceinline__ float np_small(uint32_t dsc, int q) const
     {
         const uint32_t a = (dsc >> 15) & 0xFFFFu;
@@ -182,14 +186,16 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     float *lds_sub = lds + MAX_PERIOD * NP_LT * NP_CT;
     const int wave = uni((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     // Role-major numbering: consecutive waves (which the hardware deals round-robin over the CU's four
-    // SIMDs) belong to DIFFERENT chunks, so that each SIMD hosts a mix of roles -- the last wave of a
-    // chunk usually has few live columns (r=100: 9 of 64) and would otherwise leave one SIMD idle
-    // while the other three carry all the full waves.
+    // SIMDs) belong to DIFFERENT chunks.  With four chunks per workgroup every chunk has its waves on
+    // ONE SIMD: whichever of them is on the critical path of the anti-diagonal gets that SIMD's whole
+    // issue rate while its neighbours wait for it.  (Chunk-major numbering puts all the nearly empty last
+    // waves -- r=100: 9 live columns of 64 -- on one SIMD: 15 % slower; spreading each chunk over the four
+    // SIMDs with mixed roles: 12 % slower, the critical wave then competes with three busy strangers.)
     const int cpg = (int)(blockDim.x >> 6) / NW;   // chunks per workgroup
     const int cw = wave / cpg;            // wave within the chunk
     const int cg = wave % cpg;            // chunk within the workgroup
     const int hw = p.hw;
-    float *chunk_lds = lds_sub + 64 + (size_t)cg * (4 * (NSR * hw + HIST_PAD) + 2 * p.rwin + (NW > 1 ? 2 * NW * XCH_WORDS + 8 : 0));
+    float *chunk_lds = lds_sub + SUBT_ENTRIES + (size_t)cg * (4 * (NSR * hw + HIST_PAD) + 2 * p.rwin + (NW > 1 ? 2 * NW * XCH_WORDS + 8 : 0));
     HistCell *hist = reinterpret_cast<HistCell *>(chunk_lds) + HIST_PAD;     // row 0, column 0
     uint2 *win = reinterpret_cast<uint2 *>(chunk_lds + 4 * (NSR * hw + HIST_PAD));
     uint32_t *xchg = reinterpret_cast<uint32_t *>(chunk_lds + 4 * (NSR * hw + HIST_PAD) + 2 * p.rwin);   // [2][NW][XCH_WORDS]
@@ -202,9 +208,10 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
         lds_np[idx] = b < 0 ? INF_F
                             : (n < p.max_n && a < np_dim && b < np_dim) ? p.np_scores[((size_t)n * np_dim + a) * np_dim + b] : 0.0f;
     }
-    if (threadIdx.x < 64)
-        lds_sub[threadIdx.x] = ((threadIdx.x >> 3) < 5 && (threadIdx.x & 7) < 5)
-                                   ? p.sub_scores[(threadIdx.x >> 3) * 5 + (threadIdx.x & 7)] : 0.0f;
+    for (int idx = threadIdx.x; idx < SUBT_ENTRIES; idx += blockDim.x) {
+        const int rb = idx >> 5, sb = (idx >> 2) & 7;
+        lds_sub[idx] = (rb < 5 && sb < 5) ? p.sub_scores[sb * 5 + rb] : 0.0f;
+    }
     __syncthreads();
 
     const int slot_id = blockIdx.x * cpg + cg;
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     uint32_t *tb_g = p.tb + d.tb_off;
 
     DevEnv<NSR> env;
-    env.lds_sub = lds_sub;
+    env.lds_sub = reinterpret_cast<const char *>(lds_sub);
     env.lds_np = reinterpret_cast<const char *>(lds_np);
     env.g_np = p.np_scores;
     env.win = reinterpret_cast<const uint8_t *>(win);
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
         env.t_n = (uint32_t)nl;
         env.t_low = (1u << nl) - 1u;
         env.t_recip = recip16(nl);
-        env.t_msh = nl <= MAX_PERIOD ? 3u * (uint32_t)(MAX_PERIOD - nl) : 0u;
+        env.t_msh = nl ? 32u - 3u * (uint32_t)nl : 0u;
         env.t_mmask = (1u << (3 * nl)) - 1u;
     }
 

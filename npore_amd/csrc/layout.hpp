@@ -11,24 +11,27 @@
 // Per-chunk packed annotation words (one entry per local row i / local col j):
 //
 //   seqw[i]  (i = a_row-row0, 0..drows)     "what a cell in row i needs to know"
-//     bits  0-17  the 6 read bases before row i, oldest first: code(seq[i-6+k])<<3k
-//                 (code 7 = before the chunk slice); the cell's own base seq[i-1]
-//                 is bits 15-17.
-//     bits 18-23  bit n-1: read position i-n lies in an n-polymer  (L_seq != 0)
-//     bits 24-29  bit n-1: ... and is its first copy               (L_IDX_seq == 0)
+//     bits 14-31  the 6 read bases before row i, oldest first: code(seq[i-6+k]) << (14+3k)
+//                 (code 7 = before the chunk slice); the cell's own base seq[i-1] is
+//                 bits 29-31, so the n most recent bases are simply word >> (32-3n)
+//     bits  8-13  bit n-1: read position i-n lies in an n-polymer  (L_seq != 0)
+//     bits  0-5   bit n-1: ... and is its first copy               (L_IDX_seq == 0)
 //   refw[j].x (j = a_col-col0, 0..dcols)
-//     bits  0-17  the 6 reference bases from col j on: code(ref[j+k])<<3k
+//     bits 14-31  the 6 reference bases from col j on: code(ref[j+k]) << (14+3k)
 //                 (code 6 = past the chunk slice)
-//     bits 18-23  bit n-1: reference position j starts an n-polymer (L != 0 && L_IDX == 0)
-//     bits 24-26  the cell's own reference base ref[j-1]
+//     bits  8-13  bit n-1: reference position j starts an n-polymer (L != 0 && L_IDX == 0)
+//     bits  0-2   the cell's own reference base ref[j-1]
+//                 (v_alignbit(refw.x, seqw, 25) & 0x3FC is then the byte offset of
+//                 sub_scores[seq[i-1]][ref[j-1]] in a [ref][seq][4] LDS table, see SUBT_*)
 //   refw[j].y
 //     bits  0-5   bit n-1: reference position j-n lies in an n-polymer (L != 0)
 //     bits  6-11  bit n-1: ... and is its first copy                  (L_IDX == 0)
 //   refw[j].z/.w  the column's two highest-period SHR candidates, pre-decoded (make_shr_desc):
 //     bits 2-4   period n (0 = none), so that word & 0x1C = 4n (a ds_bpermute lane address)
+//     bit  5     (.z only) the column has a second candidate (.w != 0)
 //     bit  6     L >= 32: the score row is not in the LDS table
-//     bit  7     (.w only) the column has more than two candidate periods (rare; the rest is
-//                decoded from .y and the L window)
+//     bit  7     .w: the column has more than two candidate periods (rare; the rest is decoded from
+//                .y and the L window); .z: bit 6 of either word or bit 7 of .w is set ("rare column")
 //     bits 8-14  L of reference position j-n for that period
 //     bits 15-30 byte address, inside the LDS score table, of the entry for "call length L-1":
 //                ((n-1)*32 + L)*256 + (32 + L-1)*4; a deletion of q more copies reads 4q bytes lower
@@ -54,13 +57,19 @@ namespace npore {
 
 enum : int { T_MAT = 0, T_INS = 1, T_LEN = 2, T_DEL = 3, T_SHR = 4 };
 
-constexpr uint32_t SEQW_SENTINEL = 0x3FFFFu;  // six code-7 bases, no flags
-constexpr uint32_t REFW_SENTINEL = 0x36DB6u;  // six code-6 bases, no flags
+constexpr int MER_SHIFT = 14, FLAG_SHIFT = 8;  // positions of the 18-bit base field and of the 6 "in an n-polymer" flags
+constexpr uint32_t SEQW_SENTINEL = 0x3FFFFu << MER_SHIFT;  // six code-7 bases, no flags
+constexpr uint32_t REFW_SENTINEL = 0x36DB6u << MER_SHIFT;  // six code-6 bases, no flags, own base 0
+// substitution-score table as the kernel indexes it: entry (ref << 5 | seq << 2 | g), g = 2 don't-care bits
+constexpr int SUBT_ENTRIES = 256;
 constexpr int MAX_PERIOD = 6;                  // kernels are specialised for max_n <= 6
 constexpr float INF_F = 100.0f;                // reference src/aln.pyx:428
 constexpr int HIST_PAD = 6;                    // never-written history records either side of a row (cell.hpp)
 
 constexpr uint32_t DSC_N4 = 0x1Cu, DSC_BIGL = 1u << 6, DSC_MORE = 1u << 7, DSC_START = 1u << 31;
+// summary bits, only in .z (the first candidate): the column has a second candidate / something in the
+// column needs the generic path (L >= NP_LT in either candidate, or more than two candidates)
+constexpr uint32_t DSC_HAS2 = 1u << 5, DSC_RARE = 1u << 7;
 // LDS score table: [MAX_PERIOD][NP_LT][NP_CT] floats, entry NP_C0 + call for call in [-NP_C0, NP_CT - NP_C0)
 // holding np_scores[n][L][call], and INF_F where call < 0 (np_score's "call < 0 -> 100")
 constexpr int NP_LT = 32, NP_CT = 64, NP_C0 = 32;

@@ -390,13 +390,13 @@ __global__ __launch_bounds__(1024) void annotate_kernel(PrepParams p)
             uint32_t w = 0;
             for (int q = 0; q < 6; q++) {
                 const int pp = i - 6 + q;
-                w |= ((pp < 0) ? 7u : (uint32_t)sseq[pp]) << (3 * q);
+                w |= ((pp < 0) ? 7u : (uint32_t)sseq[pp]) << (MER_SHIFT + 3 * q);
             }
             for (int n = 1; n <= p.max_n; n++) {
                 const int pp = i - n;
                 if (pp >= 0 && pp < len && Lat(pp, n) != 0) {
-                    w |= 1u << (18 + n - 1);
-                    if (idx0(pp, n)) w |= 1u << (24 + n - 1);
+                    w |= 1u << (FLAG_SHIFT + n - 1);
+                    if (idx0(pp, n)) w |= 1u << (n - 1);
                 }
             }
             seqw[i] = w;
@@ -408,13 +408,13 @@ __global__ __launch_bounds__(1024) void annotate_kernel(PrepParams p)
             uint32_t x = 0, y = 0, l03 = 0, l45 = 0;
             for (int q = 0; q < 6; q++) {
                 const int pp = j + q;
-                x |= ((pp >= len) ? 6u : (uint32_t)sseq[pp]) << (3 * q);
+                x |= ((pp >= len) ? 6u : (uint32_t)sseq[pp]) << (MER_SHIFT + 3 * q);
             }
             for (int n = 1; n <= p.max_n; n++) {
                 if (j < len) {
                     const uint32_t l = Lat(j, n);
                     if (n <= 4) l03 |= l << (8 * (n - 1)); else l45 |= l << (8 * (n - 5));
-                    if (l != 0 && idx0(j, n)) x |= 1u << (18 + n - 1);
+                    if (l != 0 && idx0(j, n)) x |= 1u << (FLAG_SHIFT + n - 1);
                 }
                 const int pp = j - n;
                 if (pp >= 0 && pp < len && Lat(pp, n) != 0) {
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(1024) void annotate_kernel(PrepParams p)
                     if (idx0(pp, n)) y |= 1u << (6 + n - 1);
                 }
             }
-            if (j >= 1) x |= (uint32_t)sseq[j - 1] << 24;
+            if (j >= 1) x |= (uint32_t)sseq[j - 1];
             // pre-decoded SHR candidates: the two highest periods flagged in y (layout.hpp)
             uint32_t dsc0 = 0u, dsc1 = 0u;
             int nd = 0;
@@ -435,6 +435,8 @@ __global__ __launch_bounds__(1024) void annotate_kernel(PrepParams p)
                 else dsc1 |= DSC_MORE;
                 nd++;
             }
+            if (dsc1 != 0u) dsc0 |= DSC_HAS2;
+            if (((dsc0 | dsc1) & DSC_BIGL) || (dsc1 & DSC_MORE)) dsc0 |= DSC_RARE;
             refw[j] = make_uint4(x, y, dsc0, dsc1);
             refl[j] = make_uint2(l03, l45);     // bytes 0..5 = L for n = 1..6 (0 past the slice)
         }

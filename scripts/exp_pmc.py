@@ -1,0 +1,10 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from npore_amd import _lib
+_lib.LIB_PATH = os.path.abspath(sys.argv[1])
+from npore_amd import aln, synth
+sub, nps, _, _ = aln.load_default_tables()
+ctx = aln.Context(sub, nps)
+refs, seqs, cigs = synth.make_batch(2, 1000, ref_len=10000)
+out, st = ctx.align_batch(refs, seqs, cigs, r=100, return_status=True)
+print('fill', ctx.timing()['fill_ms'])

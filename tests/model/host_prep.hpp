@@ -131,13 +131,13 @@ inline void pack_chunk_words(const uint8_t *seq, int slen, int drows,
         for (int k = 0; k < 6; k++) {
             int p = i - 6 + k;
             uint32_t code = (p < 0) ? 7u : (uint32_t)seq[p];
-            w |= code << (3 * k);
+            w |= code << (MER_SHIFT + 3 * k);
         }
         for (int n = 1; n <= max_n; n++) {
             int p = i - n;
             if (p >= 0 && p < slen && L[(size_t)p * max_n + (n - 1)] != 0) {
-                w |= 1u << (18 + n - 1);
-                if (I[(size_t)p * max_n + (n - 1)] == 0) w |= 1u << (24 + n - 1);
+                w |= 1u << (FLAG_SHIFT + n - 1);
+                if (I[(size_t)p * max_n + (n - 1)] == 0) w |= 1u << (n - 1);
             }
         }
         seqw[i] = w;
@@ -149,7 +149,7 @@ inline void pack_chunk_words(const uint8_t *seq, int slen, int drows,
         for (int k = 0; k < 6; k++) {
             int p = j + k;
             uint32_t code = (p >= rlen) ? 6u : (uint32_t)ref[p];
-            x |= code << (3 * k);
+            x |= code << (MER_SHIFT + 3 * k);
         }
         uint8_t *lb = refl + (size_t)j * 8;
         std::memset(lb, 0, 8);
@@ -157,7 +157,7 @@ inline void pack_chunk_words(const uint8_t *seq, int slen, int drows,
             if (j < rlen) {
                 int32_t l = L[(size_t)j * max_n + (n - 1)];
                 lb[n - 1] = (uint8_t)l;
-                if (l != 0 && I[(size_t)j * max_n + (n - 1)] == 0) x |= 1u << (18 + n - 1);
+                if (l != 0 && I[(size_t)j * max_n + (n - 1)] == 0) x |= 1u << (FLAG_SHIFT + n - 1);
             }
             int p = j - n;
             if (p >= 0 && p < rlen && L[(size_t)p * max_n + (n - 1)] != 0) {
@@ -165,7 +165,7 @@ inline void pack_chunk_words(const uint8_t *seq, int slen, int drows,
                 if (I[(size_t)p * max_n + (n - 1)] == 0) y |= 1u << (6 + n - 1);
             }
         }
-        if (j >= 1) x |= (uint32_t)ref[j - 1] << 24;
+        if (j >= 1) x |= (uint32_t)ref[j - 1];
         // pre-decoded SHR candidates: the two highest periods with y's "inside an n-polymer" bit
         uint32_t dsc[2] = {0u, 0u};
         int nd = 0;
@@ -179,6 +179,8 @@ inline void pack_chunk_words(const uint8_t *seq, int slen, int drows,
             }
             nd++;
         }
+        if (dsc[1] != 0u) dsc[0] |= DSC_HAS2;
+        if (((dsc[0] | dsc[1]) & DSC_BIGL) || (dsc[1] & DSC_MORE)) dsc[0] |= DSC_RARE;
         refw[4 * j] = x;
         refw[4 * j + 1] = y;
         refw[4 * j + 2] = dsc[0];

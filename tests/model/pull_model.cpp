@@ -30,7 +30,11 @@ struct ModelEnv {
     int refl_n;    // entries in refl_p / refw_p
     struct Tab { uint32_t hist6; };
     Tab step_tables(const StepInfo &st) const { return Tab{st.hist6}; }
-    float sub(uint32_t s, uint32_t r) const { return sub_scores[s * 5 + r]; }
+    float sub(uint32_t seqw, uint32_t refx) const
+    {
+        const uint32_t s = seqw >> 29, r = refx & 7u;
+        return (s < 5 && r < 5) ? sub_scores[s * 5 + r] : 0.0f;
+    }
     float np_full(int n_idx, int a, int b, bool active) const
     {
         return active ? np_scores[((size_t)n_idx * (max_l + 1) + a) * (max_l + 1) + b] : 0.0f;
@@ -64,7 +68,7 @@ struct ModelEnv {
         return h_at(n, c + n - popc32(t.hist6 & ((1u << n) - 1u)));
     }
     uint32_t recip(const Tab &, uint32_t n4) const { return recip16(period(n4)); }
-    int mer_shift(const Tab &, uint32_t n4) const { const int n = period(n4); return n <= MAX_PERIOD ? 3 * (MAX_PERIOD - n) : 0; }
+    int mer_shift(const Tab &, uint32_t n4) const { const int n = period(n4); return n ? 32 - 3 * n : 0; }
     uint32_t mer_mask(const Tab &, uint32_t n4) const { return (1u << (3 * period(n4))) - 1u; }
     bool any(bool x) const { return x; }
     bool any2(bool a, bool b) const { return a && b; }
