@@ -299,64 +299,79 @@ __global__ __launch_bounds__(256) void sched_scatter_kernel(PrepParams p)
 // planes: byte planes [7][pstride]: 0..5 = L for n = 1..6, 6 = mask of periods with
 // L_IDX == 0 (LDS when the slice fits, else global scratch).  Optional int32 outputs
 // Lout/Iout [len][max_n] for the get_np_info() API.
+// one period (compile-time, so that the divisions by n and the shorter-period loop unroll)
+template <int n>
+__device__ __forceinline__ void annotate_period(const uint8_t *seq, int len, int max_n, int max_l, uint8_t *planes,
+                                                int pstride, int32_t *Lout, int32_t *Iout)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    uint8_t *Ln = planes + (size_t)(n - 1) * pstride;
+    for (int base = wave * 64; base < len; base += nwaves * 64) {
+        const int pos = base + lane;
+        auto e_at = [&](int q) { return q >= 0 && q + n < len && seq[q] == seq[q + n]; };
+        const unsigned long long M0 = __builtin_amdgcn_ballot_w64(e_at(pos));
+        // forward run from pos
+        int kf;
+        {
+            const unsigned long long inv = ~(M0 >> lane);   // bits >= 64-lane of the shifted mask are 0 -> 1 here
+            kf = inv ? __builtin_ctzll(inv) : 64;
+        }
+        bool cont = (kf == 64 - lane);
+        for (int k = base + 64; k < len && __builtin_amdgcn_ballot_w64(cont) != 0ull; k += 64) {
+            const unsigned long long Mk = __builtin_amdgcn_ballot_w64(e_at(k + lane));
+            const int t = (~Mk) ? __builtin_ctzll(~Mk) : 64;
+            if (cont) { kf += t; cont = (t == 64); }
+        }
+        // backward run ending at pos-1
+        int kb = 0;
+        if (lane > 0) {
+            const unsigned long long inv = ~(M0 << (64 - lane));   // bits below are 0 after the shift -> 1 here
+            kb = __builtin_clzll(inv);                              // inv != 0 because lane > 0
+        }
+        bool contb = (kb == lane);
+        for (int k = base - 64; k >= 0 && __builtin_amdgcn_ballot_w64(contb) != 0ull; k -= 64) {
+            const unsigned long long Mk = __builtin_amdgcn_ballot_w64(e_at(k + lane));
+            const int t = (~Mk) ? __builtin_clzll(~Mk) : 64;
+            if (contb) { kb += t; contb = (t == 64); }
+        }
+        if (pos < len) {
+            const int q = (int)((unsigned)kf / (unsigned)n), J = (int)((unsigned)kb / (unsigned)n);
+            int stored = 0, idx = 0;
+            for (int j = J; j >= 0; j--) {
+                const int l = (j == 0) ? (q >= 1 ? q + 1 : 0) : j + q + 1;
+                if (stored && l <= max_l) break;
+                if (l < 3) continue;
+                const int s = pos - j * n;
+                if (!seq[s]) continue;
+                bool longest = true;
+#pragma unroll
+                for (int n2 = 1; n2 < n; n2++)
+                    if (l * n <= (int)planes[(size_t)(n2 - 1) * pstride + s] * n2) longest = false;
+                if (!longest) continue;
+                if (l > stored) { stored = max_l < l ? max_l : l; idx = j; }
+            }
+            Ln[pos] = (uint8_t)stored;
+            if (stored && idx == 0) planes[6 * pstride + pos] |= (uint8_t)(1u << (n - 1));
+            if (Lout) { Lout[(size_t)pos * max_n + (n - 1)] = stored; Iout[(size_t)pos * max_n + (n - 1)] = idx; }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+
 __device__ __forceinline__ void annotate_sequence(const uint8_t *seq, int len, int max_n, int max_l,
                                                   uint8_t *planes, int pstride, int32_t *Lout, int32_t *Iout)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     for (int p = threadIdx.x; p < len; p += blockDim.x) planes[6 * pstride + p] = 0;
-    for (int n = 1; n <= max_n; n++) {
-        uint8_t *Ln = planes + (size_t)(n - 1) * pstride;
-        for (int base = wave * 64; base < len; base += nwaves * 64) {
-            const int pos = base + lane;
-            auto e_at = [&](int q) { return q >= 0 && q + n < len && seq[q] == seq[q + n]; };
-            const unsigned long long M0 = __builtin_amdgcn_ballot_w64(e_at(pos));
-            // forward run from pos
-            int kf;
-            {
-                const unsigned long long inv = ~(M0 >> lane);   // bits >= 64-lane of the shifted mask are 0 -> 1 here
-                kf = inv ? __builtin_ctzll(inv) : 64;
-            }
-            bool cont = (kf == 64 - lane);
-            for (int k = base + 64; k < len && __builtin_amdgcn_ballot_w64(cont) != 0ull; k += 64) {
-                const unsigned long long Mk = __builtin_amdgcn_ballot_w64(e_at(k + lane));
-                const int t = (~Mk) ? __builtin_ctzll(~Mk) : 64;
-                if (cont) { kf += t; cont = (t == 64); }
-            }
-            // backward run ending at pos-1
-            int kb = 0;
-            if (lane > 0) {
-                const unsigned long long inv = ~(M0 << (64 - lane));   // bits below are 0 after the shift -> 1 here
-                kb = __builtin_clzll(inv);                              // inv != 0 because lane > 0
-            }
-            bool contb = (kb == lane);
-            for (int k = base - 64; k >= 0 && __builtin_amdgcn_ballot_w64(contb) != 0ull; k -= 64) {
-                const unsigned long long Mk = __builtin_amdgcn_ballot_w64(e_at(k + lane));
-                const int t = (~Mk) ? __builtin_clzll(~Mk) : 64;
-                if (contb) { kb += t; contb = (t == 64); }
-            }
-            if (pos < len) {
-                const int q = kf / n, J = kb / n;
-                int stored = 0, idx = 0;
-                for (int j = J; j >= 0; j--) {
-                    const int l = (j == 0) ? (q >= 1 ? q + 1 : 0) : j + q + 1;
-                    if (stored && l <= max_l) break;
-                    if (l < 3) continue;
-                    const int s = pos - j * n;
-                    if (!seq[s]) continue;
-                    bool longest = true;
-                    for (int n2 = 1; n2 < n; n2++)
-                        if (l * n <= (int)planes[(size_t)(n2 - 1) * pstride + s] * n2) longest = false;
-                    if (!longest) continue;
-                    if (l > stored) { stored = max_l < l ? max_l : l; idx = j; }
-                }
-                Ln[pos] = (uint8_t)stored;
-                if (stored && idx == 0) planes[6 * pstride + pos] |= (uint8_t)(1u << (n - 1));
-                if (Lout) { Lout[(size_t)pos * max_n + (n - 1)] = stored; Iout[(size_t)pos * max_n + (n - 1)] = idx; }
-            }
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
+    // (the first period's barrier also orders the zeroing above before the |= of its flags: each position
+    // is zeroed and flagged by different threads only across periods)
+    __syncthreads();
+    if (max_n >= 1) annotate_period<1>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
+    if (max_n >= 2) annotate_period<2>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
+    if (max_n >= 3) annotate_period<3>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
+    if (max_n >= 4) annotate_period<4>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
+    if (max_n >= 5) annotate_period<5>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
+    if (max_n >= 6) annotate_period<6>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
 }
 
 // One workgroup per (chunk, sequence).  The slice and the L planes are staged in LDS
