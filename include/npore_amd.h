@@ -134,8 +134,9 @@ int npore_standardize_batch(int64_t n_reads, const char *alns, const int64_t *al
  */
 int npore_last_timing(npore_ctx *ctx, double *ms, int n);
 
-/* Tunables: key in {"tb_budget_mb","force_nw","force_ng","force_chunks","host_threads"}
- * (waves per chunk, band columns per lane, chunks per workgroup; 0 = automatic). */
+/* Tunables: key in {"tb_budget_mb","force_chunks","host_threads"} (traceback budget in MiB, chunks per
+ * workgroup; 0 = automatic).  "force_nw" / "force_ng" are still accepted with their automatic values
+ * (0, resp. 0 or 1): waves per chunk follow from the band width, one band column per lane is the only layout. */
 int npore_ctx_set(npore_ctx *ctx, const char *key, int64_t value);
 
 /* Debug self-test: out128[l] = value lane l receives from lane l-1 (l>0),
