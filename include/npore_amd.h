@@ -139,6 +139,63 @@ int npore_last_timing(npore_ctx *ctx, double *ms, int n);
  * (0, resp. 0 or 1): waves per chunk follow from the band width, one band column per lane is the only layout. */
 int npore_ctx_set(npore_ctx *ctx, const char *key, int64_t value);
 
+/* ---------------------------------------------------------------------------------------------
+ * BAM ingest / SAM emit around the batched align(): the host side of realign_read
+ * (reference src/bam.pyx:18-47 get_read_data, :51-84 realign_read, with pysam's fetch and
+ * per-read accessors underneath), native and for a whole batch of reads at a time.
+ * npore_amd/bam.py holds a pure-Python restatement of the same logic that the tests compare with.
+ * No GPU involved except in npore_bam_realign_batch.  `threads` <= 0 means all host cores.
+ */
+typedef struct npore_bam npore_bam;
+typedef struct npore_fasta npore_fasta;
+
+/* Inflate (BGZF blocks in parallel) and index a BAM file; NULL on failure (reference: "ERROR: BAM file
+ * ... not found", src/bam.pyx:22-24). */
+npore_bam *npore_bam_open(const char *path, int threads);
+void npore_bam_close(npore_bam *bam);
+int64_t npore_bam_n_records(const npore_bam *bam);
+int npore_bam_n_refs(const npore_bam *bam);
+const char *npore_bam_ref_name(const npore_bam *bam, int i);
+int64_t npore_bam_ref_len(const npore_bam *bam, int i);
+int npore_bam_ref_has_reads(const npore_bam *bam, int i);
+
+/* The reads get_read_data yields (src/bam.pyx:26-33): for each region (BAM reference id, [start, stop)) the
+ * records overlapping it in file order, stopping after max_reads (0 = no cap), skipping secondary,
+ * supplementary and unmapped ones.  Writes up to `cap` record indices; returns the total count (or < 0). */
+int64_t npore_bam_select(const npore_bam *bam, int n_regions, const int32_t *ref_id, const int64_t *start,
+                         const int64_t *stop, int64_t max_reads, int64_t *out_idx, int64_t cap);
+
+/* {contig: upper-cased sequence} of a FASTA file (reference: pysam.FastaFile / Bio.SeqIO callers). */
+npore_fasta *npore_fasta_open(const char *path);
+void npore_fasta_close(npore_fasta *fa);
+int npore_fasta_n(const npore_fasta *fa);
+const char *npore_fasta_name(const npore_fasta *fa, int i);
+int64_t npore_fasta_len(const npore_fasta *fa, int i);
+
+/* Inputs of npore_align_batch for the selected records (src/bam.pyx:59-61): expanded CIGAR without S/H,
+ * query bases without the soft clips and the reference slice [pos, pos + reference_length) as codes.
+ * fasta_of_ref[bam reference id] = index of that contig in `fa` (or -1).  Sizes first, then the fill. */
+int npore_bam_pack_sizes(const npore_bam *bam, const int64_t *idx, int64_t n, int64_t *ref_off, int64_t *seq_off,
+                         int64_t *cig_off);
+int npore_bam_pack(const npore_bam *bam, const npore_fasta *fa, const int32_t *fasta_of_ref, const int64_t *idx,
+                   int64_t n, uint8_t *refs, const int64_t *ref_off, uint8_t *seqs, const int64_t *seq_off,
+                   char *cigs, const int64_t *cig_off, int threads);
+
+/* SAM records (src/bam.pyx:83) of the selected reads given their final collapsed CIGARs
+ * (finals[final_off[k] .. +final_len[k])); reads whose status has NPORE_ST_BAD_INPUT are left out.
+ * *sam points into storage owned by `bam`, valid until the next call on it. */
+int npore_bam_format_sam(npore_bam *bam, const int64_t *idx, int64_t n, const char *finals, const int64_t *final_off,
+                         const int64_t *final_len, const int32_t *status, int threads, const char **sam,
+                         int64_t *sam_len);
+
+/* realign_read for a batch: pack -> npore_align_batch -> npore_standardize_batch -> SAM text. */
+int npore_bam_realign_batch(npore_ctx *ctx, npore_bam *bam, const npore_fasta *fa, const int32_t *fasta_of_ref,
+                            const int64_t *idx, int64_t n, float indel_start, float indel_extend, int max_b_rows,
+                            int r, int threads, const char **sam, int64_t *sam_len, int32_t *status);
+/* Host wall time of the stages of the last npore_bam_realign_batch on `bam` (milliseconds):
+ * ms[0] pack, ms[1] npore_align_batch (incl. PCIe), ms[2] standardise, ms[3] SAM formatting. */
+int npore_bam_last_timing(const npore_bam *bam, double *ms, int n);
+
 /* Debug self-test: out128[l] = value lane l receives from lane l-1 (l>0),
  * out128[64+l] = value from lane l+1 (l<63); checks the DPP wave-shift
  * directions the fill kernel relies on. */

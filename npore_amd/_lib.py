@@ -31,6 +31,26 @@ SIGNATURES = {
     "npore_standardize_batch": (C.c_int, [C.c_int64] + [C.c_void_p] * 9 + [C.c_int]),
     "npore_last_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "npore_ctx_set": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "npore_bam_open": (C.c_void_p, [C.c_char_p, C.c_int]),
+    "npore_bam_close": (None, [C.c_void_p]),
+    "npore_bam_n_records": (C.c_int64, [C.c_void_p]),
+    "npore_bam_n_refs": (C.c_int, [C.c_void_p]),
+    "npore_bam_ref_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "npore_bam_ref_len": (C.c_int64, [C.c_void_p, C.c_int]),
+    "npore_bam_ref_has_reads": (C.c_int, [C.c_void_p, C.c_int]),
+    "npore_bam_select": (C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
+    "npore_fasta_open": (C.c_void_p, [C.c_char_p]),
+    "npore_fasta_close": (None, [C.c_void_p]),
+    "npore_fasta_n": (C.c_int, [C.c_void_p]),
+    "npore_fasta_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "npore_fasta_len": (C.c_int64, [C.c_void_p, C.c_int]),
+    "npore_bam_pack_sizes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "npore_bam_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 6 + [C.c_int]),
+    "npore_bam_format_sam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int, C.c_void_p, C.c_void_p]),
+    "npore_bam_realign_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                          C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "npore_bam_last_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "npore_debug_dpp": (C.c_int, [C.c_void_p]),
     "npore_debug_divcheck": (C.c_int, [C.c_void_p]),
     "npore_debug_fetch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
@@ -48,7 +68,7 @@ def build(force=False, verbose=False):
             all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in sources()):
         return LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-Wall", "-Wno-unused-function", "-o", LIB_PATH, os.path.join(CSRC, "npore_api.cpp")]
+           "-Wall", "-Wno-unused-function", "-o", LIB_PATH, os.path.join(CSRC, "npore_api.cpp"), "-lz"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -2,10 +2,19 @@
 127-145 (get_read_data, realign_read, create_header) and src/util.py:16-93
 (get_bam_regions), with a batch in the middle instead of one align() per call.
 
-pysam is optional: BAM is BGZF (concatenated gzip members) around a simple
-binary record stream, which zlib + struct decode directly; the reference bases
-come from the FASTA slice [reference_start, reference_start + reference_length),
-which is what pysam's get_reference_sequence() reconstructs from the MD tag.
+pysam is not needed: BAM is BGZF (concatenated gzip members) around a simple
+binary record stream; the reference bases come from the FASTA slice
+[reference_start, reference_start + reference_length), which is what pysam's
+get_reference_sequence() reconstructs from the MD tag.
+
+Two implementations of the same logic live here:
+  * NativeBam / NativeFasta / realign_native: thin ctypes wrappers of the library's
+    C++ host I/O (csrc/hostio.hpp: parallel BGZF inflate, batch packing, SAM
+    formatting) -- what realign.py runs;
+  * BamFile / read_fasta / get_read_data / realign_reads: the pure-Python
+    restatement, record by record as the reference does it -- what the tests
+    compare the native path with.
+write_bam() makes small BAM files for tests and benchmarks.
 """
 import os
 import struct
@@ -65,6 +74,9 @@ class BamRecord:
 
 class BamFile:
     """Minimal reader: header text, reference names/lengths, all records."""
+
+    def refs_with_reads(self):
+        return {r.ref_id for r in self.records if r.ref_id >= 0}
 
     def __init__(self, path):
         data = _bgzf_decompress(path)
@@ -167,7 +179,7 @@ def get_bam_regions(bam, ref_seqs):
             print("\nERROR: 'contig' not supplied, but start/endpoints set.")
             sys.exit(1)
         a.regions = []
-        with_reads = {r.ref_id for r in bam.records if r.ref_id >= 0}
+        with_reads = bam.refs_with_reads()
         for k, (ctg, l) in enumerate(zip(bam.references, bam.lengths)):
             if ctg not in ref_seqs:
                 print(f"WARNING: contig '{ctg}' present in '{a.bam}', but not '{a.ref}', skipping...")
@@ -241,6 +253,197 @@ def realign_reads(ctx, read_data, out_sam, r=30, max_b_rows=20000):
                 continue
             if st:
                 print(f"\nERROR: inconsistent traceback for read '{read_id}' (status {int(st)})")   # src/aln.pyx:689-716
-            fh.write(f"{read_id}\t{flag}\t{ref_name}\t{start + 1}\t{mapq}\t{final}\t*\t0\t"
-                     f"{stop - start}\t{sseq}\t{quals}\tHP:i:{hap}\n")
+            fh.write(sam_line(rd, final))
     return len(read_data)
+
+
+def sam_line(rd, final):
+    """SAM record of one get_read_data tuple with its final CIGAR (src/bam.pyx:83)."""
+    read_id, flag, ref_name, start, mapq, _cig, stop, sseq, quals, _ref, hap = rd
+    return (f"{read_id}\t{flag}\t{ref_name}\t{start + 1}\t{mapq}\t{final}\t*\t0\t"
+            f"{stop - start}\t{sseq}\t{quals}\tHP:i:{hap}\n")
+
+
+# ---------------------------------------------------------------------------
+# native host I/O (libnpore_amd.so, csrc/hostio.hpp)
+class NativeFasta:
+    """Contig names / lengths of a FASTA held by the library; behaves like {name: sized} for get_bam_regions."""
+
+    class _Sized:
+        def __init__(self, n):
+            self._n = n
+
+        def __len__(self):
+            return self._n
+
+    def __init__(self, path):
+        from . import _lib
+        self._lib = _lib.load()
+        self.handle = self._lib.npore_fasta_open(os.fsencode(path))
+        if not self.handle:
+            print(f"\nERROR: could not open --ref FASTA '{path}'.")
+            sys.exit(1)
+        self.names = [self._lib.npore_fasta_name(self.handle, i).decode() for i in range(self._lib.npore_fasta_n(self.handle))]
+        self._len = {n: int(self._lib.npore_fasta_len(self.handle, i)) for i, n in enumerate(self.names)}
+
+    def __contains__(self, name):
+        return name in self._len
+
+    def __getitem__(self, name):
+        return NativeFasta._Sized(self._len[name])
+
+    def __iter__(self):
+        return iter(self.names)
+
+    def close(self):
+        if self.handle:
+            self._lib.npore_fasta_close(self.handle)
+            self.handle = None
+
+
+class NativeBam:
+    """A BAM file inflated and indexed by the library (same attributes as BamFile where realign needs them)."""
+
+    def __init__(self, path, threads=0):
+        from . import _lib
+        self._lib = _lib.load()
+        self.handle = self._lib.npore_bam_open(os.fsencode(path), threads)
+        if not self.handle:
+            msg = _lib.last_error()
+            print(f"\nERROR: BAM file '{path}' not found." if "not found" in msg else f"\nERROR: {msg}.")
+            sys.exit(1)
+        n = self._lib.npore_bam_n_refs(self.handle)
+        self.references = [self._lib.npore_bam_ref_name(self.handle, i).decode() for i in range(n)]
+        self.lengths = [int(self._lib.npore_bam_ref_len(self.handle, i)) for i in range(n)]
+        self.n_records = int(self._lib.npore_bam_n_records(self.handle))
+
+    def refs_with_reads(self):
+        return {i for i in range(len(self.references)) if self._lib.npore_bam_ref_has_reads(self.handle, i)}
+
+    def select(self, regions, max_reads=0):
+        """Record indices of the reads get_read_data would yield for [(contig, start, stop)]."""
+        ids = {n: i for i, n in enumerate(self.references)}
+        rid = np.array([ids.get(c, -2) for c, _, _ in regions], np.int32)
+        beg = np.array([s for _, s, _ in regions], np.int64)
+        end = np.array([e for _, _, e in regions], np.int64)
+        out = np.zeros(max(self.n_records * max(len(regions), 1), 1), np.int64)
+        k = self._lib.npore_bam_select(self.handle, len(regions), rid.ctypes.data, beg.ctypes.data, end.ctypes.data,
+                                       int(max_reads or 0), out.ctypes.data, len(out))
+        if k < 0:
+            from . import _lib
+            raise RuntimeError(_lib.last_error())
+        return out[:k].copy()
+
+    def fasta_map(self, fasta):
+        """int32[n_refs]: index of each BAM reference in the FASTA (-1 if absent)."""
+        pos = {n: i for i, n in enumerate(fasta.names)}
+        return np.array([pos.get(n, -1) for n in self.references], np.int32)
+
+    def pack(self, fasta, idx, threads=0):
+        """(refs, ref_off, seqs, seq_off, cigs, cig_off) for npore_align_batch."""
+        idx = np.ascontiguousarray(idx, np.int64)
+        n = len(idx)
+        ro, so, co = (np.zeros(n + 1, np.int64) for _ in range(3))
+        self._check(self._lib.npore_bam_pack_sizes(self.handle, idx.ctypes.data, n, ro.ctypes.data, so.ctypes.data, co.ctypes.data))
+        refs = np.zeros(int(ro[-1]) + 64, np.uint8)
+        seqs = np.zeros(int(so[-1]) + 64, np.uint8)
+        cigs = np.zeros(int(co[-1]) + 64, np.uint8)
+        fmap = self.fasta_map(fasta)
+        self._check(self._lib.npore_bam_pack(self.handle, fasta.handle, fmap.ctypes.data, idx.ctypes.data, n, refs.ctypes.data,
+                                             ro.ctypes.data, seqs.ctypes.data, so.ctypes.data, cigs.ctypes.data,
+                                             co.ctypes.data, threads))
+        return refs, ro, seqs, so, cigs, co
+
+    def format_sam(self, idx, finals, status, threads=0):
+        """SAM text of the selected reads given their final collapsed CIGAR strings."""
+        import ctypes as C
+        idx = np.ascontiguousarray(idx, np.int64)
+        n = len(idx)
+        fb = [f.encode() for f in finals]
+        fo = np.zeros(n + 1, np.int64)
+        np.cumsum([len(f) for f in fb], out=fo[1:])
+        fl = np.diff(fo)
+        buf = np.frombuffer(b"".join(fb) + b"\0", np.uint8)
+        st = np.ascontiguousarray(status, np.int32)
+        sam, sam_len = C.c_void_p(), C.c_int64()
+        self._check(self._lib.npore_bam_format_sam(self.handle, idx.ctypes.data, n, buf.ctypes.data, fo.ctypes.data,
+                                                   fl.ctypes.data, st.ctypes.data, threads, C.byref(sam), C.byref(sam_len)))
+        return C.string_at(sam.value, sam_len.value).decode() if sam_len.value else ""
+
+    def realign_batch(self, ctx, fasta, idx, r=30, max_b_rows=20000, indel_start=5.0, indel_extend=1.0, threads=0):
+        """(SAM text, status[n]) of one batch: pack -> GPU align -> standardise -> format, all in the library."""
+        import ctypes as C
+        idx = np.ascontiguousarray(idx, np.int64)
+        n = len(idx)
+        st = np.zeros(max(n, 1), np.int32)
+        fmap = self.fasta_map(fasta)
+        sam, sam_len = C.c_void_p(), C.c_int64()
+        self._check(self._lib.npore_bam_realign_batch(ctx.handle, self.handle, fasta.handle, fmap.ctypes.data, idx.ctypes.data, n,
+                                                      indel_start, indel_extend, max_b_rows, r, threads,
+                                                      C.byref(sam), C.byref(sam_len), st.ctypes.data))
+        # a view of the library's buffer (valid until the next call on this handle): no copy before the file write
+        return (memoryview((C.c_char * sam_len.value).from_address(sam.value)) if sam_len.value else memoryview(b"")), st[:n]
+
+    def timing(self):
+        """Host wall time (ms) of the stages of the last realign_batch."""
+        ms = np.zeros(4, np.float64)
+        self._lib.npore_bam_last_timing(self.handle, ms.ctypes.data, 4)
+        return dict(zip(("pack_ms", "align_ms", "standardize_ms", "format_ms"), ms.tolist()))
+
+    def _check(self, rc):
+        if rc != 0:
+            from . import _lib
+            raise RuntimeError(f"libnpore_amd: {rc} {_lib.last_error()}")
+
+    def close(self):
+        if self.handle:
+            self._lib.npore_bam_close(self.handle)
+            self.handle = None
+
+
+def realign_native(ctx, bam, fasta, idx, out_sam, r=30, max_b_rows=20000):
+    """realign_reads() through the library's batch entry point; returns the number of reads handed in."""
+    if len(idx) == 0:
+        return 0
+    text, status = bam.realign_batch(ctx, fasta, idx, r=r, max_b_rows=max_b_rows)
+    bad = np.nonzero(status)[0]
+    for k in bad:
+        if status[k] & 32:
+            print(f"\nERROR: read #{int(idx[k])}: CIGAR does not match sequence lengths; skipped.")
+        else:
+            print(f"\nERROR: inconsistent traceback for read #{int(idx[k])} (status {int(status[k])})")   # src/aln.pyx:689-716
+    with open(out_sam, "ab") as fh:
+        fh.write(text)
+    return len(idx)
+
+
+def write_bam(path, references, records, level=6):
+    """Write a BAM file (tests / benchmarks).  references: [(name, length)]; records: dicts with
+    name, flag, ref_id, pos, mapq, cigar [(op, len)], seq (str over =ACMGRSVTWYHKDBN), qual (bytes or None),
+    hp (int or None)."""
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in references)
+    out = bytearray(b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(references)))
+    for n, l in references:
+        out += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", l)
+    code = {c: i for i, c in enumerate(_SEQ16)}
+    for r in records:
+        name = r["name"].encode() + b"\0"
+        seq = r["seq"]
+        nib = np.array([code[c] for c in seq] + ([0] if len(seq) & 1 else []), np.uint8)
+        packed = ((nib[0::2] << 4) | nib[1::2]).astype(np.uint8).tobytes() if len(seq) else b""
+        qual = r.get("qual")
+        qual = bytes([0xFF]) * len(seq) if qual is None else bytes(qual)
+        cig = b"".join(struct.pack("<I", (ln << 4) | op) for op, ln in r["cigar"])
+        aux = b"" if r.get("hp") is None else b"HPC" + bytes([r["hp"]])
+        body = struct.pack("<iiBBHHHiiii", r["ref_id"], r["pos"], len(name), r.get("mapq", 60), 4680, len(r["cigar"]),
+                           r["flag"], len(seq), -1, -1, 0) + name + cig + packed + qual + aux
+        out += struct.pack("<i", len(body)) + body
+    with open(path, "wb") as fh:
+        for p in range(0, len(out), 0xFF00):      # BGZF blocks of < 64 KiB
+            chunk = bytes(out[p:p + 0xFF00])
+            comp = zlib.compressobj(level, zlib.DEFLATED, -15)
+            data = comp.compress(chunk) + comp.flush()
+            fh.write(struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 0xFF, 6, 66, 67, 2, len(data) + 25))
+            fh.write(data)
+            fh.write(struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+        fh.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))   # BGZF EOF block

@@ -1,0 +1,278 @@
+// hostio.hpp -- BAM ingest and SAM emit around the batched align(), host side, native.
+//
+// Counterpart of the reference's compiled I/O layer for this path: pysam's fetch + the per-read
+// accessors used by get_read_data (reference src/bam.pyx:18-47), the glue of realign_read
+// (src/bam.pyx:51-84: expand_cigar / bases_to_int before align(), standardisation and the SAM
+// line after it) -- for a whole batch of reads on all host cores instead of one read per
+// Python call.  npore_amd/bam.py keeps a pure-Python restatement of the same logic; the tests
+// compare the two record by record.
+//
+// BAM = BGZF (independent deflate blocks of <= 64 KiB, each announcing its compressed size in a
+// gzip extra field and its inflated size in its trailer) around a simple binary record stream,
+// so the blocks are located with one pass over the file and inflated in parallel.
+#pragma once
+#include <zlib.h>
+
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "glue.hpp"
+
+namespace npore {
+
+// default worker count: these loops are memory-bound byte shuffles, more than 64 threads only add start-up cost
+inline int host_threads(int threads)
+{
+    return threads > 0 ? threads : (int)std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
+}
+
+// uninitialised byte buffer (a std::vector would zero hundreds of megabytes per batch)
+struct RawBuf {
+    char *p = nullptr;
+    size_t cap = 0;
+    RawBuf() = default;
+    RawBuf(const RawBuf &) = delete;
+    RawBuf &operator=(const RawBuf &) = delete;
+    ~RawBuf() { std::free(p); }
+    bool ensure(size_t n)
+    {
+        if (n <= cap) return true;
+        std::free(p);
+        p = static_cast<char *>(std::malloc(n));
+        cap = p ? n : 0;
+        return p != nullptr;
+    }
+};
+
+template <class F>
+inline void parallel_for(int64_t n, int threads, F &&body)   // body(i) for i in [0, n), dynamic
+{
+    const int nt = (int)std::min<int64_t>(host_threads(threads), n);
+    std::atomic<int64_t> next{0};
+    auto work = [&] {
+        for (;;) {
+            const int64_t i = next.fetch_add(1);
+            if (i >= n) break;
+            body(i);
+        }
+    };
+    if (nt <= 1) { work(); return; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; t++) pool.emplace_back(work);
+    for (auto &t : pool) t.join();
+}
+
+inline bool read_file(const char *path, std::vector<uint8_t> &buf)
+{
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END);
+    const long sz = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    buf.resize(sz > 0 ? (size_t)sz : 0);
+    const size_t got = buf.empty() ? 0 : std::fread(buf.data(), 1, buf.size(), f);
+    std::fclose(f);
+    return got == buf.size();
+}
+
+inline uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+inline uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline int32_t rdi32(const uint8_t *p) { return (int32_t)rd32(p); }
+
+// Inflate a BGZF file.  Falls back to member-by-member gzip decoding if a member lacks the BC field.
+inline bool bgzf_inflate(const std::vector<uint8_t> &raw, int threads, RawBuf &out, size_t &out_size, std::string &err)
+{
+    struct Blk { size_t in_off, in_len, out_off, out_len; };
+    std::vector<Blk> blocks;
+    size_t p = 0, total = 0;
+    bool is_bgzf = true;
+    while (p + 18 <= raw.size()) {
+        if (raw[p] != 31 || raw[p + 1] != 139 || raw[p + 2] != 8 || !(raw[p + 3] & 4)) { is_bgzf = false; break; }
+        const size_t xlen = rd16(&raw[p + 10]);
+        size_t q = p + 12, bsize = 0;
+        const size_t xend = q + xlen;
+        if (xend > raw.size()) { is_bgzf = false; break; }
+        while (q + 4 <= xend) {
+            const size_t slen = rd16(&raw[q + 2]);
+            if (raw[q] == 'B' && raw[q + 1] == 'C' && slen == 2 && q + 6 <= xend) bsize = (size_t)rd16(&raw[q + 4]) + 1;
+            q += 4 + slen;
+        }
+        if (!bsize || p + bsize > raw.size() || bsize < xlen + 20) { is_bgzf = false; break; }
+        const size_t isize = rd32(&raw[p + bsize - 4]);
+        blocks.push_back({xend, bsize - (xend - p) - 8, total, isize});
+        total += isize;
+        p += bsize;
+    }
+    if (is_bgzf && p == raw.size()) {
+        if (!out.ensure(total + 1)) { err = "out of memory"; return false; }
+        out_size = total;
+        std::atomic<int> bad{0};
+        parallel_for((int64_t)blocks.size(), threads, [&](int64_t i) {
+            const Blk &b = blocks[(size_t)i];
+            if (!b.out_len) return;
+            z_stream zs;
+            std::memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) { bad++; return; }
+            zs.next_in = const_cast<Bytef *>(raw.data() + b.in_off);
+            zs.avail_in = (uInt)b.in_len;
+            zs.next_out = reinterpret_cast<Bytef *>(out.p) + b.out_off;
+            zs.avail_out = (uInt)b.out_len;
+            const int rc = inflate(&zs, Z_FINISH);
+            if (rc != Z_STREAM_END || zs.total_out != b.out_len) bad++;
+            inflateEnd(&zs);
+        });
+        if (bad) { err = "corrupt BGZF block"; return false; }
+        return true;
+    }
+    // plain (multi-member) gzip
+    std::vector<uint8_t> acc;
+    p = 0;
+    std::vector<uint8_t> chunk(1 << 20);
+    while (p < raw.size()) {
+        z_stream zs;
+        std::memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, 31) != Z_OK) { err = "zlib init failed"; return false; }
+        zs.next_in = const_cast<Bytef *>(raw.data() + p);
+        zs.avail_in = (uInt)std::min<size_t>(raw.size() - p, 0x7fffffffu);
+        int rc;
+        do {
+            zs.next_out = chunk.data();
+            zs.avail_out = (uInt)chunk.size();
+            rc = inflate(&zs, Z_NO_FLUSH);
+            if (rc != Z_OK && rc != Z_STREAM_END) { inflateEnd(&zs); err = "not a gzip/BGZF stream"; return false; }
+            acc.insert(acc.end(), chunk.data(), chunk.data() + (chunk.size() - zs.avail_out));
+        } while (rc != Z_STREAM_END);
+        p += zs.total_in;
+        inflateEnd(&zs);
+        if (zs.total_in == 0) break;
+    }
+    if (!out.ensure(acc.size() + 1)) { err = "out of memory"; return false; }
+    std::memcpy(out.p, acc.data(), acc.size());
+    out_size = acc.size();
+    return true;
+}
+
+}  // namespace npore
+
+// ---- handles ---------------------------------------------------------------------------------
+struct npore_bam {
+    npore::RawBuf data_buf;               // inflated stream
+    const uint8_t *data = nullptr;
+    size_t data_size = 0;
+    std::string text;                     // header text
+    std::vector<std::string> ref_names;
+    std::vector<int64_t> ref_lens;
+    std::vector<uint8_t> ref_has_reads;
+    std::vector<int64_t> rec_off;         // offset of each record's block_size field
+    npore::RawBuf sam;                    // text of the last formatted batch
+    npore::RawBuf w_refs, w_seqs, w_cigs, w_alns, w_finals;   // per-batch work buffers, reused
+    double stage_ms[4] = {0, 0, 0, 0};    // last npore_bam_realign_batch: pack, align, standardise, format
+};
+
+struct npore_fasta {
+    std::vector<std::string> names;
+    std::vector<std::string> seqs;        // upper-cased
+};
+
+namespace npore {
+
+// fixed part of a BAM alignment record, after block_size
+struct RecView {
+    const uint8_t *p;          // start of the fixed fields
+    int32_t block_size;
+    int32_t ref_id() const { return rdi32(p); }
+    int32_t pos() const { return rdi32(p + 4); }
+    int l_read_name() const { return p[8]; }
+    int mapq() const { return p[9]; }
+    int n_cigar() const { return rd16(p + 12); }
+    int flag() const { return rd16(p + 14); }
+    int32_t l_seq() const { return rdi32(p + 16); }
+    const char *name() const { return reinterpret_cast<const char *>(p + 32); }
+    const uint8_t *cigar() const { return p + 32 + l_read_name(); }
+    const uint8_t *seq() const { return cigar() + 4 * (size_t)n_cigar(); }
+    const uint8_t *qual() const { return seq() + ((size_t)l_seq() + 1) / 2; }
+    const uint8_t *aux() const { return qual() + l_seq(); }
+    const uint8_t *end() const { return p + block_size; }
+    uint32_t cig(int k) const { return rd32(cigar() + 4 * (size_t)k); }
+};
+
+inline RecView rec_at(const npore_bam &b, int64_t i)
+{
+    const uint8_t *q = b.data + b.rec_off[(size_t)i];
+    return RecView{q + 4, rdi32(q)};
+}
+
+// reference length consumed: M, D, N, =, X  (pysam reference_length)
+inline int64_t rec_ref_len(const RecView &r)
+{
+    int64_t n = 0;
+    for (int k = 0; k < r.n_cigar(); k++) {
+        const uint32_t c = r.cig(k), op = c & 15u;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) n += c >> 4;
+    }
+    return n;
+}
+
+// soft-clipped bases at either end (a hard clip may precede / follow them), src/bam.pyx:42-44 via
+// pysam query_alignment_sequence
+inline void rec_clips(const RecView &r, int64_t &lead, int64_t &trail)
+{
+    const int nc = r.n_cigar();
+    lead = trail = 0;
+    if (nc >= 1 && (r.cig(0) & 15u) == 4) lead = r.cig(0) >> 4;
+    if (nc > 1 && (r.cig(0) & 15u) == 5 && (r.cig(1) & 15u) == 4) lead = r.cig(1) >> 4;
+    if (nc > 1 && (r.cig(nc - 1) & 15u) == 4) trail = r.cig(nc - 1) >> 4;
+    if (nc > 2 && (r.cig(nc - 1) & 15u) == 5 && (r.cig(nc - 2) & 15u) == 4) trail = r.cig(nc - 2) >> 4;
+}
+
+// integer HP tag or 0 (src/bam.pyx:46)
+inline int64_t rec_hp(const RecView &r)
+{
+    const uint8_t *q = r.aux(), *end = r.end();
+    while (q + 3 <= end) {
+        const bool is_hp = q[0] == 'H' && q[1] == 'P';
+        const char typ = (char)q[2];
+        q += 3;
+        int64_t val = 0;
+        size_t w = 0;
+        switch (typ) {
+            case 'c': val = (int8_t)q[0]; w = 1; break;
+            case 'C': val = q[0]; w = 1; break;
+            case 's': val = (int16_t)rd16(q); w = 2; break;
+            case 'S': val = rd16(q); w = 2; break;
+            case 'i': val = rdi32(q); w = 4; break;
+            case 'I': val = rd32(q); w = 4; break;
+            case 'A': w = 1; break;
+            case 'f': w = 4; break;
+            case 'Z': case 'H': { const uint8_t *z = q; while (z < end && *z) z++; w = (size_t)(z - q) + 1; break; }
+            case 'B': {
+                if (q + 5 > end) return 0;
+                const char sub = (char)q[0];
+                const uint32_t cnt = rd32(q + 1);
+                const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                w = 5 + (size_t)cnt * es;
+                break;
+            }
+            default: return 0;
+        }
+        if (is_hp && (typ == 'c' || typ == 'C' || typ == 's' || typ == 'S' || typ == 'i' || typ == 'I')) return val;
+        q += w;
+    }
+    return 0;
+}
+
+static const char SEQ16[] = "=ACMGRSVTWYHKDBN";
+static const char CIGOPS[] = "MIDNSHP=XB";
+
+inline uint8_t base_code(char c)   // src/cig.pyx:212-229: 'NACGT-' -> 0..5, anything else 0 (upper case only)
+{
+    switch (c) { case 'A': return 1; case 'C': return 2; case 'G': return 3; case 'T': return 4; case '-': return 5; default: return 0; }
+}
+
+}  // namespace npore

@@ -15,6 +15,7 @@
 
 #include "../../include/npore_amd.h"
 #include "glue.hpp"
+#include "hostio.hpp"
 #include "kernels.hpp"
 #include "prep_kernels.hpp"
 
@@ -660,6 +661,293 @@ int npore_debug_fetch(npore_ctx *ctx, int what, void *dst, int64_t bytes)
     if ((size_t)bytes > b[what]->cap) return fail(NPORE_E_INVALID, "more bytes than the buffer holds");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemcpy(dst, b[what]->p, bytes, hipMemcpyDeviceToHost));
+    return NPORE_OK;
+}
+
+
+// ---- BAM ingest / SAM emit (hostio.hpp) ---------------------------------------------------------
+npore_bam *npore_bam_open(const char *path, int threads)
+{
+    if (!path) { fail(NPORE_E_INVALID, "null path"); return nullptr; }
+    std::vector<uint8_t> raw;
+    if (!read_file(path, raw)) { fail(NPORE_E_INVALID, std::string("BAM file '") + path + "' not found"); return nullptr; }
+    auto *b = new npore_bam();
+    std::string err;
+    if (!bgzf_inflate(raw, threads, b->data_buf, b->data_size, err) || b->data_size < 12 || std::memcmp(b->data_buf.p, "BAM\1", 4) != 0) {
+        fail(NPORE_E_INVALID, std::string("'") + path + "' is not a BAM file" + (err.empty() ? "" : " (" + err + ")"));
+        delete b;
+        return nullptr;
+    }
+    b->data = reinterpret_cast<const uint8_t *>(b->data_buf.p);
+    const uint8_t *d = b->data;
+    const size_t N = b->data_size;
+    size_t p = 4;
+    const int64_t l_text = rdi32(&d[p]);
+    p += 4;
+    if (l_text < 0 || p + (size_t)l_text + 4 > N) { fail(NPORE_E_INVALID, "truncated BAM header"); delete b; return nullptr; }
+    b->text.assign(reinterpret_cast<const char *>(&d[p]), (size_t)l_text);
+    while (!b->text.empty() && b->text.back() == '\0') b->text.pop_back();
+    p += (size_t)l_text;
+    const int32_t n_ref = rdi32(&d[p]);
+    p += 4;
+    for (int32_t k = 0; k < n_ref; k++) {
+        if (p + 4 > N) { fail(NPORE_E_INVALID, "truncated BAM header"); delete b; return nullptr; }
+        const int32_t l_name = rdi32(&d[p]);
+        if (l_name < 1 || p + 8 + (size_t)l_name > N) { fail(NPORE_E_INVALID, "truncated BAM header"); delete b; return nullptr; }
+        b->ref_names.emplace_back(reinterpret_cast<const char *>(&d[p + 4]), (size_t)l_name - 1);
+        b->ref_lens.push_back(rdi32(&d[p + 4 + (size_t)l_name]));
+        p += 8 + (size_t)l_name;
+    }
+    b->ref_has_reads.assign((size_t)n_ref, 0);
+    while (p + 4 <= N) {
+        const int32_t bs = rdi32(&d[p]);
+        if (bs < 32 || p + 4 + (size_t)bs > N) { fail(NPORE_E_INVALID, "truncated BAM record"); delete b; return nullptr; }
+        b->rec_off.push_back((int64_t)p);
+        const int32_t rid = rdi32(&d[p + 4]);
+        if (rid >= 0 && rid < n_ref) b->ref_has_reads[(size_t)rid] = 1;
+        p += 4 + (size_t)bs;
+    }
+    return b;
+}
+void npore_bam_close(npore_bam *b) { delete b; }
+int64_t npore_bam_n_records(const npore_bam *b) { return b ? (int64_t)b->rec_off.size() : 0; }
+int npore_bam_n_refs(const npore_bam *b) { return b ? (int)b->ref_names.size() : 0; }
+const char *npore_bam_ref_name(const npore_bam *b, int i) { return (b && i >= 0 && i < (int)b->ref_names.size()) ? b->ref_names[(size_t)i].c_str() : ""; }
+int64_t npore_bam_ref_len(const npore_bam *b, int i) { return (b && i >= 0 && i < (int)b->ref_lens.size()) ? b->ref_lens[(size_t)i] : -1; }
+int npore_bam_ref_has_reads(const npore_bam *b, int i) { return (b && i >= 0 && i < (int)b->ref_has_reads.size()) ? b->ref_has_reads[(size_t)i] : 0; }
+
+int64_t npore_bam_select(const npore_bam *b, int n_regions, const int32_t *ref_id, const int64_t *start, const int64_t *stop,
+                         int64_t max_reads, int64_t *out_idx, int64_t cap)
+{
+    if (!b || (n_regions > 0 && (!ref_id || !start || !stop)) || (cap > 0 && !out_idx)) return fail(NPORE_E_INVALID, "null argument");
+    int64_t kept = 0;
+    const int64_t nrec = (int64_t)b->rec_off.size();
+    for (int g = 0; g < n_regions; g++) {
+        for (int64_t i = 0; i < nrec; i++) {
+            const RecView r = rec_at(*b, i);
+            if (r.ref_id() != ref_id[g]) continue;
+            const int64_t rl = rec_ref_len(r);
+            if (!(r.pos() < stop[g] && r.pos() + rl > start[g])) continue;        // overlaps [start, stop)
+            if (max_reads > 0 && kept >= max_reads) return kept;                   // src/bam.pyx:29-30
+            if (r.flag() & (0x100 | 0x800 | 0x4)) continue;                       // secondary / supplementary / unmapped, :31-32
+            if (kept < cap) out_idx[kept] = i;
+            kept++;
+        }
+    }
+    return kept;
+}
+
+npore_fasta *npore_fasta_open(const char *path)
+{
+    if (!path) { fail(NPORE_E_INVALID, "null path"); return nullptr; }
+    std::vector<uint8_t> raw;
+    if (!read_file(path, raw)) { fail(NPORE_E_INVALID, std::string("could not open FASTA '") + path + "'"); return nullptr; }
+    auto *f = new npore_fasta();
+    size_t p = 0;
+    const size_t N = raw.size();
+    std::string *cur = nullptr;
+    while (p < N) {
+        size_t e = p;
+        while (e < N && raw[e] != '\n') e++;
+        size_t le = e;
+        while (le > p && (raw[le - 1] == '\r' || raw[le - 1] == ' ' || raw[le - 1] == '\t')) le--;
+        size_t ls = p;
+        while (ls < le && (raw[ls] == ' ' || raw[ls] == '\t')) ls++;
+        if (ls < le && raw[ls] == '>') {
+            size_t q = ls + 1, w = q;
+            while (w < le && raw[w] != ' ' && raw[w] != '\t') w++;
+            f->names.emplace_back(reinterpret_cast<const char *>(&raw[q]), w - q);
+            f->seqs.emplace_back();
+            cur = &f->seqs.back();
+        } else if (cur && le > ls) {
+            if (cur->capacity() < cur->size() + (le - ls)) cur->reserve(std::max(cur->capacity() * 2, cur->size() + (N - ls)));
+            const size_t at = cur->size();
+            cur->append(reinterpret_cast<const char *>(&raw[ls]), le - ls);
+            char *w = &(*cur)[at];
+            for (size_t k = 0; k < le - ls; k++) w[k] = (w[k] >= 'a' && w[k] <= 'z') ? (char)(w[k] - 32) : w[k];
+        }
+        p = e + 1;
+    }
+    return f;
+}
+void npore_fasta_close(npore_fasta *f) { delete f; }
+int npore_fasta_n(const npore_fasta *f) { return f ? (int)f->names.size() : 0; }
+const char *npore_fasta_name(const npore_fasta *f, int i) { return (f && i >= 0 && i < (int)f->names.size()) ? f->names[(size_t)i].c_str() : ""; }
+int64_t npore_fasta_len(const npore_fasta *f, int i) { return (f && i >= 0 && i < (int)f->seqs.size()) ? (int64_t)f->seqs[(size_t)i].size() : -1; }
+
+namespace {
+bool pack_args_ok(const npore_bam *b, const int64_t *idx, int64_t n)
+{
+    if (!b || n < 0 || (n > 0 && !idx)) return false;
+    for (int64_t k = 0; k < n; k++)
+        if (idx[k] < 0 || idx[k] >= (int64_t)b->rec_off.size()) return false;
+    return true;
+}
+}  // namespace
+
+int npore_bam_pack_sizes(const npore_bam *b, const int64_t *idx, int64_t n, int64_t *ref_off, int64_t *seq_off, int64_t *cig_off)
+{
+    if (!pack_args_ok(b, idx, n) || !ref_off || !seq_off || !cig_off) return fail(NPORE_E_INVALID, "bad argument");
+    ref_off[0] = seq_off[0] = cig_off[0] = 0;
+    for (int64_t k = 0; k < n; k++) {
+        const RecView r = rec_at(*b, idx[k]);
+        int64_t lead, trail, ops = 0;
+        rec_clips(r, lead, trail);
+        for (int c = 0; c < r.n_cigar(); c++) {
+            const uint32_t w = r.cig(c), op = w & 15u;
+            if (op != 4 && op != 5) ops += w >> 4;
+        }
+        ref_off[k + 1] = ref_off[k] + rec_ref_len(r);
+        seq_off[k + 1] = seq_off[k] + std::max<int64_t>(0, (int64_t)r.l_seq() - lead - trail);
+        cig_off[k + 1] = cig_off[k] + ops;
+    }
+    return NPORE_OK;
+}
+
+int npore_bam_pack(const npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref, const int64_t *idx, int64_t n,
+                   uint8_t *refs, const int64_t *ref_off, uint8_t *seqs, const int64_t *seq_off, char *cigs,
+                   const int64_t *cig_off, int threads)
+{
+    if (!pack_args_ok(b, idx, n) || !fa || !fasta_of_ref || !ref_off || !seq_off || !cig_off ||
+        (n > 0 && (!refs || !seqs || !cigs)))
+        return fail(NPORE_E_INVALID, "bad argument");
+    std::atomic<int> bad{0};
+    parallel_for(n, threads, [&](int64_t k) {
+        const RecView r = rec_at(*b, idx[k]);
+        const int32_t rid = r.ref_id();
+        const int fi = (rid >= 0 && rid < (int32_t)b->ref_names.size()) ? fasta_of_ref[rid] : -1;
+        if (fi < 0 || fi >= (int)fa->seqs.size()) { bad++; return; }
+        // reference bases: FASTA slice [pos, pos + reference_length), what pysam rebuilds from MD (src/bam.pyx:45)
+        const std::string &ctg = fa->seqs[(size_t)fi];
+        const int64_t rl = ref_off[k + 1] - ref_off[k], pos = r.pos();
+        uint8_t *ro = refs + ref_off[k];
+        for (int64_t q = 0; q < rl; q++) ro[q] = (pos + q >= 0 && pos + q < (int64_t)ctg.size()) ? base_code(ctg[(size_t)(pos + q)]) : 0;
+        // query bases without the soft clips (src/bam.pyx:42)
+        int64_t lead, trail;
+        rec_clips(r, lead, trail);
+        const uint8_t *sq = r.seq();
+        uint8_t *so = seqs + seq_off[k];
+        const int64_t sl = seq_off[k + 1] - seq_off[k];
+        for (int64_t q = 0; q < sl; q++) {
+            const int64_t t = lead + q;
+            const int nib = (t & 1) ? (sq[t >> 1] & 15) : (sq[t >> 1] >> 4);
+            so[q] = base_code(SEQ16[nib]);
+        }
+        // expanded CIGAR without S and H (src/bam.pyx:59)
+        char *co = cigs + cig_off[k];
+        for (int c = 0; c < r.n_cigar(); c++) {
+            const uint32_t w = r.cig(c), op = w & 15u, len = w >> 4;
+            if (op == 4 || op == 5) continue;
+            std::memset(co, op < 10 ? CIGOPS[op] : '?', len);
+            co += len;
+        }
+    });
+    return bad ? fail(NPORE_E_INVALID, "a selected read lies on a contig that is not in the FASTA") : NPORE_OK;
+}
+
+int npore_bam_format_sam(npore_bam *b, const int64_t *idx, int64_t n, const char *finals, const int64_t *final_off,
+                         const int64_t *final_len, const int32_t *status, int threads, const char **sam, int64_t *sam_len)
+{
+    if (!pack_args_ok(b, idx, n) || !sam || !sam_len || (n > 0 && (!finals || !final_off || !final_len || !status)))
+        return fail(NPORE_E_INVALID, "bad argument");
+    // pass 1: line sizes; pass 2: fill (both parallel over reads)
+    std::vector<int64_t> off((size_t)n + 1, 0);
+    auto line = [&](int64_t k, char *dst) -> int64_t {    // returns the length; writes when dst != nullptr
+        if (status[k] & NPORE_ST_BAD_INPUT) return 0;    // refused reads are not written
+        const RecView r = rec_at(*b, idx[k]);
+        int64_t lead, trail;
+        rec_clips(r, lead, trail);
+        const int64_t sl = std::max<int64_t>(0, (int64_t)r.l_seq() - lead - trail);
+        const int32_t rid = r.ref_id();
+        const std::string &rn = (rid >= 0 && rid < (int32_t)b->ref_names.size()) ? b->ref_names[(size_t)rid] : std::string("*");
+        const bool noq = r.l_seq() == 0 || r.qual()[0] == 0xFF;
+        char head[96], mid[64], tail[48];
+        const int hl = std::snprintf(head, sizeof head, "\t%d\t", r.flag());
+        const int ml = std::snprintf(mid, sizeof mid, "\t%lld\t%d\t", (long long)r.pos() + 1, r.mapq());
+        const int tl = std::snprintf(tail, sizeof tail, "\tHP:i:%lld\n", (long long)rec_hp(r));
+        char rlen[32];
+        const int rll = std::snprintf(rlen, sizeof rlen, "\t*\t0\t%lld\t", (long long)rec_ref_len(r));
+        const size_t nl = std::strlen(r.name());
+        const int64_t total = (int64_t)nl + hl + (int64_t)rn.size() + ml + final_len[k] + rll + sl + 1 + (noq ? 1 : sl) + tl;
+        if (!dst) return total;
+        char *o = dst;
+        std::memcpy(o, r.name(), nl); o += nl;
+        std::memcpy(o, head, hl); o += hl;
+        std::memcpy(o, rn.data(), rn.size()); o += rn.size();
+        std::memcpy(o, mid, ml); o += ml;
+        std::memcpy(o, finals + final_off[k], (size_t)final_len[k]); o += final_len[k];
+        std::memcpy(o, rlen, rll); o += rll;
+        const uint8_t *sq = r.seq();
+        for (int64_t q = 0; q < sl; q++) {
+            const int64_t t = lead + q;
+            *o++ = SEQ16[(t & 1) ? (sq[t >> 1] & 15) : (sq[t >> 1] >> 4)];
+        }
+        *o++ = '\t';
+        if (noq) *o++ = '*';
+        else { const uint8_t *ql = r.qual() + lead; for (int64_t q = 0; q < sl; q++) *o++ = (char)(33 + ql[q]); }
+        std::memcpy(o, tail, tl); o += tl;
+        return (int64_t)(o - dst);
+    };
+    parallel_for(n, threads, [&](int64_t k) { off[(size_t)k + 1] = line(k, nullptr); });
+    for (int64_t k = 0; k < n; k++) off[(size_t)k + 1] += off[(size_t)k];
+    if (!b->sam.ensure((size_t)off[(size_t)n] + 1)) return fail(NPORE_E_NOMEM, "SAM text buffer");
+    parallel_for(n, threads, [&](int64_t k) { if (off[(size_t)k + 1] > off[(size_t)k]) line(k, b->sam.p + off[(size_t)k]); });
+    *sam = b->sam.p;
+    *sam_len = off[(size_t)n];
+    return NPORE_OK;
+}
+
+int npore_bam_realign_batch(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref, const int64_t *idx,
+                            int64_t n, float indel_start, float indel_extend, int max_b_rows, int r, int threads,
+                            const char **sam, int64_t *sam_len, int32_t *status)
+{
+    if (!ctx || !status) return fail(NPORE_E_INVALID, "null argument");
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
+    auto t0 = clk::now();
+    std::vector<int64_t> ro((size_t)n + 1), so((size_t)n + 1), co((size_t)n + 1), oo((size_t)n + 1), fo((size_t)n + 1), olen((size_t)n), flen((size_t)n);
+    if (int rc = npore_bam_pack_sizes(b, idx, n, ro.data(), so.data(), co.data())) return rc;
+    if (!b->w_refs.ensure((size_t)ro[(size_t)n] + 64) || !b->w_seqs.ensure((size_t)so[(size_t)n] + 64) ||
+        !b->w_cigs.ensure((size_t)co[(size_t)n] + 64))
+        return fail(NPORE_E_NOMEM, "batch buffers");
+    uint8_t *refs = reinterpret_cast<uint8_t *>(b->w_refs.p), *seqs = reinterpret_cast<uint8_t *>(b->w_seqs.p);
+    char *cigs = b->w_cigs.p;
+    if (int rc = npore_bam_pack(b, fa, fasta_of_ref, idx, n, refs, ro.data(), seqs, so.data(), cigs, co.data(), threads)) return rc;
+    oo[0] = fo[0] = 0;
+    for (int64_t k = 0; k < n; k++) {
+        const int64_t cap = (ro[(size_t)k + 1] - ro[(size_t)k]) + (so[(size_t)k + 1] - so[(size_t)k]);
+        oo[(size_t)k + 1] = oo[(size_t)k] + cap;
+        fo[(size_t)k + 1] = fo[(size_t)k] + 2 * cap + 16;
+    }
+    if (!b->w_alns.ensure((size_t)oo[(size_t)n] + 64) || !b->w_finals.ensure((size_t)fo[(size_t)n] + 64))
+        return fail(NPORE_E_NOMEM, "batch buffers");
+    char *alns = b->w_alns.p, *finals = b->w_finals.p;
+    b->stage_ms[0] = ms_since(t0);
+    t0 = clk::now();
+    if (int rc = npore_align_batch(ctx, n, refs, ro.data(), seqs, so.data(), cigs, co.data(), indel_start,
+                                   indel_extend, max_b_rows, r, alns, oo.data(), olen.data(), status))
+        return rc;
+    b->stage_ms[1] = ms_since(t0);
+    t0 = clk::now();
+    // realign_read's glue (src/bam.pyx:65-78); reads refused by align() have no string and get an empty CIGAR
+    parallel_for(n, threads, [&](int64_t k) {
+        const int64_t l = olen[(size_t)k] > 0 ? olen[(size_t)k] : 0;
+        const std::string c = standardize_collapsed(alns + oo[(size_t)k], l, refs + ro[(size_t)k], ro[(size_t)k + 1] - ro[(size_t)k],
+                                                    seqs + so[(size_t)k], so[(size_t)k + 1] - so[(size_t)k]);
+        std::memcpy(finals + fo[(size_t)k], c.data(), c.size());     // 2 bytes per op + 16 always suffice
+        flen[(size_t)k] = (int64_t)c.size();
+    });
+    b->stage_ms[2] = ms_since(t0);
+    t0 = clk::now();
+    const int rc = npore_bam_format_sam(b, idx, n, finals, fo.data(), flen.data(), status, threads, sam, sam_len);
+    b->stage_ms[3] = ms_since(t0);
+    return rc;
+}
+
+int npore_bam_last_timing(const npore_bam *b, double *ms, int n)
+{
+    if (!b || !ms) return fail(NPORE_E_INVALID, "null argument");
+    for (int k = 0; k < n; k++) ms[k] = k < 4 ? b->stage_ms[k] : 0.0;
     return NPORE_OK;
 }
 

@@ -41,6 +41,8 @@ def argparser():
     # additions
     parser.add_argument("--batch_reads", type=int, default=4096, help="Reads per GPU batch.")
     parser.add_argument("--device", type=int, default=int(os.environ.get("LOCAL_RANK", "0")), help="HIP device.")
+    parser.add_argument("--python_io", action="store_true",
+                        help="Use the pure-Python BAM reader / SAM writer (the restatement the native one is tested against).")
     return parser
 
 
@@ -49,10 +51,11 @@ def main():
         print("\nERROR: --plot / --recalc_cms / --recalc_exit are not available in npore_amd "
               "(they need samtools mpileup + matplotlib); the confusion matrices in --stats_dir are used as is.")
         sys.exit(1)
+    native = not cfg.args.python_io
     print("> reading reference")
-    ref_seqs = bam_mod.read_fasta(cfg.args.ref)
+    ref_seqs = bam_mod.NativeFasta(cfg.args.ref) if native else bam_mod.read_fasta(cfg.args.ref)
     print("> selecting BAM regions")
-    bam = bam_mod.BamFile(cfg.args.bam)
+    bam = bam_mod.NativeBam(cfg.args.bam) if native else bam_mod.BamFile(cfg.args.bam)
     bam_mod.get_bam_regions(bam, ref_seqs)
 
     print("> calculating score matrices")
@@ -64,18 +67,26 @@ def main():
     bam_mod.create_header(out_sam, bam)
 
     print("> extracting read data from BAM")
-    read_data = bam_mod.get_read_data(bam, ref_seqs)
-
     start = perf_counter()
-    print("> computing individual read realignments")
     ctx = aln.Context(cfg.args.sub_scores, cfg.args.np_scores, device=cfg.args.device)
-    batch, n = [], 0
-    for rd in read_data:
-        batch.append(rd)
-        if len(batch) >= cfg.args.batch_reads:
-            n += bam_mod.realign_reads(ctx, batch, out_sam)
-            batch = []
-    n += bam_mod.realign_reads(ctx, batch, out_sam)
+    n = 0
+    if native:
+        idx = bam.select(cfg.args.regions, cfg.args.max_reads)
+        print("> computing individual read realignments")
+        for k in range(0, len(idx), cfg.args.batch_reads):
+            n += bam_mod.realign_native(ctx, bam, ref_seqs, idx[k:k + cfg.args.batch_reads], out_sam)
+        bam.close()
+        ref_seqs.close()
+    else:
+        read_data = bam_mod.get_read_data(bam, ref_seqs)
+        print("> computing individual read realignments")
+        batch = []
+        for rd in read_data:
+            batch.append(rd)
+            if len(batch) >= cfg.args.batch_reads:
+                n += bam_mod.realign_reads(ctx, batch, out_sam)
+                batch = []
+        n += bam_mod.realign_reads(ctx, batch, out_sam)
     ctx.close()
     print(f"    {n} reads, runtime: {perf_counter() - start:.2f}s")
 

@@ -288,6 +288,12 @@ def test_realign_cli_end_to_end(tmp_path):
     prefix = str(tmp_path / "realigned")
     subprocess.check_call([sys.executable, "-m", "npore_amd.realign", "--bam", os.path.join(GOLDEN, "data", "reads.bam"),
                            "--ref", os.path.join(GOLDEN, "data", "ref.fasta"), "--out_prefix", prefix], cwd=REPO)
+    # the pure-Python reader / writer (the restatement the native host I/O is tested against) gives the same file
+    subprocess.check_call([sys.executable, "-m", "npore_amd.realign", "--bam", os.path.join(GOLDEN, "data", "reads.bam"),
+                           "--ref", os.path.join(GOLDEN, "data", "ref.fasta"), "--out_prefix", prefix + "_py", "--python_io"],
+                          cwd=REPO)
+    body = lambda path: [l for l in open(path) if not l.startswith("@PG")]
+    assert body(prefix + ".sam") == body(prefix + "_py.sam")
 
     def records(path):
         hdr, recs = [], {}
@@ -305,3 +311,54 @@ def test_realign_cli_end_to_end(tmp_path):
     assert got.keys() == want.keys() and len(got) == 10
     for name in want:
         assert got[name] == want[name], name
+
+
+def test_native_realign_batch_matches_python_pipeline(ctx, tmp_path):
+    """BAM records -> SAM text through npore_bam_realign_batch == the Python pipeline (get_read_data ->
+    align_batch -> standardize_batch -> sam_line) on a synthetic BAM with clips, both strands, HP tags and
+    a read whose CIGAR disagrees with its sequence (refused, not written)."""
+    import argparse
+    from npore_amd import bam, cfg
+    from npore_amd.cig import bases_to_int, expand_cigar, standardize_batch
+    rng = np.random.default_rng(5)
+    refs, seqs, cigs = synth.make_batch(77, 24, ref_len=1500, p_np=0.1)
+    dec = lambda a: "".join("NACGT"[x] for x in a)
+    contig, pos0, recs = [], [], []
+    for k, (rf, sq, cg) in enumerate(zip(refs, seqs, cigs)):
+        pos0.append(len(contig) + 20)
+        contig += list("ACGT"[x] for x in rng.integers(0, 4, 20)) + list(dec(rf))
+        cg = cg.decode() if isinstance(cg, (bytes, bytearray)) else "".join(chr(x) for x in cg) if not isinstance(cg, str) else cg
+        runs, last, cnt = [], None, 0
+        for ch in cg:
+            if ch == last: cnt += 1
+            else:
+                if last is not None: runs.append(("MIDNSHP=XB".index(last), cnt))
+                last, cnt = ch, 1
+        runs.append(("MIDNSHP=XB".index(last), cnt))
+        lead, trail = (3 if k % 2 else 0), (2 if k % 3 == 0 else 0)
+        cig = ([(4, lead)] if lead else []) + runs + ([(4, trail)] if trail else [])
+        recs.append(dict(name=f"r{k}", flag=16 if k % 4 == 1 else 0, ref_id=0, pos=pos0[-1], cigar=cig,
+                         seq="A" * lead + dec(sq) + "C" * trail, qual=None if k % 5 == 0 else bytes([30]) * (lead + len(sq) + trail),
+                         hp=k % 3))
+    recs[7]["cigar"] = recs[7]["cigar"][:-1] + [(0, 5)] if recs[7]["cigar"][-1][0] != 4 else recs[7]["cigar"] + [(0, 5)]   # lengths now disagree
+    contig = "".join(contig) + "ACGT" * 10
+    (tmp_path / "c.fa").write_text(">ctg\n" + contig + "\n")
+    bam.write_bam(str(tmp_path / "s.bam"), [("ctg", len(contig))], recs)
+    old = cfg.args
+    cfg.args = argparse.Namespace(max_n=6, max_l=100, regions=[("ctg", 0, len(contig) - 1)], max_reads=0)
+    try:
+        nb, nf = bam.NativeBam(str(tmp_path / "s.bam")), bam.NativeFasta(str(tmp_path / "c.fa"))
+        idx = nb.select(cfg.args.regions)
+        text, st = nb.realign_batch(ctx, nf, idx, r=30)
+        text = bytes(text)
+        py = bam.BamFile(str(tmp_path / "s.bam"))
+        rds = list(bam.get_read_data(py, bam.read_fasta(str(tmp_path / "c.fa"))))
+        pc = [expand_cigar(rd[5]).replace("S", "").replace("H", "") for rd in rds]
+        pr, ps = [bases_to_int(rd[9]) for rd in rds], [bases_to_int(rd[7]) for rd in rds]
+        alns, pst = ctx.align_batch(pr, ps, pc, r=30, return_status=True)
+        finals = standardize_batch(alns, pr, ps)
+        want = "".join(bam.sam_line(rd, f) for rd, f, s_ in zip(rds, finals, pst) if not s_ & 32)
+        assert np.array_equal(st, pst) and ((st & 32) != 0).sum() == 1
+        assert text.decode() == want and text.count(b"\n") == len(rds) - 1
+    finally:
+        cfg.args = old

@@ -157,3 +157,78 @@ def test_sharding_and_reduction_gloo_world2():
     assert res[0][1] == [0, 2, 4] and res[1][1] == [1, 3, 5]
     for _, _, sums, maxes in res:
         assert sums["reads"] == 1001 and sums["cells"] == sum(range(1001)) and maxes["elapsed"] == 2.0
+
+
+# ---- native host I/O (csrc/hostio.hpp) against the pure-Python restatement in npore_amd/bam.py ----
+def _native_vs_python(bam_path, fasta_path, regions, max_reads=0):
+    import argparse
+    from npore_amd import bam, cfg
+    from npore_amd.cig import bases_to_int, expand_cigar
+    old = cfg.args
+    cfg.args = argparse.Namespace(max_n=6, max_l=100, regions=regions, max_reads=max_reads)
+    try:
+        py = bam.BamFile(bam_path)
+        refs = bam.read_fasta(fasta_path)
+        rds = list(bam.get_read_data(py, refs))
+        nb, nf = bam.NativeBam(bam_path, threads=3), bam.NativeFasta(fasta_path)
+        assert nb.references == py.references and nb.lengths == py.lengths
+        assert nb.n_records == len(py.records) and nb.refs_with_reads() == py.refs_with_reads()
+        assert list(nf) == list(refs) and all(len(nf[k]) == len(refs[k]) for k in refs)
+        idx = nb.select(regions, max_reads)
+        assert len(idx) == len(rds)
+        assert [py.records[i].query_name for i in idx] == [rd[0] for rd in rds]
+        r, ro, s, so, c, co = nb.pack(nf, idx, threads=3)
+        for k, rd in enumerate(rds):
+            assert np.array_equal(r[ro[k]:ro[k + 1]], bases_to_int(rd[9])), k
+            assert np.array_equal(s[so[k]:so[k + 1]], bases_to_int(rd[7])), k
+            assert c[co[k]:co[k + 1]].tobytes().decode() == expand_cigar(rd[5]).replace("S", "").replace("H", ""), k
+        finals = [f"{7 + k}M{k % 3 + 1}I2D" for k in range(len(rds))]
+        status = np.array([32 if k % 5 == 4 else (4 if k % 7 == 3 else 0) for k in range(len(rds))], np.int32)
+        want = "".join(bam.sam_line(rd, f) for rd, f, st in zip(rds, finals, status) if not st & 32)
+        assert nb.format_sam(idx, finals, status, threads=3) == want
+        nb.close(); nf.close()
+        return len(rds)
+    finally:
+        cfg.args = old
+
+
+def test_native_bam_matches_python_reader_on_reference_data():
+    d = os.path.join(GOLDEN, "data")
+    assert _native_vs_python(os.path.join(d, "reads.bam"), os.path.join(d, "ref.fasta"), [("ref", 0, 1000)]) == 10
+    assert _native_vs_python(os.path.join(d, "reads.bam"), os.path.join(d, "ref.fasta"), [("ref", 0, 1000)], max_reads=3) == 3
+    assert _native_vs_python(os.path.join(d, "reads.bam"), os.path.join(d, "ref.fasta"), [("ref", 400, 450), ("ref", 0, 30)]) > 0
+
+
+def test_native_bam_clips_flags_tags(tmp_path):
+    """A synthetic BAM with soft/hard clips, IUPAC bases, missing qualities, HP tags of several widths,
+    secondary / supplementary / unmapped records, two contigs and reads hanging over a contig end."""
+    from npore_amd import bam
+    rng = np.random.default_rng(11)
+    contigs = {"chrA": "".join(rng.choice(list("ACGT"), 700)), "chrB": "".join(rng.choice(list("acgtN"), 300))}
+    fa = tmp_path / "r.fa"
+    fa.write_text("".join(f">{n} description\n" + "\n".join(s[i:i + 60] for i in range(0, len(s), 60)) + "\n" for n, s in contigs.items()))
+    recs = []
+    for k in range(60):
+        rid = int(rng.integers(0, 2))
+        clen = len(contigs["chrA" if rid == 0 else "chrB"])
+        core = [(int(rng.choice([0, 7, 8, 1, 2])), int(rng.integers(1, 9))) for _ in range(int(rng.integers(1, 8)))]
+        cig = list(core)
+        if k % 3 == 0: cig = [(4, int(rng.integers(1, 6)))] + cig
+        if k % 4 == 0: cig = cig + [(4, int(rng.integers(1, 6)))]
+        if k % 6 == 0: cig = [(5, 3)] + cig
+        if k % 10 == 0: cig = cig + [(5, 2)]
+        qlen = sum(n for op, n in cig if op in (0, 1, 4, 7, 8))
+        rlen = sum(n for op, n in cig if op in (0, 2, 3, 7, 8))
+        pos = int(rng.integers(0, max(1, clen - rlen + (3 if k % 9 == 0 else 0))))
+        seq = "".join(rng.choice(list("ACGTNRY="), qlen, p=[.23, .23, .23, .23, .03, .02, .02, .01]))
+        flag = [0, 16, 0x100, 0x800, 4, 0, 16, 0][k % 8]
+        recs.append(dict(name=f"read{k}", flag=flag, ref_id=rid, pos=pos, mapq=int(rng.integers(0, 61)), cigar=cig, seq=seq,
+                         qual=None if k % 5 == 0 else rng.integers(0, 42, qlen).astype(np.uint8).tobytes(),
+                         hp=None if k % 3 == 1 else int(rng.integers(0, 3))))
+    recs.sort(key=lambda r: (r["ref_id"], r["pos"]))
+    bp = tmp_path / "x.bam"
+    bam.write_bam(str(bp), [(n, len(s)) for n, s in contigs.items()], recs)
+    n1 = _native_vs_python(str(bp), str(fa), [("chrA", 0, 699), ("chrB", 0, 299)])
+    n2 = _native_vs_python(str(bp), str(fa), [("chrB", 100, 200)])
+    n3 = _native_vs_python(str(bp), str(fa), [("chrA", 0, 699), ("chrB", 0, 299)], max_reads=7)
+    assert n1 > 20 and 0 < n2 < n1 and n3 == 7
