@@ -11,6 +11,7 @@
 // gzip extra field and its inflated size in its trailer) around a simple binary record stream,
 // so the blocks are located with one pass over the file and inflated in parallel.
 #pragma once
+#include <hip/hip_runtime.h>
 #include <zlib.h>
 
 #include <atomic>
@@ -36,15 +37,31 @@ inline int host_threads(int threads)
 struct RawBuf {
     char *p = nullptr;
     size_t cap = 0;
+    bool pinned = false;       // page-locked (hipHostMalloc): buffers that cross PCIe every batch
     RawBuf() = default;
+    explicit RawBuf(bool pin) : pinned(pin) {}
     RawBuf(const RawBuf &) = delete;
     RawBuf &operator=(const RawBuf &) = delete;
-    ~RawBuf() { std::free(p); }
+    ~RawBuf() { release(); }
+    void release()
+    {
+        if (!p) return;
+        if (pinned) (void)hipHostFree(p);
+        else std::free(p);
+        p = nullptr;
+        cap = 0;
+    }
     bool ensure(size_t n)
     {
         if (n <= cap) return true;
-        std::free(p);
-        p = static_cast<char *>(std::malloc(n));
+        release();
+        n += n / 4;            // head-room: batches of a run differ a little in size
+        if (pinned) {
+            void *q = nullptr;
+            if (hipHostMalloc(&q, n, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pinned = false; }
+            else p = static_cast<char *>(q);
+        }
+        if (!pinned) p = static_cast<char *>(std::malloc(n));
         cap = p ? n : 0;
         return p != nullptr;
     }
@@ -171,7 +188,7 @@ struct npore_bam {
     std::vector<uint8_t> ref_has_reads;
     std::vector<int64_t> rec_off;         // offset of each record's block_size field
     npore::RawBuf sam;                    // text of the last formatted batch
-    npore::RawBuf w_refs, w_seqs, w_cigs, w_alns, w_finals;   // per-batch work buffers, reused
+    npore::RawBuf w_finals;               // final CIGARs of the last batch (work buffer, reused)
     double stage_ms[4] = {0, 0, 0, 0};    // last npore_bam_realign_batch: pack, align, standardise, format
 };
 

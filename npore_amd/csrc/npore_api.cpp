@@ -107,6 +107,8 @@ struct npore_ctx {
     DevBuf seqw, refw, refl, seql;                                   // annotation
     DevBuf tb, cout_, clen, cstat;                                   // fill / traceback
     DevBuf out, out_off, out_len, status;                            // outputs (host-buffer entry point)
+    // page-locked host staging of npore_bam_realign_batch (grow-only, reused across batches and files)
+    RawBuf h_refs{true}, h_seqs{true}, h_cigs{true}, h_alns{true};
     double timing[8] = {};
 };
 
@@ -907,11 +909,12 @@ int npore_bam_realign_batch(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa,
     auto t0 = clk::now();
     std::vector<int64_t> ro((size_t)n + 1), so((size_t)n + 1), co((size_t)n + 1), oo((size_t)n + 1), fo((size_t)n + 1), olen((size_t)n), flen((size_t)n);
     if (int rc = npore_bam_pack_sizes(b, idx, n, ro.data(), so.data(), co.data())) return rc;
-    if (!b->w_refs.ensure((size_t)ro[(size_t)n] + 64) || !b->w_seqs.ensure((size_t)so[(size_t)n] + 64) ||
-        !b->w_cigs.ensure((size_t)co[(size_t)n] + 64))
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->h_refs.ensure((size_t)ro[(size_t)n] + 64) || !ctx->h_seqs.ensure((size_t)so[(size_t)n] + 64) ||
+        !ctx->h_cigs.ensure((size_t)co[(size_t)n] + 64))
         return fail(NPORE_E_NOMEM, "batch buffers");
-    uint8_t *refs = reinterpret_cast<uint8_t *>(b->w_refs.p), *seqs = reinterpret_cast<uint8_t *>(b->w_seqs.p);
-    char *cigs = b->w_cigs.p;
+    uint8_t *refs = reinterpret_cast<uint8_t *>(ctx->h_refs.p), *seqs = reinterpret_cast<uint8_t *>(ctx->h_seqs.p);
+    char *cigs = ctx->h_cigs.p;
     if (int rc = npore_bam_pack(b, fa, fasta_of_ref, idx, n, refs, ro.data(), seqs, so.data(), cigs, co.data(), threads)) return rc;
     oo[0] = fo[0] = 0;
     for (int64_t k = 0; k < n; k++) {
@@ -919,9 +922,9 @@ int npore_bam_realign_batch(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa,
         oo[(size_t)k + 1] = oo[(size_t)k] + cap;
         fo[(size_t)k + 1] = fo[(size_t)k] + 2 * cap + 16;
     }
-    if (!b->w_alns.ensure((size_t)oo[(size_t)n] + 64) || !b->w_finals.ensure((size_t)fo[(size_t)n] + 64))
+    if (!ctx->h_alns.ensure((size_t)oo[(size_t)n] + 64) || !b->w_finals.ensure((size_t)fo[(size_t)n] + 64))
         return fail(NPORE_E_NOMEM, "batch buffers");
-    char *alns = b->w_alns.p, *finals = b->w_finals.p;
+    char *alns = ctx->h_alns.p, *finals = b->w_finals.p;
     b->stage_ms[0] = ms_since(t0);
     t0 = clk::now();
     if (int rc = npore_align_batch(ctx, n, refs, ro.data(), seqs, so.data(), cigs, co.data(), indel_start,
