@@ -257,6 +257,24 @@ def realign_reads(ctx, read_data, out_sam, r=30, max_b_rows=20000):
     return len(read_data)
 
 
+def realign_haps(ctx, hap_data, r=30, max_b_rows=20000):
+    """Batched realign_hap (src/bam.pyx:93-123), the second caller of align() in the reference
+    (standardize_vcf.py:32-34: whole haplotype sequences against the reference, thousands of
+    independent chunks per sequence): [(contig, hap, seq, ref, cigar)] -> the same tuples with the
+    realigned, standardised, expanded 'MID' CIGAR."""
+    hap_data = list(hap_data)
+    if not hap_data:
+        return []
+    refs = [bases_to_int(h[3]) for h in hap_data]
+    seqs = [bases_to_int(h[2]) for h in hap_data]
+    alns, status = ctx.align_batch(refs, seqs, [h[4] for h in hap_data], r=r, max_b_rows=max_b_rows, return_status=True)
+    for h, st in zip(hap_data, status):
+        if st:
+            print(f"\nERROR: inconsistent traceback for {h[0]} hap {h[1]} (status {int(st)})")
+    finals = standardize_batch(alns, refs, seqs)
+    return [(h[0], h[1], h[2], h[3], expand_cigar(f)) for h, f in zip(hap_data, finals)]
+
+
 def sam_line(rd, final):
     """SAM record of one get_read_data tuple with its final CIGAR (src/bam.pyx:83)."""
     read_id, flag, ref_name, start, mapq, _cig, stop, sseq, quals, _ref, hap = rd

@@ -362,3 +362,23 @@ def test_native_realign_batch_matches_python_pipeline(ctx, tmp_path):
         assert text.decode() == want and text.count(b"\n") == len(rds) - 1
     finally:
         cfg.args = old
+
+
+def test_realign_hap_long_sequences(ctx, tables):
+    """realign_hap's use of align(): whole haplotype-length sequences (tens of chunks each) --
+    raw strings equal the oracle's, final CIGARs equal the Python standardisation of them."""
+    from npore_amd import bam
+    from npore_amd.cig import standardize
+    sub, nps = tables
+    dec = lambda a: "".join("NACGT"[x] for x in a)
+    haps = []
+    for k, L in enumerate((150_000, 61_000)):
+        ref, seq, cig = synth.make_pair(91, k, L, 0.05, 0.3, False)
+        haps.append(("chrT", k + 1, dec(seq), dec(ref), cig.decode() if isinstance(cig, bytes) else cig))
+    out = bam.realign_haps(ctx, haps, r=30)
+    for h, o in zip(haps, out):
+        r_, s_ = np.frombuffer(h[3].encode().translate(bytes.maketrans(b"NACGT", bytes(range(5)))), np.uint8), \
+                 np.frombuffer(h[2].encode().translate(bytes.maketrans(b"NACGT", bytes(range(5)))), np.uint8)
+        want_raw = oracle.align(r_, s_, h[4], sub, nps, r=30)
+        assert ctx.align_batch([r_], [s_], [h[4]], r=30)[0] == want_raw
+        assert o[:4] == h[:4] and o[4] == standardize(want_raw, r_, s_)
