@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--r", type=int, default=100)
     ap.add_argument("--max-b-rows", type=int, default=20000)
     ap.add_argument("--base-seed", type=int, default=2)
-    ap.add_argument("--cpu-sample", type=int, default=8, help="reads timed on one host core with the oracle")
+    ap.add_argument("--cpu-sample", type=int, default=64, help="reads timed on one host core with the oracle (~10 s)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 

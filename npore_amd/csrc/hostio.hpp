@@ -187,6 +187,9 @@ struct npore_bam {
     std::vector<int64_t> ref_lens;
     std::vector<uint8_t> ref_has_reads;
     std::vector<int64_t> rec_off;         // offset of each record's block_size field
+    std::vector<std::vector<int64_t>> by_ref;   // record indices per reference id, file order
+    std::vector<uint8_t> ref_sorted;      // ... which is ascending in position (regions then need no full scan)
+    std::vector<int64_t> ref_max_len;     // longest reference span of a record on that reference
     npore::RawBuf sam;                    // text of the last formatted batch
     npore::RawBuf w_finals;               // final CIGARs of the last batch (work buffer, reused)
     double stage_ms[4] = {0, 0, 0, 0};    // last npore_bam_realign_batch: pack, align, standardise, format

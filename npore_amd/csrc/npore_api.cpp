@@ -701,12 +701,24 @@ npore_bam *npore_bam_open(const char *path, int threads)
         p += 8 + (size_t)l_name;
     }
     b->ref_has_reads.assign((size_t)n_ref, 0);
+    b->by_ref.assign((size_t)n_ref, {});
+    b->ref_sorted.assign((size_t)n_ref, 1);
+    b->ref_max_len.assign((size_t)n_ref, 0);
+    std::vector<int64_t> last_pos((size_t)n_ref, -1);
     while (p + 4 <= N) {
         const int32_t bs = rdi32(&d[p]);
         if (bs < 32 || p + 4 + (size_t)bs > N) { fail(NPORE_E_INVALID, "truncated BAM record"); delete b; return nullptr; }
+        const int64_t i = (int64_t)b->rec_off.size();
         b->rec_off.push_back((int64_t)p);
         const int32_t rid = rdi32(&d[p + 4]);
-        if (rid >= 0 && rid < n_ref) b->ref_has_reads[(size_t)rid] = 1;
+        if (rid >= 0 && rid < n_ref) {
+            const RecView r = rec_at(*b, i);
+            b->ref_has_reads[(size_t)rid] = 1;
+            b->by_ref[(size_t)rid].push_back(i);
+            if (r.pos() < last_pos[(size_t)rid]) b->ref_sorted[(size_t)rid] = 0;
+            last_pos[(size_t)rid] = r.pos();
+            b->ref_max_len[(size_t)rid] = std::max(b->ref_max_len[(size_t)rid], rec_ref_len(r));
+        }
         p += 4 + (size_t)bs;
     }
     return b;
@@ -723,11 +735,20 @@ int64_t npore_bam_select(const npore_bam *b, int n_regions, const int32_t *ref_i
 {
     if (!b || (n_regions > 0 && (!ref_id || !start || !stop)) || (cap > 0 && !out_idx)) return fail(NPORE_E_INVALID, "null argument");
     int64_t kept = 0;
-    const int64_t nrec = (int64_t)b->rec_off.size();
     for (int g = 0; g < n_regions; g++) {
-        for (int64_t i = 0; i < nrec; i++) {
+        if (ref_id[g] < 0 || ref_id[g] >= (int32_t)b->by_ref.size()) continue;
+        const std::vector<int64_t> &recs = b->by_ref[(size_t)ref_id[g]];     // file order
+        size_t first = 0;
+        if (b->ref_sorted[(size_t)ref_id[g]]) {
+            // coordinate-sorted (the usual case): skip everything that ends before the region can start
+            const int64_t lo = start[g] - b->ref_max_len[(size_t)ref_id[g]];
+            first = (size_t)(std::lower_bound(recs.begin(), recs.end(), lo,
+                                              [&](int64_t i, int64_t v) { return (int64_t)rec_at(*b, i).pos() < v; }) - recs.begin());
+        }
+        for (size_t q = first; q < recs.size(); q++) {
+            const int64_t i = recs[q];
             const RecView r = rec_at(*b, i);
-            if (r.ref_id() != ref_id[g]) continue;
+            if (b->ref_sorted[(size_t)ref_id[g]] && r.pos() >= stop[g]) break;
             const int64_t rl = rec_ref_len(r);
             if (!(r.pos() < stop[g] && r.pos() + rl > start[g])) continue;        // overlaps [start, stop)
             if (max_reads > 0 && kept >= max_reads) return kept;                   // src/bam.pyx:29-30

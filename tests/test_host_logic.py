@@ -232,3 +232,8 @@ def test_native_bam_clips_flags_tags(tmp_path):
     n2 = _native_vs_python(str(bp), str(fa), [("chrB", 100, 200)])
     n3 = _native_vs_python(str(bp), str(fa), [("chrA", 0, 699), ("chrB", 0, 299)], max_reads=7)
     assert n1 > 20 and 0 < n2 < n1 and n3 == 7
+    # not coordinate-sorted: the per-reference index falls back to a scan in file order
+    rng.shuffle(recs)
+    bam.write_bam(str(tmp_path / "u.bam"), [(n, len(s)) for n, s in contigs.items()], recs)
+    assert _native_vs_python(str(tmp_path / "u.bam"), str(fa), [("chrA", 0, 699), ("chrB", 0, 299)]) == n1
+    assert _native_vs_python(str(tmp_path / "u.bam"), str(fa), [("chrB", 100, 200)]) == n2
