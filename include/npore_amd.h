@@ -192,6 +192,12 @@ int npore_bam_format_sam(npore_bam *bam, const int64_t *idx, int64_t n, const ch
 int npore_bam_realign_batch(npore_ctx *ctx, npore_bam *bam, const npore_fasta *fa, const int32_t *fasta_of_ref,
                             const int64_t *idx, int64_t n, float indel_start, float indel_extend, int max_b_rows,
                             int r, int threads, const char **sam, int64_t *sam_len, int32_t *status);
+/* The same for all `n` selected reads in batches of `batch_reads`, appended to the file `out_path` in input
+ * order, with the three stages overlapped: while the GPU aligns batch k, batch k+1 is packed and batch k-1
+ * standardised, formatted and written.  status[n] as for npore_align_batch. */
+int npore_bam_realign_file(npore_ctx *ctx, npore_bam *bam, const npore_fasta *fa, const int32_t *fasta_of_ref,
+                           const int64_t *idx, int64_t n, int64_t batch_reads, float indel_start, float indel_extend,
+                           int max_b_rows, int r, int threads, const char *out_path, int32_t *status);
 /* Host wall time of the stages of the last npore_bam_realign_batch on `bam` (milliseconds):
  * ms[0] pack, ms[1] npore_align_batch (incl. PCIe), ms[2] standardise, ms[3] SAM formatting. */
 int npore_bam_last_timing(const npore_bam *bam, double *ms, int n);

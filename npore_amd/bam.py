@@ -402,6 +402,18 @@ class NativeBam:
         # a view of the library's buffer (valid until the next call on this handle): no copy before the file write
         return (memoryview((C.c_char * sam_len.value).from_address(sam.value)) if sam_len.value else memoryview(b"")), st[:n]
 
+    def realign_file(self, ctx, fasta, idx, out_sam, batch_reads=4096, r=30, max_b_rows=20000, indel_start=5.0,
+                     indel_extend=1.0, threads=0):
+        """All selected reads, batch by batch, appended to out_sam by the library with packing, GPU work and
+        formatting/writing of neighbouring batches overlapped.  Returns status[n]."""
+        idx = np.ascontiguousarray(idx, np.int64)
+        st = np.zeros(max(len(idx), 1), np.int32)
+        fmap = self.fasta_map(fasta)
+        self._check(self._lib.npore_bam_realign_file(ctx.handle, self.handle, fasta.handle, fmap.ctypes.data, idx.ctypes.data,
+                                                     len(idx), int(batch_reads), indel_start, indel_extend, max_b_rows, r,
+                                                     threads, os.fsencode(out_sam), st.ctypes.data))
+        return st[:len(idx)]
+
     def timing(self):
         """Host wall time (ms) of the stages of the last realign_batch."""
         ms = np.zeros(4, np.float64)
@@ -419,19 +431,24 @@ class NativeBam:
             self.handle = None
 
 
-def realign_native(ctx, bam, fasta, idx, out_sam, r=30, max_b_rows=20000):
-    """realign_reads() through the library's batch entry point; returns the number of reads handed in."""
+def realign_native(ctx, bam, fasta, idx, out_sam, r=30, max_b_rows=20000, batch_reads=0):
+    """realign_reads() through the library; returns the number of reads handed in.  batch_reads > 0: the whole
+    index list in overlapped batches written by the library itself; 0: one batch, text written here."""
     if len(idx) == 0:
         return 0
-    text, status = bam.realign_batch(ctx, fasta, idx, r=r, max_b_rows=max_b_rows)
+    if batch_reads > 0:
+        text, status = None, bam.realign_file(ctx, fasta, idx, out_sam, batch_reads=batch_reads, r=r, max_b_rows=max_b_rows)
+    else:
+        text, status = bam.realign_batch(ctx, fasta, idx, r=r, max_b_rows=max_b_rows)
     bad = np.nonzero(status)[0]
     for k in bad:
         if status[k] & 32:
             print(f"\nERROR: read #{int(idx[k])}: CIGAR does not match sequence lengths; skipped.")
         else:
             print(f"\nERROR: inconsistent traceback for read #{int(idx[k])} (status {int(status[k])})")   # src/aln.pyx:689-716
-    with open(out_sam, "ab") as fh:
-        fh.write(text)
+    if text is not None:
+        with open(out_sam, "ab") as fh:
+            fh.write(text)
     return len(idx)
 
 

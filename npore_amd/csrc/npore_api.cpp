@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <future>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -92,6 +93,15 @@ struct HostBuf {   // pinned staging
 
 }  // namespace
 
+// One batch on its way through the BAM -> SAM pipeline: host staging (page-locked where it crosses PCIe) and offsets.
+struct npore_batch_slot {
+    RawBuf refs{true}, seqs{true}, cigs{true}, alns{true}, finals, sam;
+    std::vector<int64_t> ro, so, co, oo, fo, olen, flen;
+    int64_t sam_len = 0;
+    int rc = 0;
+    std::string err;
+};
+
 struct npore_ctx {
     int device = 0;
     int max_n = 6, max_l = 100;
@@ -107,8 +117,8 @@ struct npore_ctx {
     DevBuf seqw, refw, refl, seql;                                   // annotation
     DevBuf tb, cout_, clen, cstat;                                   // fill / traceback
     DevBuf out, out_off, out_len, status;                            // outputs (host-buffer entry point)
-    // page-locked host staging of npore_bam_realign_batch (grow-only, reused across batches and files)
-    RawBuf h_refs{true}, h_seqs{true}, h_cigs{true}, h_alns{true};
+    // host staging of the BAM -> SAM pipeline (npore_bam_realign_batch / _file): grow-only, reused across batches and files
+    npore_batch_slot *slots[3] = {nullptr, nullptr, nullptr};
     double timing[8] = {};
 };
 
@@ -458,6 +468,7 @@ void npore_ctx_destroy(npore_ctx *ctx)
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    for (auto *sp : ctx->slots) delete sp;
     delete ctx;
 }
 
@@ -868,10 +879,11 @@ int npore_bam_pack(const npore_bam *b, const npore_fasta *fa, const int32_t *fas
     return bad ? fail(NPORE_E_INVALID, "a selected read lies on a contig that is not in the FASTA") : NPORE_OK;
 }
 
-int npore_bam_format_sam(npore_bam *b, const int64_t *idx, int64_t n, const char *finals, const int64_t *final_off,
-                         const int64_t *final_len, const int32_t *status, int threads, const char **sam, int64_t *sam_len)
+namespace {
+int format_sam_into(const npore_bam *b, const int64_t *idx, int64_t n, const char *finals, const int64_t *final_off,
+                    const int64_t *final_len, const int32_t *status, int threads, RawBuf &out, int64_t *sam_len)
 {
-    if (!pack_args_ok(b, idx, n) || !sam || !sam_len || (n > 0 && (!finals || !final_off || !final_len || !status)))
+    if (!pack_args_ok(b, idx, n) || !sam_len || (n > 0 && (!finals || !final_off || !final_len || !status)))
         return fail(NPORE_E_INVALID, "bad argument");
     // pass 1: line sizes; pass 2: fill (both parallel over reads)
     std::vector<int64_t> off((size_t)n + 1, 0);
@@ -913,59 +925,146 @@ int npore_bam_format_sam(npore_bam *b, const int64_t *idx, int64_t n, const char
     };
     parallel_for(n, threads, [&](int64_t k) { off[(size_t)k + 1] = line(k, nullptr); });
     for (int64_t k = 0; k < n; k++) off[(size_t)k + 1] += off[(size_t)k];
-    if (!b->sam.ensure((size_t)off[(size_t)n] + 1)) return fail(NPORE_E_NOMEM, "SAM text buffer");
-    parallel_for(n, threads, [&](int64_t k) { if (off[(size_t)k + 1] > off[(size_t)k]) line(k, b->sam.p + off[(size_t)k]); });
-    *sam = b->sam.p;
+    if (!out.ensure((size_t)off[(size_t)n] + 1)) return fail(NPORE_E_NOMEM, "SAM text buffer");
+    parallel_for(n, threads, [&](int64_t k) { if (off[(size_t)k + 1] > off[(size_t)k]) line(k, out.p + off[(size_t)k]); });
     *sam_len = off[(size_t)n];
     return NPORE_OK;
 }
+}  // namespace
+
+int npore_bam_format_sam(npore_bam *b, const int64_t *idx, int64_t n, const char *finals, const int64_t *final_off,
+                         const int64_t *final_len, const int32_t *status, int threads, const char **sam, int64_t *sam_len)
+{
+    if (!b || !sam) return fail(NPORE_E_INVALID, "bad argument");
+    const int rc = format_sam_into(b, idx, n, finals, final_off, final_len, status, threads, b->sam, sam_len);
+    *sam = b->sam.p;
+    return rc;
+}
+
+namespace {
+// pack the selected records into the slot (inputs of npore_align_batch) and size its output buffers
+int slot_pack(const npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref, const int64_t *idx, int64_t n, int threads,
+              npore_batch_slot &s)
+{
+    for (auto *v : {&s.ro, &s.so, &s.co, &s.oo, &s.fo}) v->assign((size_t)n + 1, 0);
+    s.olen.assign((size_t)n, 0);
+    s.flen.assign((size_t)n, 0);
+    if (int rc = npore_bam_pack_sizes(b, idx, n, s.ro.data(), s.so.data(), s.co.data())) return rc;
+    if (!s.refs.ensure((size_t)s.ro[(size_t)n] + 64) || !s.seqs.ensure((size_t)s.so[(size_t)n] + 64) || !s.cigs.ensure((size_t)s.co[(size_t)n] + 64))
+        return fail(NPORE_E_NOMEM, "batch buffers");
+    if (int rc = npore_bam_pack(b, fa, fasta_of_ref, idx, n, reinterpret_cast<uint8_t *>(s.refs.p), s.ro.data(),
+                                reinterpret_cast<uint8_t *>(s.seqs.p), s.so.data(), s.cigs.p, s.co.data(), threads))
+        return rc;
+    for (int64_t k = 0; k < n; k++) {
+        const int64_t cap = (s.ro[(size_t)k + 1] - s.ro[(size_t)k]) + (s.so[(size_t)k + 1] - s.so[(size_t)k]);
+        s.oo[(size_t)k + 1] = s.oo[(size_t)k] + cap;
+        s.fo[(size_t)k + 1] = s.fo[(size_t)k] + 2 * cap + 16;
+    }
+    if (!s.alns.ensure((size_t)s.oo[(size_t)n] + 64) || !s.finals.ensure((size_t)s.fo[(size_t)n] + 64))
+        return fail(NPORE_E_NOMEM, "batch buffers");
+    return NPORE_OK;
+}
+int slot_align(npore_ctx *ctx, int64_t n, float indel_start, float indel_extend, int max_b_rows, int r, int32_t *status,
+               npore_batch_slot &s)
+{
+    return npore_align_batch(ctx, n, reinterpret_cast<uint8_t *>(s.refs.p), s.ro.data(), reinterpret_cast<uint8_t *>(s.seqs.p),
+                             s.so.data(), s.cigs.p, s.co.data(), indel_start, indel_extend, max_b_rows, r, s.alns.p, s.oo.data(),
+                             s.olen.data(), status);
+}
+// realign_read's glue (src/bam.pyx:65-78) and the SAM lines; reads refused by align() have no string and get an empty CIGAR
+int slot_post(const npore_bam *b, const int64_t *idx, int64_t n, const int32_t *status, int threads, npore_batch_slot &s,
+              double *ms_std = nullptr)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint8_t *refs = reinterpret_cast<const uint8_t *>(s.refs.p), *seqs = reinterpret_cast<const uint8_t *>(s.seqs.p);
+    parallel_for(n, threads, [&](int64_t k) {
+        const int64_t l = s.olen[(size_t)k] > 0 ? s.olen[(size_t)k] : 0;
+        const std::string c = standardize_collapsed(s.alns.p + s.oo[(size_t)k], l, refs + s.ro[(size_t)k],
+                                                    s.ro[(size_t)k + 1] - s.ro[(size_t)k], seqs + s.so[(size_t)k],
+                                                    s.so[(size_t)k + 1] - s.so[(size_t)k]);
+        std::memcpy(s.finals.p + s.fo[(size_t)k], c.data(), c.size());     // 2 bytes per op + 16 always suffice
+        s.flen[(size_t)k] = (int64_t)c.size();
+    });
+    if (ms_std) *ms_std = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return format_sam_into(b, idx, n, s.finals.p, s.fo.data(), s.flen.data(), status, threads, s.sam, &s.sam_len);
+}
+}  // namespace
+
 
 int npore_bam_realign_batch(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref, const int64_t *idx,
                             int64_t n, float indel_start, float indel_extend, int max_b_rows, int r, int threads,
                             const char **sam, int64_t *sam_len, int32_t *status)
 {
-    if (!ctx || !status) return fail(NPORE_E_INVALID, "null argument");
+    if (!ctx || !b || !status || !sam || !sam_len) return fail(NPORE_E_INVALID, "null argument");
     using clk = std::chrono::steady_clock;
     auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
-    auto t0 = clk::now();
-    std::vector<int64_t> ro((size_t)n + 1), so((size_t)n + 1), co((size_t)n + 1), oo((size_t)n + 1), fo((size_t)n + 1), olen((size_t)n), flen((size_t)n);
-    if (int rc = npore_bam_pack_sizes(b, idx, n, ro.data(), so.data(), co.data())) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
-    if (!ctx->h_refs.ensure((size_t)ro[(size_t)n] + 64) || !ctx->h_seqs.ensure((size_t)so[(size_t)n] + 64) ||
-        !ctx->h_cigs.ensure((size_t)co[(size_t)n] + 64))
-        return fail(NPORE_E_NOMEM, "batch buffers");
-    uint8_t *refs = reinterpret_cast<uint8_t *>(ctx->h_refs.p), *seqs = reinterpret_cast<uint8_t *>(ctx->h_seqs.p);
-    char *cigs = ctx->h_cigs.p;
-    if (int rc = npore_bam_pack(b, fa, fasta_of_ref, idx, n, refs, ro.data(), seqs, so.data(), cigs, co.data(), threads)) return rc;
-    oo[0] = fo[0] = 0;
-    for (int64_t k = 0; k < n; k++) {
-        const int64_t cap = (ro[(size_t)k + 1] - ro[(size_t)k]) + (so[(size_t)k + 1] - so[(size_t)k]);
-        oo[(size_t)k + 1] = oo[(size_t)k] + cap;
-        fo[(size_t)k + 1] = fo[(size_t)k] + 2 * cap + 16;
-    }
-    if (!ctx->h_alns.ensure((size_t)oo[(size_t)n] + 64) || !b->w_finals.ensure((size_t)fo[(size_t)n] + 64))
-        return fail(NPORE_E_NOMEM, "batch buffers");
-    char *alns = ctx->h_alns.p, *finals = b->w_finals.p;
+    if (!ctx->slots[0]) ctx->slots[0] = new npore_batch_slot();
+    npore_batch_slot &s = *ctx->slots[0];
+    auto t0 = clk::now();
+    if (int rc = slot_pack(b, fa, fasta_of_ref, idx, n, threads, s)) return rc;
     b->stage_ms[0] = ms_since(t0);
     t0 = clk::now();
-    if (int rc = npore_align_batch(ctx, n, refs, ro.data(), seqs, so.data(), cigs, co.data(), indel_start,
-                                   indel_extend, max_b_rows, r, alns, oo.data(), olen.data(), status))
-        return rc;
+    if (int rc = slot_align(ctx, n, indel_start, indel_extend, max_b_rows, r, status, s)) return rc;
     b->stage_ms[1] = ms_since(t0);
     t0 = clk::now();
-    // realign_read's glue (src/bam.pyx:65-78); reads refused by align() have no string and get an empty CIGAR
-    parallel_for(n, threads, [&](int64_t k) {
-        const int64_t l = olen[(size_t)k] > 0 ? olen[(size_t)k] : 0;
-        const std::string c = standardize_collapsed(alns + oo[(size_t)k], l, refs + ro[(size_t)k], ro[(size_t)k + 1] - ro[(size_t)k],
-                                                    seqs + so[(size_t)k], so[(size_t)k + 1] - so[(size_t)k]);
-        std::memcpy(finals + fo[(size_t)k], c.data(), c.size());     // 2 bytes per op + 16 always suffice
-        flen[(size_t)k] = (int64_t)c.size();
-    });
-    b->stage_ms[2] = ms_since(t0);
-    t0 = clk::now();
-    const int rc = npore_bam_format_sam(b, idx, n, finals, fo.data(), flen.data(), status, threads, sam, sam_len);
-    b->stage_ms[3] = ms_since(t0);
+    double ms_std = 0.0;
+    const int rc = slot_post(b, idx, n, status, threads, s, &ms_std);
+    b->stage_ms[2] = ms_std;
+    b->stage_ms[3] = ms_since(t0) - ms_std;
+    *sam = s.sam.p;
+    *sam_len = s.sam_len;
     return rc;
+}
+
+int npore_bam_realign_file(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref, const int64_t *idx,
+                           int64_t n, int64_t batch_reads, float indel_start, float indel_extend, int max_b_rows, int r,
+                           int threads, const char *out_path, int32_t *status)
+{
+    if (!ctx || !b || !fa || !out_path || (n > 0 && (!idx || !status)) || batch_reads < 1) return fail(NPORE_E_INVALID, "bad argument");
+    FILE *fh = std::fopen(out_path, "ab");
+    if (!fh) return fail(NPORE_E_INVALID, std::string("cannot open '") + out_path + "' for appending");
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (auto &sp : ctx->slots)
+        if (!sp) sp = new npore_batch_slot();
+    const int64_t nb = (n + batch_reads - 1) / batch_reads;
+    auto first = [&](int64_t k) { return k * batch_reads; };
+    auto count = [&](int64_t k) { return std::min(batch_reads, n - k * batch_reads); };
+    // Three stages, three slots: while the GPU aligns batch k (this thread: a context takes one call at a time),
+    // one helper packs batch k+1 and another standardises, formats and writes batch k-1.
+    std::vector<std::future<void>> packed((size_t)nb), posted((size_t)nb);
+    auto start_pack = [&](int64_t k) {
+        packed[(size_t)k] = std::async(std::launch::async, [&, k] {
+            npore_batch_slot &s = *ctx->slots[(size_t)(k % 3)];
+            if (k >= 3) posted[(size_t)(k - 3)].wait();        // the slot's previous batch has been written
+            s.rc = slot_pack(b, fa, fasta_of_ref, idx + first(k), count(k), threads, s);
+            if (s.rc) s.err = npore_last_error();
+        });
+    };
+    int rc = NPORE_OK;
+    std::string err;
+    if (nb > 0) start_pack(0);
+    for (int64_t k = 0; k < nb && rc == NPORE_OK; k++) {
+        npore_batch_slot &s = *ctx->slots[(size_t)(k % 3)];
+        packed[(size_t)k].wait();
+        if (k + 1 < nb) start_pack(k + 1);
+        if (s.rc) { rc = s.rc; err = s.err; break; }
+        rc = slot_align(ctx, count(k), indel_start, indel_extend, max_b_rows, r, status + first(k), s);
+        if (rc) { err = npore_last_error(); break; }
+        posted[(size_t)k] = std::async(std::launch::async, [&, k] {
+            npore_batch_slot &t = *ctx->slots[(size_t)(k % 3)];
+            t.rc = slot_post(b, idx + first(k), count(k), status + first(k), threads, t);
+            if (t.rc) { t.err = npore_last_error(); return; }
+            if (k > 0) posted[(size_t)(k - 1)].wait();         // records in input order
+            if (std::fwrite(t.sam.p, 1, (size_t)t.sam_len, fh) != (size_t)t.sam_len) { t.rc = NPORE_E_INVALID; t.err = "short write"; }
+        });
+    }
+    for (auto &f : packed) if (f.valid()) f.wait();
+    for (auto &f : posted) if (f.valid()) f.wait();
+    for (auto &sp : ctx->slots)
+        if (rc == NPORE_OK && sp->rc) { rc = sp->rc; err = sp->err; }
+    if (std::fclose(fh) != 0 && rc == NPORE_OK) { rc = NPORE_E_INVALID; err = "close failed"; }
+    return rc == NPORE_OK ? NPORE_OK : fail(rc, err);
 }
 
 int npore_bam_last_timing(const npore_bam *b, double *ms, int n)

@@ -73,8 +73,7 @@ def main():
     if native:
         idx = bam.select(cfg.args.regions, cfg.args.max_reads)
         print("> computing individual read realignments")
-        for k in range(0, len(idx), cfg.args.batch_reads):
-            n += bam_mod.realign_native(ctx, bam, ref_seqs, idx[k:k + cfg.args.batch_reads], out_sam)
+        n += bam_mod.realign_native(ctx, bam, ref_seqs, idx, out_sam, batch_reads=cfg.args.batch_reads)
         bam.close()
         ref_seqs.close()
     else:

@@ -360,6 +360,10 @@ def test_native_realign_batch_matches_python_pipeline(ctx, tmp_path):
         want = "".join(bam.sam_line(rd, f) for rd, f, s_ in zip(rds, finals, pst) if not s_ & 32)
         assert np.array_equal(st, pst) and ((st & 32) != 0).sum() == 1
         assert text.decode() == want and text.count(b"\n") == len(rds) - 1
+        # the library's own overlapped batch loop (pack k+1 | GPU k | format + write k-1) writes the same file
+        out = tmp_path / "pipe.sam"
+        st2 = nb.realign_file(ctx, nf, idx, str(out), batch_reads=5, r=30)
+        assert np.array_equal(st2, pst) and out.read_bytes() == text
     finally:
         cfg.args = old
 
