@@ -541,19 +541,31 @@ struct TParams {
     const int32_t *n_chunks;
     const uint32_t *tb;
     const int32_t *inss;       // per read: inss[b] for every anti-diagonal of its input path
-    const uint8_t *seqs, *refs;
-    uint8_t *chunk_out;        // per-chunk slots, ops right-aligned
-    int32_t *chunk_len;        // ops emitted
+    uint32_t *chunk_runs;      // per-chunk slots (same offsets as the op slots): typ | length << 3 per run, last run first
+    int32_t *chunk_nruns;      // runs recorded
+    int32_t *chunk_len;        // ops they stand for
     int32_t *chunk_status;
     int r;
     int tbstride;
 };
 
-// One wavefront per chunk.  Every hop of the traceback needs the cell's word and the
-// band position of its anti-diagonal (inss[b]): ONE coalesced load of the whole row
-// (16 bytes per lane) plus one scalar-like load of inss[b], both requested before the
-// ops of the current run are emitted (lane-parallel), so emission overlaps their latency.
-template <int NL>   // uint4 loads per lane covering a row: tbstride <= 256 * NL
+// One wavefront per chunk.  A hop of the traceback needs the word of one cell and the band position
+// of its anti-diagonal (inss[b]); the next cell is only known once that word has arrived, so the
+// traceback is a chain of dependent HBM round trips.  The path moves slowly through the band (its
+// column changes only where the new alignment leaves the input one), so instead of one row per hop the
+// wave gathers WINDOWS: lane l holds 8 consecutive columns of anti-diagonal top - l (and its inss) --
+// 64 anti-diagonals of the band strip around the path in one round trip.  Two windows are kept: the
+// one the path is in and the one below it, requested the moment the path enters the upper one, so its
+// latency overlaps the hops through the current window.  Hops inside a window are register reads
+// (v_readlane).  The kernel records RUNS (type, length), 64 at a time from a register buffer -- no store
+// per hop whose completion the next hop's counter wait would expose; gather_kernel expands them into ops.
+struct TbWindow {
+    uint4 lo, hi;   // columns wc..wc+7 of anti-diagonal top - lane
+    int ins;        // inss of that anti-diagonal
+    int top;        // newest anti-diagonal held (lane 0); rows top-63..top
+    int wc;         // first column (multiple of 4)
+};
+
 __global__ __launch_bounds__(64) void traceback_kernel(TParams p)
 {
     const int k = blockIdx.x;
@@ -561,82 +573,101 @@ __global__ __launch_bounds__(64) void traceback_kernel(TParams p)
     const int lane = threadIdx.x;
     const ChunkDesc d = p.descs[k];
     const uint32_t *tb = p.tb + d.tb_off;
-    const uint8_t *seq = p.seqs + d.seq_off, *ref = p.refs + d.ref_off;
-    uint8_t *out = p.chunk_out + d.out_off;
+    uint32_t *runs = p.chunk_runs + d.out_off;
     const int W = 2 * p.r + 1, stride = p.tbstride;
     int a_row = d.row0 + d.drows, a_col = d.col0 + d.dcols;
-    int pos = d.out_cap;   // ops are written backwards
+    int pos = d.out_cap;   // ops still available in the chunk's slot
     int status = 0;
+    int nruns = 0;
+    uint32_t rbuf = 0u;    // lane l: run number (nruns & ~63) + l
 
     const int32_t *inss = p.inss + d.inss_off + d.brk;
-    uint4 row[NL];
-    int row_ins = 0;
-    auto load_row = [&](int bl) {
-        row_ins = inss[bl];
-#pragma unroll
-        for (int q = 0; q < NL; q++) {
-            const int idx = (q * 64 + lane) * 4;
-            row[q] = (idx < stride) ? *reinterpret_cast<const uint4 *>(tb + (size_t)bl * stride + idx)
-                                    : make_uint4(0u, 0u, 0u, 0u);
+    constexpr int NONE = -(1 << 30);
+    TbWindow w0, w1;
+    w0.top = w1.top = NONE;
+    w0.wc = w1.wc = 0;
+    w0.lo = w0.hi = w1.lo = w1.hi = make_uint4(0u, 0u, 0u, 0u);
+    w0.ins = w1.ins = 0;
+    auto load_window = [&](TbWindow &w, int top, int col0) {
+        w.top = top;
+        w.wc = col0;
+        const int row = top - lane;
+        w.lo = w.hi = make_uint4(0u, 0u, 0u, 0u);
+        w.ins = 0;
+        if (row >= 0 && row < d.nrows) {
+            const uint32_t *q = tb + (size_t)row * stride + col0;      // col0 + 3 < stride: both multiples of 4
+            w.lo = *reinterpret_cast<const uint4 *>(q);
+            if (col0 + 4 < stride) w.hi = *reinterpret_cast<const uint4 *>(q + 4);
+            w.ins = inss[row];
         }
     };
-    auto word = [&](int col) -> uint32_t {   // col is wave-uniform
-        uint4 v = row[0];
-        if constexpr (NL > 1) { if ((col >> 8) & 1) v = row[NL - 1]; }
-        const int comp = col & 3;
-        const uint32_t sel = comp == 0 ? v.x : comp == 1 ? v.y : comp == 2 ? v.z : v.w;
-        return (uint32_t)__builtin_amdgcn_readlane((int)sel, (col & 255) >> 2);
+    auto col_base = [&](int bc) { const int c = (bc - 2) & ~3; return c < 0 ? 0 : c; };   // bc lands at offset 2..5
+    // word of column bc (wave-uniform) on anti-diagonal bl of window w: per-lane selects on uniform
+    // conditions (no branch tree), then one cross-lane read
+    auto word = [&](const TbWindow &w, int bl, int bc) -> uint32_t {
+        const int kk = bc - w.wc;
+        const uint32_t a0 = (kk & 1) ? w.lo.y : w.lo.x, a1 = (kk & 1) ? w.lo.w : w.lo.z;
+        const uint32_t b0 = (kk & 1) ? w.hi.y : w.hi.x, b1 = (kk & 1) ? w.hi.w : w.hi.z;
+        const uint32_t lo2 = (kk & 2) ? a1 : a0, hi2 = (kk & 2) ? b1 : b0;
+        return (uint32_t)__builtin_amdgcn_readlane((int)((kk & 4) ? hi2 : lo2), w.top - bl);
     };
-    auto in_chunk = [&](int ar, int ac) {
-        const int bl = ar + ac - d.brk;
-        return ar >= d.row0 && ac >= d.col0 && bl >= 0 && bl < d.nrows;
-    };
-
-    if ((a_row > d.row0 || a_col > d.col0) && in_chunk(a_row, a_col)) load_row(a_row + a_col - d.brk);
+    TbWindow &cur = w0, &nxt = w1;              // the window the path is in / the one below it (prefetched)
+    const int row_end = a_row, col_end = a_col;
+    (void)row_end; (void)col_end;
+    if (a_row > d.row0 || a_col > d.col0) load_window(cur, a_row + a_col - d.brk, col_base(p.r));   // the path ends on the input path: column r
     while (a_row > d.row0 || a_col > d.col0) {
-        if (!in_chunk(a_row, a_col)) { status |= 16; break; }
-        const int bc = row_ins - a_row + p.r;     // inss[b] - a_row + r, src/aln.pyx:322-326
+        const int bl = a_row + a_col - d.brk;
+        if (a_row < d.row0 || a_col < d.col0 || bl < 0 || bl >= d.nrows) { status |= 16; break; }
+        if (bl <= cur.top - 64) {               // the path left the current window
+            if (nxt.top == cur.top - 64 && bl > nxt.top - 64) { cur = nxt; nxt.top = NONE; }
+            else { load_window(cur, bl, cur.wc); nxt.top = NONE; }
+        }
+        const int bc = __builtin_amdgcn_readlane(cur.ins, cur.top - bl) - a_row + p.r;     // inss[b] - a_row + r, src/aln.pyx:322-326
         if (bc < 0 || bc >= W) { status |= 16; break; }
-        const uint32_t w = (bc == 0 || bc == W - 1) ? 0u : word(bc);   // band edge: TYP = MAT, RUN = 0 (src/aln.pyx:502-507)
+        if (bc < cur.wc || bc > cur.wc + 7) {   // the path drifted out of the strip (rare): new columns
+            load_window(cur, cur.top, col_base(bc));
+            nxt.top = NONE;
+        }
+        if (nxt.top == NONE && cur.top >= 64) load_window(nxt, cur.top - 64, cur.wc);   // request the window below early
+        const uint32_t w = (bc == 0 || bc == W - 1) ? 0u : word(cur, bl, bc);   // band edge: TYP = MAT, RUN = 0 (src/aln.pyx:502-507)
         const int typ = (int)(w & 7u), run = (int)(w >> 3);     // src/aln.pyx:684-685
         if (run < 1) { status |= 4; break; }
         if (run > pos) { status |= 16; break; }
-        int n_row = a_row, n_col = a_col, emit = run;
-        uint8_t ch = 0;
-        if (typ == T_LEN || typ == T_INS) { ch = 'I'; n_row -= run; }
-        else if (typ == T_SHR || typ == T_DEL) { ch = 'D'; n_col -= run; }
-        else if (typ == T_MAT) {
+        int emit = run;
+        const bool ins = (typ == T_LEN || typ == T_INS), del = (typ == T_SHR || typ == T_DEL);
+        if (!ins && !del) {
+            if (typ != T_MAT) { status |= 8; break; }
             const int lim = min(a_row - d.row0, a_col - d.col0);
             emit = run < lim ? run : lim;                          // diagonal steps that stay in the chunk
-            n_row -= emit; n_col -= emit;
-        } else { status |= 8; break; }
-        // request the next row now; the emission below overlaps its latency
-        if ((n_row > d.row0 || n_col > d.col0) && in_chunk(n_row, n_col)) load_row(n_row + n_col - d.brk);
-        if (ch) {
-            for (int q = lane; q < emit; q += 64) out[pos - 1 - q] = ch;
-        } else {
-            for (int q = lane; q < emit; q += 64)
-                out[pos - 1 - q] = (ref[a_col - 1 - q] == seq[a_row - 1 - q]) ? '=' : 'X';   // src/aln.pyx:732-735
+        }
+        if (emit > 0) {
+            rbuf = (lane == (nruns & 63)) ? ((uint32_t)typ | ((uint32_t)emit << 3)) : rbuf;
+            nruns++;
+            if ((nruns & 63) == 0) runs[nruns - 64 + lane] = rbuf;
         }
         pos -= emit;
         if (emit < run) { status |= 16; break; }
-        a_row = n_row;
-        a_col = n_col;
+        a_row -= del ? 0 : emit;
+        a_col -= ins ? 0 : emit;
     }
     if (lane == 0) {
         p.chunk_len[k] = d.out_cap - pos;
         p.chunk_status[k] = status;
+        p.chunk_nruns[k] = nruns;
     }
+    if (lane < (nruns & 63)) runs[(nruns & ~63) + lane] = rbuf;
 }
 
 // ---------------------------------------------------------------------------
 struct GParams {
     const ChunkDesc *descs;
     const int32_t *read_first_chunk;   // [n_reads+1]
-    const uint8_t *chunk_out;
+    const uint32_t *chunk_runs;
+    const int32_t *chunk_nruns;
     const int32_t *chunk_len, *chunk_status;
     const int32_t *read_status_in;     // prep status per read (bad input)
     const int32_t *counters;
+    const uint8_t *seqs, *refs;        // the batch's read / reference bases ('=' vs 'X')
     uint8_t *out;
     const int64_t *out_off;            // [n_reads+1] in the caller's buffer
     int64_t *out_len;
@@ -659,11 +690,72 @@ __global__ __launch_bounds__(256) void gather_kernel(GParams p)
     if (total < 0) return;
     uint8_t *dst = p.out + p.out_off[grd];
     int64_t w = 0;
+    // Expand each chunk's runs (recorded last run first) into ops.  Run j ends where the ops of the runs before
+    // it (in recording order) begin, counted from the chunk's end, and pairs the bases below the cell reached
+    // after those runs: three prefix sums in recording order -- ops, read bases, reference bases.  Every thread
+    // takes an equal share of the OUTPUT positions (runs differ wildly in length) and finds its first run
+    // through per-thread-segment sums.
+    __shared__ int s_ops[257], s_rows[257], s_cols[257];
+    const int T = (int)blockDim.x, t = (int)threadIdx.x;
     for (int c = c0; c < c1; c++) {
         const ChunkDesc d = p.descs[c];
-        const int len = p.chunk_len[c];
-        const uint8_t *src = p.chunk_out + d.out_off + (d.out_cap - len);
-        for (int q = threadIdx.x; q < len; q += blockDim.x) dst[w + q] = src[q];
+        const int len = p.chunk_len[c], nr = p.chunk_nruns[c];
+        const uint32_t *runs = p.chunk_runs + d.out_off;
+        const uint8_t *seq = p.seqs + d.seq_off, *ref = p.refs + d.ref_off;
+        const int seg = (nr + T - 1) / T;
+        const int e0 = min(nr, t * seg), e1 = min(nr, e0 + seg);
+        int so = 0, sr = 0, sc = 0;
+        for (int e = e0; e < e1; e++) {
+            const uint32_t x = runs[e];
+            const int typ = (int)(x & 7u), l = (int)(x >> 3);
+            so += l;
+            sr += (typ == T_DEL || typ == T_SHR) ? 0 : l;
+            sc += (typ == T_INS || typ == T_LEN) ? 0 : l;
+        }
+        __syncthreads();            // the previous chunk's readers are done with the shared sums
+        s_ops[t + 1] = so; s_rows[t + 1] = sr; s_cols[t + 1] = sc;
+        __syncthreads();
+        if (t == 0) {
+            s_ops[0] = s_rows[0] = s_cols[0] = 0;
+            for (int q = 1; q <= T; q++) { s_ops[q] += s_ops[q - 1]; s_rows[q] += s_rows[q - 1]; s_cols[q] += s_cols[q - 1]; }
+        }
+        __syncthreads();
+        // output positions u (0 = the chunk's LAST op) of this thread
+        const int useg = (len + T - 1) / T;
+        const int u0 = min(len, t * useg), u1 = min(len, u0 + useg);
+        if (u0 < u1) {
+            int lo = 0, hi = T;                     // segment sgm with s_ops[sgm] <= u0 < s_ops[sgm + 1]
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_ops[mid] <= u0) lo = mid; else hi = mid; }
+            int e = min(nr, lo * seg), ao = s_ops[lo], ar = s_rows[lo], ac = s_cols[lo];
+            int typ = 0, l = 0;
+            for (;; e++) {                          // first run that reaches beyond u0
+                const uint32_t x = runs[e];
+                typ = (int)(x & 7u); l = (int)(x >> 3);
+                if (ao + l > u0) break;
+                ao += l;
+                ar += (typ == T_DEL || typ == T_SHR) ? 0 : l;
+                ac += (typ == T_INS || typ == T_LEN) ? 0 : l;
+            }
+            const int row_end = d.row0 + d.drows, col_end = d.col0 + d.dcols;
+            for (int u = u0; u < u1; u++) {
+                while (u >= ao + l) {               // next run
+                    ao += l;
+                    ar += (typ == T_DEL || typ == T_SHR) ? 0 : l;
+                    ac += (typ == T_INS || typ == T_LEN) ? 0 : l;
+                    e++;
+                    const uint32_t x = runs[e];
+                    typ = (int)(x & 7u); l = (int)(x >> 3);
+                }
+                uint8_t op;
+                if (typ == T_MAT) {                 // '=' / 'X' by comparing the paired bases, src/aln.pyx:732-735
+                    const int q = u - ao;
+                    op = (ref[col_end - ac - q - 1] == seq[row_end - ar - q - 1]) ? '=' : 'X';
+                } else {
+                    op = (typ == T_INS || typ == T_LEN) ? 'I' : 'D';
+                }
+                dst[w + (len - 1 - u)] = op;
+            }
+        }
         w += len;
     }
 }

@@ -115,7 +115,7 @@ struct npore_ctx {
     DevBuf in_refs, in_seqs, in_cigs, in_off;                       // raw inputs (host-buffer entry point)
     DevBuf rd_i32, rd_i64, steps, inss, descs, sched, hist, counters; // path + chunks
     DevBuf seqw, refw, refl, seql;                                   // annotation
-    DevBuf tb, cout_, clen, cstat;                                   // fill / traceback
+    DevBuf tb, cout_, clen, cstat, cnruns;                           // fill / traceback (cout_: uint32 runs)
     DevBuf out, out_off, out_len, status;                            // outputs (host-buffer entry point)
     // host staging of the BAM -> SAM pipeline (npore_bam_realign_batch / _file): grow-only, reused across batches and files
     npore_batch_slot *slots[3] = {nullptr, nullptr, nullptr};
@@ -223,7 +223,8 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     if (int rc = ctx->refw.ensure((size_t)(R_tot + max_chunks + 16) * 16)) return rc;
     if (int rc = ctx->refl.ensure((size_t)(R_tot + max_chunks + 16) * 8)) return rc;
     if (int rc = ctx->tb.ensure((size_t)tb_words * 4 + 64)) return rc;
-    if (int rc = ctx->cout_.ensure((size_t)(S_tot + R_tot) + 64)) return rc;
+    if (int rc = ctx->cout_.ensure(((size_t)(S_tot + R_tot) + 64) * 4)) return rc;
+    if (int rc = ctx->cnruns.ensure((size_t)max_chunks * 4 + 64)) return rc;
     if (int rc = ctx->clen.ensure((size_t)max_chunks * 4 + 64)) return rc;
     if (int rc = ctx->cstat.ensure((size_t)max_chunks * 4 + 64)) return rc;
 
@@ -317,25 +318,26 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     tp.n_chunks = pp.counters;
     tp.tb = kp.tb;
     tp.inss = pp.inss;
-    tp.seqs = a.d_seqs;
-    tp.refs = a.d_refs;
-    tp.chunk_out = ctx->cout_.as<uint8_t>();
+    tp.chunk_runs = ctx->cout_.as<uint32_t>();
+    tp.chunk_nruns = ctx->cnruns.as<int32_t>();
     tp.chunk_len = ctx->clen.as<int32_t>();
     tp.chunk_status = ctx->cstat.as<int32_t>();
     tp.r = r;
     tp.tbstride = tbs;
-    if (tbs <= 256) hipLaunchKernelGGL(traceback_kernel<1>, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
-    else hipLaunchKernelGGL(traceback_kernel<2>, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
+    hipLaunchKernelGGL(traceback_kernel, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
     HIP_TRY(hipGetLastError());
 
     GParams gp;
     gp.descs = pp.descs;
     gp.read_first_chunk = pp.rd_chunk_first;
-    gp.chunk_out = tp.chunk_out;
+    gp.chunk_runs = tp.chunk_runs;
+    gp.chunk_nruns = tp.chunk_nruns;
     gp.chunk_len = tp.chunk_len;
     gp.chunk_status = tp.chunk_status;
     gp.read_status_in = pp.rd_status;
     gp.counters = pp.counters;
+    gp.seqs = a.d_seqs;
+    gp.refs = a.d_refs;
     gp.out = ot.d_out;
     gp.out_off = ot.d_out_off;
     gp.out_len = ot.d_out_len;
@@ -460,7 +462,7 @@ void npore_ctx_destroy(npore_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     for (DevBuf *b : {&ctx->in_refs, &ctx->in_seqs, &ctx->in_cigs, &ctx->in_off, &ctx->rd_i32, &ctx->rd_i64,
                       &ctx->steps, &ctx->inss, &ctx->descs, &ctx->sched, &ctx->hist, &ctx->counters, &ctx->seqw,
-                      &ctx->refw, &ctx->refl, &ctx->seql, &ctx->tb, &ctx->cout_, &ctx->clen, &ctx->cstat,
+                      &ctx->refw, &ctx->refl, &ctx->seql, &ctx->tb, &ctx->cout_, &ctx->clen, &ctx->cstat, &ctx->cnruns,
                       &ctx->out, &ctx->out_off, &ctx->out_len, &ctx->status})
         b->release();
     if (ctx->d_sub) (void)hipFree(ctx->d_sub);
