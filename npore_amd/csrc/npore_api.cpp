@@ -200,6 +200,11 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     const int tbs = tb_stride(r);
     const int64_t cig_bytes = a.h_cig_off[g1] - a.h_cig_off[g0];
     const int64_t S_tot = a.h_seq_off[g1] - a.h_seq_off[g0], R_tot = a.h_ref_off[g1] - a.h_ref_off[g0];
+    // longest chunk slice of the group: a slice never exceeds its sequence, nor max_b_rows + 1 bases
+    int64_t max_len = 0;
+    for (int64_t i = g0; i < g1; i++)
+        max_len = std::max({max_len, a.h_seq_off[i + 1] - a.h_seq_off[i], a.h_ref_off[i + 1] - a.h_ref_off[i]});
+    const size_t pstride = ((size_t)std::min<int64_t>(max_len, a.max_b_rows) + 1 + 15) & ~(size_t)15;
     int64_t max_chunks = 0;
     for (int64_t k = g0; k < g1; k++) max_chunks += chunk_bound(a.h_cig_off[k + 1] - a.h_cig_off[k], a.max_b_rows);
     if (max_chunks > (1ll << 30)) return fail(NPORE_E_UNSUPPORTED, "too many chunks in one group");
@@ -216,8 +221,7 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     if (int rc = ctx->counters.ensure(64)) return rc;
     if (int rc = ctx->seqw.ensure((size_t)(S_tot + max_chunks + 16) * 4)) return rc;
     {
-        const size_t pstride = ((size_t)a.max_b_rows + 1 + 15) & ~(size_t)15;
-        const size_t need = (8 * pstride <= 160 * 1024) ? 64 : (size_t)2 * max_chunks * 7 * pstride;
+        const size_t need = (7 * pstride <= 160 * 1024) ? 64 : (size_t)2 * max_chunks * 6 * pstride;
         if (int rc = ctx->seql.ensure(need)) return rc;
     }
     if (int rc = ctx->refw.ensure((size_t)(R_tot + max_chunks + 16) * 16)) return rc;
@@ -234,6 +238,7 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     pp.seqs = a.d_seqs; pp.seq_off = a.d_seq_off + g0;
     pp.cigs = a.d_cigs; pp.cig_off = a.d_cig_off + g0;
     pp.max_b_rows = a.max_b_rows; pp.r = r; pp.tbstride = tbs; pp.max_n = ctx->max_n; pp.max_l = ctx->max_l;
+    pp.pstride = (int)pstride;
     pp.max_chunks = (int)max_chunks;
     int32_t *i32 = ctx->rd_i32.as<int32_t>();
     pp.rd_nsteps = i32;
@@ -262,10 +267,10 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, s, pp);
     hipLaunchKernelGGL(sched_scatter_kernel, dim3(ch_blocks), dim3(256), 0, s, pp);
     {
-        // slice bytes + 7 byte planes per position in LDS when that fits (it does for the default max_b_rows)
-        const size_t pstride = ((size_t)a.max_b_rows + 1 + 15) & ~(size_t)15;
-        const int planes_in_lds = 8 * pstride <= 160 * 1024;
-        const size_t alds = planes_in_lds ? 8 * pstride : pstride;
+        // slice bytes + 6 byte planes per position in LDS when that fits (it does for the default max_b_rows);
+        // sized by the longest slice of the group, so that two workgroups share a CU on 10 kb reads
+        const int planes_in_lds = 7 * pstride <= 160 * 1024;
+        const size_t alds = planes_in_lds ? 7 * pstride : pstride;
         if (planes_in_lds) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&annotate_kernel<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
@@ -422,7 +427,7 @@ int npore_device_count(void)
 
 npore_ctx *npore_ctx_create(const float *sub_scores, const float *np_scores, int max_n, int max_l, int device_id)
 {
-    if (!sub_scores || !np_scores || max_n < 1 || max_n > MAX_PERIOD || max_l < 2 || max_l > 255) {
+    if (!sub_scores || !np_scores || max_n < 1 || max_n > MAX_PERIOD || max_l < 2 || max_l > 127) {   // repeat counts travel in 7-bit fields (layout.hpp, annotate planes)
         fail(NPORE_E_INVALID, "npore_ctx_create: need tables, 1 <= max_n <= 6, 2 <= max_l <= 255");
         return nullptr;
     }

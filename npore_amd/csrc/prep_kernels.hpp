@@ -31,6 +31,7 @@ struct PrepParams {
     const char *cigs;
     const int64_t *cig_off;
     int max_b_rows, r, tbstride, max_n, max_l;
+    int pstride;               // annotate: bytes per plane (>= longest chunk slice, multiple of 16)
     int max_chunks;            // capacity of the chunk arrays
     // per read
     int32_t *rd_nsteps;        // [n]
@@ -296,8 +297,8 @@ __global__ __launch_bounds__(256) void sched_scatter_kernel(PrepParams p)
 // Each wave handles windows of 64 consecutive positions; the run lengths come from
 // ballots of e_n over whole windows (count trailing / leading ones), so a long run
 // costs one step per 64 positions instead of one per position.
-// planes: byte planes [7][pstride]: 0..5 = L for n = 1..6, 6 = mask of periods with
-// L_IDX == 0 (LDS when the slice fits, else global scratch).  Optional int32 outputs
+// planes: byte planes [6][pstride], one per period: bits 0-6 = L (max_l <= 127), bit 7 = L_IDX == 0
+// (LDS when the slice fits, else global scratch).  Optional int32 outputs
 // Lout/Iout [len][max_n] for the get_np_info() API.
 // one period (compile-time, so that the divisions by n and the shorter-period loop unroll)
 template <int n>
@@ -346,12 +347,11 @@ __device__ __forceinline__ void annotate_period(const uint8_t *seq, int len, int
                 bool longest = true;
 #pragma unroll
                 for (int n2 = 1; n2 < n; n2++)
-                    if (l * n <= (int)planes[(size_t)(n2 - 1) * pstride + s] * n2) longest = false;
+                    if (l * n <= (int)(planes[(size_t)(n2 - 1) * pstride + s] & 127u) * n2) longest = false;
                 if (!longest) continue;
                 if (l > stored) { stored = max_l < l ? max_l : l; idx = j; }
             }
-            Ln[pos] = (uint8_t)stored;
-            if (stored && idx == 0) planes[6 * pstride + pos] |= (uint8_t)(1u << (n - 1));
+            Ln[pos] = (uint8_t)(stored | ((stored && idx == 0) ? 128 : 0));
             if (Lout) { Lout[(size_t)pos * max_n + (n - 1)] = stored; Iout[(size_t)pos * max_n + (n - 1)] = idx; }
         }
     }
@@ -362,10 +362,6 @@ __device__ __forceinline__ void annotate_period(const uint8_t *seq, int len, int
 __device__ __forceinline__ void annotate_sequence(const uint8_t *seq, int len, int max_n, int max_l,
                                                   uint8_t *planes, int pstride, int32_t *Lout, int32_t *Iout)
 {
-    for (int p = threadIdx.x; p < len; p += blockDim.x) planes[6 * pstride + p] = 0;
-    // (the first period's barrier also orders the zeroing above before the |= of its flags: each position
-    // is zeroed and flagged by different threads only across periods)
-    __syncthreads();
     if (max_n >= 1) annotate_period<1>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
     if (max_n >= 2) annotate_period<2>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
     if (max_n >= 3) annotate_period<3>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
@@ -375,7 +371,7 @@ __device__ __forceinline__ void annotate_sequence(const uint8_t *seq, int len, i
 }
 
 // One workgroup per (chunk, sequence).  The slice and the L planes are staged in LDS
-// (8 bytes per position) when they fit; otherwise the planes live in global scratch.
+// (7 bytes per position) when they fit; otherwise the planes live in global scratch.
 template <bool PLANES_IN_LDS>
 __global__ __launch_bounds__(1024) void annotate_kernel(PrepParams p)
 {
@@ -389,16 +385,16 @@ __global__ __launch_bounds__(1024) void annotate_kernel(PrepParams p)
     const int start = is_ref ? d.col0 : d.row0, span = is_ref ? d.dcols : d.drows;
     const int len = (int)(((int64_t)start + span + 1 < T ? (int64_t)start + span + 1 : T) - start);   // src/aln.pyx:453-454
     const uint8_t *g = (is_ref ? p.refs + p.ref_off[rd] : p.seqs + p.seq_off[rd]) + start;
-    const int pstride = (p.max_b_rows + 1 + 15) & ~15;
+    const int pstride = p.pstride;
     uint8_t *sseq = sbuf;
     uint8_t *planes;   // a compile-time choice, so that the LDS case uses ds_* instructions rather than flat ones
     if constexpr (PLANES_IN_LDS) planes = sbuf + pstride;
-    else planes = reinterpret_cast<uint8_t *>(p.seql) + ((size_t)blockIdx.x * 7) * pstride;
+    else planes = reinterpret_cast<uint8_t *>(p.seql) + ((size_t)blockIdx.x * 6) * pstride;
     for (int q = threadIdx.x; q < len; q += blockDim.x) sseq[q] = g[q];
     __syncthreads();
     annotate_sequence(sseq, len, p.max_n, p.max_l, planes, pstride, nullptr, nullptr);
-    auto Lat = [&](int pos, int n) -> uint32_t { return planes[(size_t)(n - 1) * pstride + pos]; };
-    auto idx0 = [&](int pos, int n) -> bool { return (planes[(size_t)6 * pstride + pos] >> (n - 1)) & 1u; };
+    auto Lat = [&](int pos, int n) -> uint32_t { return planes[(size_t)(n - 1) * pstride + pos] & 127u; };
+    auto idx0 = [&](int pos, int n) -> bool { return (planes[(size_t)(n - 1) * pstride + pos] >> 7) != 0u; };
     if (!is_ref) {
         uint32_t *seqw = p.seqw + d.seqw_off;
         for (int i = threadIdx.x; i <= span; i += blockDim.x) {
