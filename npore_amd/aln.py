@@ -37,6 +37,11 @@ def _u8(a):
     return np.ascontiguousarray(a)
 
 
+def device_count():
+    """Number of visible gfx950 devices."""
+    return int(_lib.load().npore_device_count())
+
+
 class Context:
     """One per GPU: owns the device copy of the penalty tables and work buffers."""
 

@@ -28,3 +28,32 @@ def reduce_counters(sums, maxes, device=None):
     dist.all_reduce(ts, op=dist.ReduceOp.SUM)
     dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     return dict(zip(ks, ts.tolist())), dict(zip(km, tm.tolist()))
+
+
+def gather_parts(final_path, out_prefix, n_local):
+    """End of a multi-process realign: wait for every rank's part file, let rank 0 append them to the
+    final SAM in rank order and remove them.  Returns the total number of reads (on every rank).
+    Uses a gloo process group (CPU): the payload is one barrier and one small sum."""
+    import torch
+    import torch.distributed as dist
+    rank, world_size, _ = world()
+    own_group = not dist.is_initialized()
+    if own_group:
+        dist.init_process_group("gloo")
+    t = torch.tensor([float(n_local)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)        # also the barrier: every part is complete
+    if rank == 0:
+        with open(final_path, "ab") as out:
+            for k in range(world_size):
+                part = f"{out_prefix}.part{k}.sam"
+                with open(part, "rb") as fh:
+                    while True:
+                        buf = fh.read(1 << 24)
+                        if not buf:
+                            break
+                        out.write(buf)
+                os.remove(part)
+    dist.barrier()
+    if own_group:
+        dist.destroy_process_group()
+    return int(t.item())

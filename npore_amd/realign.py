@@ -6,7 +6,10 @@
 
 The per-read DP runs on an MI355X through libnpore_amd.so; reads are handed to
 it in batches instead of one align() call per pool worker
-(src/realign.py:110-114).  --recalc_cms / --plot need samtools / matplotlib
+(src/realign.py:110-114).  Several GPUs: launch one process per GPU with
+`python -m torch.distributed.run --nproc-per-node N -m npore_amd.realign ...`;
+rank k realigns reads k, k+N, ... into its own part file and rank 0 appends
+the parts to the SAM (record order is arbitrary in the reference too).  --recalc_cms / --plot need samtools / matplotlib
 pipelines that are out of scope here (the shipped guppy5_stats are loaded).
 """
 import argparse
@@ -16,7 +19,7 @@ from time import perf_counter
 
 import numpy as np
 
-from . import aln, bam as bam_mod, cfg
+from . import aln, bam as bam_mod, cfg, dist as dist_mod
 
 
 def argparser():
@@ -62,20 +65,32 @@ def main():
     cfg.args.sub_scores, cfg.args.np_scores, cfg.args.ins_scores, cfg.args.del_scores = \
         aln.load_default_tables(cfg.args.stats_dir)
 
+    rank, world, _ = dist_mod.world()
+    if world > 1 and not native:
+        print("\nERROR: --python_io runs on one GPU only.")
+        sys.exit(1)
     print("> creating output SAM")
-    out_sam = f"{cfg.args.out_prefix}.sam"
-    bam_mod.create_header(out_sam, bam)
+    final_sam = f"{cfg.args.out_prefix}.sam"
+    out_sam = final_sam if world == 1 else f"{cfg.args.out_prefix}.part{rank}.sam"
+    if rank == 0:
+        bam_mod.create_header(final_sam, bam)
+    if world > 1:
+        open(out_sam, "w").close()
 
     print("> extracting read data from BAM")
     start = perf_counter()
-    ctx = aln.Context(cfg.args.sub_scores, cfg.args.np_scores, device=cfg.args.device)
+    n_dev = max(aln.device_count(), 1)
+    ctx = aln.Context(cfg.args.sub_scores, cfg.args.np_scores, device=cfg.args.device % n_dev)
     n = 0
     if native:
         idx = bam.select(cfg.args.regions, cfg.args.max_reads)
+        idx = idx[rank::world]                      # reads are independent: dealt by index, no data-path collective
         print("> computing individual read realignments")
         n += bam_mod.realign_native(ctx, bam, ref_seqs, idx, out_sam, batch_reads=cfg.args.batch_reads)
         bam.close()
         ref_seqs.close()
+        if world > 1:
+            n = dist_mod.gather_parts(final_sam, cfg.args.out_prefix, n)
     else:
         read_data = bam_mod.get_read_data(bam, ref_seqs)
         print("> computing individual read realignments")

@@ -386,3 +386,20 @@ def test_realign_hap_long_sequences(ctx, tables):
         want_raw = oracle.align(r_, s_, h[4], sub, nps, r=30)
         assert ctx.align_batch([r_], [s_], [h[4]], r=30)[0] == want_raw
         assert o[:4] == h[:4] and o[4] == standardize(want_raw, r_, s_)
+
+
+def test_realign_cli_two_processes(tmp_path):
+    """`torch.distributed.run --nproc-per-node 2 -m npore_amd.realign`: reads dealt by index over the ranks
+    (both on this box's one GPU), part files merged by rank 0 -- same records as the reference's golden SAM."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    prefix = str(tmp_path / "mp")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(29800 + os.getpid() % 100), "-m",
+                           "npore_amd.realign", "--bam", os.path.join(GOLDEN, "data", "reads.bam"),
+                           "--ref", os.path.join(GOLDEN, "data", "ref.fasta"), "--out_prefix", prefix], cwd=REPO)
+    recs = lambda path: sorted(l for l in open(path) if not l.startswith("@"))
+    got, want = recs(prefix + ".sam"), recs(os.path.join(GOLDEN, "data", "npore_realigned.sam"))
+    assert len(got) == 10 and got == want
+    assert not os.path.exists(prefix + ".part0.sam") and not os.path.exists(prefix + ".part1.sam")

@@ -159,6 +159,36 @@ def test_sharding_and_reduction_gloo_world2():
         assert sums["reads"] == 1001 and sums["cells"] == sum(range(1001)) and maxes["elapsed"] == 2.0
 
 
+def _parts_worker(rank, world_size, port, prefix, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size),
+                      LOCAL_RANK=str(rank))
+    with open(f"{prefix}.part{rank}.sam", "w") as fh:
+        for k in range(rank, 7, world_size):
+            fh.write(f"read{k}\n")
+    q.put((rank, dist.gather_parts(prefix + ".sam", prefix, len(range(rank, 7, world_size)))))
+
+
+def test_realign_part_files_gloo_world2(tmp_path):
+    """The multi-process end of realign.py: each rank wrote its reads (rank, rank+N, ...) to a part file;
+    one sum over gloo is the barrier, rank 0 appends the parts to the SAM and removes them."""
+    import torch.multiprocessing as mp
+    prefix = str(tmp_path / "o")
+    open(prefix + ".sam", "w").write("@HD\n")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_parts_worker, args=(r, 2, port, prefix, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, 7), (1, 7)]
+    assert open(prefix + ".sam").read().split() == ["@HD", "read0", "read2", "read4", "read6", "read1", "read3", "read5"]
+    assert not os.path.exists(prefix + ".part0.sam") and not os.path.exists(prefix + ".part1.sam")
+
+
 # ---- native host I/O (csrc/hostio.hpp) against the pure-Python restatement in npore_amd/bam.py ----
 def _native_vs_python(bam_path, fasta_path, regions, max_reads=0):
     import argparse
