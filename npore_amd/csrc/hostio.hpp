@@ -261,6 +261,9 @@ inline int64_t rec_hp(const RecView &r)
         q += 3;
         int64_t val = 0;
         size_t w = 0;
+        if (q + 4 > end && typ != 'c' && typ != 'C' && typ != 'A' && typ != 'Z' && typ != 'H' && !(q + 2 <= end && (typ == 's' || typ == 'S')))
+            return 0;                   // not enough bytes left for a 4-byte value
+        if (q >= end) return 0;
         switch (typ) {
             case 'c': val = (int8_t)q[0]; w = 1; break;
             case 'C': val = q[0]; w = 1; break;
@@ -281,6 +284,7 @@ inline int64_t rec_hp(const RecView &r)
             }
             default: return 0;
         }
+        if (q + w > end) return 0;      // truncated tag
         if (is_hp && (typ == 'c' || typ == 'C' || typ == 's' || typ == 'S' || typ == 'i' || typ == 'I')) return val;
         q += w;
     }

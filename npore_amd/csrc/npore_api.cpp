@@ -726,6 +726,15 @@ npore_bam *npore_bam_open(const char *path, int threads)
     while (p + 4 <= N) {
         const int32_t bs = rdi32(&d[p]);
         if (bs < 32 || p + 4 + (size_t)bs > N) { fail(NPORE_E_INVALID, "truncated BAM record"); delete b; return nullptr; }
+        {   // the variable-length parts the accessors will walk must lie inside the record
+            const uint8_t *f = &d[p + 4];
+            const int64_t l_rn = f[8], n_cig = rd16(f + 12), l_seq = rdi32(f + 16);
+            if (l_rn < 1 || l_seq < 0 || 32 + l_rn + 4 * n_cig + (l_seq + 1) / 2 + l_seq > bs || f[32 + l_rn - 1] != 0) {
+                fail(NPORE_E_INVALID, "corrupt BAM record");
+                delete b;
+                return nullptr;
+            }
+        }
         const int64_t i = (int64_t)b->rec_off.size();
         b->rec_off.push_back((int64_t)p);
         const int32_t rid = rdi32(&d[p + 4]);

@@ -403,3 +403,34 @@ def test_realign_cli_two_processes(tmp_path):
     got, want = recs(prefix + ".sam"), recs(os.path.join(GOLDEN, "data", "npore_realigned.sam"))
     assert len(got) == 10 and got == want
     assert not os.path.exists(prefix + ".part0.sam") and not os.path.exists(prefix + ".part1.sam")
+
+
+def test_long_polymers_and_many_periods(ctx, tables):
+    """Engineered repeats: n-polymers longer than the LDS score table (L >= 32) and longer than max_l,
+    units whose repeats are n-polymers for several periods at once (more than two SHR candidates in a
+    column), with copy-number changes between read and reference -- the generic SHR pass, the global-memory
+    score fallback and the "more periods" loop -- against the oracle at three band widths."""
+    sub, nps = tables
+    rng = np.random.default_rng(12)
+    A, C, G, T = 1, 2, 3, 4
+    blocks = [[A] * 150, [A, C] * 70, [A, C, G] * 45, [A] * 40 + [C] * 33, [A, A, C, A, A, C] * 30,
+              [G, T, G, T, G, T, G, T, A] * 12, [T] * 101, [C, A, G, T] * 36, [A] * 12 + [A, C] * 9 + [A, C, G] * 7]
+    refs, seqs, cigs = [], [], []
+    for k in range(12):
+        ref, seq, cig = [], [], []
+        for b in rng.permutation(len(blocks))[:6]:
+            unit = blocks[b]
+            flank = [int(x) for x in rng.integers(1, 5, int(rng.integers(5, 30)))]
+            ref += flank; seq += flank; cig += ["="] * len(flank)
+            drop = int(rng.integers(0, 9)) * (1 if k % 2 else -1)      # copy-number change: read shorter / longer
+            ref += unit
+            if drop >= 0:
+                seq += unit[:len(unit) - drop]; cig += ["="] * (len(unit) - drop) + ["D"] * drop
+            else:
+                seq += unit + unit[:(-drop)]; cig += ["="] * len(unit) + ["I"] * (-drop)
+        refs.append(np.array(ref, np.uint8)); seqs.append(np.array(seq, np.uint8)); cigs.append("".join(cig))
+    for r in (30, 100, 12):
+        got, st = ctx.align_batch(refs, seqs, cigs, r=r, return_status=True)
+        for k in range(len(refs)):
+            want, wst = oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=r, return_status=True)
+            assert got[k] == want and st[k] == wst, (r, k)

@@ -267,3 +267,41 @@ def test_native_bam_clips_flags_tags(tmp_path):
     bam.write_bam(str(tmp_path / "u.bam"), [(n, len(s)) for n, s in contigs.items()], recs)
     assert _native_vs_python(str(tmp_path / "u.bam"), str(fa), [("chrA", 0, 699), ("chrB", 0, 299)]) == n1
     assert _native_vs_python(str(tmp_path / "u.bam"), str(fa), [("chrB", 100, 200)]) == n2
+
+
+def test_native_bam_rejects_corrupt_files(tmp_path):
+    """Truncated / damaged BAM files are refused with a message (the reference: pysam raises), never walked."""
+    from npore_amd import _lib, bam
+    import zlib, struct
+    lib = _lib.load()
+    good = open(os.path.join(GOLDEN, "data", "reads.bam"), "rb").read()
+    raw = bam._bgzf_decompress(os.path.join(GOLDEN, "data", "reads.bam"))
+
+    def bgzf(payload):
+        out = b""
+        for p in range(0, len(payload), 0xFF00):
+            chunk = payload[p:p + 0xFF00]
+            c = zlib.compressobj(6, zlib.DEFLATED, -15)
+            data = c.compress(chunk) + c.flush()
+            out += struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 0xFF, 6, 66, 67, 2, len(data) + 25) + data + \
+                struct.pack("<II", zlib.crc32(chunk), len(chunk))
+        return out
+
+    # find the first record and damage its l_seq / cut the stream inside a record
+    l_text, = struct.unpack_from("<i", raw, 4)
+    p = 8 + l_text
+    n_ref, = struct.unpack_from("<i", raw, p); p += 4
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<i", raw, p); p += 8 + l_name
+    bad_lseq = bytearray(raw); struct.pack_into("<i", bad_lseq, p + 4 + 16, 1 << 28)
+    cases = {"cut.bam": good[:len(good) // 2], "notbam.bam": b"hello world" * 10, "lseq.bam": bgzf(bytes(bad_lseq)),
+             "short.bam": bgzf(raw[:p + 40]), "ok.bam": bgzf(raw)}
+    for name, content in cases.items():
+        path = tmp_path / name
+        path.write_bytes(content)
+        h = lib.npore_bam_open(os.fsencode(str(path)), 2)
+        if name == "ok.bam":
+            assert h and lib.npore_bam_n_records(h) == 10
+            lib.npore_bam_close(h)
+        else:
+            assert not h and _lib.last_error(), name
