@@ -11,13 +11,15 @@
 //                     through the lanes systolically: an 'I' step of the input
 //                     path shifts the read words one column up, a 'D' step shifts
 //                     the reference words one column down; the word entering at
-//                     the band edge comes from a 64-entry per-wave queue register.
+//                     the band edge comes from a 64-entry queue register (first /
+//                     last wave) and crosses between waves in the exchange record.
 //                     The only per-cell HBM traffic is one 32-bit traceback word.
 //   traceback_kernel  one wavefront per chunk: follows MAT.TYP/MAT.RUN words
-//                     (reference src/aln.pyx:670-742), writes ops right-aligned
-//                     into the chunk's output slot.
-//   gather_kernel     one workgroup per read: concatenates its chunks' op
-//                     strings into the caller's output buffer (src/aln.pyx:742).
+//                     (reference src/aln.pyx:670-742) through register windows of
+//                     the band strip around the path and records the path as
+//                     (type, length) runs.
+//   gather_kernel     one workgroup per read: expands its chunks' runs into the op
+//                     string in the caller's output buffer (src/aln.pyx:719-742).
 #pragma once
 #include <hip/hip_runtime.h>
 
