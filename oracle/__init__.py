@@ -4,5 +4,5 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
 import this package.  Nothing under npore_amd/ does.
 """
 from .oracle import (  # noqa: F401
-    build, load, align, align_batch, get_np_info, lib_path,
+    build, load, align, align_batch, align_batch_procs, get_np_info, lib_path,
 )

@@ -107,3 +107,28 @@ def align_batch(refs, seqs, cigars, sub_scores, np_scores, indel_start=5, indel_
                                  out.ctypes.data, oo.ctypes.data, olen.ctypes.data, st.ctypes.data)
     res = [out[oo[i]:oo[i] + max(olen[i], 0)].tobytes().decode() for i in range(n)]
     return res, st
+
+
+def _pool_worker(args):
+    refs, seqs, cigs, sub, nps, kw = args
+    return align_batch(refs, seqs, cigs, sub, nps, **kw)
+
+
+def align_batch_procs(refs, seqs, cigars, sub_scores, np_scores, procs, **kw):
+    """align_batch on `procs` forked worker processes, the way the reference itself runs align()
+    (multiprocessing.Pool over reads, src/realign.py:110-114).  Processes rather than threads: every
+    align() allocates and zeroes its own 60 B/cell state matrix (241 MB at max_b_rows=20000, r=100), and
+    threads of one address space serialise on those page faults."""
+    import multiprocessing as mp
+    n = len(refs)
+    procs = max(1, min(int(procs), n))
+    if procs == 1:
+        return align_batch(refs, seqs, cigars, sub_scores, np_scores, **kw)
+    step = (n + 4 * procs - 1) // (4 * procs)          # a few slices per worker: reads differ in length
+    jobs = [(refs[i:i + step], seqs[i:i + step], cigars[i:i + step], sub_scores, np_scores, kw) for i in range(0, n, step)]
+    load()                                            # build / load before forking
+    with mp.get_context("fork").Pool(procs) as pool:
+        parts = pool.map(_pool_worker, jobs)
+    out = [a for p in parts for a in p[0]]
+    st = np.concatenate([p[1] for p in parts]) if parts else np.zeros(0, np.int32)
+    return out, st
