@@ -28,20 +28,10 @@ def expand_cigar(cigar):
 
 
 def collapse_cigar(extended_cigar, return_groups=False):
-    """'DMMMII' -> '1D3M2I' (src/cig.pyx:13-38)."""
-    groups, last, count = [], None, 1
-    for op in extended_cigar:
-        if last and op == last:
-            count += 1
-        elif last:
-            groups.append((count, last))
-            count = 1
-        last = op
-    if last:
-        groups.append((count, last))
-    if return_groups:
-        return groups
-    return "".join(f"{n}{op}" for n, op in groups)
+    """'DMMMII' -> '1D3M2I' (run-length encoding; src/cig.pyx:13-38)."""
+    from itertools import groupby
+    groups = [(sum(1 for _ in run), op) for op, run in groupby(extended_cigar)]
+    return groups if return_groups else "".join(f"{n}{op}" for n, op in groups)
 
 
 def bases_to_int(seq):
