@@ -1,3 +1,5 @@
+"""Stage times of one C2 batch through a given build of the library (perf experiments:
+    python scripts/exp_pmc.py path/to/libnpore_amd.so   -- also the program to put behind `rocprofv3 --pmc ... --`)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from npore_amd import _lib
