@@ -134,8 +134,8 @@ int npore_standardize_batch(int64_t n_reads, const char *alns, const int64_t *al
  */
 int npore_last_timing(npore_ctx *ctx, double *ms, int n);
 
-/* Tunables: key in {"tb_budget_mb","force_chunks","host_threads"} (traceback budget in MiB, chunks per
- * workgroup; 0 = automatic).  "force_nw" / "force_ng" are still accepted with their automatic values
+/* Tunables: key in {"tb_budget_mb","force_chunks","traceback_kernel","host_threads"} (traceback budget in MiB,
+ * chunks per workgroup, 1 = windowed / 2 = row-per-hop traceback; 0 = automatic).  "force_nw" / "force_ng" are still accepted with their automatic values
  * (0, resp. 0 or 1): waves per chunk follow from the band width, one band column per lane is the only layout. */
 int npore_ctx_set(npore_ctx *ctx, const char *key, int64_t value);
 

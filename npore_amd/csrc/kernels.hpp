@@ -660,6 +660,87 @@ __global__ __launch_bounds__(64) void traceback_kernel(TParams p)
     if (lane < (nruns & 63)) runs[(nruns & ~63) + lane] = rbuf;
 }
 
+// The same traceback with ONE coalesced load of the whole anti-diagonal (16 bytes per lane) plus inss[b] per
+// hop, requested as soon as the next cell is known: a third of the instructions per hop of the windowed
+// kernel, one memory round trip per hop instead of one per ~4 hops.  With thousands of chunks in flight the
+// round trips of different chunks overlap and the instruction count decides; with one wave per SIMD (a
+// batch of 1 000 reads) the windows win.  NL: uint4 loads per lane covering a row (tbstride <= 256 * NL).
+template <int NL>
+__global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
+{
+    const int k = blockIdx.x;
+    if (k >= *p.n_chunks) return;
+    const int lane = threadIdx.x;
+    const ChunkDesc d = p.descs[k];
+    const uint32_t *tb = p.tb + d.tb_off;
+    uint32_t *runs = p.chunk_runs + d.out_off;
+    const int W = 2 * p.r + 1, stride = p.tbstride;
+    int a_row = d.row0 + d.drows, a_col = d.col0 + d.dcols;
+    int pos = d.out_cap;   // ops still available in the chunk's slot
+    int status = 0;
+    int nruns = 0;
+    uint32_t rbuf = 0u;    // lane l: run number (nruns & ~63) + l
+
+    const int32_t *inss = p.inss + d.inss_off + d.brk;
+    uint4 row[NL];
+    int row_ins = 0;
+    auto load_row = [&](int bl) {
+        row_ins = inss[bl];
+#pragma unroll
+        for (int q = 0; q < NL; q++) {
+            const int idx = (q * 64 + lane) * 4;
+            row[q] = (idx < stride) ? *reinterpret_cast<const uint4 *>(tb + (size_t)bl * stride + idx)
+                                    : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto word = [&](int col) -> uint32_t {   // col is wave-uniform
+        uint4 v = row[0];
+        if constexpr (NL > 1) { if ((col >> 8) & 1) v = row[NL - 1]; }
+        const uint32_t lo = (col & 1) ? v.y : v.x, hi = (col & 1) ? v.w : v.z;
+        return (uint32_t)__builtin_amdgcn_readlane((int)((col & 2) ? hi : lo), (col & 255) >> 2);
+    };
+    auto in_chunk = [&](int ar, int ac) {
+        const int bl = ar + ac - d.brk;
+        return ar >= d.row0 && ac >= d.col0 && bl >= 0 && bl < d.nrows;
+    };
+
+    if ((a_row > d.row0 || a_col > d.col0) && in_chunk(a_row, a_col)) load_row(a_row + a_col - d.brk);
+    while (a_row > d.row0 || a_col > d.col0) {
+        if (!in_chunk(a_row, a_col)) { status |= 16; break; }
+        const int bc = row_ins - a_row + p.r;     // inss[b] - a_row + r, src/aln.pyx:322-326
+        if (bc < 0 || bc >= W) { status |= 16; break; }
+        const uint32_t x = (bc == 0 || bc == W - 1) ? 0u : word(bc);   // band edge: TYP = MAT, RUN = 0 (src/aln.pyx:502-507)
+        const int typ = (int)(x & 7u), run = (int)(x >> 3);     // src/aln.pyx:684-685
+        if (run < 1) { status |= 4; break; }
+        if (run > pos) { status |= 16; break; }
+        int n_row = a_row, n_col = a_col, emit = run;
+        if (typ == T_LEN || typ == T_INS) n_row -= run;
+        else if (typ == T_SHR || typ == T_DEL) n_col -= run;
+        else if (typ == T_MAT) {
+            const int lim = min(a_row - d.row0, a_col - d.col0);
+            emit = run < lim ? run : lim;                          // diagonal steps that stay in the chunk
+            n_row -= emit; n_col -= emit;
+        } else { status |= 8; break; }
+        // request the next row now
+        if (emit == run && (n_row > d.row0 || n_col > d.col0) && in_chunk(n_row, n_col)) load_row(n_row + n_col - d.brk);
+        if (emit > 0) {
+            rbuf = (lane == (nruns & 63)) ? ((uint32_t)typ | ((uint32_t)emit << 3)) : rbuf;
+            nruns++;
+            if ((nruns & 63) == 0) runs[nruns - 64 + lane] = rbuf;
+        }
+        pos -= emit;
+        if (emit < run) { status |= 16; break; }
+        a_row = n_row;
+        a_col = n_col;
+    }
+    if (lane == 0) {
+        p.chunk_len[k] = d.out_cap - pos;
+        p.chunk_status[k] = status;
+        p.chunk_nruns[k] = nruns;
+    }
+    if (lane < (nruns & 63)) runs[(nruns & ~63) + lane] = rbuf;
+}
+
 // ---------------------------------------------------------------------------
 struct GParams {
     const ChunkDesc *descs;

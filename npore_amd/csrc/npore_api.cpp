@@ -110,6 +110,7 @@ struct npore_ctx {
     float *d_sub = nullptr, *d_np = nullptr;
     // tunables
     int64_t tb_budget_mb = 0;   // 0 = auto
+    int tb_kernel = 0;          // 0 = by batch size, 1 = windowed traceback, 2 = row per hop
     int force_chunks = 0;
     // device buffers (grow-only, reused across calls)
     DevBuf in_refs, in_seqs, in_cigs, in_off;                       // raw inputs (host-buffer entry point)
@@ -329,7 +330,11 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     tp.chunk_status = ctx->cstat.as<int32_t>();
     tp.r = r;
     tp.tbstride = tbs;
-    hipLaunchKernelGGL(traceback_kernel, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
+    // windowed traceback for small batches (about one wave per SIMD), row-per-hop for large ones (kernels.hpp)
+    const int tb_mode = ctx->tb_kernel ? ctx->tb_kernel : (max_chunks > 4096 ? 2 : 1);
+    if (tb_mode == 1) hipLaunchKernelGGL(traceback_kernel, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
+    else if (tbs <= 256) hipLaunchKernelGGL(traceback_rows_kernel<1>, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
+    else hipLaunchKernelGGL(traceback_rows_kernel<2>, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
     HIP_TRY(hipGetLastError());
 
     GParams gp;
@@ -610,6 +615,7 @@ int npore_ctx_set(npore_ctx *ctx, const char *key, int64_t value)
     if (k == "tb_budget_mb") ctx->tb_budget_mb = value;
     else if (k == "force_ng") { if (value > 1) return fail(NPORE_E_UNSUPPORTED, "one band column per lane is the only layout"); }
     else if (k == "force_chunks") ctx->force_chunks = (int)value;
+    else if (k == "traceback_kernel") { if (value < 0 || value > 2) return fail(NPORE_E_INVALID, "traceback_kernel: 0, 1 or 2"); ctx->tb_kernel = (int)value; }
     else if (k == "force_nw") { if (value > 0) return fail(NPORE_E_UNSUPPORTED, "waves per chunk follow from the band width"); }
     else if (k == "host_threads") { /* accepted for compatibility: there is no host-side preparation any more */ }
     else return fail(NPORE_E_INVALID, "unknown key " + k);

@@ -434,3 +434,27 @@ def test_long_polymers_and_many_periods(ctx, tables):
         for k in range(len(refs)):
             want, wst = oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=r, return_status=True)
             assert got[k] == want and st[k] == wst, (r, k)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_both_traceback_kernels(tables, mode):
+    """The windowed traceback (small batches) and the row-per-hop one (large batches) record the same runs:
+    strings and status bits equal the oracle's at several band widths, incl. tiny max_b_rows (many chunks)
+    and reads whose input CIGAR is far from the best path (the path drifts through the band)."""
+    sub, nps = tables
+    c = aln.Context(sub, nps, max_n=6, max_l=100, device=0)
+    c.set("traceback_kernel", mode)
+    rng = np.random.default_rng(44)
+    refs, seqs, cigs = synth.make_batch(808, 10, ref_len=1200, p_np=0.1)
+    # a few reads with a deliberately bad input path: all insertions first, then all deletions, then matches
+    for k in range(3):
+        ref, seq = refs[k], seqs[k]
+        m = min(len(ref), len(seq)) - 40
+        refs.append(ref); seqs.append(seq)
+        cigs.append("I" * (len(seq) - m) + "D" * (len(ref) - m) + "=" * m)
+    for r, mbr in ((30, 20000), (100, 20000), (140, 300), (10, 37)):
+        got, st = c.align_batch(refs, seqs, cigs, r=r, max_b_rows=mbr, return_status=True)
+        for k in range(len(refs)):
+            want, wst = oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=r, max_b_rows=mbr, return_status=True)
+            assert got[k] == want and st[k] == wst, (mode, r, mbr, k)
+    c.close()
