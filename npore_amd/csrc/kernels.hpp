@@ -18,7 +18,8 @@
 //                     (reference src/aln.pyx:670-742) through register windows of
 //                     the band strip around the path and records the path as
 //                     (type, length) runs.
-//   gather_kernel     one workgroup per read: expands its chunks' runs into the op
+//   gather_scan /     per read: length and status of the output, where every chunk's ops go;
+//   gather_kernel     one workgroup per chunk: expands the chunk's runs into the op
 //                     string in the caller's output buffer (src/aln.pyx:719-742).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -756,90 +757,112 @@ struct GParams {
     int64_t *out_len;
     int32_t *status;
     int64_t read_base;                 // index of this group's first read in the caller's arrays
+    int64_t n_reads;                   // reads of this group
+    int64_t *chunk_woff;               // [chunks] position of the chunk's ops in its read's string
 };
 
-__global__ __launch_bounds__(256) void gather_kernel(GParams p)
+// wave per read: status, output length, and the position of every chunk's ops in the read's string
+__global__ __launch_bounds__(256) void gather_scan_kernel(GParams p)
 {
-    const int rd = blockIdx.x;
+    const int64_t rd = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (rd >= p.n_reads) return;
     const int64_t grd = p.read_base + rd;
     const int c0 = p.read_first_chunk[rd], c1 = p.read_first_chunk[rd + 1];
     int st = p.read_status_in[rd];
     int64_t total = 0;
-    for (int c = c0; c < c1; c++) { total += p.chunk_len[c]; st |= p.chunk_status[c]; }
+    for (int cb = c0; cb < c1; cb += 64) {
+        const int c = cb + lane;
+        const int len = (c < c1) ? p.chunk_len[c] : 0;
+        int s_ = (c < c1) ? p.chunk_status[c] : 0;
+        int64_t inc = len;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int64_t up = __shfl_up(inc, o);
+            if (lane >= o) inc += up;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s_ |= __shfl_xor(s_, o);
+        if (c < c1) p.chunk_woff[c] = total + inc - len;
+        total += __shfl(inc, 63);
+        st |= s_;
+    }
     const int64_t cap = p.out_off[grd + 1] - p.out_off[grd];
     if (st & 32) total = -1;
     else if (total > cap) { st |= 64; total = -1; }
-    if (threadIdx.x == 0) { p.out_len[grd] = total; p.status[grd] = st; }
-    if (total < 0) return;
-    uint8_t *dst = p.out + p.out_off[grd];
-    int64_t w = 0;
-    // Expand each chunk's runs (recorded last run first) into ops.  Run j ends where the ops of the runs before
+    if (lane == 0) { p.out_len[grd] = total; p.status[grd] = st; }
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(GParams p)
+{
+    const int c = blockIdx.x;
+    if (c >= p.counters[0]) return;
+    const ChunkDesc d = p.descs[c];
+    const int64_t grd = p.read_base + d.read_id;
+    if (p.out_len[grd] < 0) return;
+    uint8_t *dst = p.out + p.out_off[grd] + p.chunk_woff[c];
+    // Expand the chunk's runs (recorded last run first) into ops.  Run j ends where the ops of the runs before
     // it (in recording order) begin, counted from the chunk's end, and pairs the bases below the cell reached
     // after those runs: three prefix sums in recording order -- ops, read bases, reference bases.  Every thread
     // takes an equal share of the OUTPUT positions (runs differ wildly in length) and finds its first run
     // through per-thread-segment sums.
     __shared__ int s_ops[257], s_rows[257], s_cols[257];
     const int T = (int)blockDim.x, t = (int)threadIdx.x;
-    for (int c = c0; c < c1; c++) {
-        const ChunkDesc d = p.descs[c];
-        const int len = p.chunk_len[c], nr = p.chunk_nruns[c];
-        const uint32_t *runs = p.chunk_runs + d.out_off;
-        const uint8_t *seq = p.seqs + d.seq_off, *ref = p.refs + d.ref_off;
-        const int seg = (nr + T - 1) / T;
-        const int e0 = min(nr, t * seg), e1 = min(nr, e0 + seg);
-        int so = 0, sr = 0, sc = 0;
-        for (int e = e0; e < e1; e++) {
+    const int len = p.chunk_len[c], nr = p.chunk_nruns[c];
+    const uint32_t *runs = p.chunk_runs + d.out_off;
+    const uint8_t *seq = p.seqs + d.seq_off, *ref = p.refs + d.ref_off;
+    const int seg = (nr + T - 1) / T;
+    const int e0 = min(nr, t * seg), e1 = min(nr, e0 + seg);
+    int so = 0, sr = 0, sc = 0;
+    for (int e = e0; e < e1; e++) {
+        const uint32_t x = runs[e];
+        const int typ = (int)(x & 7u), l = (int)(x >> 3);
+        so += l;
+        sr += (typ == T_DEL || typ == T_SHR) ? 0 : l;
+        sc += (typ == T_INS || typ == T_LEN) ? 0 : l;
+    }
+    s_ops[t + 1] = so; s_rows[t + 1] = sr; s_cols[t + 1] = sc;
+    __syncthreads();
+    if (t == 0) {
+        s_ops[0] = s_rows[0] = s_cols[0] = 0;
+        for (int q = 1; q <= T; q++) { s_ops[q] += s_ops[q - 1]; s_rows[q] += s_rows[q - 1]; s_cols[q] += s_cols[q - 1]; }
+    }
+    __syncthreads();
+    // output positions u (0 = the chunk's LAST op) of this thread
+    const int useg = (len + T - 1) / T;
+    const int u0 = min(len, t * useg), u1 = min(len, u0 + useg);
+    if (u0 < u1) {
+        int lo = 0, hi = T;                     // segment sgm with s_ops[sgm] <= u0 < s_ops[sgm + 1]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_ops[mid] <= u0) lo = mid; else hi = mid; }
+        int e = min(nr, lo * seg), ao = s_ops[lo], ar = s_rows[lo], ac = s_cols[lo];
+        int typ = 0, l = 0;
+        for (;; e++) {                          // first run that reaches beyond u0
             const uint32_t x = runs[e];
-            const int typ = (int)(x & 7u), l = (int)(x >> 3);
-            so += l;
-            sr += (typ == T_DEL || typ == T_SHR) ? 0 : l;
-            sc += (typ == T_INS || typ == T_LEN) ? 0 : l;
+            typ = (int)(x & 7u); l = (int)(x >> 3);
+            if (ao + l > u0) break;
+            ao += l;
+            ar += (typ == T_DEL || typ == T_SHR) ? 0 : l;
+            ac += (typ == T_INS || typ == T_LEN) ? 0 : l;
         }
-        __syncthreads();            // the previous chunk's readers are done with the shared sums
-        s_ops[t + 1] = so; s_rows[t + 1] = sr; s_cols[t + 1] = sc;
-        __syncthreads();
-        if (t == 0) {
-            s_ops[0] = s_rows[0] = s_cols[0] = 0;
-            for (int q = 1; q <= T; q++) { s_ops[q] += s_ops[q - 1]; s_rows[q] += s_rows[q - 1]; s_cols[q] += s_cols[q - 1]; }
-        }
-        __syncthreads();
-        // output positions u (0 = the chunk's LAST op) of this thread
-        const int useg = (len + T - 1) / T;
-        const int u0 = min(len, t * useg), u1 = min(len, u0 + useg);
-        if (u0 < u1) {
-            int lo = 0, hi = T;                     // segment sgm with s_ops[sgm] <= u0 < s_ops[sgm + 1]
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_ops[mid] <= u0) lo = mid; else hi = mid; }
-            int e = min(nr, lo * seg), ao = s_ops[lo], ar = s_rows[lo], ac = s_cols[lo];
-            int typ = 0, l = 0;
-            for (;; e++) {                          // first run that reaches beyond u0
-                const uint32_t x = runs[e];
-                typ = (int)(x & 7u); l = (int)(x >> 3);
-                if (ao + l > u0) break;
+        const int row_end = d.row0 + d.drows, col_end = d.col0 + d.dcols;
+        for (int u = u0; u < u1; u++) {
+            while (u >= ao + l) {               // next run
                 ao += l;
                 ar += (typ == T_DEL || typ == T_SHR) ? 0 : l;
                 ac += (typ == T_INS || typ == T_LEN) ? 0 : l;
+                e++;
+                const uint32_t x = runs[e];
+                typ = (int)(x & 7u); l = (int)(x >> 3);
             }
-            const int row_end = d.row0 + d.drows, col_end = d.col0 + d.dcols;
-            for (int u = u0; u < u1; u++) {
-                while (u >= ao + l) {               // next run
-                    ao += l;
-                    ar += (typ == T_DEL || typ == T_SHR) ? 0 : l;
-                    ac += (typ == T_INS || typ == T_LEN) ? 0 : l;
-                    e++;
-                    const uint32_t x = runs[e];
-                    typ = (int)(x & 7u); l = (int)(x >> 3);
-                }
-                uint8_t op;
-                if (typ == T_MAT) {                 // '=' / 'X' by comparing the paired bases, src/aln.pyx:732-735
-                    const int q = u - ao;
-                    op = (ref[col_end - ac - q - 1] == seq[row_end - ar - q - 1]) ? '=' : 'X';
-                } else {
-                    op = (typ == T_INS || typ == T_LEN) ? 'I' : 'D';
-                }
-                dst[w + (len - 1 - u)] = op;
+            uint8_t op;
+            if (typ == T_MAT) {                 // '=' / 'X' by comparing the paired bases, src/aln.pyx:732-735
+                const int q = u - ao;
+                op = (ref[col_end - ac - q - 1] == seq[row_end - ar - q - 1]) ? '=' : 'X';
+            } else {
+                op = (typ == T_INS || typ == T_LEN) ? 'I' : 'D';
             }
+            dst[len - 1 - u] = op;
         }
-        w += len;
     }
 }
 

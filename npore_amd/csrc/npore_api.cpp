@@ -115,6 +115,7 @@ struct npore_ctx {
     // device buffers (grow-only, reused across calls)
     DevBuf in_refs, in_seqs, in_cigs, in_off;                       // raw inputs (host-buffer entry point)
     DevBuf rd_i32, rd_i64, steps, inss, descs, sched, hist, counters; // path + chunks
+    DevBuf tiles, cwoff;                                             // CIGAR tiles; chunk positions in the output
     DevBuf seqw, refw, refl, seql;                                   // annotation
     DevBuf tb, cout_, clen, cstat, cnruns;                           // fill / traceback (cout_: uint32 runs)
     DevBuf out, out_off, out_len, status;                            // outputs (host-buffer entry point)
@@ -212,7 +213,14 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     const int64_t steps_cap = 2 * cig_bytes + 512;
     const int64_t tb_words = (2 * cig_bytes + max_chunks) * tbs;
 
-    if (int rc = ctx->rd_i32.ensure((size_t)(4 * nr + 8) * 4)) return rc;
+    // CIGAR tiles (prep_kernels.hpp): every read has at least one
+    int64_t max_tiles = 0;
+    for (int64_t k = g0; k < g1; k++)
+        max_tiles += std::max<int64_t>(1, (a.h_cig_off[k + 1] - a.h_cig_off[k] + CIGAR_TILE - 1) / CIGAR_TILE);
+    if (max_tiles > (1ll << 30)) return fail(NPORE_E_UNSUPPORTED, "too many CIGAR tiles in one group");
+    if (int rc = ctx->rd_i32.ensure((size_t)(5 * nr + 16) * 4)) return rc;
+    if (int rc = ctx->tiles.ensure((size_t)max_tiles * 24 + 64)) return rc;
+    if (int rc = ctx->cwoff.ensure((size_t)max_chunks * 8 + 64)) return rc;
     if (int rc = ctx->rd_i64.ensure((size_t)(nr + 2) * 8)) return rc;
     if (int rc = ctx->steps.ensure(steps_cap)) return rc;
     if (int rc = ctx->inss.ensure((size_t)(2 * cig_bytes + nr + 16) * 4)) return rc;
@@ -246,6 +254,9 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     pp.rd_nchunks = i32 + nr;
     pp.rd_status = i32 + 2 * nr;
     pp.rd_chunk_first = i32 + 3 * nr;   // nr + 1 entries
+    pp.rd_tile_first = i32 + 4 * nr + 4;   // nr + 1 entries
+    pp.tile_cnt = ctx->tiles.as<int4>();
+    pp.tile_base = reinterpret_cast<int2 *>(ctx->tiles.as<char>() + (size_t)max_tiles * 16);
     pp.rd_steps_off = ctx->rd_i64.as<int64_t>();
     pp.steps = ctx->steps.as<uint8_t>();
     pp.inss = ctx->inss.as<int32_t>();
@@ -261,9 +272,12 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     HIP_TRY(hipEventRecord(ctx->ev[0], s));
     HIP_TRY(hipMemsetAsync(pp.hist, 0, (size_t)(a.max_b_rows + 2) * 4, s));
     const unsigned rd_blocks = (unsigned)((nr + 3) / 4), ch_blocks = (unsigned)((max_chunks + 255) / 256);
+    const unsigned tile_blocks = (unsigned)((max_tiles + 3) / 4);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, pp);
+    hipLaunchKernelGGL(cigar_tile_kernel, dim3(tile_blocks), dim3(256), 0, s, pp);
     hipLaunchKernelGGL(cigar_scan_kernel, dim3(rd_blocks), dim3(256), 0, s, pp);
     hipLaunchKernelGGL(read_scan_kernel, dim3(1), dim3(1024), 0, s, pp);
-    hipLaunchKernelGGL(expand_path_kernel, dim3(rd_blocks), dim3(256), 0, s, pp);
+    hipLaunchKernelGGL(expand_path_kernel, dim3(tile_blocks), dim3(256), 0, s, pp);
     hipLaunchKernelGGL(make_chunks_kernel, dim3(ch_blocks), dim3(256), 0, s, pp);
     hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, s, pp);
     hipLaunchKernelGGL(sched_scatter_kernel, dim3(ch_blocks), dim3(256), 0, s, pp);
@@ -353,7 +367,10 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     gp.out_len = ot.d_out_len;
     gp.status = ot.d_status;
     gp.read_base = g0;
-    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)nr), dim3(256), 0, s, gp);
+    gp.n_reads = nr;
+    gp.chunk_woff = ctx->cwoff.as<int64_t>();
+    hipLaunchKernelGGL(gather_scan_kernel, dim3(rd_blocks), dim3(256), 0, s, gp);
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)max_chunks), dim3(256), 0, s, gp);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev[3], s));
     return NPORE_OK;
@@ -470,7 +487,7 @@ void npore_ctx_destroy(npore_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (DevBuf *b : {&ctx->in_refs, &ctx->in_seqs, &ctx->in_cigs, &ctx->in_off, &ctx->rd_i32, &ctx->rd_i64,
+    for (DevBuf *b : {&ctx->in_refs, &ctx->in_seqs, &ctx->in_cigs, &ctx->in_off, &ctx->rd_i32, &ctx->rd_i64, &ctx->tiles, &ctx->cwoff,
                       &ctx->steps, &ctx->inss, &ctx->descs, &ctx->sched, &ctx->hist, &ctx->counters, &ctx->seqw,
                       &ctx->refw, &ctx->refl, &ctx->seql, &ctx->tb, &ctx->cout_, &ctx->clen, &ctx->cstat, &ctx->cnruns,
                       &ctx->out, &ctx->out_off, &ctx->out_len, &ctx->status})

@@ -1,10 +1,13 @@
 // prep_kernels.hpp -- device-side preparation of a batch, so that the whole path
 // runs from the raw (ref, read, CIGAR) bytes resident in HBM without a host
 // round trip:
+//   tile_scan       tiles (CIGAR_TILE ops) of every read: a read of any length is
+//                   scanned by as many waves as it has tiles
+//   cigar_tile      per tile: op counts, input validity
 //   cigar_scan      per read: converted path length, validity, number of chunks
-//                   (reference src/aln.pyx:386, 391-392, 344-345)
+//                   (reference src/aln.pyx:386, 391-392, 344-345); path offset of every tile
 //   read_scan       exclusive scans over reads (path offsets, first chunk)
-//   expand_path     per read: step bytes and insertion prefix counts
+//   expand_path     per tile: step bytes and insertion prefix counts
 //                   (src/aln.pyx:279-292; dels[b] = b - inss[b])
 //   make_chunks     per chunk: break points incl. the "don't split DI" shift
 //                   (src/aln.pyx:349-357), rectangle, sizes, size histogram
@@ -39,6 +42,10 @@ struct PrepParams {
     int32_t *rd_status;        // [n]  NPORE_ST_BAD_INPUT or 0
     int64_t *rd_steps_off;     // [n+1] exclusive scan of nsteps
     int32_t *rd_chunk_first;   // [n+1]
+    int32_t *rd_tile_first;    // [n+1] exclusive scan of the reads' tile counts
+    // per CIGAR tile
+    int4 *tile_cnt;            // ops of the tile: x = X/=/M, y = I, z = D, w = invalid ops / bases
+    int2 *tile_base;           // steps / 'I' steps of the read before the tile
     // path
     uint8_t *steps;            // [sum nsteps + pad]
     int32_t *inss;             // [sum (nsteps+1)]  read k starts at rd_steps_off[k] + k
@@ -55,18 +62,59 @@ struct PrepParams {
 };
 
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cigar_scan_kernel(PrepParams p)
+constexpr int CIGAR_TILE = 16384;   // ops per tile (a 10 kb read is one tile, a chromosome thousands)
+
+__device__ __forceinline__ int64_t cigar_tiles(int64_t clen) { return clen <= CIGAR_TILE ? 1 : (clen + CIGAR_TILE - 1) / CIGAR_TILE; }
+
+// single workgroup: exclusive scan of the reads' tile counts
+__global__ __launch_bounds__(1024) void tile_scan_kernel(PrepParams p)
 {
-    const int64_t rd = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    __shared__ int64_t s_t[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (p.n_reads + 1023) / 1024;
+    const int64_t a = (int64_t)t * per, b = (a + per < p.n_reads) ? a + per : p.n_reads;
+    int64_t l = 0;
+    for (int64_t k = a; k < b; k++) l += cigar_tiles(p.cig_off[k + 1] - p.cig_off[k]);
+    s_t[t] = l;
+    __syncthreads();
+    if (t == 0) {
+        int64_t acc = 0;
+        for (int k = 0; k < 1024; k++) { const int64_t v = s_t[k]; s_t[k] = acc; acc += v; }
+        p.rd_tile_first[p.n_reads] = (int32_t)acc;
+    }
+    __syncthreads();
+    int64_t acc = s_t[t];
+    for (int64_t k = a; k < b; k++) { p.rd_tile_first[k] = (int32_t)acc; acc += cigar_tiles(p.cig_off[k + 1] - p.cig_off[k]); }
+}
+
+// read owning tile t: last rd with rd_tile_first[rd] <= t  (-1: no such tile)
+__device__ __forceinline__ int64_t tile_owner(const PrepParams &p, int64_t t)
+{
+    if (t >= p.rd_tile_first[p.n_reads]) return -1;
+    int64_t lo = 0, hi = p.n_reads;   // invariant: first[lo] <= t < first[hi]
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (p.rd_tile_first[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// wave per tile: op counts; the tile also checks its share of the read's and the reference's bases
+__global__ __launch_bounds__(256) void cigar_tile_kernel(PrepParams p)
+{
+    const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (rd >= p.n_reads) return;
+    const int64_t rd = tile_owner(p, tile);
+    if (rd < 0) return;
+    const int64_t j = tile - p.rd_tile_first[rd], nt = p.rd_tile_first[rd + 1] - p.rd_tile_first[rd];
     const char *cig = p.cigs + p.cig_off[rd];
     const int64_t clen = p.cig_off[rd + 1] - p.cig_off[rd];
     const int64_t S = p.seq_off[rd + 1] - p.seq_off[rd], R = p.ref_off[rd + 1] - p.ref_off[rd];
-    int64_t nM = 0, nI = 0, nD = 0, nBad = 0;
-    for (int64_t k = lane; k - lane < clen; k += 64) {
-        const char c = (k < clen) ? cig[k] : 'I';
-        const bool v = k < clen;
+    const int64_t k0 = j * CIGAR_TILE, k1 = (k0 + CIGAR_TILE < clen) ? k0 + CIGAR_TILE : clen;
+    int nM = 0, nI = 0, nD = 0, nBad = 0;
+    for (int64_t k = k0 + lane; k - lane < k1; k += 64) {
+        const bool v = k < k1;
+        const char c = v ? cig[k] : 'I';
         const bool m = v && (c == 'X' || c == '=' || c == 'M');
         const bool i = v && c == 'I';
         const bool d = v && c == 'D';
@@ -76,8 +124,38 @@ __global__ __launch_bounds__(256) void cigar_scan_kernel(PrepParams p)
         nBad += __popcll(__builtin_amdgcn_ballot_w64(v && !m && !i && !d));
     }
     const uint8_t *sq = p.seqs + p.seq_off[rd], *rf = p.refs + p.ref_off[rd];
-    for (int64_t k = lane; k - lane < S; k += 64) nBad += __popcll(__builtin_amdgcn_ballot_w64(k < S && sq[k] > 4));
-    for (int64_t k = lane; k - lane < R; k += 64) nBad += __popcll(__builtin_amdgcn_ballot_w64(k < R && rf[k] > 4));
+    const int64_t s0 = S * j / nt, s1 = S * (j + 1) / nt, r0 = R * j / nt, r1 = R * (j + 1) / nt;
+    for (int64_t k = s0 + lane; k - lane < s1; k += 64) nBad += __popcll(__builtin_amdgcn_ballot_w64(k < s1 && sq[k] > 4));
+    for (int64_t k = r0 + lane; k - lane < r1; k += 64) nBad += __popcll(__builtin_amdgcn_ballot_w64(k < r1 && rf[k] > 4));
+    if (lane == 0) p.tile_cnt[tile] = make_int4(nM, nI, nD, nBad);
+}
+
+// wave per read: totals over its tiles and every tile's position in the read's path
+__global__ __launch_bounds__(256) void cigar_scan_kernel(PrepParams p)
+{
+    const int64_t rd = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (rd >= p.n_reads) return;
+    const int64_t S = p.seq_off[rd + 1] - p.seq_off[rd], R = p.ref_off[rd + 1] - p.ref_off[rd];
+    const int t0 = p.rd_tile_first[rd], t1 = p.rd_tile_first[rd + 1];
+    int64_t nM = 0, nI = 0, nD = 0, nBad = 0;
+    for (int tb = t0; tb < t1; tb += 64) {
+        const int t = tb + lane;
+        const int4 c = (t < t1) ? p.tile_cnt[t] : make_int4(0, 0, 0, 0);
+        // inclusive scans over the lanes of (steps, 'I' steps) = (2M + I + D, M + I): both < 2 * CIGAR_TILE * 64
+        int st = 2 * c.x + c.y + c.z, is = c.x + c.y, m = c.x, i = c.y, d = c.z, bad = c.w;
+        const int own_st = st, own_is = is;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int a_st = __shfl_up(st, o), a_is = __shfl_up(is, o);
+            if (lane >= o) { st += a_st; is += a_is; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { m += __shfl_xor(m, o); i += __shfl_xor(i, o); d += __shfl_xor(d, o); bad += __shfl_xor(bad, o); }
+        const int64_t before = 2 * nM + nI + nD + (st - own_st), beforeI = nM + nI + (is - own_is);
+        if (t < t1) p.tile_base[t] = make_int2((int)(before < (1ll << 30) ? before : 0), (int)(beforeI < (1ll << 30) ? beforeI : 0));
+        nM += m; nI += i; nD += d; nBad += bad;
+    }
     const int64_t nsteps = 2 * nM + nI + nD;
     const bool ok = nBad == 0 && nM + nI == S && nM + nD == R && nsteps < (1ll << 30);
     if (lane == 0) {
@@ -123,22 +201,27 @@ __global__ __launch_bounds__(1024) void read_scan_kernel(PrepParams p)
     }
 }
 
+// wave per tile
 __global__ __launch_bounds__(256) void expand_path_kernel(PrepParams p)
 {
-    const int64_t rd = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (rd >= p.n_reads || p.rd_status[rd] != 0) return;
+    const int64_t rd = tile_owner(p, tile);
+    if (rd < 0 || p.rd_status[rd] != 0) return;
+    const int64_t j = tile - p.rd_tile_first[rd];
     const char *cig = p.cigs + p.cig_off[rd];
     const int64_t clen = p.cig_off[rd + 1] - p.cig_off[rd];
+    const int64_t k_beg = j * CIGAR_TILE, k_end = (k_beg + CIGAR_TILE < clen) ? k_beg + CIGAR_TILE : clen;
     uint8_t *steps = p.steps + p.rd_steps_off[rd];
     int32_t *inss = p.inss + p.rd_steps_off[rd] + rd;
-    if (lane == 0) inss[0] = 0;
+    if (j == 0 && lane == 0) inss[0] = 0;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    int64_t base = 0;      // steps emitted so far
-    int32_t baseI = 0;     // 'I' steps emitted so far
-    for (int64_t k0 = 0; k0 < clen; k0 += 64) {
+    const int2 tbase = p.tile_base[tile];
+    int64_t base = tbase.x;      // steps emitted so far
+    int32_t baseI = tbase.y;     // 'I' steps emitted so far
+    for (int64_t k0 = k_beg; k0 < k_end; k0 += 64) {
         const int64_t k = k0 + lane;
-        const bool v = k < clen;
+        const bool v = k < k_end;
         const char c = v ? cig[k] : 'D';
         const bool m = v && (c == 'X' || c == '=' || c == 'M');
         const bool i = v && c == 'I';
