@@ -124,6 +124,12 @@ int npore_standardize_batch(int64_t n_reads, const char *alns, const int64_t *al
                             const uint8_t *refs, const int64_t *ref_off,
                             const uint8_t *seqs, const int64_t *seq_off,
                             char *out, const int64_t *out_off, int64_t *out_len, int threads);
+/* The same without the run-length encoding: the expanded op string over 'MID' that realign_hap returns
+ * (reference src/bam.pyx:116); read i needs at most as many bytes as its align() string has. */
+int npore_standardize_ops_batch(int64_t n_reads, const char *alns, const int64_t *aln_off,
+                                const uint8_t *refs, const int64_t *ref_off,
+                                const uint8_t *seqs, const int64_t *seq_off,
+                                char *out, const int64_t *out_off, int64_t *out_len, int threads);
 
 /*
  * Timing of the stages of the last npore_align_batch* call on this context,

@@ -29,6 +29,7 @@ SIGNATURES = {
                                  [C.c_void_p, C.c_int]),
     "npore_get_np_info": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "npore_standardize_batch": (C.c_int, [C.c_int64] + [C.c_void_p] * 9 + [C.c_int]),
+    "npore_standardize_ops_batch": (C.c_int, [C.c_int64] + [C.c_void_p] * 9 + [C.c_int]),
     "npore_last_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "npore_ctx_set": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "npore_bam_open": (C.c_void_p, [C.c_char_p, C.c_int]),

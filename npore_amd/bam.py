@@ -271,8 +271,8 @@ def realign_haps(ctx, hap_data, r=30, max_b_rows=20000):
     for h, st in zip(hap_data, status):
         if st:
             print(f"\nERROR: inconsistent traceback for {h[0]} hap {h[1]} (status {int(st)})")
-    finals = standardize_batch(alns, refs, seqs)
-    return [(h[0], h[1], h[2], h[3], expand_cigar(f)) for h, f in zip(hap_data, finals)]
+    finals = standardize_batch(alns, refs, seqs, expanded=True)
+    return [(h[0], h[1], h[2], h[3], f) for h, f in zip(hap_data, finals)]
 
 
 def sam_line(rd, final):

@@ -17,6 +17,8 @@ for _c, _v in (("N", 0), ("A", 1), ("C", 2), ("G", 3), ("T", 4), ("-", 5)):
 
 def expand_cigar(cigar):
     """'1D3M2I' -> 'DMMMII' (src/cig.pyx:42-57)."""
+    if len(cigar) > 4096:
+        return _expand_cigar_np(cigar)       # chromosome-length strings (realign_haps): same result, vectorised
     out, count = [], 0
     for ch in cigar:
         if "0" <= ch <= "9":
@@ -25,6 +27,27 @@ def expand_cigar(cigar):
             out.append(ch * count)
             count = 0
     return "".join(out)
+
+
+def _expand_cigar_np(cigar):
+    b = np.frombuffer(cigar.encode(), dtype=np.uint8)
+    is_digit = (b >= 48) & (b <= 57)
+    op_pos = np.flatnonzero(~is_digit)
+    if len(op_pos) == 0:
+        return ""
+    # the digits in front of every op, least significant first
+    counts = np.zeros(len(op_pos), np.int64)
+    alive = np.ones(len(op_pos), bool)
+    mult = 1
+    for k in range(1, 19):
+        idx = op_pos - k
+        d = b[np.maximum(idx, 0)]
+        alive &= (idx >= 0) & (d >= 48) & (d <= 57)
+        if not alive.any():
+            break
+        counts += np.where(alive, (d.astype(np.int64) - 48) * mult, 0)
+        mult *= 10
+    return np.repeat(b[op_pos], counts).tobytes().decode()
 
 
 def collapse_cigar(extended_cigar, return_groups=False):
@@ -124,9 +147,10 @@ def standardize(aln, int_ref, int_seq):
     return "".join("MID"[c] for c in cig).replace("ID", "M")
 
 
-def standardize_batch(alns, int_refs, int_seqs, threads=0):
+def standardize_batch(alns, int_refs, int_seqs, threads=0, expanded=False):
     """Collapsed final CIGARs for a batch: `collapse_cigar(standardize(...))` per read, done by
-    the library's C++ glue (npore_standardize_batch) on all host cores."""
+    the library's C++ glue (npore_standardize_batch) on all host cores.  expanded=True: the op strings
+    over 'MID' themselves (npore_standardize_ops_batch; what realign_hap returns)."""
     import ctypes as C
     from . import _lib
     lib = _lib.load()
@@ -145,15 +169,15 @@ def standardize_batch(alns, int_refs, int_seqs, threads=0):
     ao = pack(ab, [len(a) for a in ab])
     ro = pack(refs, [len(x) for x in refs])
     so = pack(seqs, [len(x) for x in seqs])
-    oo = pack(ab, [2 * len(a) + 16 for a in ab])
+    oo = pack(ab, [(1 if expanded else 2) * len(a) + 16 for a in ab])
     abuf = np.frombuffer(b"".join(ab) + b"\0", dtype=np.uint8)
     rbuf = np.concatenate(refs + [np.zeros(1, np.uint8)])
     sbuf = np.concatenate(seqs + [np.zeros(1, np.uint8)])
-    out = np.zeros(int(oo[-1]) + 1, np.uint8)
+    out = np.empty(int(oo[-1]) + 1, np.uint8)
     olen = np.zeros(n, np.int64)
-    rc = lib.npore_standardize_batch(n, abuf.ctypes.data, ao.ctypes.data, rbuf.ctypes.data, ro.ctypes.data,
-                                     sbuf.ctypes.data, so.ctypes.data, out.ctypes.data, oo.ctypes.data,
-                                     olen.ctypes.data, threads)
+    fn = lib.npore_standardize_ops_batch if expanded else lib.npore_standardize_batch
+    rc = fn(n, abuf.ctypes.data, ao.ctypes.data, rbuf.ctypes.data, ro.ctypes.data,
+            sbuf.ctypes.data, so.ctypes.data, out.ctypes.data, oo.ctypes.data, olen.ctypes.data, threads)
     if rc != 0:
         raise RuntimeError(f"npore_standardize_batch: {rc} {_lib.last_error()}")
     return [out[oo[i]:oo[i] + olen[i]].tobytes().decode() for i in range(n)]

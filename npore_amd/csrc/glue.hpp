@@ -63,10 +63,12 @@ inline void push_inss_thru_dels(std::vector<uint8_t> &cigar)
     }
 }
 
-// src/bam.pyx:65-78 + collapse_cigar (src/cig.pyx:13-38): one pass (the reference's loop always
-// stops after one: its `old_cig` is a view of the array the push functions modify), 'ID' -> 'M'.
-inline std::string standardize_collapsed(const char *aln, int64_t aln_len, const uint8_t *ref, int64_t ref_len,
-                                         const uint8_t *seq, int64_t seq_len)
+// src/bam.pyx:65-78: one pass (the reference's loop always stops after one: its `old_cig` is a view of
+// the array the push functions modify), 'ID' -> 'M' (left to right, non-overlapping, like str.replace).
+// Calls emit(op) for every op of the expanded result ('M', 'I' or 'D').
+template <class Emit>
+inline void standardize_ops(const char *aln, int64_t aln_len, const uint8_t *ref, int64_t ref_len,
+                            const uint8_t *seq, int64_t seq_len, Emit emit)
 {
     std::vector<uint8_t> cig((size_t)aln_len);
     for (int64_t i = 0; i < aln_len; i++) {
@@ -77,22 +79,37 @@ inline std::string standardize_collapsed(const char *aln, int64_t aln_len, const
     push_inss_thru_dels(cig);
     push_indels_left(cig, seq, seq_len, OP_I);
     push_inss_thru_dels(cig);
-    // 'ID' -> 'M' (left to right, non-overlapping, like str.replace), then run-length encode
+    for (int64_t i = 0; i < aln_len;) {
+        if (cig[i] == OP_I && i + 1 < aln_len && cig[i + 1] == OP_D) { emit('M'); i += 2; }
+        else { emit("MID"[cig[i]]); i += 1; }
+    }
+}
+
+// ... + collapse_cigar (src/cig.pyx:13-38): run-length encoded text
+inline std::string standardize_collapsed(const char *aln, int64_t aln_len, const uint8_t *ref, int64_t ref_len,
+                                         const uint8_t *seq, int64_t seq_len)
+{
     std::string out;
     char last = 0;
     int64_t count = 0;
     auto flush = [&] {
         if (count) { out += std::to_string(count); out += last; }
     };
-    for (int64_t i = 0; i < aln_len;) {
-        char op;
-        if (cig[i] == OP_I && i + 1 < aln_len && cig[i + 1] == OP_D) { op = 'M'; i += 2; }
-        else { op = "MID"[cig[i]]; i += 1; }
+    standardize_ops(aln, aln_len, ref, ref_len, seq, seq_len, [&](char op) {
         if (op == last) count++;
         else { flush(); last = op; count = 1; }
-    }
+    });
     flush();
     return out;
+}
+
+// the expanded op string itself (what realign_hap returns, src/bam.pyx:116); at most aln_len ops
+inline int64_t standardize_expanded(const char *aln, int64_t aln_len, const uint8_t *ref, int64_t ref_len,
+                                    const uint8_t *seq, int64_t seq_len, char *out)
+{
+    int64_t n = 0;
+    standardize_ops(aln, aln_len, ref, ref_len, seq, seq_len, [&](char op) { out[n++] = op; });
+    return n;
 }
 
 }  // namespace npore

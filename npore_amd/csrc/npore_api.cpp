@@ -639,7 +639,7 @@ int npore_ctx_set(npore_ctx *ctx, const char *key, int64_t value)
     return NPORE_OK;
 }
 
-int npore_standardize_batch(int64_t n_reads, const char *alns, const int64_t *aln_off, const uint8_t *refs,
+static int standardize_batch_impl(bool expanded, int64_t n_reads, const char *alns, const int64_t *aln_off, const uint8_t *refs,
                             const int64_t *ref_off, const uint8_t *seqs, const int64_t *seq_off, char *out,
                             const int64_t *out_off, int64_t *out_len, int threads)
 {
@@ -652,6 +652,13 @@ int npore_standardize_batch(int64_t n_reads, const char *alns, const int64_t *al
         for (;;) {
             const int64_t i = next.fetch_add(1);
             if (i >= n_reads) break;
+            if (expanded) {       // never longer than the align() string
+                if (aln_off[i + 1] - aln_off[i] > out_off[i + 1] - out_off[i]) { out_len[i] = -1; bad++; continue; }
+                out_len[i] = standardize_expanded(alns + aln_off[i], aln_off[i + 1] - aln_off[i], refs + ref_off[i],
+                                                  ref_off[i + 1] - ref_off[i], seqs + seq_off[i],
+                                                  seq_off[i + 1] - seq_off[i], out + out_off[i]);
+                continue;
+            }
             const std::string c = standardize_collapsed(alns + aln_off[i], aln_off[i + 1] - aln_off[i],
                                                         refs + ref_off[i], ref_off[i + 1] - ref_off[i],
                                                         seqs + seq_off[i], seq_off[i + 1] - seq_off[i]);
@@ -667,6 +674,20 @@ int npore_standardize_batch(int64_t n_reads, const char *alns, const int64_t *al
         for (auto &t : pool) t.join();
     }
     return bad ? fail(NPORE_E_INVALID, "output slot too small") : NPORE_OK;
+}
+
+int npore_standardize_batch(int64_t n_reads, const char *alns, const int64_t *aln_off, const uint8_t *refs,
+                            const int64_t *ref_off, const uint8_t *seqs, const int64_t *seq_off, char *out,
+                            const int64_t *out_off, int64_t *out_len, int threads)
+{
+    return standardize_batch_impl(false, n_reads, alns, aln_off, refs, ref_off, seqs, seq_off, out, out_off, out_len, threads);
+}
+
+int npore_standardize_ops_batch(int64_t n_reads, const char *alns, const int64_t *aln_off, const uint8_t *refs,
+                                const int64_t *ref_off, const uint8_t *seqs, const int64_t *seq_off, char *out,
+                                const int64_t *out_off, int64_t *out_len, int threads)
+{
+    return standardize_batch_impl(true, n_reads, alns, aln_off, refs, ref_off, seqs, seq_off, out, out_off, out_len, threads);
 }
 
 // debug / self-test entries (used by tests -m gpu)

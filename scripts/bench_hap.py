@@ -33,6 +33,10 @@ for rep in range(2):
     tm = ctx.timing()
     print(f"realign_haps rep={rep}: {dt:.2f}s ({sum(len(h[3]) for h in haps) / dt / 1e6:.1f} Mbp/s)  fill={tm['fill_ms']:.0f}ms "
           f"tb={tm['traceback_ms']:.0f}ms prep={tm['dev_prep_ms']:.0f}ms h2d={tm['h2d_ms']:.0f} d2h={tm['d2h_ms']:.0f}", flush=True)
+if os.environ.get("NPORE_PROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable(); bam.realign_haps(ctx, haps, r=30); pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
 t = time.time()
 recs = V.gen_records(out)
 print(f"gen_records {time.time() - t:.2f}s: {len(recs)} variants", flush=True)

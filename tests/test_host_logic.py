@@ -96,6 +96,10 @@ def test_cpp_glue_equals_python_glue(tables):
     want = [cig.collapse_cigar(cig.standardize(a, r_, s_)) for a, r_, s_ in zip(alns, refs, seqs)]
     assert cig.standardize_batch(alns, refs, seqs) == want
     assert cig.standardize_batch(alns, refs, seqs, threads=1) == want
+    # the expanded form (what realign_hap returns), and expand_cigar's vectorised twin for long strings
+    ops = [cig.standardize(a, r_, s_) for a, r_, s_ in zip(alns, refs, seqs)]
+    assert cig.standardize_batch(alns, refs, seqs, expanded=True) == ops
+    assert [cig._expand_cigar_np(w) for w in want] == ops == [cig.expand_cigar(w) for w in want]
 
 
 def test_bam_reader_equals_sam():
