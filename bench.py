@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=32,
                     help="worker processes for the whole-batch CPU run (each holds a 241 MB state matrix at r=100; 0/1 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="batches in flight per GPU: each has its own context (stream + work buffers) and host thread, "
+                         "so one batch's traceback / gather and the next one's preparation run beside a fill kernel")
     args = ap.parse_args()
 
     import torch
@@ -72,7 +75,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)                 # "nccl" is RCCL on ROCm
 
     sub, nps, _, _ = aln.load_default_tables()
-    ctx = aln.Context(sub, nps, max_n=6, max_l=100, device=local)
+    n_ctx = max(1, args.inflight)
+    ctxs = [aln.Context(sub, nps, max_n=6, max_l=100, device=local) for _ in range(n_ctx)]
+    ctx = ctxs[0]
     lib = _lib.load()
 
     # ---- synthetic batch for this rank (reads rank, rank+world, ... : round-robin by index)
@@ -85,17 +90,49 @@ def main():
     np.cumsum([len(a) + len(b) for a, b in zip(refs, seqs)], out=oo[1:])
     t = lambda a: torch.from_numpy(a).to(dev)
     d_rb, d_ro, d_sb, d_so, d_cb, d_co, d_oo = map(t, (rb, ro, sb, so, cb, co, oo))
-    d_out = torch.zeros(int(oo[-1]) + 64, dtype=torch.uint8, device=dev)
-    d_len = torch.zeros(n, dtype=torch.int64, device=dev)
-    d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+    # one set of outputs per batch in flight (inputs are read-only and shared)
+    outs = [(torch.zeros(int(oo[-1]) + 64, dtype=torch.uint8, device=dev), torch.zeros(n, dtype=torch.int64, device=dev),
+             torch.zeros(n, dtype=torch.int32, device=dev)) for _ in range(n_ctx)]
+    d_out, d_len, d_st = outs[0]
 
-    def step():
+    def step(j=0):
+        o, ln, st_ = outs[j]
         rc = lib.npore_align_batch_device(
-            ctx.handle, n, d_rb.data_ptr(), d_ro.data_ptr(), d_sb.data_ptr(), d_so.data_ptr(),
+            ctxs[j].handle, n, d_rb.data_ptr(), d_ro.data_ptr(), d_sb.data_ptr(), d_so.data_ptr(),
             d_cb.data_ptr(), d_co.data_ptr(), 5.0, 1.0, args.max_b_rows, args.r,
-            d_out.data_ptr(), d_oo.data_ptr(), d_len.data_ptr(), d_st.data_ptr(), None, 1)
+            o.data_ptr(), d_oo.data_ptr(), ln.data_ptr(), st_.data_ptr(), None, 1)
         if rc != 0:
             raise RuntimeError(f"npore_align_batch_device: {rc} {_lib.last_error()}")
+
+    def run_steps(k):
+        """Exactly k steps; with several batches in flight, host thread j drives steps j, j + n_ctx, ... on its
+        own context (the library call blocks its thread and releases the GIL)."""
+        times = [[] for _ in range(n_ctx)]
+
+        def worker(j):
+            for _ in range(j, k, n_ctx):
+                step(j)
+                tm = ctxs[j].timing()       # HIP events recorded on the library's own stream
+                times[j].append((tm["fill_ms"], tm["traceback_ms"], tm["dev_prep_ms"]))
+        if n_ctx == 1:
+            worker(0)
+        else:
+            import threading
+            errs = []
+
+            def guarded(j):
+                try:
+                    worker(j)
+                except BaseException as e:      # noqa: BLE001 -- re-raised on the main thread
+                    errs.append(e)
+            th = [threading.Thread(target=guarded, args=(j,)) for j in range(n_ctx)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            if errs:
+                raise errs[0]
+        return [t_ for per in times for t_ in per]
 
     def barrier():
         torch.cuda.synchronize()
@@ -103,20 +140,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    warmup = max(args.warmup, n_ctx) if args.warmup else 0        # every context warmed up (buffers allocated)
+    run_steps(warmup)
     barrier()
     t0 = time.perf_counter()
-    fill_ms, tb_ms, prep_ms = [], [], []
-    for _ in range(args.steps):
-        step()
-        tm = ctx.timing()           # HIP events recorded on the library's own stream
-        fill_ms.append(tm["fill_ms"]); tb_ms.append(tm["traceback_ms"]); prep_ms.append(tm["dev_prep_ms"])
+    stage = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    assert len(stage) == args.steps
+    for o in outs[1:min(n_ctx, args.steps + warmup)]:             # every batch in flight produced the same strings
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+    fill_ms, tb_ms, prep_ms = ([x[i] for x in stage] for i in range(3))
     # the only collective of the job: sum of counters, max of the elapsed time
     from npore_amd.dist import reduce_counters
-    sums, maxes = reduce_counters({"reads": n * args.steps, "bad": int((d_st != 0).sum().item())},
+    sums, maxes = reduce_counters({"reads": n * args.steps, "bad": int(sum((o[2] != 0).sum().item() for o in outs))},
                                   {"elapsed": elapsed}, device=dev)
     elapsed = maxes["elapsed"]
     n_bad = int(sums["bad"])
@@ -176,13 +213,14 @@ def main():
     if rank == 0:
         line = {
             "metric": "realigned reads/sec (10 kb ONT-like)", "value": round(value, 1), "unit": "reads/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n} synthetic {args.ref_len // 1000} kb reads per GPU, r={args.r} "
                                    f"(band={args.r}), max_b_rows={args.max_b_rows}, guppy5_stats penalties "
                                    f"(SURVEY 8d C2 generator, base_seed={args.base_seed})",
-                       "reads_per_gpu": n, "ref_len": args.ref_len, "r": args.r, "parallelism": f"reads x{world}"},
+                       "reads_per_gpu": n, "ref_len": args.ref_len, "r": args.r, "parallelism": f"reads x{world}",
+                       "batches_in_flight": n_ctx},
             "roofline": roofline, "cpu_baseline": cpu,
             "stage_ms": {"fill": round(fill_avg_ms, 2), "traceback_gather": round(float(np.mean(tb_ms)), 2),
                          "prep": round(float(np.mean(prep_ms)), 2)},
