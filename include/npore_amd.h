@@ -113,6 +113,18 @@ int npore_align_batch_device(npore_ctx *ctx, int64_t n_reads,
 int npore_get_np_info(npore_ctx *ctx, const uint8_t *seq, int64_t len, int32_t *out);
 
 /*
+ * get_np_regions (reference src/bed.py:56-76) for a batch of independent slices of a genome (the reference
+ * cuts every region into --chunk_width pieces, src/bam.pyx:149-162, and annotates each on its own):
+ * get_np_info on every slice, then the n-polymer starts (L != 0 and L_IDX == 0) per period.
+ * seqs: base codes, slice k = seqs[seq_off[k] .. seq_off[k+1]).  counts[(n-1) * n_slices + k] = starts of
+ * period n in slice k; *pos / *reps (position within the slice, repeat count L) list them ordered by
+ * (period, slice, position) -- the region of an entry is [pos, pos + n * L).  *pos and *reps point into
+ * storage owned by ctx, valid until the next call on it.
+ */
+int npore_np_regions(npore_ctx *ctx, const uint8_t *seqs, const int64_t *seq_off, int64_t n_slices,
+                     int64_t *counts, const int32_t **pos, const int32_t **reps, int64_t *total);
+
+/*
  * Host-side glue after align(): what realign_read does with the returned string
  * (reference src/bam.pyx:65-78 with src/cig.pyx:102-192 and collapse_cigar, src/cig.pyx:13-38):
  * X,= -> M, one pass of push-D-left / I-through-D / push-I-left / I-through-D, 'ID' -> 'M',

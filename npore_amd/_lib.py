@@ -28,6 +28,8 @@ SIGNATURES = {
                                  [C.c_float, C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 4 +
                                  [C.c_void_p, C.c_int]),
     "npore_get_np_info": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "npore_np_regions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p),
+                                   C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "npore_standardize_batch": (C.c_int, [C.c_int64] + [C.c_void_p] * 9 + [C.c_int]),
     "npore_standardize_ops_batch": (C.c_int, [C.c_int64] + [C.c_void_p] * 9 + [C.c_int]),
     "npore_last_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),

@@ -113,6 +113,32 @@ class Context:
         _check(self.lib.npore_get_np_info(self.handle, seq.ctypes.data, len(seq), out.ctypes.data))
         return out
 
+    def np_regions(self, slices):
+        """get_np_regions (src/bed.py:56-76) for a batch of independent base-code slices: per period n
+        (index n-1) and slice, (positions within the slice, repeat counts L) of the n-polymer starts, in
+        position order -- the region of an entry is [pos, pos + n * L)."""
+        import ctypes as C
+        slices = [_u8(x) for x in slices]
+        k = len(slices)
+        if k == 0:
+            return [[] for _ in range(self.max_n)]
+        off = np.zeros(k + 1, np.int64)
+        np.cumsum([len(x) for x in slices], out=off[1:])
+        buf = np.concatenate(slices + [np.zeros(1, np.uint8)])
+        counts = np.zeros(self.max_n * k, np.int64)
+        pos, reps, total = C.c_void_p(), C.c_void_p(), C.c_int64()
+        _check(self.lib.npore_np_regions(self.handle, buf.ctypes.data, off.ctypes.data, k, counts.ctypes.data,
+                                         C.byref(pos), C.byref(reps), C.byref(total)))
+        t = total.value
+        if t:
+            ap = np.ctypeslib.as_array(C.cast(pos, C.POINTER(C.c_int32)), shape=(t,)).copy()
+            ar = np.ctypeslib.as_array(C.cast(reps, C.POINTER(C.c_int32)), shape=(t,)).copy()
+        else:
+            ap = ar = np.zeros(0, np.int32)
+        cuts = np.concatenate(([0], np.cumsum(counts)))
+        return [[(ap[cuts[n * k + j]:cuts[n * k + j + 1]], ar[cuts[n * k + j]:cuts[n * k + j + 1]]) for j in range(k)]
+                for n in range(self.max_n)]
+
 
 def _context_for(sub_scores, np_scores, device=0):
     key = (device, id(sub_scores), id(np_scores), int(cfg.args.max_n), int(cfg.args.max_l))

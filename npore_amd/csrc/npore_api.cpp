@@ -116,6 +116,7 @@ struct npore_ctx {
     DevBuf in_refs, in_seqs, in_cigs, in_off;                       // raw inputs (host-buffer entry point)
     DevBuf rd_i32, rd_i64, steps, inss, descs, sched, hist, counters; // path + chunks
     DevBuf tiles, cwoff;                                             // CIGAR tiles; chunk positions in the output
+    std::vector<int32_t> regions;                                    // npore_np_regions: positions, then repeat counts
     DevBuf seqw, refw, refl, seql;                                   // annotation
     DevBuf tb, cout_, clen, cstat, cnruns;                           // fill / traceback (cout_: uint32 runs)
     DevBuf out, out_off, out_len, status;                            // outputs (host-buffer entry point)
@@ -615,6 +616,66 @@ int npore_get_np_info(npore_ctx *ctx, const uint8_t *seq, int64_t len, int32_t *
             out[(p * 2 + 0) * mn + n] = L[p * mn + n];
             out[(p * 2 + 1) * mn + n] = I[p * mn + n];
         }
+    return NPORE_OK;
+}
+
+int npore_np_regions(npore_ctx *ctx, const uint8_t *seqs, const int64_t *seq_off, int64_t n_slices, int64_t *counts,
+                     const int32_t **pos, const int32_t **reps, int64_t *total)
+{
+    if (!ctx || n_slices < 0 || (n_slices > 0 && (!seqs || !seq_off || !counts)) || !pos || !reps || !total)
+        return fail(NPORE_E_INVALID, "null argument");
+    *pos = *reps = nullptr;
+    *total = 0;
+    if (n_slices == 0) return NPORE_OK;
+    if (n_slices > (1 << 24)) return fail(NPORE_E_UNSUPPORTED, "too many slices in one call");
+    const int64_t bases = seq_off[n_slices] - seq_off[0];
+    for (int64_t k = 0; k < n_slices; k++) {
+        const int64_t l = seq_off[k + 1] - seq_off[k];
+        if (l < 0 || l >= (1ll << 30)) return fail(NPORE_E_INVALID, "slice length out of range");
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int mn = ctx->max_n;
+    const size_t m = (size_t)mn * n_slices;
+    // work buffers of the align path are reused (nothing else runs on this context meanwhile)
+    if (int rc = ctx->in_seqs.ensure((size_t)bases + 16)) return rc;
+    if (int rc = ctx->in_off.ensure((size_t)(n_slices + 1) * 8)) return rc;
+    if (int rc = ctx->seql.ensure((size_t)bases * mn + 64)) return rc;
+    if (int rc = ctx->rd_i64.ensure((m + 2) * 8)) return rc;
+    std::vector<int64_t> off((size_t)n_slices + 1);
+    for (int64_t k = 0; k <= n_slices; k++) off[k] = seq_off[k] - seq_off[0];
+    hipStream_t s = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ctx->in_seqs.p, seqs + seq_off[0], (size_t)bases, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ctx->in_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, s));
+    RegionParams rp;
+    rp.seqs = ctx->in_seqs.as<uint8_t>();
+    rp.seq_off = ctx->in_off.as<int64_t>();
+    rp.n_slices = (int)n_slices;
+    rp.max_n = mn;
+    rp.max_l = ctx->max_l;
+    rp.planes = ctx->seql.as<uint8_t>();
+    rp.counts = ctx->rd_i64.as<int64_t>();
+    rp.out_pos = rp.out_reps = nullptr;
+    hipLaunchKernelGGL(region_annotate_kernel, dim3((unsigned)n_slices), dim3(1024), 0, s, rp);
+    hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(1024), 0, s, rp);
+    HIP_TRY(hipGetLastError());
+    std::vector<int64_t> offs(m + 1);
+    HIP_TRY(hipMemcpyAsync(offs.data(), rp.counts, (m + 1) * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const int64_t tot = offs[m];
+    for (size_t k = 0; k < m; k++) counts[k] = offs[k + 1] - offs[k];
+    ctx->regions.resize((size_t)tot * 2);
+    if (tot > 0) {
+        if (int rc = ctx->out.ensure((size_t)tot * 8)) return rc;
+        rp.out_pos = ctx->out.as<int32_t>();
+        rp.out_reps = rp.out_pos + tot;
+        hipLaunchKernelGGL(region_emit_kernel, dim3((unsigned)n_slices, (unsigned)mn), dim3(256), 0, s, rp);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(ctx->regions.data(), rp.out_pos, (size_t)tot * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    *pos = ctx->regions.data();
+    *reps = ctx->regions.data() + tot;
+    *total = tot;
     return NPORE_OK;
 }
 

@@ -400,8 +400,12 @@ __device__ __forceinline__ void annotate_period(const uint8_t *seq, int len, int
             const unsigned long long inv = ~(M0 >> lane);   // bits >= 64-lane of the shifted mask are 0 -> 1 here
             kf = inv ? __builtin_ctzll(inv) : 64;
         }
+        // Runs are followed for at most `cap` positions beyond the window: with q = kf/n >= max_l + 1 every start
+        // has more than max_l repeats whatever kf is, and J = kb/n only matters up to max_l (below) -- so a
+        // megabase run (assembly gaps of N, satellite arrays) costs a constant per window.
+        const int cap = (max_l + 2) * n;
         bool cont = (kf == 64 - lane);
-        for (int k = base + 64; k < len && __builtin_amdgcn_ballot_w64(cont) != 0ull; k += 64) {
+        for (int k = base + 64; k < len && k <= base + 64 + cap && __builtin_amdgcn_ballot_w64(cont) != 0ull; k += 64) {
             const unsigned long long Mk = __builtin_amdgcn_ballot_w64(e_at(k + lane));
             const int t = (~Mk) ? __builtin_ctzll(~Mk) : 64;
             if (cont) { kf += t; cont = (t == 64); }
@@ -413,7 +417,7 @@ __device__ __forceinline__ void annotate_period(const uint8_t *seq, int len, int
             kb = __builtin_clzll(inv);                              // inv != 0 because lane > 0
         }
         bool contb = (kb == lane);
-        for (int k = base - 64; k >= 0 && __builtin_amdgcn_ballot_w64(contb) != 0ull; k -= 64) {
+        for (int k = base - 64; k >= 0 && k >= base - 64 - cap && __builtin_amdgcn_ballot_w64(contb) != 0ull; k -= 64) {
             const unsigned long long Mk = __builtin_amdgcn_ballot_w64(e_at(k + lane));
             const int t = (~Mk) ? __builtin_clzll(~Mk) : 64;
             if (contb) { kb += t; contb = (t == 64); }
@@ -421,7 +425,16 @@ __device__ __forceinline__ void annotate_period(const uint8_t *seq, int len, int
         if (pos < len) {
             const int q = (int)((unsigned)kf / (unsigned)n), J = (int)((unsigned)kb / (unsigned)n);
             int stored = 0, idx = 0;
-            for (int j = J; j >= 0; j--) {
+            // every candidate start s = pos - j*n (j <= J) lies in the run ending at pos-1, so seq[s] == seq[pos]:
+            // at an N none is eligible; and starts with more than max_l repeats are all eligible (l*n > 100*n2) and
+            // overwrite each other in turn, the last of them (j = max_l - q, or 0) stays
+            int jtop = seq[pos] ? J : -1;
+            if (jtop >= 0 && jtop + q + 1 > max_l && (jtop > 0 || q >= 1)) {
+                stored = max_l;
+                idx = max_l - q > 0 ? max_l - q : 0;
+                jtop = -1;
+            }
+            for (int j = jtop; j >= 0; j--) {
                 const int l = (j == 0) ? (q >= 1 ? q + 1 : 0) : j + q + 1;
                 if (stored && l <= max_l) break;
                 if (l < 3) continue;
@@ -542,6 +555,91 @@ __global__ __launch_bounds__(1024) void np_info_kernel(const uint8_t *seq, int l
                                                        uint8_t *planes, int pstride, int32_t *Lout, int32_t *Iout)
 {
     annotate_sequence(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
+}
+
+// ---------------------------------------------------------------------------
+// get_np_regions (reference src/bed.py:56-76) for a batch of independent slices of a genome: the n-polymer
+// starts (L != 0 and L_IDX == 0) of every slice and period, in position order.
+struct RegionParams {
+    const uint8_t *seqs;       // base codes, slices back to back
+    const int64_t *seq_off;    // [n_slices + 1]
+    int n_slices, max_n, max_l;
+    uint8_t *planes;           // max_n bytes per base: slice k's planes at planes + max_n * seq_off[k], stride = its length
+    int64_t *counts;           // [max_n][n_slices] counts, then (region_scan) exclusive offsets; total at the end
+    int32_t *out_pos;          // position within the slice
+    int32_t *out_reps;         // repeat count L (capped at max_l)
+};
+
+// workgroup per slice: annotation, then the number of starts per period
+__global__ __launch_bounds__(1024) void region_annotate_kernel(RegionParams p)
+{
+    const int k = blockIdx.x;
+    const int64_t off = p.seq_off[k];
+    const int len = (int)(p.seq_off[k + 1] - off);
+    uint8_t *planes = p.planes + (size_t)p.max_n * off;
+    annotate_sequence(p.seqs + off, len, p.max_n, p.max_l, planes, len, nullptr, nullptr);
+    __shared__ int cnt[MAX_PERIOD];
+    if (threadIdx.x < MAX_PERIOD) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int n = 0; n < p.max_n; n++) {
+        int c = 0;
+        for (int pos = threadIdx.x; pos < len; pos += blockDim.x) c += planes[(size_t)n * len + pos] >> 7;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if ((threadIdx.x & 63) == 0 && c) atomicAdd(&cnt[n], c);
+    }
+    __syncthreads();
+    if (threadIdx.x < p.max_n) p.counts[(size_t)threadIdx.x * p.n_slices + k] = cnt[threadIdx.x];
+}
+
+// single workgroup: counts -> exclusive offsets (order: period, slice), total behind them
+__global__ __launch_bounds__(1024) void region_scan_kernel(RegionParams p)
+{
+    __shared__ int64_t s_t[1024];
+    const int t = threadIdx.x;
+    const int64_t m = (int64_t)p.max_n * p.n_slices;
+    const int64_t per = (m + 1023) / 1024;
+    const int64_t a = (int64_t)t * per, b = (a + per < m) ? a + per : m;
+    int64_t l = 0;
+    for (int64_t k = a; k < b; k++) l += p.counts[k];
+    s_t[t] = l;
+    __syncthreads();
+    if (t == 0) {
+        int64_t acc = 0;
+        for (int k = 0; k < 1024; k++) { const int64_t v = s_t[k]; s_t[k] = acc; acc += v; }
+        p.counts[m] = acc;
+    }
+    __syncthreads();
+    int64_t acc = s_t[t];
+    for (int64_t k = a; k < b; k++) { const int64_t v = p.counts[k]; p.counts[k] = acc; acc += v; }
+}
+
+// workgroup per (slice, period): ordered compaction of the starts
+__global__ __launch_bounds__(256) void region_emit_kernel(RegionParams p)
+{
+    const int k = blockIdx.x, n = blockIdx.y;
+    const int64_t off = p.seq_off[k];
+    const int len = (int)(p.seq_off[k + 1] - off);
+    const uint8_t *plane = p.planes + (size_t)p.max_n * off + (size_t)n * len;
+    int64_t w = p.counts[(size_t)n * p.n_slices + k];
+    __shared__ int s_w[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < len; base += 256) {
+        const int pos = base + threadIdx.x;
+        const uint8_t v = pos < len ? plane[pos] : 0;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64((v & 128) != 0);
+        __syncthreads();                 // the previous round's readers are done
+        if (lane == 0) s_w[wave] = __popcll(m);
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int q = 0; q < 4; q++) { before += q < wave ? s_w[q] : 0; total += s_w[q]; }
+        if (v & 128) {
+            const int64_t at = w + before + __popcll(m & ((1ull << lane) - 1ull));
+            p.out_pos[at] = pos;
+            p.out_reps[at] = v & 127;
+        }
+        w += total;
+    }
 }
 
 }  // namespace npore
