@@ -62,28 +62,43 @@ struct PrepParams {
 };
 
 // ---------------------------------------------------------------------------
-constexpr int CIGAR_TILE = 16384;   // ops per tile (a 10 kb read is one tile, a chromosome thousands)
+// exclusive scan of one value per thread over a 1024-thread workgroup (wave scans by shuffles, the 16 wave sums
+// through LDS); *total = sum over the workgroup.  s_wave: 16 entries of shared memory, reusable afterwards.
+template <class T>
+__device__ __forceinline__ T block_scan_1024(T v, T *s_wave, T *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const T up = __shfl_up(inc, o);
+        if (lane >= o) inc += up;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    T before = 0, tot = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) { const T w = s_wave[q]; before += q < wave ? w : (T)0; tot += w; }
+    __syncthreads();
+    *total = tot;
+    return before + inc - v;
+}
+
+constexpr int CIGAR_TILE = 2048;   // ops per tile (a 10 kb read is a handful of tiles, a chromosome 10^5)
 
 __device__ __forceinline__ int64_t cigar_tiles(int64_t clen) { return clen <= CIGAR_TILE ? 1 : (clen + CIGAR_TILE - 1) / CIGAR_TILE; }
 
 // single workgroup: exclusive scan of the reads' tile counts
 __global__ __launch_bounds__(1024) void tile_scan_kernel(PrepParams p)
 {
-    __shared__ int64_t s_t[1024];
+    __shared__ int64_t s_w[16];
     const int t = threadIdx.x;
     const int64_t per = (p.n_reads + 1023) / 1024;
     const int64_t a = (int64_t)t * per, b = (a + per < p.n_reads) ? a + per : p.n_reads;
-    int64_t l = 0;
+    int64_t l = 0, total;
     for (int64_t k = a; k < b; k++) l += cigar_tiles(p.cig_off[k + 1] - p.cig_off[k]);
-    s_t[t] = l;
-    __syncthreads();
-    if (t == 0) {
-        int64_t acc = 0;
-        for (int k = 0; k < 1024; k++) { const int64_t v = s_t[k]; s_t[k] = acc; acc += v; }
-        p.rd_tile_first[p.n_reads] = (int32_t)acc;
-    }
-    __syncthreads();
-    int64_t acc = s_t[t];
+    int64_t acc = block_scan_1024(l, s_w, &total);
+    if (t == 0) p.rd_tile_first[p.n_reads] = (int32_t)total;
     for (int64_t k = a; k < b; k++) { p.rd_tile_first[k] = (int32_t)acc; acc += cigar_tiles(p.cig_off[k + 1] - p.cig_off[k]); }
 }
 
@@ -169,30 +184,19 @@ __global__ __launch_bounds__(256) void cigar_scan_kernel(PrepParams p)
 // single workgroup: exclusive scans over reads
 __global__ __launch_bounds__(1024) void read_scan_kernel(PrepParams p)
 {
-    __shared__ int64_t s_steps[1024];
-    __shared__ int64_t s_chunks[1024];
+    __shared__ int64_t s_w[16];
     const int t = threadIdx.x;
     const int64_t per = (p.n_reads + 1023) / 1024;
     const int64_t a = (int64_t)t * per, b = (a + per < p.n_reads) ? a + per : p.n_reads;
-    int64_t ls = 0, lc = 0;
+    int64_t ls = 0, lc = 0, tot_s, tot_c;
     for (int64_t k = a; k < b; k++) { ls += p.rd_nsteps[k]; lc += p.rd_nchunks[k]; }
-    s_steps[t] = ls;
-    s_chunks[t] = lc;
-    __syncthreads();
+    int64_t as = block_scan_1024(ls, s_w, &tot_s), ac = block_scan_1024(lc, s_w, &tot_c);
     if (t == 0) {
-        int64_t as = 0, ac = 0;
-        for (int k = 0; k < 1024; k++) {
-            const int64_t vs = s_steps[k], vc = s_chunks[k];
-            s_steps[k] = as; s_chunks[k] = ac;
-            as += vs; ac += vc;
-        }
-        p.rd_steps_off[p.n_reads] = as;
-        p.rd_chunk_first[p.n_reads] = (int32_t)(ac > p.max_chunks ? p.max_chunks : ac);
-        p.counters[0] = (int32_t)(ac > p.max_chunks ? p.max_chunks : ac);
-        p.counters[1] = ac > p.max_chunks;
+        p.rd_steps_off[p.n_reads] = tot_s;
+        p.rd_chunk_first[p.n_reads] = (int32_t)(tot_c > p.max_chunks ? p.max_chunks : tot_c);
+        p.counters[0] = (int32_t)(tot_c > p.max_chunks ? p.max_chunks : tot_c);
+        p.counters[1] = tot_c > p.max_chunks;
     }
-    __syncthreads();
-    int64_t as = s_steps[t], ac = s_chunks[t];
     for (int64_t k = a; k < b; k++) {
         p.rd_steps_off[k] = as;
         p.rd_chunk_first[k] = (int32_t)ac;
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(256) void make_chunks_kernel(PrepParams p)
 // single workgroup: size -> offset for the four per-chunk arrays; histogram -> start positions
 __global__ __launch_bounds__(1024) void chunk_scan_kernel(PrepParams p)
 {
-    __shared__ int64_t s[4][1024];
+    __shared__ int64_t s_w[16];
     const int t = threadIdx.x;
     const int n = p.counters[0];
     const int per = (n + 1023) / 1024;
@@ -324,14 +328,8 @@ __global__ __launch_bounds__(1024) void chunk_scan_kernel(PrepParams p)
         const ChunkDesc &d = p.descs[k];
         l[0] += d.seqw_off; l[1] += d.refw_off; l[2] += d.tb_off; l[3] += d.out_off;
     }
-    for (int q = 0; q < 4; q++) s[q][t] = l[q];
-    __syncthreads();
-    if (t < 4) {
-        int64_t acc = 0;
-        for (int k = 0; k < 1024; k++) { const int64_t v = s[t][k]; s[t][k] = acc; acc += v; }
-    }
-    __syncthreads();
-    int64_t acc[4] = {s[0][t], s[1][t], s[2][t], s[3][t]};
+    int64_t acc[4], tot;
+    for (int q = 0; q < 4; q++) acc[q] = block_scan_1024(l[q], s_w, &tot);
     for (int k = a; k < b; k++) {
         ChunkDesc &d = p.descs[k];
         const int64_t v0 = d.seqw_off, v1 = d.refw_off, v2 = d.tb_off, v3 = d.out_off;
@@ -339,20 +337,13 @@ __global__ __launch_bounds__(1024) void chunk_scan_kernel(PrepParams p)
         acc[0] += v0; acc[1] += v1; acc[2] += v2; acc[3] += v3;
     }
     // histogram (max_b_rows + 2 bins) -> exclusive start positions
-    __shared__ int32_t hs[1024];
+    __shared__ int32_t hs_w[16];
     const int nb = p.max_b_rows + 2;
     const int hper = (nb + 1023) / 1024;
     const int ha = t * hper, hb = (ha + hper < nb) ? ha + hper : nb;
-    int32_t hl = 0;
+    int32_t hl = 0, htot;
     for (int k = ha; k < hb; k++) hl += p.hist[k];
-    hs[t] = hl;
-    __syncthreads();
-    if (t == 0) {
-        int32_t acc2 = 0;
-        for (int k = 0; k < 1024; k++) { const int32_t v = hs[k]; hs[k] = acc2; acc2 += v; }
-    }
-    __syncthreads();
-    int32_t hacc = hs[t];
+    int32_t hacc = block_scan_1024(hl, hs_w, &htot);
     for (int k = ha; k < hb; k++) { const int32_t v = p.hist[k]; p.hist[k] = hacc; hacc += v; }
 }
 
@@ -595,22 +586,15 @@ __global__ __launch_bounds__(1024) void region_annotate_kernel(RegionParams p)
 // single workgroup: counts -> exclusive offsets (order: period, slice), total behind them
 __global__ __launch_bounds__(1024) void region_scan_kernel(RegionParams p)
 {
-    __shared__ int64_t s_t[1024];
+    __shared__ int64_t s_w[16];
     const int t = threadIdx.x;
     const int64_t m = (int64_t)p.max_n * p.n_slices;
     const int64_t per = (m + 1023) / 1024;
     const int64_t a = (int64_t)t * per, b = (a + per < m) ? a + per : m;
-    int64_t l = 0;
+    int64_t l = 0, total;
     for (int64_t k = a; k < b; k++) l += p.counts[k];
-    s_t[t] = l;
-    __syncthreads();
-    if (t == 0) {
-        int64_t acc = 0;
-        for (int k = 0; k < 1024; k++) { const int64_t v = s_t[k]; s_t[k] = acc; acc += v; }
-        p.counts[m] = acc;
-    }
-    __syncthreads();
-    int64_t acc = s_t[t];
+    int64_t acc = block_scan_1024(l, s_w, &total);
+    if (t == 0) p.counts[m] = total;
     for (int64_t k = a; k < b; k++) { const int64_t v = p.counts[k]; p.counts[k] = acc; acc += v; }
 }
 
