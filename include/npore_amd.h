@@ -189,6 +189,8 @@ void npore_fasta_close(npore_fasta *fa);
 int npore_fasta_n(const npore_fasta *fa);
 const char *npore_fasta_name(const npore_fasta *fa, int i);
 int64_t npore_fasta_len(const npore_fasta *fa, int i);
+/* the upper-cased bases of contig i (npore_fasta_len(fa, i) bytes, not NUL-terminated), owned by fa */
+const char *npore_fasta_seq(const npore_fasta *fa, int i);
 
 /* Inputs of npore_align_batch for the selected records (src/bam.pyx:59-61): expanded CIGAR without S/H,
  * query bases without the soft clips and the reference slice [pos, pos + reference_length) as codes.

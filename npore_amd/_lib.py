@@ -47,6 +47,7 @@ SIGNATURES = {
     "npore_fasta_n": (C.c_int, [C.c_void_p]),
     "npore_fasta_name": (C.c_char_p, [C.c_void_p, C.c_int]),
     "npore_fasta_len": (C.c_int64, [C.c_void_p, C.c_int]),
+    "npore_fasta_seq": (C.c_void_p, [C.c_void_p, C.c_int]),
     "npore_bam_pack_sizes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "npore_bam_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 6 + [C.c_int]),
     "npore_bam_format_sam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

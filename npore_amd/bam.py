@@ -313,6 +313,12 @@ class NativeFasta:
     def __iter__(self):
         return iter(self.names)
 
+    def sequence(self, name):
+        """The upper-cased bases of a contig as a str (a copy)."""
+        import ctypes as C
+        i = len(self.names) - 1 - self.names[::-1].index(name)       # a repeated name: the last one, like a dict
+        return C.string_at(self._lib.npore_fasta_seq(self.handle, i), self._len[name]).decode()
+
     def close(self):
         if self.handle:
             self._lib.npore_fasta_close(self.handle)

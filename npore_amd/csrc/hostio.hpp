@@ -12,6 +12,10 @@
 // so the blocks are located with one pass over the file and inflated in parallel.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <atomic>
@@ -85,25 +89,46 @@ inline void parallel_for(int64_t n, int threads, F &&body)   // body(i) for i in
     for (auto &t : pool) t.join();
 }
 
-inline bool read_file(const char *path, std::vector<uint8_t> &buf)
-{
-    FILE *f = std::fopen(path, "rb");
-    if (!f) return false;
-    std::fseek(f, 0, SEEK_END);
-    const long sz = std::ftell(f);
-    std::fseek(f, 0, SEEK_SET);
-    buf.resize(sz > 0 ? (size_t)sz : 0);
-    const size_t got = buf.empty() ? 0 : std::fread(buf.data(), 1, buf.size(), f);
-    std::fclose(f);
-    return got == buf.size();
-}
+// a whole file, read-only: mapped (pages come in as the worker threads touch them, nothing is copied or zeroed)
+struct MappedFile {
+    const uint8_t *p = nullptr;
+    size_t n = 0;
+    bool ok = false;
+    MappedFile() = default;
+    MappedFile(const MappedFile &) = delete;
+    MappedFile &operator=(const MappedFile &) = delete;
+    ~MappedFile() { if (p && n) ::munmap(const_cast<uint8_t *>(p), n); }
+    bool open(const char *path)
+    {
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (::fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { ::close(fd); return false; }
+        n = (size_t)st.st_size;
+        if (n) {
+            void *q = ::mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (q == MAP_FAILED) { ::close(fd); n = 0; return false; }
+            p = static_cast<const uint8_t *>(q);
+        }
+        ::close(fd);
+        return ok = true;
+    }
+};
 
 inline uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 inline uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 inline int32_t rdi32(const uint8_t *p) { return (int32_t)rd32(p); }
 
 // Inflate a BGZF file.  Falls back to member-by-member gzip decoding if a member lacks the BC field.
-inline bool bgzf_inflate(const std::vector<uint8_t> &raw, int threads, RawBuf &out, size_t &out_size, std::string &err)
+struct ByteSpan {
+    const uint8_t *p;
+    size_t n;
+    size_t size() const { return n; }
+    const uint8_t *data() const { return p; }
+    const uint8_t &operator[](size_t i) const { return p[i]; }
+};
+
+inline bool bgzf_inflate(const ByteSpan &raw, int threads, RawBuf &out, size_t &out_size, std::string &err)
 {
     struct Blk { size_t in_off, in_len, out_off, out_len; };
     std::vector<Blk> blocks;
@@ -197,7 +222,10 @@ struct npore_bam {
 
 struct npore_fasta {
     std::vector<std::string> names;
-    std::vector<std::string> seqs;        // upper-cased
+    npore::RawBuf bases;                  // all contigs back to back, upper-cased
+    std::vector<int64_t> off;             // [n + 1] contig k = bases[off[k] .. off[k+1])
+    int64_t len(size_t k) const { return off[k + 1] - off[k]; }
+    const char *seq(size_t k) const { return bases.p + off[k]; }
 };
 
 namespace npore {
@@ -297,6 +325,85 @@ static const char CIGOPS[] = "MIDNSHP=XB";
 inline uint8_t base_code(char c)   // src/cig.pyx:212-229: 'NACGT-' -> 0..5, anything else 0 (upper case only)
 {
     switch (c) { case 'A': return 1; case 'C': return 2; case 'G': return 3; case 'T': return 4; case '-': return 5; default: return 0; }
+}
+
+// FASTA -> contig names + upper-cased bases, on all cores: the file is cut into pieces at line starts; a first
+// pass counts the bases every piece contributes to the contig open at its start and to the contigs whose
+// headers it contains, a second pass copies the lines to their final place.  Lines are trimmed of blanks, tabs
+// and '\r' at both ends; a header's name is the text after '>' up to the first blank; bases before the first
+// header are ignored.
+inline bool fasta_parse(const ByteSpan &raw, int threads, npore_fasta &f)
+{
+    struct Piece {
+        size_t beg = 0, end = 0;
+        int64_t pre = 0;                              // bases before the piece's first header
+        std::vector<std::pair<std::string, int64_t>> hdrs;   // (name, bases until the next header / piece end)
+        int64_t pre_ctg = -1, pre_at = 0;             // destination of `pre`
+        int64_t first_ctg = 0;                        // contig index of hdrs[0]
+    };
+    const size_t N = raw.n;
+    const uint8_t *d = raw.p;
+    const int nt = host_threads(threads);
+    size_t np = std::max<size_t>(1, std::min<size_t>((size_t)nt * 4, N >> 18));
+    std::vector<Piece> pc(np);
+    size_t at = 0;
+    for (size_t k = 0; k < np; k++) {
+        pc[k].beg = at;
+        size_t e = (k + 1 == np) ? N : std::max(at, N / np * (k + 1));
+        if (e < N) {
+            const void *nl = std::memchr(d + e, '\n', N - e);
+            e = nl ? (size_t)(static_cast<const uint8_t *>(nl) - d) + 1 : N;
+        }
+        pc[k].end = at = e;
+    }
+    auto blank = [](uint8_t c) { return c == ' ' || c == '\t' || c == '\r'; };
+    // calls on_header(name_begin, name_end) / on_bases(begin, end) for every line of [beg, end)
+    auto walk = [&](size_t beg, size_t end, auto &&on_header, auto &&on_bases) {
+        size_t p = beg;
+        while (p < end) {
+            const void *nl = std::memchr(d + p, '\n', end - p);
+            const size_t e = nl ? (size_t)(static_cast<const uint8_t *>(nl) - d) : end;
+            size_t le = e, ls = p;
+            while (le > p && blank(d[le - 1])) le--;
+            while (ls < le && (d[ls] == ' ' || d[ls] == '\t')) ls++;
+            if (ls < le && d[ls] == '>') {
+                size_t w = ls + 1;
+                while (w < le && d[w] != ' ' && d[w] != '\t') w++;
+                on_header(ls + 1, w);
+            } else if (le > ls) {
+                on_bases(ls, le);
+            }
+            p = e + 1;
+        }
+    };
+    parallel_for((int64_t)np, threads, [&](int64_t k) {
+        Piece &q = pc[(size_t)k];
+        walk(q.beg, q.end,
+             [&](size_t a, size_t b) { q.hdrs.emplace_back(std::string(reinterpret_cast<const char *>(d + a), b - a), 0); },
+             [&](size_t a, size_t b) { (q.hdrs.empty() ? q.pre : q.hdrs.back().second) += (int64_t)(b - a); });
+    });
+    std::vector<int64_t> sizes;
+    for (Piece &q : pc) {
+        q.pre_ctg = (int64_t)sizes.size() - 1;
+        if (q.pre_ctg >= 0) { q.pre_at = sizes.back(); sizes.back() += q.pre; }
+        q.first_ctg = (int64_t)sizes.size();
+        for (auto &h : q.hdrs) { f.names.push_back(std::move(h.first)); sizes.push_back(h.second); }
+    }
+    f.off.assign(sizes.size() + 1, 0);
+    for (size_t k = 0; k < sizes.size(); k++) f.off[k + 1] = f.off[k] + sizes[k];
+    if (!f.bases.ensure((size_t)f.off.back() + 1)) return false;
+    parallel_for((int64_t)np, threads, [&](int64_t k) {
+        const Piece &q = pc[(size_t)k];
+        int64_t ctg = q.pre_ctg, next = q.first_ctg;
+        char *w = ctg >= 0 ? f.bases.p + f.off[(size_t)ctg] + q.pre_at : nullptr;
+        walk(q.beg, q.end,
+             [&](size_t, size_t) { ctg = next++; w = f.bases.p + f.off[(size_t)ctg]; },
+             [&](size_t a, size_t b) {
+                 if (!w) return;
+                 for (size_t i = a; i < b; i++) { const uint8_t c = d[i]; *w++ = (char)((c >= 'a' && c <= 'z') ? c - 32 : c); }
+             });
+    });
+    return true;
 }
 
 }  // namespace npore

@@ -794,8 +794,9 @@ int npore_debug_fetch(npore_ctx *ctx, int what, void *dst, int64_t bytes)
 npore_bam *npore_bam_open(const char *path, int threads)
 {
     if (!path) { fail(NPORE_E_INVALID, "null path"); return nullptr; }
-    std::vector<uint8_t> raw;
-    if (!read_file(path, raw)) { fail(NPORE_E_INVALID, std::string("BAM file '") + path + "' not found"); return nullptr; }
+    MappedFile mf;
+    if (!mf.open(path)) { fail(NPORE_E_INVALID, std::string("BAM file '") + path + "' not found"); return nullptr; }
+    const ByteSpan raw{mf.p, mf.n};
     auto *b = new npore_bam();
     std::string err;
     if (!bgzf_inflate(raw, threads, b->data_buf, b->data_size, err) || b->data_size < 12 || std::memcmp(b->data_buf.p, "BAM\1", 4) != 0) {
@@ -827,31 +828,40 @@ npore_bam *npore_bam_open(const char *path, int threads)
     b->by_ref.assign((size_t)n_ref, {});
     b->ref_sorted.assign((size_t)n_ref, 1);
     b->ref_max_len.assign((size_t)n_ref, 0);
-    std::vector<int64_t> last_pos((size_t)n_ref, -1);
+    // records: offsets (one hop per record), then validation + reference spans on all cores, then the per-reference lists
     while (p + 4 <= N) {
         const int32_t bs = rdi32(&d[p]);
         if (bs < 32 || p + 4 + (size_t)bs > N) { fail(NPORE_E_INVALID, "truncated BAM record"); delete b; return nullptr; }
-        {   // the variable-length parts the accessors will walk must lie inside the record
-            const uint8_t *f = &d[p + 4];
-            const int64_t l_rn = f[8], n_cig = rd16(f + 12), l_seq = rdi32(f + 16);
-            if (l_rn < 1 || l_seq < 0 || 32 + l_rn + 4 * n_cig + (l_seq + 1) / 2 + l_seq > bs || f[32 + l_rn - 1] != 0) {
-                fail(NPORE_E_INVALID, "corrupt BAM record");
-                delete b;
-                return nullptr;
-            }
-        }
-        const int64_t i = (int64_t)b->rec_off.size();
         b->rec_off.push_back((int64_t)p);
-        const int32_t rid = rdi32(&d[p + 4]);
+        p += 4 + (size_t)bs;
+    }
+    const int64_t n_rec = (int64_t)b->rec_off.size();
+    std::vector<int64_t> span((size_t)n_rec, 0);
+    std::atomic<int> corrupt{0};
+    const int64_t per = 256;
+    parallel_for((n_rec + per - 1) / per, threads, [&](int64_t blk) {
+        for (int64_t i = blk * per; i < std::min(n_rec, (blk + 1) * per); i++) {
+            // the variable-length parts the accessors will walk must lie inside the record
+            const uint8_t *q = d + b->rec_off[(size_t)i];
+            const int32_t bs = rdi32(q);
+            const uint8_t *f = q + 4;
+            const int64_t l_rn = f[8], n_cig = rd16(f + 12), l_seq = rdi32(f + 16);
+            if (l_rn < 1 || l_seq < 0 || 32 + l_rn + 4 * n_cig + (l_seq + 1) / 2 + l_seq > bs || f[32 + l_rn - 1] != 0) { corrupt++; return; }
+            span[(size_t)i] = rec_ref_len(rec_at(*b, i));
+        }
+    });
+    if (corrupt) { fail(NPORE_E_INVALID, "corrupt BAM record"); delete b; return nullptr; }
+    std::vector<int64_t> last_pos((size_t)n_ref, -1);
+    for (int64_t i = 0; i < n_rec; i++) {
+        const int32_t rid = rdi32(d + b->rec_off[(size_t)i] + 4);
         if (rid >= 0 && rid < n_ref) {
-            const RecView r = rec_at(*b, i);
+            const int64_t pos = rdi32(d + b->rec_off[(size_t)i] + 8);
             b->ref_has_reads[(size_t)rid] = 1;
             b->by_ref[(size_t)rid].push_back(i);
-            if (r.pos() < last_pos[(size_t)rid]) b->ref_sorted[(size_t)rid] = 0;
-            last_pos[(size_t)rid] = r.pos();
-            b->ref_max_len[(size_t)rid] = std::max(b->ref_max_len[(size_t)rid], rec_ref_len(r));
+            if (pos < last_pos[(size_t)rid]) b->ref_sorted[(size_t)rid] = 0;
+            last_pos[(size_t)rid] = pos;
+            b->ref_max_len[(size_t)rid] = std::max(b->ref_max_len[(size_t)rid], span[(size_t)i]);
         }
-        p += 4 + (size_t)bs;
     }
     return b;
 }
@@ -895,40 +905,17 @@ int64_t npore_bam_select(const npore_bam *b, int n_regions, const int32_t *ref_i
 npore_fasta *npore_fasta_open(const char *path)
 {
     if (!path) { fail(NPORE_E_INVALID, "null path"); return nullptr; }
-    std::vector<uint8_t> raw;
-    if (!read_file(path, raw)) { fail(NPORE_E_INVALID, std::string("could not open FASTA '") + path + "'"); return nullptr; }
+    MappedFile mf;
+    if (!mf.open(path)) { fail(NPORE_E_INVALID, std::string("could not open FASTA '") + path + "'"); return nullptr; }
     auto *f = new npore_fasta();
-    size_t p = 0;
-    const size_t N = raw.size();
-    std::string *cur = nullptr;
-    while (p < N) {
-        size_t e = p;
-        while (e < N && raw[e] != '\n') e++;
-        size_t le = e;
-        while (le > p && (raw[le - 1] == '\r' || raw[le - 1] == ' ' || raw[le - 1] == '\t')) le--;
-        size_t ls = p;
-        while (ls < le && (raw[ls] == ' ' || raw[ls] == '\t')) ls++;
-        if (ls < le && raw[ls] == '>') {
-            size_t q = ls + 1, w = q;
-            while (w < le && raw[w] != ' ' && raw[w] != '\t') w++;
-            f->names.emplace_back(reinterpret_cast<const char *>(&raw[q]), w - q);
-            f->seqs.emplace_back();
-            cur = &f->seqs.back();
-        } else if (cur && le > ls) {
-            if (cur->capacity() < cur->size() + (le - ls)) cur->reserve(std::max(cur->capacity() * 2, cur->size() + (N - ls)));
-            const size_t at = cur->size();
-            cur->append(reinterpret_cast<const char *>(&raw[ls]), le - ls);
-            char *w = &(*cur)[at];
-            for (size_t k = 0; k < le - ls; k++) w[k] = (w[k] >= 'a' && w[k] <= 'z') ? (char)(w[k] - 32) : w[k];
-        }
-        p = e + 1;
-    }
+    if (!fasta_parse(ByteSpan{mf.p, mf.n}, 0, *f)) { fail(NPORE_E_NOMEM, "FASTA: out of memory"); delete f; return nullptr; }
     return f;
 }
 void npore_fasta_close(npore_fasta *f) { delete f; }
 int npore_fasta_n(const npore_fasta *f) { return f ? (int)f->names.size() : 0; }
 const char *npore_fasta_name(const npore_fasta *f, int i) { return (f && i >= 0 && i < (int)f->names.size()) ? f->names[(size_t)i].c_str() : ""; }
-int64_t npore_fasta_len(const npore_fasta *f, int i) { return (f && i >= 0 && i < (int)f->seqs.size()) ? (int64_t)f->seqs[(size_t)i].size() : -1; }
+const char *npore_fasta_seq(const npore_fasta *f, int i) { return (f && i >= 0 && i < (int)f->names.size()) ? f->seq((size_t)i) : nullptr; }
+int64_t npore_fasta_len(const npore_fasta *f, int i) { return (f && i >= 0 && i < (int)f->names.size()) ? f->len((size_t)i) : -1; }
 
 namespace {
 bool pack_args_ok(const npore_bam *b, const int64_t *idx, int64_t n)
@@ -971,12 +958,13 @@ int npore_bam_pack(const npore_bam *b, const npore_fasta *fa, const int32_t *fas
         const RecView r = rec_at(*b, idx[k]);
         const int32_t rid = r.ref_id();
         const int fi = (rid >= 0 && rid < (int32_t)b->ref_names.size()) ? fasta_of_ref[rid] : -1;
-        if (fi < 0 || fi >= (int)fa->seqs.size()) { bad++; return; }
+        if (fi < 0 || fi >= (int)fa->names.size()) { bad++; return; }
         // reference bases: FASTA slice [pos, pos + reference_length), what pysam rebuilds from MD (src/bam.pyx:45)
-        const std::string &ctg = fa->seqs[(size_t)fi];
+        const char *ctg = fa->seq((size_t)fi);
+        const int64_t ctg_len = fa->len((size_t)fi);
         const int64_t rl = ref_off[k + 1] - ref_off[k], pos = r.pos();
         uint8_t *ro = refs + ref_off[k];
-        for (int64_t q = 0; q < rl; q++) ro[q] = (pos + q >= 0 && pos + q < (int64_t)ctg.size()) ? base_code(ctg[(size_t)(pos + q)]) : 0;
+        for (int64_t q = 0; q < rl; q++) ro[q] = (pos + q >= 0 && pos + q < ctg_len) ? base_code(ctg[pos + q]) : 0;
         // query bases without the soft clips (src/bam.pyx:42)
         int64_t lead, trail;
         rec_clips(r, lead, trail);

@@ -309,3 +309,31 @@ def test_native_bam_rejects_corrupt_files(tmp_path):
             lib.npore_bam_close(h)
         else:
             assert not h and _lib.last_error(), name
+
+
+def test_native_fasta_equals_python_reader(tmp_path):
+    """The library's parallel FASTA parser (pieces cut at line starts) against read_fasta: odd line ends, blanks,
+    lower case, empty contigs, a contig spanning several pieces, bases before the first header."""
+    from npore_amd import bam
+    rng = np.random.default_rng(8)
+    big = "".join(rng.choice(list("ACGTacgtN"), 1_500_000))
+    parts = ["ACGT\n", ">c1 description here\n", "acgtn\r\n", "\n", "  GG TT\t\n", ">empty\n", ">c3\tx\n"]
+    parts += [big[i:i + 70] + ("\r\n" if (i // 70) % 1000 == 0 else "\n") for i in range(0, len(big), 70)]
+    parts += [">c4\n", "TTTT", ]                       # no newline at the end
+    path = tmp_path / "odd.fa"
+    path.write_text("".join(parts))
+    want = bam.read_fasta(str(path))
+    nf = bam.NativeFasta(str(path))
+    try:
+        assert nf.names == list(want) == ["c1", "empty", "c3", "c4"]
+        for name in nf.names:
+            assert len(nf[name]) == len(want[name]) and nf.sequence(name) == want[name], name
+        assert want["c1"] == "ACGTNGG TT" and len(want["c3"]) == 1_500_000
+    finally:
+        nf.close()
+    (tmp_path / "none.fa").write_text("")
+    nf = bam.NativeFasta(str(tmp_path / "none.fa"))
+    assert nf.names == []
+    nf.close()
+    with pytest.raises(SystemExit):
+        bam.NativeFasta(str(tmp_path / "missing.fa"))
