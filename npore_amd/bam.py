@@ -325,6 +325,37 @@ class NativeFasta:
             self.handle = None
 
 
+class NativeFastaSeqs:
+    """{contig: upper-cased sequence}, like read_fasta(), backed by the library's parallel parser; a contig's
+    str is made on first use (callers that only need a few contigs of a genome)."""
+
+    def __init__(self, path):
+        self._fa = NativeFasta(path)
+        self._cache = {}
+
+    def __contains__(self, name):
+        return name in self._fa
+
+    def __iter__(self):
+        return iter(dict.fromkeys(self._fa.names))
+
+    def __len__(self):
+        return len(dict.fromkeys(self._fa.names))
+
+    def __getitem__(self, name):
+        if name not in self._cache:
+            if name not in self._fa:
+                raise KeyError(name)
+            self._cache[name] = self._fa.sequence(name)
+        return self._cache[name]
+
+    def items(self):
+        return ((n, self[n]) for n in self)
+
+    def keys(self):
+        return list(self)
+
+
 class NativeBam:
     """A BAM file inflated and indexed by the library (same attributes as BamFile where realign needs them)."""
 

@@ -255,7 +255,7 @@ def save_np_region_beds(names, per_n, out_prefix, bed_path, slop=1):
 def main():
     print("> extracting reference contigs")
     start = perf_counter()
-    ref_seqs = bam_mod.read_fasta(cfg.args.ref)
+    ref_seqs = bam_mod.NativeFastaSeqs(cfg.args.ref)
     get_regions(ref_seqs)
     for ctg, _s, _e in cfg.args.regions:
         if ctg not in ref_seqs:

@@ -64,7 +64,7 @@ def standardize(vcf, ref_seqs, regions, ctx, out_prefix=None, min_qual=0, r=30, 
 def main():
     start = perf_counter()
     print("> selecting vcf regions")
-    ref_seqs = bam_mod.read_fasta(cfg.args.ref)
+    ref_seqs = bam_mod.NativeFastaSeqs(cfg.args.ref)
     vcf = vcf_mod.VcfFile(cfg.args.vcf)
     vcf_mod.get_vcf_regions(ref_seqs, vcf)
 

@@ -331,6 +331,9 @@ def test_native_fasta_equals_python_reader(tmp_path):
         assert want["c1"] == "ACGTNGG TT" and len(want["c3"]) == 1_500_000
     finally:
         nf.close()
+    lazy = bam.NativeFastaSeqs(str(path))
+    assert list(lazy) == list(want) and len(lazy) == 4 and "c3" in lazy and "zz" not in lazy
+    assert dict(lazy.items()) == want
     (tmp_path / "none.fa").write_text("")
     nf = bam.NativeFasta(str(tmp_path / "none.fa"))
     assert nf.names == []
