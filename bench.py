@@ -140,6 +140,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    torch.cuda.synchronize()     # the library's streams are not ordered with torch's: inputs / zero-fills are complete
     warmup = max(args.warmup, n_ctx) if args.warmup else 0        # every context warmed up (buffers allocated)
     run_steps(warmup)
     barrier()

@@ -93,8 +93,10 @@ int npore_align_batch(npore_ctx *ctx, int64_t n_reads,
  * Device-resident variant used by bench.py and by pipelines that already hold
  * the reads in HBM: same arguments, but every pointer except ctx is a DEVICE
  * pointer (hipMalloc'ed by the caller, e.g. a torch.cuda tensor's data_ptr()).
- * `stream` is a hipStream_t passed as void* (NULL = the context's own stream).
- * Asynchronous with respect to the host unless `sync` is non-zero.
+ * `stream` is a hipStream_t passed as void* (NULL = the context's own stream, which is a
+ * non-blocking stream: it is NOT ordered with work on the NULL stream, so that several contexts
+ * run side by side -- the buffers must be ready when the call is made, or pass the stream that
+ * produces them).  The call returns after the batch has completed.
  */
 int npore_align_batch_device(npore_ctx *ctx, int64_t n_reads,
                              const uint8_t *d_refs, const int64_t *d_ref_off,

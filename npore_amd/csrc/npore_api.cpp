@@ -121,7 +121,12 @@ struct npore_ctx {
     DevBuf tb, cout_, clen, cstat, cnruns;                           // fill / traceback (cout_: uint32 runs)
     DevBuf out, out_off, out_len, status;                            // outputs (host-buffer entry point)
     // host staging of the BAM -> SAM pipeline (npore_bam_realign_batch / _file): grow-only, reused across batches and files
-    npore_batch_slot *slots[3] = {nullptr, nullptr, nullptr};
+    static constexpr int N_SLOTS = 6;
+    npore_batch_slot *slots[N_SLOTS] = {};
+    // second context of the file pipeline (its own stream and work buffers), so that the transfers, preparation and
+    // traceback of one batch run beside the fill kernel of its neighbour; made on first use from the host copy of the tables
+    std::vector<float> h_sub, h_np;
+    npore_ctx *peer = nullptr;
     double timing[8] = {};
 };
 
@@ -422,7 +427,8 @@ int run_core(npore_ctx *ctx, const AlignArgs &a, const OutTarget &ot, hipStream_
         HIP_TRY(hipStreamSynchronize(s));
         if (int rc = collect_group_timing(ctx, cells)) return rc;
         int32_t cnt[2] = {0, 0};
-        HIP_TRY(hipMemcpy(cnt, ctx->counters.p, 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpyAsync(cnt, ctx->counters.p, 8, hipMemcpyDeviceToHost, s));   // (a NULL-stream copy would wait for every other context's kernels)
+        HIP_TRY(hipStreamSynchronize(s));
         if (cnt[1]) return fail(NPORE_E_HIP, "internal: chunk bound exceeded");
         g0 = g1;
     }
@@ -470,7 +476,9 @@ npore_ctx *npore_ctx_create(const float *sub_scores, const float *np_scores, int
     ctx->max_n = max_n;
     ctx->max_l = max_l;
     const size_t np_elems = (size_t)max_n * (max_l + 1) * (max_l + 1);
-    bool ok = hipSetDevice(device_id) == hipSuccess && hipStreamCreate(&ctx->stream) == hipSuccess &&
+    ctx->h_sub.assign(sub_scores, sub_scores + 25);
+    ctx->h_np.assign(np_scores, np_scores + np_elems);
+    bool ok = hipSetDevice(device_id) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
               hipMalloc((void **)&ctx->d_sub, 25 * sizeof(float)) == hipSuccess &&
               hipMalloc((void **)&ctx->d_np, np_elems * sizeof(float)) == hipSuccess &&
               hipMemcpy(ctx->d_sub, sub_scores, 25 * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
@@ -487,6 +495,7 @@ npore_ctx *npore_ctx_create(const float *sub_scores, const float *np_scores, int
 void npore_ctx_destroy(npore_ctx *ctx)
 {
     if (!ctx) return;
+    npore_ctx_destroy(ctx->peer);
     (void)hipSetDevice(ctx->device);
     for (DevBuf *b : {&ctx->in_refs, &ctx->in_seqs, &ctx->in_cigs, &ctx->in_off, &ctx->rd_i32, &ctx->rd_i64, &ctx->tiles, &ctx->cwoff,
                       &ctx->steps, &ctx->inss, &ctx->descs, &ctx->sched, &ctx->hist, &ctx->counters, &ctx->seqw,
@@ -1137,37 +1146,65 @@ int npore_bam_realign_file(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, 
     for (auto &sp : ctx->slots)
         if (!sp) sp = new npore_batch_slot();
     const int64_t nb = (n + batch_reads - 1) / batch_reads;
+    if (nb > 1 && !ctx->peer) {
+        ctx->peer = npore_ctx_create(ctx->h_sub.data(), ctx->h_np.data(), ctx->max_n, ctx->max_l, ctx->device);
+        if (!ctx->peer) { std::fclose(fh); return NPORE_E_HIP; }
+    }
+    npore_ctx *gctx[2] = {ctx, ctx->peer ? ctx->peer : ctx};
+    for (npore_ctx *g : gctx) { g->tb_budget_mb = ctx->tb_budget_mb; g->tb_kernel = ctx->tb_kernel; g->force_chunks = ctx->force_chunks; }
+    constexpr int S = npore_ctx::N_SLOTS;
     auto first = [&](int64_t k) { return k * batch_reads; };
     auto count = [&](int64_t k) { return std::min(batch_reads, n - k * batch_reads); };
-    // Three stages, three slots: while the GPU aligns batch k (this thread: a context takes one call at a time),
-    // one helper packs batch k+1 and another standardises, formats and writes batch k-1.
-    std::vector<std::future<void>> packed((size_t)nb), posted((size_t)nb);
+    // Stages: pack (helpers, two batches ahead) | align (two batches in flight, one per context, each call on its own
+    // helper thread) | standardise + format + write (helper; files are written in input order).  A slot carries a batch
+    // through all stages; six slots cover 2 packing + 2 aligning + 2 posting.
+    std::vector<std::future<void>> packed((size_t)nb), aligned((size_t)nb), posted((size_t)nb);
     auto start_pack = [&](int64_t k) {
         packed[(size_t)k] = std::async(std::launch::async, [&, k] {
-            npore_batch_slot &s = *ctx->slots[(size_t)(k % 3)];
-            if (k >= 3) posted[(size_t)(k - 3)].wait();        // the slot's previous batch has been written
+            npore_batch_slot &s = *ctx->slots[(size_t)(k % S)];
+            if (k >= S) posted[(size_t)(k - S)].wait();        // the slot's previous batch has been written
             s.rc = slot_pack(b, fa, fasta_of_ref, idx + first(k), count(k), threads, s);
             if (s.rc) s.err = npore_last_error();
         });
     };
-    int rc = NPORE_OK;
-    std::string err;
-    if (nb > 0) start_pack(0);
-    for (int64_t k = 0; k < nb && rc == NPORE_OK; k++) {
-        npore_batch_slot &s = *ctx->slots[(size_t)(k % 3)];
-        packed[(size_t)k].wait();
-        if (k + 1 < nb) start_pack(k + 1);
-        if (s.rc) { rc = s.rc; err = s.err; break; }
-        rc = slot_align(ctx, count(k), indel_start, indel_extend, max_b_rows, r, status + first(k), s);
-        if (rc) { err = npore_last_error(); break; }
+    auto start_post = [&](int64_t k) {
         posted[(size_t)k] = std::async(std::launch::async, [&, k] {
-            npore_batch_slot &t = *ctx->slots[(size_t)(k % 3)];
+            npore_batch_slot &t = *ctx->slots[(size_t)(k % S)];
+            if (t.rc) return;
             t.rc = slot_post(b, idx + first(k), count(k), status + first(k), threads, t);
             if (t.rc) { t.err = npore_last_error(); return; }
             if (k > 0) posted[(size_t)(k - 1)].wait();         // records in input order
             if (std::fwrite(t.sam.p, 1, (size_t)t.sam_len, fh) != (size_t)t.sam_len) { t.rc = NPORE_E_INVALID; t.err = "short write"; }
         });
+    };
+    int rc = NPORE_OK;
+    std::string err;
+    auto retire = [&](int64_t k) {                             // batch k's align call has to be over: post it
+        aligned[(size_t)k].wait();
+        npore_batch_slot &s = *ctx->slots[(size_t)(k % S)];
+        if (s.rc && rc == NPORE_OK) { rc = s.rc; err = s.err; }
+        start_post(k);                                         // (a failed batch posts nothing, but keeps the order chain)
+    };
+    for (int64_t k = 0; k < std::min<int64_t>(2, nb); k++) start_pack(k);
+    int64_t launched = 0;
+    for (int64_t k = 0; k < nb && rc == NPORE_OK; k++) {
+        npore_batch_slot &s = *ctx->slots[(size_t)(k % S)];
+        packed[(size_t)k].wait();
+        if (s.rc) { rc = s.rc; err = s.err; break; }
+        if (k >= 2) retire(k - 2);                             // frees the context batch k will use
+        if (rc != NPORE_OK) break;
+        if (k + 2 < nb) start_pack(k + 2);
+        aligned[(size_t)k] = std::async(std::launch::async, [&, k] {
+            npore_batch_slot &t = *ctx->slots[(size_t)(k % S)];
+            (void)hipSetDevice(ctx->device);
+            t.rc = slot_align(gctx[k & 1], count(k), indel_start, indel_extend, max_b_rows, r, status + first(k), t);
+            if (t.rc) t.err = npore_last_error();
+        });
+        launched = k + 1;
     }
+    for (int64_t k = std::max<int64_t>(0, launched - 2); k < launched; k++)
+        if (!posted[(size_t)k].valid()) retire(k);
+    for (auto &f : aligned) if (f.valid()) f.wait();
     for (auto &f : packed) if (f.valid()) f.wait();
     for (auto &f : posted) if (f.valid()) f.wait();
     for (auto &sp : ctx->slots)
