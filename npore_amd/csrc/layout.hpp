@@ -34,7 +34,7 @@
 //                .y and the L window); .z: bit 6 of either word or bit 7 of .w is set ("rare column")
 //     bits 8-14  L of reference position j-n for that period
 //     bits 15-30 byte address, inside the LDS score table, of the entry for "call length L-1":
-//                ((n-1)*32 + L)*256 + (32 + L-1)*4; a deletion of q more copies reads 4q bytes lower
+//                ((n-1)*32 + min(L, max_l-1))*256 + (32 + L-1)*4; a deletion of q more copies reads 4q bytes lower
 //     bit  31    "first copy": start a deletion rather than continue one
 //   refl[j]  8 bytes: byte n-1 = L of reference position j for period n (0..max_l)
 //
@@ -73,9 +73,12 @@ constexpr uint32_t DSC_HAS2 = 1u << 5, DSC_RARE = 1u << 7;
 // LDS score table: [MAX_PERIOD][NP_LT][NP_CT] floats, entry NP_C0 + call for call in [-NP_C0, NP_CT - NP_C0)
 // holding np_scores[n][L][call], and INF_F where call < 0 (np_score's "call < 0 -> 100")
 constexpr int NP_LT = 32, NP_CT = 64, NP_C0 = 32;
-NPORE_HD uint32_t make_shr_desc(int n, bool start, uint32_t L)
+// max_l: np_score clamps the table ROW to max_l - 1 (src/aln.pyx:257-274 as called); L itself is capped at max_l, so
+// the call length L - 1 - q never needs the clamp
+NPORE_HD uint32_t make_shr_desc(int n, bool start, uint32_t L, int max_l)
 {
-    const uint32_t addr = L < (uint32_t)NP_LT ? (((uint32_t)(n - 1) * NP_LT + L) * NP_CT + NP_C0 + L - 1u) * 4u : 0u;
+    const uint32_t row = L < (uint32_t)max_l ? L : (uint32_t)(max_l - 1);
+    const uint32_t addr = L < (uint32_t)NP_LT ? (((uint32_t)(n - 1) * NP_LT + row) * NP_CT + NP_C0 + L - 1u) * 4u : 0u;
     return ((uint32_t)n << 2) | (L >= (uint32_t)NP_LT ? DSC_BIGL : 0u) | (L << 8) | (addr << 15) | (start ? DSC_START : 0u);
 }
 

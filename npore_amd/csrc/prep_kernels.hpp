@@ -527,7 +527,7 @@ __global__ __launch_bounds__(1024) void annotate_kernel(PrepParams p)
             for (int n = p.max_n; n >= 1; n--) {
                 if (!((y >> (n - 1)) & 1u)) continue;
                 const uint32_t l = Lat(j - n, n);
-                const uint32_t v = make_shr_desc(n, ((y >> (6 + n - 1)) & 1u) != 0u, l);
+                const uint32_t v = make_shr_desc(n, ((y >> (6 + n - 1)) & 1u) != 0u, l, p.max_l);
                 if (nd == 0) dsc0 = v;
                 else if (nd == 1) dsc1 = v;
                 else dsc1 |= DSC_MORE;

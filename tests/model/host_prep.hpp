@@ -173,7 +173,7 @@ inline void pack_chunk_words(const uint8_t *seq, int slen, int drows,
             if (!((y >> (n - 1)) & 1u)) continue;
             if (nd < 2) {
                 const uint32_t l = (uint32_t)L[(size_t)(j - n) * max_n + (n - 1)];
-                dsc[nd] = make_shr_desc(n, ((y >> (6 + n - 1)) & 1u) != 0u, l);
+                dsc[nd] = make_shr_desc(n, ((y >> (6 + n - 1)) & 1u) != 0u, l, max_l);
             } else {
                 dsc[1] |= DSC_MORE;
             }

@@ -44,7 +44,8 @@ struct ModelEnv {
         const int n = (int)((dsc >> 2) & 7u), L = (int)((dsc >> 8) & 127u);
         const int call = L - 1 - q;
         if (n == 0 || call < 0) return INF_F;
-        return np_scores[((size_t)(n - 1) * (max_l + 1) + L) * (max_l + 1) + call];
+        const int row = L < max_l ? L : max_l - 1;          // np_score clamps the row to max_l - 1
+        return np_scores[((size_t)(n - 1) * (max_l + 1) + row) * (max_l + 1) + call];
     }
     int clamp() const { return max_l - 1; }
     int refl(int j, int n_idx) const { return (j >= 0 && j < refl_n) ? refl_p[(size_t)j * 8 + n_idx] : 0; }

@@ -458,3 +458,24 @@ def test_both_traceback_kernels(tables, mode):
             want, wst = oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=r, max_b_rows=mbr, return_status=True)
             assert got[k] == want and st[k] == wst, (mode, r, mbr, k)
     c.close()
+
+
+@pytest.mark.parametrize("max_n,max_l", [(6, 20), (4, 20), (1, 5), (6, 31), (6, 32), (3, 127)])
+def test_other_table_shapes(tables, max_n, max_l):
+    """Contexts with other max_n / max_l (the CLI's --max_n / --max_l): row clamp at max_l - 1 also where the
+    capped repeat count goes through the descriptor's table address (max_l < 32)."""
+    from test_model_vs_oracle import polymer_pairs, small_tables
+    sub, nps = tables
+    t = small_tables(nps, max_n, max_l, max_l)
+    c = aln.Context(sub, t, max_n=max_n, max_l=max_l, device=0)
+    pairs = polymer_pairs(100 + max_l, 25) + [(r_, s_, cg.decode()) for r_, s_, cg in zip(*synth.make_batch(55, 6, ref_len=1500, p_np=0.2))]
+    for r in (5, 30, 64, 100):
+        for mbr in (20000, 64):
+            got, st = c.align_batch([p[0] for p in pairs], [p[1] for p in pairs], [p[2] for p in pairs], r=r, max_b_rows=mbr,
+                                    return_status=True)
+            for k, (ref, seq, cig) in enumerate(pairs):
+                want, wst = oracle.align(ref, seq, cig, sub, t, max_b_rows=mbr, r=r, max_n=max_n, max_l=max_l, return_status=True)
+                assert got[k] == want and st[k] == wst, (max_n, max_l, r, mbr, k)
+    for seq in (pairs[0][0], pairs[3][1]):
+        assert np.array_equal(c.get_np_info(seq), np.asarray(oracle.get_np_info(seq, max_n=max_n, max_l=max_l)))
+    c.close()

@@ -65,3 +65,47 @@ def test_long_polymers(tables):
             a, sa = oracle.align(ref, seq, cig, sub, nps, r=r, return_status=True)
             b, sb = model.align(ref, seq, cig, sub, nps, r=r)
             assert a == b and sa == sb, (k, r)
+
+
+def small_tables(nps, max_n, max_l, seed):
+    """Tables of another shape: the shipped ones cut / edge-padded, entries jittered so that clamped rows differ."""
+    rng = np.random.default_rng(seed)
+    m = min(max_l, 100)
+    t = nps[:max_n, :m + 1, :m + 1]
+    if max_l > 100:
+        t = np.pad(t, ((0, 0), (0, max_l - 100), (0, max_l - 100)), mode="edge")
+    t = np.ascontiguousarray(t).copy()
+    t[:, 3:, :] += (rng.integers(0, 8, t[:, 3:, :].shape) / 8.0).astype(np.float32)
+    return t
+
+
+def polymer_pairs(seed, count):
+    """Reads whose n-polymers reach and exceed small max_l values (copies 3..60)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(count):
+        parts_r, parts_s, cig = [], [], []
+        for _ in range(int(rng.integers(2, 7))):
+            f = rng.integers(1, 5, size=int(rng.integers(3, 25))).astype(np.uint8)
+            parts_r.append(f); parts_s.append(f); cig.append("=" * len(f))
+            unit = rng.integers(1, 5, size=int(rng.integers(1, 7))).astype(np.uint8)
+            c = int(rng.integers(3, 60)); d = int(rng.integers(-3, 4)); c2 = max(1, c + d)
+            parts_r.append(np.tile(unit, c)); parts_s.append(np.tile(unit, c2))
+            m = min(c, c2) * len(unit)
+            cig.append("=" * m + ("D" * ((c - c2) * len(unit)) if c > c2 else "I" * ((c2 - c) * len(unit))))
+        out.append((np.concatenate(parts_r), np.concatenate(parts_s), "".join(cig)))
+    return out
+
+
+def test_other_table_shapes(tables):
+    """max_n / max_l other than 6 / 100: np_score clamps rows and call lengths to max_l - 1, and with max_l below
+    the device table's 32 rows the capped repeat count max_l itself goes through the table-address shortcut."""
+    sub, nps = tables
+    for max_n, max_l in ((6, 20), (4, 20), (1, 5), (6, 31), (6, 32), (3, 127)):
+        t = small_tables(nps, max_n, max_l, max_l)
+        for k, (ref, seq, cig) in enumerate(polymer_pairs(100 + max_l, 25)):
+            r = (5, 30, 64)[k % 3]
+            a, sa = oracle.align(ref, seq, cig, sub, t, max_b_rows=(20000, 64)[k % 2], r=r, max_n=max_n, max_l=max_l,
+                                 return_status=True)
+            b, sb = model.align(ref, seq, cig, sub, t, max_b_rows=(20000, 64)[k % 2], r=r, max_n=max_n, max_l=max_l)
+            assert a == b and sa == sb, (max_n, max_l, k)
