@@ -41,6 +41,34 @@ def tables(kind, max_n, max_l):
     return sub, nps
 
 
+def random_script_pair(r2, L, r):
+    """A pair from a random edit script with long indel runs (up to ~3r: the band follows the input path, so the new
+    path can run along the band edges), low-complexity reference."""
+    alpha = r2.integers(1, 5, size=int(r2.integers(1, 5)))
+    ref = r2.choice(alpha, size=L).astype(np.uint8)
+    ops = []
+    j = 0
+    seq = []
+    while j < L:
+        kind = r2.integers(0, 10)
+        if kind < 6:
+            n = int(min(L - j, r2.integers(1, 40)))
+            ops.append(b"=" * n); seq.append(ref[j:j + n]); j += n
+        elif kind == 6:
+            n = int(min(L - j, r2.integers(1, 4)))
+            ops.append(b"X" * n); seq.append((ref[j:j + n] % 4 + 1).astype(np.uint8)); j += n
+        elif kind == 7:
+            n = int(r2.integers(1, max(2, 3 * r)))
+            ops.append(b"I" * n); seq.append(r2.choice(alpha, size=n).astype(np.uint8))
+        elif kind == 8:
+            n = int(min(L - j, r2.integers(1, max(2, 3 * r))))
+            ops.append(b"D" * n); j += n
+        else:
+            n = int(min(L - j, r2.integers(1, 30)))
+            ops.append(b"M" * n); seq.append(ref[j:j + n]); j += n
+    return ref, (np.concatenate(seq) if seq else np.zeros(0, np.uint8)), b"".join(ops)
+
+
 while time.time() < t_end:
     max_n = int(rng.choice([6, 6, 6, 4, 1]))
     max_l = int(rng.choice([100, 100, 100, 20, 127]))
@@ -56,6 +84,8 @@ while time.time() < t_end:
         L = int(rng.choice([0, 1, 2, 5, 40, 150, 700, 2500]))
         if L == 0:
             ref, seq, cig = np.zeros(0, np.uint8), np.zeros(0, np.uint8), b""
+        elif rng.random() < 0.35:
+            ref, seq, cig = random_script_pair(np.random.default_rng(int(rng.integers(1 << 30))), L, min(r, 60))
         else:
             ref, seq, cig = synth.make_pair(int(rng.integers(1 << 30)), k, L, float(rng.choice([0.0, 0.05, 0.2, 0.6])),
                                             float(rng.choice([0.0, 0.3, 1.0])))
