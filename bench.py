@@ -35,6 +35,28 @@ def pack(seqs):
     return buf, off
 
 
+def _gen_span(a):
+    from npore_amd import synth
+    seed, cnt, ref_len, mixed, first, stride = a
+    return synth.make_batch(seed, cnt, ref_len=ref_len, mixed=mixed, first=first, stride=stride)
+
+
+def make_reads(synth, args, count, rank, world):
+    """Reads rank, rank + world, ... of the generator; spans of them on a forked pool when there are many."""
+    if count < 2000:
+        return synth.make_batch(args.base_seed, count, ref_len=args.ref_len, mixed=args.mixed, first=rank, stride=world)
+    import multiprocessing as mp
+    nproc = max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
+    span = 250
+    jobs = [(args.base_seed, min(span, count - k), args.ref_len, args.mixed, rank + k * world, world)
+            for k in range(0, count, span)]
+    refs, seqs, cigs = [], [], []
+    with mp.get_context("fork").Pool(nproc) as pool:
+        for r_, s_, c_ in pool.imap(_gen_span, jobs):
+            refs += r_; seqs += s_; cigs += c_
+    return refs, seqs, cigs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -45,6 +67,10 @@ def main():
     ap.add_argument("--r", type=int, default=100)
     ap.add_argument("--max-b-rows", type=int, default=20000)
     ap.add_argument("--base-seed", type=int, default=2)
+    ap.add_argument("--mixed", action="store_true",
+                    help="p_np drawn per read from {0, 0.02, 0.05, 0.15} (SURVEY 8d configs C3 / C4)")
+    ap.add_argument("--unique", type=int, default=0,
+                    help="generate only this many distinct reads and repeat them to --reads (0 = all distinct)")
     ap.add_argument("--cpu-sample", type=int, default=64, help="reads timed on one host core with the oracle (~10 s)")
     ap.add_argument("--cpu-threads", type=int, default=32,
                     help="worker processes for the whole-batch CPU run (each holds a 241 MB state matrix at r=100; 0/1 = skip)")
@@ -54,12 +80,22 @@ def main():
                          "so one batch's traceback / gather and the next one's preparation run beside a fill kernel")
     args = ap.parse_args()
 
-    import torch
-    from npore_amd import _lib, aln, synth
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    # ---- synthetic batch for this rank (reads rank, rank+world, ... : round-robin by index), generated
+    # before anything touches the GPU so that large batches can use a forked worker pool
+    from npore_amd import synth
+    n = args.reads
+    n_uniq = min(args.unique, n) if args.unique > 0 else n
+    refs, seqs, cigs = make_reads(synth, args, n_uniq, rank, world)
+    if n_uniq < n:
+        rep = [k % n_uniq for k in range(n)]
+        refs = [refs[k] for k in rep]; seqs = [seqs[k] for k in rep]; cigs = [cigs[k] for k in rep]
+
+    import torch
+    from npore_amd import _lib, aln
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
@@ -80,9 +116,6 @@ def main():
     ctx = ctxs[0]
     lib = _lib.load()
 
-    # ---- synthetic batch for this rank (reads rank, rank+world, ... : round-robin by index)
-    n = args.reads
-    refs, seqs, cigs = synth.make_batch(args.base_seed, n, ref_len=args.ref_len, first=rank, stride=world)
     rb, ro = pack(refs)
     sb, so = pack(seqs)
     cb, co = pack(cigs)
@@ -167,6 +200,12 @@ def main():
     W = 2 * args.r + 1
     bytes_alg = sum(4 * (len(s) + len(r_) + 1) * W + 2 * (len(s) + len(r_)) + int(ol)
                     for s, r_, ol in zip(seqs, refs, out_len))
+    if n_uniq < n:
+        # repeated reads: every copy must give the string of its original (checked for all lengths, 256 strings)
+        assert np.array_equal(out_len, out_len[np.arange(n) % n_uniq]), "copies of one read differ in length"
+        for k in np.random.default_rng(0).integers(n_uniq, n, 256):
+            a, b = int(oo[k]), int(oo[k % n_uniq])
+            assert torch.equal(d_out[a:a + int(out_len[k])], d_out[b:b + int(out_len[k])]), "copies of one read differ"
     fill_avg_ms = float(np.mean(fill_ms))
     achieved = bytes_alg / (fill_avg_ms * 1e-3) / 1e9
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same default command
@@ -190,7 +229,8 @@ def main():
         import oracle
         oracle.build()
         out_host = d_out.cpu().numpy()
-        got_all = [out_host[oo[i]:oo[i] + out_len[i]].tobytes().decode() for i in range(n)]
+        n_chk = min(n, max(args.cpu_sample, 10_000_000 // max(1, args.ref_len)))
+        got_all = [out_host[oo[i]:oo[i] + out_len[i]].tobytes().decode() for i in range(n_chk)]
         k = min(args.cpu_sample, n)
         tc = time.perf_counter()
         want, st = oracle.align_batch(refs[:k], seqs[:k], cigs[:k], sub, nps, max_b_rows=args.max_b_rows, r=args.r)
@@ -203,12 +243,15 @@ def main():
         nt = min(args.cpu_threads, os.cpu_count() or 1)
         if nt > 1:
             tc = time.perf_counter()
-            want, st = oracle.align_batch_procs(refs, seqs, cigs, sub, nps, nt, max_b_rows=args.max_b_rows, r=args.r)
+            # bounded: about 10 M bases of reads (1 000 reads of 10 kb) keep this leg within ~15 s
+            m = max(1, min(n, 10_000_000 // max(1, args.ref_len)))
+            want, st = oracle.align_batch_procs(refs[:m], seqs[:m], cigs[:m], sub, nps, nt,
+                                                max_b_rows=args.max_b_rows, r=args.r)
             dtn = time.perf_counter() - tc
-            if got_all != want:
+            if got_all[:m] != want:
                 raise RuntimeError("bench.py: GPU output differs from the oracle on the whole batch")
-            cpu["all_reads"] = {"value": round(n / dtn, 2), "unit": "reads/s", "cores": nt,
-                                "sample": f"all {n} reads of the batch on {nt} worker processes (the reference's own "
+            cpu["all_reads"] = {"value": round(m / dtn, 2), "unit": "reads/s", "cores": nt,
+                                "sample": f"{'all' if m == n else 'first'} {m} reads of the batch on {nt} worker processes (the reference's own "
                                           f"parallelism: a pool over reads), every string equal to the GPU output"}
 
     if rank == 0:
@@ -219,7 +262,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n} synthetic {args.ref_len // 1000} kb reads per GPU, r={args.r} "
                                    f"(band={args.r}), max_b_rows={args.max_b_rows}, guppy5_stats penalties "
-                                   f"(SURVEY 8d C2 generator, base_seed={args.base_seed})",
+                                   f"(SURVEY 8d generator{', mixed p_np' if args.mixed else ''}, base_seed={args.base_seed}"
+                                   f"{f', {n_uniq} distinct reads repeated' if n_uniq < n else ''})",
                        "reads_per_gpu": n, "ref_len": args.ref_len, "r": args.r, "parallelism": f"reads x{world}",
                        "batches_in_flight": n_ctx},
             "roofline": roofline, "cpu_baseline": cpu,
