@@ -225,7 +225,7 @@ def main():
     # independent: the reference's own parallelism is a process pool over reads); every string is compared
     # with the GPU output
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:      # reported at N=1 only
         import oracle
         oracle.build()
         out_host = d_out.cpu().numpy()

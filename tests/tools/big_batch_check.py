@@ -1,7 +1,7 @@
 """One very large batch of short reads through the HIP path, every string against the oracle (scale edge: grid
 sizes, scans over > 10^5 reads / chunks).  usage: big_batch_check.py [reads=120000] [ref_len=150] [r=30]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import oracle
 from npore_amd import aln, synth

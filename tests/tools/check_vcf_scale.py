@@ -4,7 +4,7 @@ nothing (except where an insertion and a deletion that would cancel sit on eithe
 run: chunks are aligned independently between end points fixed by the input path, src/aln.pyx:445-456, and the second
 run's borders fall elsewhere; 60 Mbp: 1 such site in 60 780 records).  usage: check_vcf_scale.py [mbases=5] [variants_per_kb=1.0]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from npore_amd import aln, synth, vcf as V, standardize_vcf as S
 
