@@ -59,6 +59,7 @@ struct KParams {
     int hw;                 // history records per ring row: 2r+1 columns + HIST_PAD
     int rwin;               // reference-L window entries (power of two)
     float indel_start, indel_extend;
+    int resident;           // workgroups resident at a time (a "round" of the chunk schedule)
 };
 
 // LDS floats: shared score tables + per chunk (history ring, reference-L window, exchange)
@@ -98,6 +99,18 @@ __device__ __forceinline__ uint32_t lane_table(uint32_t addr4, uint32_t tab)
     return (uint32_t)__builtin_amdgcn_ds_bpermute((int)addr4, (int)tab);
 }
 
+// LDS reads of the workgroup-shared score tables by ABSOLUTE LDS byte address.  The kernels here use dynamic LDS only,
+// so the `lds` array starts at LDS address 0 (checked once per launch configuration on the host:
+// hipFuncGetAttributes().sharedSizeBytes == 0, npore_api.cpp); going through the array symbol instead costs one
+// `v_add_u32 v, <lds>, v` per lookup, because the symbol's value is only known at link time.
+typedef const __attribute__((address_space(3))) float lds_cfloat;
+__device__ __forceinline__ float lds_abs_f32(uint32_t byte_addr)
+{
+    return *reinterpret_cast<lds_cfloat *>(byte_addr);
+}
+constexpr uint32_t LDS_NP_BASE = 0u;                                      // [6][NP_LT][NP_CT] floats
+constexpr uint32_t LDS_SUB_BASE = MAX_PERIOD * NP_LT * NP_CT * 4u;        // then the substitution table
+
 template <int NSR>
 struct DevEnv {
     const char *lds_sub;      // [ref 8][seq 8][4] copy of sub_scores (layout.hpp SUBT_*)
@@ -132,12 +145,12 @@ struct DevEnv {
     __device__ __forceinline__ float sub(uint32_t seqw, uint32_t refx) const
     {
         // bits 2-9 of {refx, seqw} >> 25: ref[j-1] (3 bits) | seq[i-1] (3 bits) | 2 bits of seq[i-2] (don't care)
-        return *reinterpret_cast<const float *>(lds_sub + (__builtin_amdgcn_alignbit(refx, seqw, 25) & 0x3FCu));
+        return lds_abs_f32(LDS_SUB_BASE + (__builtin_amdgcn_alignbit(refx, seqw, 25) & 0x3FCu));
     }
     __device__ __forceinline__ float np_small(uint32_t dsc, int q) const
     {
         const uint32_t a = (dsc >> 15) & 0xFFFFu;
-        return *reinterpret_cast<const float *>(lds_np + (a - 4u * (uint32_t)min(q, NP_C0)));
+        return lds_abs_f32(LDS_NP_BASE + a - 4u * (uint32_t)min(q, NP_C0));
     }
     __device__ __forceinline__ int clamp() const { return clampv; }
     __device__ __forceinline__ int refl(int j, int n_idx) const { return win[(j & wmask) * 8 + n_idx]; }
@@ -163,8 +176,8 @@ struct DevEnv {
         // wait also drains the outstanding traceback stores.)
         const bool big = (unsigned)(a | b) >= (unsigned)NP_LT;     // a, b >= 0 and NP_LT == NP_CT - NP_C0 is a power of two
         const bool oot = active && big;
-        float out = reinterpret_cast<const float *>(lds_np)[((n_idx * NP_LT + (a & (NP_LT - 1))) * NP_CT) + NP_C0 +
-                                                            (b & (NP_CT - NP_C0 - 1))];
+        float out = lds_abs_f32(LDS_NP_BASE + 4u * (uint32_t)(((n_idx * NP_LT + (a & (NP_LT - 1))) * NP_CT) + NP_C0 +
+                                                              (b & (NP_CT - NP_C0 - 1))));
         asm volatile("" : "+v"(out));   // keep this a ds_read: do not fold it with the global load below
         if (any2(active, big)) {
             if (oot) {
@@ -197,6 +210,9 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     const int cpg = (int)(blockDim.x >> 6) / NW;   // chunks per workgroup
     const int cw = wave / cpg;            // wave within the chunk
     const int cg = wave % cpg;            // chunk within the workgroup
+    // The middle waves of a chunk (all 64 lanes live, a neighbour wave on either side) are issued first when
+    // several waves of the SIMD are ready: measured 1.5-2 % on the fill at NW = 3...7 (r = 70, 100, 140, 200)
+    if (NW > 2 && cw != 0 && cw != NW - 1) __builtin_amdgcn_s_setprio(1);
     const int hw = p.hw;
     float *chunk_lds = lds_sub + SUBT_ENTRIES + (size_t)cg * (4 * (NSR * hw + HIST_PAD) + 2 * p.rwin + (NW > 1 ? 2 * NW * XCH_WORDS + 8 : 0));
     HistCell *hist = reinterpret_cast<HistCell *>(chunk_lds) + HIST_PAD;     // row 0, column 0
@@ -217,7 +233,12 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     }
     __syncthreads();
 
-    const int slot_id = blockIdx.x * cpg + cg;
+    // Chunk slots (largest chunks first) are dealt over the workgroups of a round: slot q of round k goes to
+    // workgroup q % R, position q / R, so every workgroup of the round gets its share of the heavy chunks
+    const int R = min((int)gridDim.x, p.resident);
+    const int round = (int)blockIdx.x / R, within = (int)blockIdx.x - round * R;
+    const int Rr = min(R, (int)gridDim.x - round * R);       // workgroups in this (possibly last, shorter) round
+    const int slot_id = round * R * cpg + cg * Rr + within;
     if (slot_id >= *p.n_chunks) return;    // hardware barriers only count waves that are still alive
     ChunkDesc d = p.descs[uni(p.sched[slot_id])];
     d.brk = uni(d.brk); d.nrows = uni(d.nrows); d.row0 = uni(d.row0); d.col0 = uni(d.col0);

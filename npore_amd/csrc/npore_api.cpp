@@ -104,6 +104,7 @@ struct npore_batch_slot {
 
 struct npore_ctx {
     int device = 0;
+    int n_cus = 256;
     int max_n = 6, max_l = 100;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
@@ -149,7 +150,7 @@ int pow2_at_least(int x)
 
 // NW waves per chunk, `chunks` chunks per workgroup (they share the LDS score table).
 template <int NW>
-hipError_t launch_fill(KParams kp, int max_chunks, int force_chunks, hipStream_t s)
+hipError_t launch_fill(KParams kp, int max_chunks, int force_chunks, int n_cus, hipStream_t s)
 {
     constexpr int MAXT = 1024;
     const int W = 2 * kp.r + 1;
@@ -163,6 +164,19 @@ hipError_t launch_fill(KParams kp, int max_chunks, int force_chunks, hipStream_t
     int chunks = std::min(cmax, std::max(1, (max_chunks + 255) / 256));
     if (force_chunks > 0) chunks = std::min(cmax, force_chunks);
     const size_t lds = fill_lds_floats(NW, chunks, kp.hw, kp.rwin) * sizeof(float);
+    // Workgroups that are resident together (one "round"): the schedule lists the chunks largest first, and the
+    // kernel deals them over the workgroups of a round like cards, so that the heavy chunks of a small batch
+    // are spread over all CUs instead of filling the first workgroups
+    const int wg_per_cu = std::max(1, std::min((int)((160 * 1024) / std::max<size_t>(lds, 1)), 2048 / (64 * NW * chunks)));
+    kp.resident = std::max(1, n_cus) * wg_per_cu;
+    // the kernel addresses its score tables by absolute LDS address (kernels.hpp: lds_abs_f32): it must not
+    // own any static LDS, so that the dynamic array starts at address 0
+    static const hipError_t no_static_lds = [] {
+        hipFuncAttributes at;
+        const hipError_t e0 = hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&fill_kernel<NW, MAXT>));
+        return e0 != hipSuccess ? e0 : (at.sharedSizeBytes == 0 ? hipSuccess : hipErrorInvalidDeviceFunction);
+    }();
+    if (no_static_lds != hipSuccess) return no_static_lds;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fill_kernel<NW, MAXT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -326,14 +340,14 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     hipError_t e = hipSuccess;
     const int mc = (int)max_chunks;
     switch (shape) {
-        case 1: e = launch_fill<1>(kp, mc, ctx->force_chunks, s); break;
-        case 2: e = launch_fill<2>(kp, mc, ctx->force_chunks, s); break;
-        case 3: e = launch_fill<3>(kp, mc, ctx->force_chunks, s); break;
-        case 4: e = launch_fill<4>(kp, mc, ctx->force_chunks, s); break;
-        case 5: e = launch_fill<5>(kp, mc, ctx->force_chunks, s); break;
-        case 6: e = launch_fill<6>(kp, mc, ctx->force_chunks, s); break;
-        case 7: e = launch_fill<7>(kp, mc, ctx->force_chunks, s); break;
-        case 8: e = launch_fill<8>(kp, mc, ctx->force_chunks, s); break;
+        case 1: e = launch_fill<1>(kp, mc, ctx->force_chunks, ctx->n_cus, s); break;
+        case 2: e = launch_fill<2>(kp, mc, ctx->force_chunks, ctx->n_cus, s); break;
+        case 3: e = launch_fill<3>(kp, mc, ctx->force_chunks, ctx->n_cus, s); break;
+        case 4: e = launch_fill<4>(kp, mc, ctx->force_chunks, ctx->n_cus, s); break;
+        case 5: e = launch_fill<5>(kp, mc, ctx->force_chunks, ctx->n_cus, s); break;
+        case 6: e = launch_fill<6>(kp, mc, ctx->force_chunks, ctx->n_cus, s); break;
+        case 7: e = launch_fill<7>(kp, mc, ctx->force_chunks, ctx->n_cus, s); break;
+        case 8: e = launch_fill<8>(kp, mc, ctx->force_chunks, ctx->n_cus, s); break;
         default: return fail(NPORE_E_UNSUPPORTED, "unsupported waves-per-chunk count");
     }
     if (e != hipSuccess) return fail(NPORE_E_HIP, std::string("fill launch: ") + hipGetErrorString(e));
@@ -473,6 +487,7 @@ npore_ctx *npore_ctx_create(const float *sub_scores, const float *np_scores, int
     }
     auto *ctx = new npore_ctx();
     ctx->device = device_id;
+    ctx->n_cus = pr.multiProcessorCount;
     ctx->max_n = max_n;
     ctx->max_l = max_l;
     const size_t np_elems = (size_t)max_n * (max_l + 1) * (max_l + 1);
