@@ -168,7 +168,11 @@ hipError_t launch_fill(KParams kp, int max_chunks, int force_chunks, int n_cus, 
     // kernel deals them over the workgroups of a round like cards, so that the heavy chunks of a small batch
     // are spread over all CUs instead of filling the first workgroups
     const int wg_per_cu = std::max(1, std::min((int)((160 * 1024) / std::max<size_t>(lds, 1)), 2048 / (64 * NW * chunks)));
-    kp.resident = std::max(1, n_cus) * wg_per_cu;
+    // ... minus a few: the workgroups of later rounds (small chunks once the list is sorted) then start at once
+    // on the CUs left free and run beside the heavy round instead of after it (C2: 1 000 chunks of 20 000 rows
+    // on 250 CUs, the 1 000 chunks of ~200 rows on the other 6 meanwhile)
+    const int all = std::max(1, n_cus) * wg_per_cu;
+    kp.resident = std::max(1, all - std::max(1, all / 40));
     // the kernel addresses its score tables by absolute LDS address (kernels.hpp: lds_abs_f32): it must not
     // own any static LDS, so that the dynamic array starts at address 0
     static const hipError_t no_static_lds = [] {
