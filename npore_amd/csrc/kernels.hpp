@@ -233,12 +233,8 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     }
     __syncthreads();
 
-    // Chunk slots (largest chunks first) are dealt over the workgroups of a round: slot q of round k goes to
-    // workgroup q % R, position q / R, so every workgroup of the round gets its share of the heavy chunks
-    const int R = min((int)gridDim.x, p.resident);
-    const int round = (int)blockIdx.x / R, within = (int)blockIdx.x - round * R;
-    const int Rr = min(R, (int)gridDim.x - round * R);       // workgroups in this (possibly last, shorter) round
-    const int slot_id = round * R * cpg + cg * Rr + within;
+    // chunk slots (largest chunks first) are dealt over the workgroups of a round (layout.hpp)
+    const int slot_id = deal_slot((int)blockIdx.x, cg, cpg, (int)gridDim.x, p.resident);
     if (slot_id >= *p.n_chunks) return;    // hardware barriers only count waves that are still alive
     ChunkDesc d = p.descs[uni(p.sched[slot_id])];
     d.brk = uni(d.brk); d.nrows = uni(d.nrows); d.row0 = uni(d.row0); d.col0 = uni(d.col0);

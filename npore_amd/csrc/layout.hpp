@@ -64,6 +64,18 @@ constexpr uint32_t REFW_SENTINEL = 0x36DB6u << MER_SHIFT;  // six code-6 bases, 
 constexpr int SUBT_ENTRIES = 256;
 constexpr int MAX_PERIOD = 6;                  // kernels are specialised for max_n <= 6
 constexpr float INF_F = 100.0f;                // reference src/aln.pyx:428
+// Which slot of the chunk schedule (chunks sorted largest first) position `cg` of workgroup `block` works on.
+// The workgroups of a "round" (`resident` of them: what the GPU holds at a time) are dealt the next
+// resident * cpg slots like cards -- slot q of the round goes to workgroup q % R, position q / R -- so every
+// workgroup of the round gets its share of the heavy chunks; the last round may be shorter.
+NPORE_HD int deal_slot(int block, int cg, int cpg, int grid, int resident)
+{
+    const int R = resident < grid ? (resident > 0 ? resident : 1) : grid;
+    const int round = block / R, within = block - round * R;
+    const int Rr = (grid - round * R) < R ? (grid - round * R) : R;
+    return round * R * cpg + cg * Rr + within;
+}
+
 constexpr int HIST_PAD = 6;                    // never-written history records either side of a row (cell.hpp)
 
 constexpr uint32_t DSC_N4 = 0x1Cu, DSC_BIGL = 1u << 6, DSC_MORE = 1u << 7, DSC_START = 1u << 31;

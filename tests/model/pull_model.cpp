@@ -242,3 +242,9 @@ extern "C" void pull_model_np_info(const uint8_t *seq, int64_t len, int max_n, i
             out[(p * 2 + 1) * max_n + n] = I[p * max_n + n];
         }
 }
+
+// the fill kernel's workgroup -> schedule-slot map (layout.hpp), for the permutation test
+extern "C" int pull_model_deal_slot(int block, int cg, int cpg, int grid, int resident)
+{
+    return npore::deal_slot(block, cg, cpg, grid, resident);
+}
