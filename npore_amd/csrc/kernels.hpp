@@ -631,44 +631,84 @@ __global__ __launch_bounds__(64) void traceback_kernel(TParams p)
         const uint32_t lo2 = (kk & 2) ? a1 : a0, hi2 = (kk & 2) ? b1 : b0;
         return (uint32_t)__builtin_amdgcn_readlane((int)((kk & 4) ? hi2 : lo2), w.top - bl);
     };
-    TbWindow &cur = w0, &nxt = w1;              // the window the path is in / the one below it (prefetched)
-    const int row_end = a_row, col_end = a_col;
-    (void)row_end; (void)col_end;
-    if (a_row > d.row0 || a_col > d.col0) load_window(cur, a_row + a_col - d.brk, col_base(p.r));   // the path ends on the input path: column r
-    while (a_row > d.row0 || a_col > d.col0) {
-        const int bl = a_row + a_col - d.brk;
-        if (a_row < d.row0 || a_col < d.col0 || bl < 0 || bl >= d.nrows) { status |= 16; break; }
-        if (bl <= cur.top - 64) {               // the path left the current window
-            if (nxt.top == cur.top - 64 && bl > nxt.top - 64) { cur = nxt; nxt.top = NONE; }
-            else { load_window(cur, bl, cur.wc); nxt.top = NONE; }
+    // Software pipeline over windows: the window below the current one is requested at the top of the outer
+    // loop, the inner loop hops through the current window with register reads only (no load of either window
+    // inside it, so nothing in it waits on vmcnt), and the request is only waited for where the path leaves
+    // the current window.  A reload of the CURRENT window (the path jumped over a window, or drifted out of the
+    // 8-column strip) is waited for before the next request is issued: vmcnt completes in order, and a pending
+    // `cur` would make the first hop wait for the request behind it as well.
+    TbWindow &cur = w0, &nxt = w1;
+    constexpr int VMCNT0 = 0x0F70;              // s_waitcnt vmcnt(0) (expcnt / lgkmcnt fields at their maxima)
+    bool more = (a_row > d.row0 || a_col > d.col0);
+    if (more) {
+        load_window(cur, a_row + a_col - d.brk, col_base(p.r));   // the path ends on the input path: column r
+        __builtin_amdgcn_s_waitcnt(VMCNT0);
+    }
+    while (more) {
+        // (all of these are wave-uniform; saying so keeps them and the control flow below in scalar registers)
+        a_row = uni(a_row); a_col = uni(a_col); pos = uni(pos); nruns = uni(nruns); status = uni(status);
+        cur.top = uni(cur.top); cur.wc = uni(cur.wc);
+        const bool have_nxt = cur.top >= 64;
+        if (have_nxt) load_window(nxt, cur.top - 64, cur.wc);
+        int why = 0;                            // 1: the path left the window, 2: it left the strip, 3: finished / error
+        int bl = 0, bc = 0;
+        // The ordinary hop (a cell inside the window and the strip, a valid word) takes two combined tests; what
+        // exactly stopped the loop is sorted out afterwards, in the order the reference tests things
+        // (src/aln.pyx:680-716), so the status bits are the same as with one test per condition.
+        for (;;) {
+            bl = a_row + a_col - d.brk;
+            const int li = cur.top - bl;        // lane that holds anti-diagonal bl
+            const bool live = (a_row > d.row0) | (a_col > d.col0);
+            const bool inside = (a_row >= d.row0) & (a_col >= d.col0) & (bl >= 0) & (bl < d.nrows);
+            if (!(live & inside & (li < 64))) {
+                if (!live) why = 3;
+                else if (!inside) { status |= 16; why = 3; }
+                else why = 1;
+                break;
+            }
+            bc = __builtin_amdgcn_readlane(cur.ins, li) - a_row + p.r;     // inss[b] - a_row + r, src/aln.pyx:322-326
+            const unsigned kk = (unsigned)(bc - cur.wc);
+            if ((bc <= 0) | (bc >= W - 1) | (kk > 7u)) {
+                if (bc < 0 || bc >= W) { status |= 16; why = 3; }
+                else if (kk > 7u) why = 2;
+                else { status |= 4; why = 3; }      // band edge: TYP = MAT, RUN = 0 (src/aln.pyx:502-507) -> "run < 1"
+                break;
+            }
+            const uint32_t w = word(cur, bl, bc);
+            const int typ = (int)(w & 7u), run = (int)(w >> 3);     // src/aln.pyx:684-685
+            if ((run < 1) | (run > pos) | (typ > T_SHR)) {
+                status |= (run < 1) ? 4 : (run > pos) ? 16 : 8;
+                why = 3;
+                break;
+            }
+            int emit = run;
+            const bool ins = (typ == T_LEN) | (typ == T_INS), del = (typ == T_SHR) | (typ == T_DEL);
+            if (typ == T_MAT) {
+                const int lim = min(a_row - d.row0, a_col - d.col0);
+                emit = run < lim ? run : lim;                          // diagonal steps that stay in the chunk
+            }
+            if (emit > 0) {
+                {   // rbuf[lane nruns & 63] = typ | emit << 3 (both operands are wave-uniform: one v_writelane)
+                    const uint32_t rv = (uint32_t)uni((int)((uint32_t)typ | ((uint32_t)emit << 3)));
+                    const int rl = uni(nruns & 63);
+                    // (the lane select goes through M0: VOP3 takes a single SGPR operand on gfx9)
+                    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(rbuf) : "s"(rv), "s"(rl) : "m0");
+                }
+                nruns++;
+                if ((nruns & 63) == 0) runs[nruns - 64 + lane] = rbuf;
+            }
+            pos -= emit;
+            if (emit < run) { status |= 16; why = 3; break; }
+            a_row -= del ? 0 : emit;
+            a_col -= ins ? 0 : emit;
         }
-        const int bc = __builtin_amdgcn_readlane(cur.ins, cur.top - bl) - a_row + p.r;     // inss[b] - a_row + r, src/aln.pyx:322-326
-        if (bc < 0 || bc >= W) { status |= 16; break; }
-        if (bc < cur.wc || bc > cur.wc + 7) {   // the path drifted out of the strip (rare): new columns
-            load_window(cur, cur.top, col_base(bc));
-            nxt.top = NONE;
+        if (why == 3) break;
+        if (why == 1 && have_nxt && bl > nxt.top - 64) cur = nxt;       // the usual case: one window down
+        else {
+            if (why == 1) load_window(cur, bl, cur.wc);                 // a long run jumped over the window below
+            else load_window(cur, cur.top, col_base(bc));               // same anti-diagonals, other columns
+            __builtin_amdgcn_s_waitcnt(VMCNT0);
         }
-        if (nxt.top == NONE && cur.top >= 64) load_window(nxt, cur.top - 64, cur.wc);   // request the window below early
-        const uint32_t w = (bc == 0 || bc == W - 1) ? 0u : word(cur, bl, bc);   // band edge: TYP = MAT, RUN = 0 (src/aln.pyx:502-507)
-        const int typ = (int)(w & 7u), run = (int)(w >> 3);     // src/aln.pyx:684-685
-        if (run < 1) { status |= 4; break; }
-        if (run > pos) { status |= 16; break; }
-        int emit = run;
-        const bool ins = (typ == T_LEN || typ == T_INS), del = (typ == T_SHR || typ == T_DEL);
-        if (!ins && !del) {
-            if (typ != T_MAT) { status |= 8; break; }
-            const int lim = min(a_row - d.row0, a_col - d.col0);
-            emit = run < lim ? run : lim;                          // diagonal steps that stay in the chunk
-        }
-        if (emit > 0) {
-            rbuf = (lane == (nruns & 63)) ? ((uint32_t)typ | ((uint32_t)emit << 3)) : rbuf;
-            nruns++;
-            if ((nruns & 63) == 0) runs[nruns - 64 + lane] = rbuf;
-        }
-        pos -= emit;
-        if (emit < run) { status |= 16; break; }
-        a_row -= del ? 0 : emit;
-        a_col -= ins ? 0 : emit;
     }
     if (lane == 0) {
         p.chunk_len[k] = d.out_cap - pos;
