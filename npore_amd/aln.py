@@ -74,6 +74,11 @@ class Context:
     def set(self, key, value):
         _check(self.lib.npore_ctx_set(self.handle, key.encode(), int(value)))
 
+    def round_chunks(self, r=30):
+        """Chunks (units of at most max_b_rows anti-diagonals) the GPU works on at a time at band half-width r:
+        batches whose full-size chunks fill whole rounds run at the best rate (include/npore_amd.h)."""
+        return int(self.lib.npore_round_chunks(self.handle, int(r)))
+
     def timing(self):
         t = (C.c_double * 8)()
         _check(self.lib.npore_last_timing(self.handle, t, 8))

@@ -763,26 +763,39 @@ __global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
     };
 
     if ((a_row > d.row0 || a_col > d.col0) && in_chunk(a_row, a_col)) load_row(a_row + a_col - d.brk);
-    while (a_row > d.row0 || a_col > d.col0) {
-        if (!in_chunk(a_row, a_col)) { status |= 16; break; }
-        const int bc = row_ins - a_row + p.r;     // inss[b] - a_row + r, src/aln.pyx:322-326
-        if (bc < 0 || bc >= W) { status |= 16; break; }
-        const uint32_t x = (bc == 0 || bc == W - 1) ? 0u : word(bc);   // band edge: TYP = MAT, RUN = 0 (src/aln.pyx:502-507)
+    // two combined tests per ordinary hop; what stopped the loop is sorted out in the reference's order
+    // (src/aln.pyx:680-716) where it stops, so the status bits are those of one test per condition
+    for (;;) {
+        a_row = uni(a_row); a_col = uni(a_col); pos = uni(pos); nruns = uni(nruns);
+        const bool live = (a_row > d.row0) | (a_col > d.col0);
+        if (!(live & in_chunk(a_row, a_col))) {
+            if (live) status |= 16;
+            break;
+        }
+        const int bc = uni(row_ins) - a_row + p.r;     // inss[b] - a_row + r, src/aln.pyx:322-326
+        if ((bc <= 0) | (bc >= W - 1)) {
+            status |= (bc < 0 || bc >= W) ? 16 : 4;    // band edge: TYP = MAT, RUN = 0 (src/aln.pyx:502-507) -> "run < 1"
+            break;
+        }
+        const uint32_t x = word(bc);
         const int typ = (int)(x & 7u), run = (int)(x >> 3);     // src/aln.pyx:684-685
-        if (run < 1) { status |= 4; break; }
-        if (run > pos) { status |= 16; break; }
-        int n_row = a_row, n_col = a_col, emit = run;
-        if (typ == T_LEN || typ == T_INS) n_row -= run;
-        else if (typ == T_SHR || typ == T_DEL) n_col -= run;
-        else if (typ == T_MAT) {
+        if ((run < 1) | (run > pos) | (typ > T_SHR)) {
+            status |= (run < 1) ? 4 : (run > pos) ? 16 : 8;
+            break;
+        }
+        const bool ins = (typ == T_LEN) | (typ == T_INS), del = (typ == T_SHR) | (typ == T_DEL);
+        int emit = run;
+        if (typ == T_MAT) {
             const int lim = min(a_row - d.row0, a_col - d.col0);
             emit = run < lim ? run : lim;                          // diagonal steps that stay in the chunk
-            n_row -= emit; n_col -= emit;
-        } else { status |= 8; break; }
+        }
+        const int n_row = a_row - (del ? 0 : emit), n_col = a_col - (ins ? 0 : emit);
         // request the next row now
         if (emit == run && (n_row > d.row0 || n_col > d.col0) && in_chunk(n_row, n_col)) load_row(n_row + n_col - d.brk);
         if (emit > 0) {
-            rbuf = (lane == (nruns & 63)) ? ((uint32_t)typ | ((uint32_t)emit << 3)) : rbuf;
+            const uint32_t rv = (uint32_t)uni((int)((uint32_t)typ | ((uint32_t)emit << 3)));
+            const int rl = uni(nruns & 63);
+            asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(rbuf) : "s"(rv), "s"(rl) : "m0");
             nruns++;
             if ((nruns & 63) == 0) runs[nruns - 64 + lane] = rbuf;
         }

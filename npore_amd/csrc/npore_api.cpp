@@ -149,31 +149,46 @@ int pow2_at_least(int x)
     return p;
 }
 
+// Geometry of a fill launch for band half-width r: LDS sizes, chunks per workgroup and how many workgroups the
+// GPU holds at a time.
+struct FillGeom {
+    int nw = 0, hw = 0, rwin = 0, cmax = 0;
+};
+bool fill_geometry(int r, FillGeom &g)
+{
+    g.nw = pick_shape(r);
+    if (!g.nw) return false;
+    g.hw = 2 * r + 1 + HIST_PAD;
+    g.rwin = pow2_at_least(2 * r + 101);
+    const size_t lds_cap = 160 * 1024 / sizeof(float);
+    if (fill_lds_floats(g.nw, 1, g.hw, g.rwin) > lds_cap) return false;
+    g.cmax = 1;
+    while ((g.cmax + 1) * g.nw * 64 <= 1024 && fill_lds_floats(g.nw, g.cmax + 1, g.hw, g.rwin) <= lds_cap) g.cmax++;
+    return true;
+}
+// workgroups of `chunks` chunks that are resident together, minus a few (see launch_fill)
+int fill_round_workgroups(const FillGeom &g, int chunks, int n_cus)
+{
+    const size_t lds = fill_lds_floats(g.nw, chunks, g.hw, g.rwin) * sizeof(float);
+    const int wg_per_cu = std::max(1, std::min((int)((160 * 1024) / std::max<size_t>(lds, 1)), 2048 / (64 * g.nw * chunks)));
+    const int all = std::max(1, n_cus) * wg_per_cu;
+    return std::max(1, all - std::max(1, all / 40));
+}
+
 // NW waves per chunk, `chunks` chunks per workgroup (they share the LDS score table).
 template <int NW>
 hipError_t launch_fill(KParams kp, int max_chunks, int force_chunks, int n_cus, hipStream_t s)
 {
     constexpr int MAXT = 1024;
-    const int W = 2 * kp.r + 1;
-    kp.hw = W + HIST_PAD;
-    kp.rwin = pow2_at_least(2 * kp.r + 101);
-    const size_t lds_cap = 160 * 1024 / sizeof(float);
-    if (fill_lds_floats(NW, 1, kp.hw, kp.rwin) > lds_cap) return hipErrorInvalidValue;
-    int cmax = 1;
-    while ((cmax + 1) * NW * 64 <= MAXT && fill_lds_floats(NW, cmax + 1, kp.hw, kp.rwin) <= lds_cap) cmax++;
+    FillGeom g;
+    if (!fill_geometry(kp.r, g) || g.nw != NW) return hipErrorInvalidValue;
+    kp.hw = g.hw;
+    kp.rwin = g.rwin;
+    const int cmax = g.cmax;
     // few chunks: spread them over the CUs; many: pack workgroups so that the table is amortised
     int chunks = std::min(cmax, std::max(1, (max_chunks + 255) / 256));
     if (force_chunks > 0) chunks = std::min(cmax, force_chunks);
     const size_t lds = fill_lds_floats(NW, chunks, kp.hw, kp.rwin) * sizeof(float);
-    // Workgroups that are resident together (one "round"): the schedule lists the chunks largest first, and the
-    // kernel deals them over the workgroups of a round like cards, so that the heavy chunks of a small batch
-    // are spread over all CUs instead of filling the first workgroups
-    const int wg_per_cu = std::max(1, std::min((int)((160 * 1024) / std::max<size_t>(lds, 1)), 2048 / (64 * NW * chunks)));
-    // ... minus a few: the workgroups of later rounds (small chunks once the list is sorted) then start at once
-    // on the CUs left free and run beside the heavy round instead of after it (C2: 1 000 chunks of 20 000 rows
-    // on 250 CUs, the 1 000 chunks of ~200 rows on the other 6 meanwhile)
-    const int all = std::max(1, n_cus) * wg_per_cu;
-    kp.resident = std::max(1, all - std::max(1, all / 40));
     // the kernel addresses its score tables by absolute LDS address (kernels.hpp: lds_abs_f32): it must not
     // own any static LDS, so that the dynamic array starts at address 0
     static const hipError_t no_static_lds = [] {
@@ -182,6 +197,13 @@ hipError_t launch_fill(KParams kp, int max_chunks, int force_chunks, int n_cus, 
         return e0 != hipSuccess ? e0 : (at.sharedSizeBytes == 0 ? hipSuccess : hipErrorInvalidDeviceFunction);
     }();
     if (no_static_lds != hipSuccess) return no_static_lds;
+    // Workgroups that are resident together (one "round"): the schedule lists the chunks largest first, and the
+    // kernel deals them over the workgroups of a round like cards, so that the heavy chunks of a small batch
+    // are spread over all CUs instead of filling the first workgroups.  A round is a few workgroups short of what
+    // the GPU holds: the workgroups of later rounds (small chunks once the list is sorted) then start at once
+    // on the CUs left free and run beside the heavy round instead of after it (C2: 1 000 chunks of 20 000 rows
+    // on 250 CUs, the 1 000 chunks of ~200 rows on the other 6 meanwhile)
+    kp.resident = fill_round_workgroups(g, chunks, n_cus);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fill_kernel<NW, MAXT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -716,6 +738,13 @@ int npore_last_timing(npore_ctx *ctx, double *ms, int n)
     if (!ctx || !ms) return fail(NPORE_E_INVALID, "null argument");
     for (int i = 0; i < n && i < 8; i++) ms[i] = ctx->timing[i];
     return NPORE_OK;
+}
+
+int64_t npore_round_chunks(npore_ctx *ctx, int r)
+{
+    FillGeom g;
+    if (!ctx || !fill_geometry(r, g)) return 0;
+    return (int64_t)fill_round_workgroups(g, g.cmax, ctx->n_cus) * g.cmax;
 }
 
 int npore_ctx_set(npore_ctx *ctx, const char *key, int64_t value)

@@ -479,3 +479,11 @@ def test_other_table_shapes(tables, max_n, max_l):
     for seq in (pairs[0][0], pairs[3][1]):
         assert np.array_equal(c.get_np_info(seq), np.asarray(oracle.get_np_info(seq, max_n=max_n, max_l=max_l)))
     c.close()
+
+
+@pytest.mark.gpu
+def test_round_chunks(ctx):
+    """npore_round_chunks: the batch-sizing hint of the C ABI (chunks the GPU holds at a time)."""
+    assert ctx.round_chunks(30) > ctx.round_chunks(100) > ctx.round_chunks(200) > 0
+    assert ctx.round_chunks(100) % 4 == 0          # four chunks share a workgroup at r = 100
+    assert ctx.round_chunks(256) == 0              # band wider than the kernels cover
