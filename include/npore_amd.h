@@ -163,7 +163,7 @@ int npore_ctx_set(npore_ctx *ctx, const char *key, int64_t value);
  * 445-456) is one unit of work of the fill kernel, and the GPU works on "rounds" of them: as many chunks as it
  * holds at a time for band half-width r.  A round takes about as long whether it is full or not, so throughput
  * is best when the full-size chunks of a batch (one per 10 kb read at max_b_rows = 20000) fill whole rounds:
- * 3 250 at r = 30, 1 000 at r = 100 on an MI355X; 3 400 reads at r = 30 take 1.7 x as long as 3 250.
+ * 4 000 at r = 30, 1 000 at r = 100 on an MI355X; a batch one read over a round takes about 1.7 x as long.
  * Returns the chunks per round, 0 for a band the kernels do not cover (r > 255).  Replaces nothing in the
  * reference (its pool has no such granularity, src/realign.py:110-114). */
 int64_t npore_round_chunks(npore_ctx *ctx, int r);

@@ -150,7 +150,9 @@ struct DevEnv {
     __device__ __forceinline__ float np_small(uint32_t dsc, int q) const
     {
         const uint32_t a = (dsc >> 15) & 0xFFFFu;
-        return lds_abs_f32(LDS_NP_BASE + a - 4u * (uint32_t)min(q, NP_C0));
+        // q >= L copies deleted: the call length L - 1 - q is negative -> the guard entry in front of the row
+        const uint32_t L = (dsc >> 8) & 0xFFu;      // bits 8-14; bit 15 is clear (the address field holds a multiple of 4)
+        return lds_abs_f32(LDS_NP_BASE + a - 4u * min((uint32_t)q, L));
     }
     __device__ __forceinline__ int clamp() const { return clampv; }
     __device__ __forceinline__ int refl(int j, int n_idx) const { return win[(j & wmask) * 8 + n_idx]; }
@@ -688,12 +690,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(TParams p)
                 emit = run < lim ? run : lim;                          // diagonal steps that stay in the chunk
             }
             if (emit > 0) {
-                {   // rbuf[lane nruns & 63] = typ | emit << 3 (both operands are wave-uniform: one v_writelane)
-                    const uint32_t rv = (uint32_t)uni((int)((uint32_t)typ | ((uint32_t)emit << 3)));
-                    const int rl = uni(nruns & 63);
-                    // (the lane select goes through M0: VOP3 takes a single SGPR operand on gfx9)
-                    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(rbuf) : "s"(rv), "s"(rl) : "m0");
-                }
+                rbuf = (lane == (nruns & 63)) ? ((uint32_t)typ | ((uint32_t)emit << 3)) : rbuf;
                 nruns++;
                 if ((nruns & 63) == 0) runs[nruns - 64 + lane] = rbuf;
             }
@@ -793,9 +790,7 @@ __global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
         // request the next row now
         if (emit == run && (n_row > d.row0 || n_col > d.col0) && in_chunk(n_row, n_col)) load_row(n_row + n_col - d.brk);
         if (emit > 0) {
-            const uint32_t rv = (uint32_t)uni((int)((uint32_t)typ | ((uint32_t)emit << 3)));
-            const int rl = uni(nruns & 63);
-            asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(rbuf) : "s"(rv), "s"(rl) : "m0");
+            rbuf = (lane == (nruns & 63)) ? ((uint32_t)typ | ((uint32_t)emit << 3)) : rbuf;
             nruns++;
             if ((nruns & 63) == 0) runs[nruns - 64 + lane] = rbuf;
         }

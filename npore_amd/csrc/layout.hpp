@@ -83,8 +83,10 @@ constexpr uint32_t DSC_N4 = 0x1Cu, DSC_BIGL = 1u << 6, DSC_MORE = 1u << 7, DSC_S
 // column needs the generic path (L >= NP_LT in either candidate, or more than two candidates)
 constexpr uint32_t DSC_HAS2 = 1u << 5, DSC_RARE = 1u << 7;
 // LDS score table: [MAX_PERIOD][NP_LT][NP_CT] floats, entry NP_C0 + call for call in [-NP_C0, NP_CT - NP_C0)
-// holding np_scores[n][L][call], and INF_F where call < 0 (np_score's "call < 0 -> 100")
-constexpr int NP_LT = 32, NP_CT = 64, NP_C0 = 32;
+// holding np_scores[n][L][call], and INF_F where call < 0 (np_score's "call < 0 -> 100"): one guard entry in
+// front of each row, which a candidate reaches by clamping "copies deleted so far" at the row's own L (byte 1 of
+// its descriptor).  25 KB; the odd row length also spreads the rows over the LDS banks.
+constexpr int NP_LT = 32, NP_CT = 33, NP_C0 = 1;
 // max_l: np_score clamps the table ROW to max_l - 1 (src/aln.pyx:257-274 as called); L itself is capped at max_l, so
 // the call length L - 1 - q never needs the clamp
 NPORE_HD uint32_t make_shr_desc(int n, bool start, uint32_t L, int max_l)
