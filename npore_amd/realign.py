@@ -42,7 +42,7 @@ def argparser():
     parser.add_argument("--recalc_cms", action="store_true", help="(not supported in this build)")
     parser.add_argument("--recalc_exit", action="store_true", help="(not supported in this build)")
     # additions
-    parser.add_argument("--batch_reads", type=int, default=4096, help="Reads per GPU batch.")
+    parser.add_argument("--batch_reads", type=int, default=2000, help="Reads per GPU batch (file to file the host stages bound the pipeline: 2 000 measured best; device-resident callers fill whole rounds, Context.round_chunks).")
     parser.add_argument("--device", type=int, default=int(os.environ.get("LOCAL_RANK", "0")), help="HIP device.")
     parser.add_argument("--python_io", action="store_true",
                         help="Use the pure-Python BAM reader / SAM writer (the restatement the native one is tested against).")

@@ -4,7 +4,7 @@ reads of the bench generator laid end to end on one contig.  Times the native ho
 (libnpore_amd: inflate/index, select, pack + GPU align + standardise + format per batch, file write) and,
 on a subset, the pure-Python restatement of the same steps.
 
-    python scripts/bench_realign.py [--reads 4000] [--ref-len 10000] [--r 30] [--batch 4096] [--py-reads 64]
+    python scripts/bench_realign.py [--reads 4000] [--ref-len 10000] [--r 30] [--batch 2000] [--py-reads 64]
 """
 import argparse, json, os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--reads", type=int, default=4000)
     ap.add_argument("--ref-len", type=int, default=10000)
     ap.add_argument("--r", type=int, default=30)
-    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--batch", type=int, default=2000)
     ap.add_argument("--py-reads", type=int, default=64)
     ap.add_argument("--seed", type=int, default=3)
     a = ap.parse_args()
