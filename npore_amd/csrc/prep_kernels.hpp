@@ -379,7 +379,8 @@ template <int n>
 __device__ __forceinline__ void annotate_period(const uint8_t *seq, int len, int max_n, int max_l, uint8_t *planes,
                                                 int pstride, int32_t *Lout, int32_t *Iout)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    // (the wave index is wave-uniform: saying so keeps the window loops and their bounds in scalar registers)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = blockDim.x >> 6;
     uint8_t *Ln = planes + (size_t)(n - 1) * pstride;
     for (int base = wave * 64; base < len; base += nwaves * 64) {
         const int pos = base + lane;
