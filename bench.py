@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=32,
                     help="worker processes for the whole-batch CPU run (each holds a 241 MB state matrix at r=100; 0/1 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--tb-kernel", type=int, default=0,
+                    help="traceback kernel: 0 = chosen by batch size, 1 = windowed, 2 = row per hop (experiments)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="batches in flight per GPU: each has its own context (stream + work buffers) and host thread, "
                          "so one batch's traceback / gather and the next one's preparation run beside a fill kernel")
@@ -114,6 +116,9 @@ def main():
     n_ctx = max(1, args.inflight)
     ctxs = [aln.Context(sub, nps, max_n=6, max_l=100, device=local) for _ in range(n_ctx)]
     ctx = ctxs[0]
+    if args.tb_kernel:
+        for c in ctxs:
+            c.set("traceback_kernel", args.tb_kernel)
     lib = _lib.load()
 
     rb, ro = pack(refs)
