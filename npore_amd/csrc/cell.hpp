@@ -145,6 +145,7 @@ NPORE_HD int div_recip(int run, uint32_t m)
 //   uint32_t recip(Tab, uint32_t n4)        RECIP16[n]
 //   int   mer_shift(Tab, uint32_t n4)       32 - 3n (0 for n = 0)
 //   uint32_t mer_mask(Tab, uint32_t n4)     (1 << 3n) - 1
+//   static constexpr bool LEN_ARITH         how the LEN filter forms its n-mer shift (see there)
 //   bool  any(bool), any2(bool a, bool b)   wave-level "any lane" of x / of a && b (identity on the host)
 // Lanes without a candidate call these with n4 = 0 (or, in the LEN filter, 4*33) and ignore the result.
 // The table lookups are cross-lane reads on the device: call them where all lanes are active
@@ -316,11 +317,19 @@ NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, 
             const int nm1 = top_index(lm);                 // period - 1 (32 if this lane has none left)
             lm = low_bits(lm, nm1);
             const uint32_t n4 = (uint32_t)(nm1 + 1) << 2;  // (4*33 where none: tables are 8-periodic)
-            // both lookups BEFORE any per-lane condition: on the device they read other lanes' registers,
-            // which only works while every lane of the wave is executing
-            const uint32_t smer = in.seqw >> env.mer_shift(tab, n4);      // the n most recent read bases
-            const uint32_t mmask = env.mer_mask(tab, n4);
-            const bool match = ((smer ^ refm) & mmask) == 0u;                                     // match(), :606-607
+            // match(), :606-607: the n most recent read bases against the next n reference bases.  The shift
+            // count 32 - 3n either comes from the lane tables (two cross-lane reads, to be made BEFORE any per-lane
+            // condition: they only work while every lane of the wave is executing) or is computed per lane; on the
+            // GPU the second is faster for chunks of several waves (-1.5...2 % fill at r = 70...200) and slightly
+            // slower for one wave per chunk (+0.4 % at r = 30), so the Env says which
+            bool match;
+            if constexpr (Env::LEN_ARITH) {
+                const uint32_t sh = (uint32_t)(29 - 3 * nm1) & 31u;
+                match = (((in.seqw >> sh) ^ refm) << sh) == 0u;
+            } else {
+                const uint32_t smer = in.seqw >> env.mer_shift(tab, n4);
+                match = ((smer ^ refm) & env.mer_mask(tab, n4)) == 0u;
+            }
             const bool inside = FAST || i - (nm1 + 1) >= 0;
             const bool good = valid && inside && match;
             if (!(FAST ? env.any2(valid, match) : env.any(good))) continue;

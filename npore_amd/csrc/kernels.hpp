@@ -113,6 +113,7 @@ constexpr uint32_t LDS_SUB_BASE = MAX_PERIOD * NP_LT * NP_CT * 4u;        // the
 
 template <int NSR>
 struct DevEnv {
+    static constexpr bool LEN_ARITH = NSR != 6;   // several waves per chunk (ring_rows): cell.hpp, LEN filter
     const char *lds_sub;      // [ref 8][seq 8][4] copy of sub_scores (layout.hpp SUBT_*)
     const char *lds_np;       // [6][NP_LT][NP_CT] floats (layout.hpp)
     const float *g_np;        // full table in global memory

@@ -28,6 +28,7 @@ struct ModelEnv {
     const uint32_t *hr;
     int W, slot;   // slot of the current row; row b-n is (slot - n) mod NS
     int refl_n;    // entries in refl_p / refw_p
+    static constexpr bool LEN_ARITH = true;
     struct Tab { uint32_t hist6; };
     Tab step_tables(const StepInfo &st) const { return Tab{st.hist6}; }
     float sub(uint32_t seqw, uint32_t refx) const
