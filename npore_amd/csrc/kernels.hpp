@@ -809,6 +809,7 @@ __global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
 }
 
 // ---------------------------------------------------------------------------
+constexpr int GATHER_TILE = 256 * 33;      // output positions per LDS tile of gather_kernel (33 per thread: odd, for the LDS banks)
 struct GParams {
     const ChunkDesc *descs;
     const int32_t *read_first_chunk;   // [n_reads+1]
@@ -825,6 +826,7 @@ struct GParams {
     int64_t read_base;                 // index of this group's first read in the caller's arrays
     int64_t n_reads;                   // reads of this group
     int64_t *chunk_woff;               // [chunks] position of the chunk's ops in its read's string
+    int slice_cap;                     // gather_kernel: LDS bytes per staged base slice (0: bases are read from global memory)
 };
 
 // wave per read: status, output length, and the position of every chunk's ops in the read's string
@@ -869,14 +871,27 @@ __global__ __launch_bounds__(256) void gather_kernel(GParams p)
     uint8_t *dst = p.out + p.out_off[grd] + p.chunk_woff[c];
     // Expand the chunk's runs (recorded last run first) into ops.  Run j ends where the ops of the runs before
     // it (in recording order) begin, counted from the chunk's end, and pairs the bases below the cell reached
-    // after those runs: three prefix sums in recording order -- ops, read bases, reference bases.  Every thread
-    // takes an equal share of the OUTPUT positions (runs differ wildly in length) and finds its first run
-    // through per-thread-segment sums.
+    // after those runs: three prefix sums in recording order -- ops, read bases, reference bases.  The output is
+    // produced in tiles of GATHER_TILE positions: every thread takes an equal, contiguous share of the tile (runs
+    // differ wildly in length), finds its first run through per-thread-segment sums and writes its ops into an
+    // LDS tile, which the workgroup then stores with consecutive lanes on consecutive bytes; the chunk's two base
+    // slices are staged in LDS the same way when they fit (a share per thread means addresses ~33 bytes apart
+    // across the lanes: uncoalesced when it goes to memory directly).
+    extern __shared__ __attribute__((aligned(16))) uint8_t gl[];
     __shared__ int s_ops[257], s_rows[257], s_cols[257];
     const int T = (int)blockDim.x, t = (int)threadIdx.x;
     const int len = p.chunk_len[c], nr = p.chunk_nruns[c];
     const uint32_t *runs = p.chunk_runs + d.out_off;
-    const uint8_t *seq = p.seqs + d.seq_off, *ref = p.refs + d.ref_off;
+    const int row_end = d.row0 + d.drows, col_end = d.col0 + d.dcols;
+    uint8_t *l_ops = gl;
+    // bases below the chunk's end cell: seq[row0, row_end), ref[col0, col_end)
+    const bool staged = p.slice_cap > 0 && d.drows <= p.slice_cap && d.dcols <= p.slice_cap;
+    const uint8_t *seq = p.seqs + d.seq_off + d.row0, *ref = p.refs + d.ref_off + d.col0;   // local row / column 0
+    if (staged) {
+        uint8_t *l_seq = gl + GATHER_TILE, *l_ref = l_seq + p.slice_cap;
+        for (int k = t; k < d.drows; k += T) l_seq[k] = seq[k];
+        for (int k = t; k < d.dcols; k += T) l_ref[k] = ref[k];
+    }
     const int seg = (nr + T - 1) / T;
     const int e0 = min(nr, t * seg), e1 = min(nr, e0 + seg);
     int so = 0, sr = 0, sc = 0;
@@ -894,41 +909,50 @@ __global__ __launch_bounds__(256) void gather_kernel(GParams p)
         for (int q = 1; q <= T; q++) { s_ops[q] += s_ops[q - 1]; s_rows[q] += s_rows[q - 1]; s_cols[q] += s_cols[q - 1]; }
     }
     __syncthreads();
-    // output positions u (0 = the chunk's LAST op) of this thread
-    const int useg = (len + T - 1) / T;
-    const int u0 = min(len, t * useg), u1 = min(len, u0 + useg);
-    if (u0 < u1) {
-        int lo = 0, hi = T;                     // segment sgm with s_ops[sgm] <= u0 < s_ops[sgm + 1]
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_ops[mid] <= u0) lo = mid; else hi = mid; }
-        int e = min(nr, lo * seg), ao = s_ops[lo], ar = s_rows[lo], ac = s_cols[lo];
-        int typ = 0, l = 0;
-        for (;; e++) {                          // first run that reaches beyond u0
-            const uint32_t x = runs[e];
-            typ = (int)(x & 7u); l = (int)(x >> 3);
-            if (ao + l > u0) break;
-            ao += l;
-            ar += (typ == T_DEL || typ == T_SHR) ? 0 : l;
-            ac += (typ == T_INS || typ == T_LEN) ? 0 : l;
-        }
-        const int row_end = d.row0 + d.drows, col_end = d.col0 + d.dcols;
-        for (int u = u0; u < u1; u++) {
-            while (u >= ao + l) {               // next run
+    auto base_pair_equal = [&](int ri, int ci) -> bool {   // local read row ri, local reference column ci
+        if (staged) return gl[GATHER_TILE + ri] == gl[GATHER_TILE + p.slice_cap + ci];
+        return seq[ri] == ref[ci];
+    };
+    for (int U0 = 0; U0 < len; U0 += GATHER_TILE) {
+        const int U1 = min(len, U0 + GATHER_TILE);
+        // output positions u (0 = the chunk's LAST op) of this thread within the tile
+        const int useg = (U1 - U0 + T - 1) / T;
+        const int u0 = min(U1, U0 + t * useg), u1 = min(U1, u0 + useg);
+        if (u0 < u1) {
+            int lo = 0, hi = T;                     // segment sgm with s_ops[sgm] <= u0 < s_ops[sgm + 1]
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_ops[mid] <= u0) lo = mid; else hi = mid; }
+            int e = min(nr, lo * seg), ao = s_ops[lo], ar = s_rows[lo], ac = s_cols[lo];
+            int typ = 0, l = 0;
+            for (;; e++) {                          // first run that reaches beyond u0
+                const uint32_t x = runs[e];
+                typ = (int)(x & 7u); l = (int)(x >> 3);
+                if (ao + l > u0) break;
                 ao += l;
                 ar += (typ == T_DEL || typ == T_SHR) ? 0 : l;
                 ac += (typ == T_INS || typ == T_LEN) ? 0 : l;
-                e++;
-                const uint32_t x = runs[e];
-                typ = (int)(x & 7u); l = (int)(x >> 3);
             }
-            uint8_t op;
-            if (typ == T_MAT) {                 // '=' / 'X' by comparing the paired bases, src/aln.pyx:732-735
-                const int q = u - ao;
-                op = (ref[col_end - ac - q - 1] == seq[row_end - ar - q - 1]) ? '=' : 'X';
-            } else {
-                op = (typ == T_INS || typ == T_LEN) ? 'I' : 'D';
+            for (int u = u0; u < u1; u++) {
+                while (u >= ao + l) {               // next run
+                    ao += l;
+                    ar += (typ == T_DEL || typ == T_SHR) ? 0 : l;
+                    ac += (typ == T_INS || typ == T_LEN) ? 0 : l;
+                    e++;
+                    const uint32_t x = runs[e];
+                    typ = (int)(x & 7u); l = (int)(x >> 3);
+                }
+                uint8_t op;
+                if (typ == T_MAT) {                 // '=' / 'X' by comparing the paired bases, src/aln.pyx:732-735
+                    const int q = u - ao;
+                    op = base_pair_equal(d.drows - ar - q - 1, d.dcols - ac - q - 1) ? '=' : 'X';
+                } else {
+                    op = (typ == T_INS || typ == T_LEN) ? 'I' : 'D';
+                }
+                l_ops[u - U0] = op;
             }
-            dst[len - 1 - u] = op;
         }
+        __syncthreads();
+        for (int k = t; k < U1 - U0; k += T) dst[len - 1 - U0 - k] = l_ops[k];
+        __syncthreads();
     }
 }
 

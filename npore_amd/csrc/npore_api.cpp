@@ -417,7 +417,15 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     gp.n_reads = nr;
     gp.chunk_woff = ctx->cwoff.as<int64_t>();
     hipLaunchKernelGGL(gather_scan_kernel, dim3(rd_blocks), dim3(256), 0, s, gp);
-    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)max_chunks), dim3(256), 0, s, gp);
+    // LDS of gather_kernel: one tile of ops + (when a chunk's two base slices fit beside it) the slices
+    {
+        const int64_t rows_max = std::min<int64_t>(max_len, a.max_b_rows) + 1;    // longest slice of any chunk
+        gp.slice_cap = rows_max <= 24 * 1024 ? (int)((rows_max + 15) & ~(int64_t)15) : 0;
+        const size_t glds = (size_t)GATHER_TILE + 2 * (size_t)gp.slice_cap;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&gather_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)max_chunks), dim3(256), glds, s, gp);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev[3], s));
     return NPORE_OK;
