@@ -882,7 +882,6 @@ __global__ __launch_bounds__(256) void gather_kernel(GParams p)
     const int T = (int)blockDim.x, t = (int)threadIdx.x;
     const int len = p.chunk_len[c], nr = p.chunk_nruns[c];
     const uint32_t *runs = p.chunk_runs + d.out_off;
-    const int row_end = d.row0 + d.drows, col_end = d.col0 + d.dcols;
     uint8_t *l_ops = gl;
     // bases below the chunk's end cell: seq[row0, row_end), ref[col0, col_end)
     const bool staged = p.slice_cap > 0 && d.drows <= p.slice_cap && d.dcols <= p.slice_cap;
