@@ -196,6 +196,12 @@ def test_large_max_b_rows(ctx, tables):
         assert not st.any()
         for k in range(2):
             assert got[k] == oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=30, max_b_rows=mbr), (mbr, k)
+    # chunk slices longer than gather_kernel stages in LDS (> 24 K bases): its global-memory path, several output tiles
+    refs2, seqs2, cigs2 = synth.make_batch(78, 1, ref_len=30_000)
+    for mbr in (40000, 60000):
+        got, st = ctx.align_batch(refs2, seqs2, cigs2, r=30, max_b_rows=mbr, return_status=True)
+        assert not st.any()
+        assert got[0] == oracle.align(refs2[0], seqs2[0], cigs2[0], sub, nps, r=30, max_b_rows=mbr), mbr
     with pytest.raises(aln.NporeError):
         ctx.align_batch(refs, seqs, cigs, r=30, max_b_rows=70000)     # refused loudly, not silently wrong
     with pytest.raises(aln.NporeError):
