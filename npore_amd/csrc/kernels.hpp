@@ -583,7 +583,10 @@ struct TParams {
 // (v_readlane).  The kernel records RUNS (type, length), 64 at a time from a register buffer -- no store
 // per hop whose completion the next hop's counter wait would expose; gather_kernel expands them into ops.
 struct TbWindow {
-    uint4 lo, hi;   // columns wc..wc+7 of anti-diagonal top - lane
+    // columns wc..wc+7 of anti-diagonal top - lane, as eight scalars: picking a column is a tree of selects on
+    // wave-uniform conditions (with vector types the compiler turns the pick into a dynamically indexed array,
+    // which it keeps in LDS: two LDS round trips per hop)
+    uint32_t c0, c1, c2, c3, c4, c5, c6, c7;
     int ins;        // inss of that anti-diagonal
     int top;        // newest anti-diagonal held (lane 0); rows top-63..top
     int wc;         // first column (multiple of 4)
@@ -609,28 +612,31 @@ __global__ __launch_bounds__(64) void traceback_kernel(TParams p)
     TbWindow w0, w1;
     w0.top = w1.top = NONE;
     w0.wc = w1.wc = 0;
-    w0.lo = w0.hi = w1.lo = w1.hi = make_uint4(0u, 0u, 0u, 0u);
+    w0.c0 = w0.c1 = w0.c2 = w0.c3 = w0.c4 = w0.c5 = w0.c6 = w0.c7 = 0u;
+    w1.c0 = w1.c1 = w1.c2 = w1.c3 = w1.c4 = w1.c5 = w1.c6 = w1.c7 = 0u;
     w0.ins = w1.ins = 0;
     auto load_window = [&](TbWindow &w, int top, int col0) {
         w.top = top;
         w.wc = col0;
         const int row = top - lane;
-        w.lo = w.hi = make_uint4(0u, 0u, 0u, 0u);
+        uint4 lo = make_uint4(0u, 0u, 0u, 0u), hi = lo;
         w.ins = 0;
         if (row >= 0 && row < d.nrows) {
             const uint32_t *q = tb + (size_t)row * stride + col0;      // col0 + 3 < stride: both multiples of 4
-            w.lo = *reinterpret_cast<const uint4 *>(q);
-            if (col0 + 4 < stride) w.hi = *reinterpret_cast<const uint4 *>(q + 4);
+            lo = *reinterpret_cast<const uint4 *>(q);
+            if (col0 + 4 < stride) hi = *reinterpret_cast<const uint4 *>(q + 4);
             w.ins = inss[row];
         }
+        w.c0 = lo.x; w.c1 = lo.y; w.c2 = lo.z; w.c3 = lo.w;
+        w.c4 = hi.x; w.c5 = hi.y; w.c6 = hi.z; w.c7 = hi.w;
     };
     auto col_base = [&](int bc) { const int c = (bc - 2) & ~3; return c < 0 ? 0 : c; };   // bc lands at offset 2..5
     // word of column bc (wave-uniform) on anti-diagonal bl of window w: per-lane selects on uniform
     // conditions (no branch tree), then one cross-lane read
     auto word = [&](const TbWindow &w, int bl, int bc) -> uint32_t {
         const int kk = bc - w.wc;
-        const uint32_t a0 = (kk & 1) ? w.lo.y : w.lo.x, a1 = (kk & 1) ? w.lo.w : w.lo.z;
-        const uint32_t b0 = (kk & 1) ? w.hi.y : w.hi.x, b1 = (kk & 1) ? w.hi.w : w.hi.z;
+        const uint32_t a0 = (kk & 1) ? w.c1 : w.c0, a1 = (kk & 1) ? w.c3 : w.c2;
+        const uint32_t b0 = (kk & 1) ? w.c5 : w.c4, b1 = (kk & 1) ? w.c7 : w.c6;
         const uint32_t lo2 = (kk & 2) ? a1 : a0, hi2 = (kk & 2) ? b1 : b0;
         return (uint32_t)__builtin_amdgcn_readlane((int)((kk & 4) ? hi2 : lo2), w.top - bl);
     };
