@@ -392,7 +392,9 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     tp.r = r;
     tp.tbstride = tbs;
     // windowed traceback for small batches (about one wave per SIMD), row-per-hop for large ones (kernels.hpp)
-    const int tb_mode = ctx->tb_kernel ? ctx->tb_kernel : (max_chunks > 4096 ? 2 : 1);
+    // windowed traceback up to ~one wave per SIMD, row per hop beyond (measured crossover: 2 000 chunk slots tie at
+    // r=30 and favour the windows by 15 % at r=100; 3 000-4 000 slots favour the rows by 12-30 %)
+    const int tb_mode = ctx->tb_kernel ? ctx->tb_kernel : (max_chunks > 2500 ? 2 : 1);
     if (tb_mode == 1) hipLaunchKernelGGL(traceback_kernel, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
     else if (tbs <= 256) hipLaunchKernelGGL(traceback_rows_kernel<1>, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
     else hipLaunchKernelGGL(traceback_rows_kernel<2>, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
