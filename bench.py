@@ -11,9 +11,20 @@ reads dealt by index); the only collective is the final max/sum reduction.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Order of business (one JSON line on rank 0 at the end):
+  1. synthetic reads of this rank                                   (host, before anything touches HIP)
+  2. CPU baseline: oracle/ (plain-C port of the reference DP) on one core and on the host's cores -- forked
+     worker pools, so this also runs BEFORE the GPU runtime is initialised; N=1 only
+  3. W warm-up steps, then EXACTLY K timed steps, device-resident    -> value, ms_per_step, roofline
+  4. the same batch through the host-buffer entry point (pinned host memory in and out) -> value_pcie_inclusive
+  5. a sustained leg: device-resident steps for >= --sustain seconds -> sustained (the GPU is busy long enough
+     for an outside sampler to see it; not part of `value`)
+  6. every CPU string compared with the GPU's.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -25,6 +36,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
+N_SIMD = 256 * 4        # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 4 cycles
 
 
 def pack(seqs):
@@ -35,26 +47,141 @@ def pack(seqs):
     return buf, off
 
 
-def _gen_span(a):
-    from npore_amd import synth
-    seed, cnt, ref_len, mixed, first, stride = a
-    return synth.make_batch(seed, cnt, ref_len=ref_len, mixed=mixed, first=first, stride=stride)
-
-
 def make_reads(synth, args, count, rank, world):
     """Reads rank, rank + world, ... of the generator; spans of them on a forked pool when there are many."""
     if count < 2000:
         return synth.make_batch(args.base_seed, count, ref_len=args.ref_len, mixed=args.mixed, first=rank, stride=world)
     import multiprocessing as mp
-    nproc = max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
+    nproc = max(1, min(16, host_cpus()["usable"] // max(1, world)))
     span = 250
     jobs = [(args.base_seed, min(span, count - k), args.ref_len, args.mixed, rank + k * world, world)
             for k in range(0, count, span)]
     refs, seqs, cigs = [], [], []
     with mp.get_context("fork").Pool(nproc) as pool:
-        for r_, s_, c_ in pool.imap(_gen_span, jobs):
+        for r_, s_, c_ in pool.imap(synth.make_span, jobs):
             refs += r_; seqs += s_; cigs += c_
     return refs, seqs, cigs
+
+
+def host_cpus():
+    """What this process may use of the host: logical CPUs, its affinity mask, a cgroup CPU quota if any."""
+    n = os.cpu_count() or 1
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = n
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    usable = min(n, aff)
+    return {"cpu_count": n, "affinity": aff, "cgroup_cpus": quota, "usable": usable}
+
+
+def host_mem_available():
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            t = open(path).read().strip()
+            if t != "max":
+                lim = int(t)
+                used = 0
+                try:
+                    used = int(open(path.replace("memory.max", "memory.current")
+                                    .replace("memory.limit_in_bytes", "memory.usage_in_bytes")).read())
+                except (OSError, ValueError):
+                    pass
+                avail = min(avail, lim - used) if avail is not None else lim - used
+            break
+        except (OSError, ValueError):
+            continue
+    return avail
+
+
+def csrc_sha():
+    """Digest of the kernel sources the library is built from (what a committed PMC profile is valid for)."""
+    h = hashlib.sha256()
+    d = os.path.join(REPO, "npore_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(args, refs, seqs, cigs, sub, nps):
+    """The oracle (plain-C port of the reference's align(), proven equal to the Cython build in the build
+    container) on the GPU box's host cores: one core on a sample, then a process pool over reads -- the
+    reference's own parallelism (mp.Pool() over reads, src/realign.py:110-114) -- at several pool sizes up to
+    every usable core.  Returns (json dict, {read index: expected string}) for the later comparison."""
+    import oracle
+    oracle.build()
+    n = len(refs)
+    want = {}
+    k = min(args.cpu_sample, n)
+    tc = time.perf_counter()
+    got, _ = oracle.align_batch(refs[:k], seqs[:k], cigs[:k], sub, nps, max_b_rows=args.max_b_rows, r=args.r)
+    dt1 = time.perf_counter() - tc
+    want.update(enumerate(got))
+    hc = host_cpus()
+    cpu = {"value": round(k / dt1, 3), "unit": "reads/s", "cores": 1, "kind": "port",
+           "sample": f"first {k} reads of the same batch, oracle/npore_oracle.c single thread, "
+                     f"every string compared with the GPU output",
+           "host": {kk: hc[kk] for kk in ("cpu_count", "affinity", "cgroup_cpus")}}
+    # k = Cython / port, measured in the build container where the reference can be compiled
+    kfile = os.path.join(REPO, "tests", "golden", "k_cython_over_port.json")
+    kval = None
+    if os.path.exists(kfile):
+        kj = json.load(open(kfile))["by_r"]
+        rk = min(kj, key=lambda q: abs(int(q) - args.r))
+        kval = float(kj[rk]["k"])
+        cpu["k_cython_over_port"] = {"k": kval, "measured_at_r": int(rk), "source": "tests/golden/k_cython_over_port.json "
+                                     "(tests/golden/measure_k.py, build container: reference Cython vs this port, same reads)"}
+        cpu["cython_equivalent"] = {"value": round(k / dt1 * kval, 3), "unit": "reads/s", "cores": 1}
+    if args.cpu_threads != 1:
+        state_bytes = 60 * (args.max_b_rows + 1) * (2 * args.r + 1)     # the reference's / the port's state matrix per worker
+        avail = host_mem_available()
+        cap = hc["usable"] if args.cpu_threads <= 0 else min(args.cpu_threads, hc["usable"])
+        if avail:
+            cap = max(1, min(cap, int(0.6 * avail // max(1, state_bytes))))
+        sizes = sorted({p for p in (16, 32, 64, 128, 256, 512) if p < cap} | {cap})
+        if args.cpu_threads > 1:
+            sizes = [cap]
+        sweep = []
+        for p in sizes:
+            m = min(n, max(128, 4 * p))
+            tc = time.perf_counter()
+            got, _ = oracle.align_batch_procs(refs[:m], seqs[:m], cigs[:m], sub, nps, p,
+                                              max_b_rows=args.max_b_rows, r=args.r)
+            dt = time.perf_counter() - tc
+            want.update(enumerate(got))
+            sweep.append({"procs": p, "reads": m, "value": round(m / dt, 2)})
+            if time.perf_counter() - tc > 40:      # bounded: never more than a couple of slow points
+                break
+        best = max(sweep, key=lambda e: e["value"])
+        cpu["all_reads"] = {"value": best["value"], "unit": "reads/s", "cores": best["procs"],
+                            "sample": f"first {best['reads']} reads of the batch on a pool of {best['procs']} worker processes "
+                                      f"(the reference's own parallelism; each worker holds a {state_bytes >> 20} MB state matrix); "
+                                      f"best of the pool sizes in `sweep`, every string compared with the GPU output",
+                            "sweep": sweep}
+        if kval is not None:
+            cpu["all_reads"]["cython_equivalent"] = round(best["value"] * kval, 2)
+    return cpu, want
 
 
 def main():
@@ -72,9 +199,12 @@ def main():
     ap.add_argument("--unique", type=int, default=0,
                     help="generate only this many distinct reads and repeat them to --reads (0 = all distinct)")
     ap.add_argument("--cpu-sample", type=int, default=64, help="reads timed on one host core with the oracle (~10 s)")
-    ap.add_argument("--cpu-threads", type=int, default=32,
-                    help="worker processes for the whole-batch CPU run (each holds a 241 MB state matrix at r=100; 0/1 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="whole-host CPU leg: 0 = sweep pool sizes up to every usable core (memory permitting), "
+                         "1 = skip, N > 1 = that many worker processes only")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--pcie-steps", type=int, default=3, help="steps of the host-buffer (PCIe-inclusive) leg; 0 = skip")
+    ap.add_argument("--sustain", type=float, default=5.0, help="seconds of the sustained device-resident leg; 0 = skip")
     ap.add_argument("--tb-kernel", type=int, default=0,
                     help="traceback kernel: 0 = chosen by batch size, 1 = windowed, 2 = row per hop (experiments)")
     ap.add_argument("--inflight", type=int, default=1,
@@ -85,36 +215,50 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
 
-    # ---- synthetic batch for this rank (reads rank, rank+world, ... : round-robin by index), generated
-    # before anything touches the GPU so that large batches can use a forked worker pool
-    from npore_amd import synth
+    # ---- 1. synthetic batch for this rank (reads rank, rank+world, ... : round-robin by index)
+    from npore_amd import synth, aln
     n = args.reads
     n_uniq = min(args.unique, n) if args.unique > 0 else n
     refs, seqs, cigs = make_reads(synth, args, n_uniq, rank, world)
     if n_uniq < n:
         rep = [k % n_uniq for k in range(n)]
         refs = [refs[k] for k in rep]; seqs = [seqs[k] for k in rep]; cigs = [cigs[k] for k in rep]
+    sub, nps, _, _ = aln.load_default_tables()
+
+    # ---- 2. CPU baseline (forked pools: before the HIP runtime exists in this process)
+    cpu, cpu_want = None, {}
+    if rank == 0 and world == 1 and not args.no_cpu:      # reported at N=1 only
+        cpu, cpu_want = cpu_baseline(args, refs, seqs, cigs, sub, nps)
 
     import torch
-    from npore_amd import _lib, aln
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        sys.exit(2)
-    if not torch.cuda.is_available():
+    from npore_amd import _lib
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0 or not torch.cuda.is_available():
         print("bench.py: no GPU visible (the HIP path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    # one rank per GPU; on a box with fewer GPUs than ranks (rehearsing the N > 1 path on one card) ranks share
+    # devices, and the counter reduction then goes over gloo: RCCL needs one device per rank
+    dev_index = local % n_dev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ    # launched by torch.distributed.run
+    backend = None
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)                 # "nccl" is RCCL on ROCm
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        backend = "nccl" if local_world <= n_dev else "gloo"           # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
-    sub, nps, _, _ = aln.load_default_tables()
     n_ctx = max(1, args.inflight)
-    ctxs = [aln.Context(sub, nps, max_n=6, max_l=100, device=local) for _ in range(n_ctx)]
+    ctxs = [aln.Context(sub, nps, max_n=6, max_l=100, device=dev_index) for _ in range(n_ctx)]
     ctx = ctxs[0]
     if args.tb_kernel:
         for c in ctxs:
@@ -178,6 +322,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- 3. the timed region: W warm-up steps, then exactly K steps between barriers
     torch.cuda.synchronize()     # the library's streams are not ordered with torch's: inputs / zero-fills are complete
     warmup = max(args.warmup, n_ctx) if args.warmup else 0        # every context warmed up (buffers allocated)
     run_steps(warmup)
@@ -193,15 +338,71 @@ def main():
     # the only collective of the job: sum of counters, max of the elapsed time
     from npore_amd.dist import reduce_counters
     sums, maxes = reduce_counters({"reads": n * args.steps, "bad": int(sum((o[2] != 0).sum().item() for o in outs))},
-                                  {"elapsed": elapsed}, device=dev)
+                                  {"elapsed": elapsed}, device=dev if backend == "nccl" else None)
     elapsed = maxes["elapsed"]
     n_bad = int(sums["bad"])
     total_reads = int(sums["reads"])
     assert total_reads == n * world * args.steps
     value = total_reads / elapsed
+    out_len = d_len.cpu().numpy()
+    out_host = d_out.cpu().numpy()
+
+    # ---- 4. PCIe-inclusive: the same batch through the host-buffer entry point, pinned host memory both ways
+    pcie = None
+    if args.pcie_steps > 0:
+        pin = lambda a: torch.from_numpy(a).pin_memory()
+        p_rb, p_sb, p_cb = pin(rb), pin(sb), pin(cb)
+        p_out = torch.zeros(int(oo[-1]) + 64, dtype=torch.uint8).pin_memory()
+        p_len = torch.zeros(n, dtype=torch.int64).pin_memory()
+        p_st = torch.zeros(n, dtype=torch.int32).pin_memory()
+
+        def host_step():
+            rc = lib.npore_align_batch(ctx.handle, n, p_rb.data_ptr(), ro.ctypes.data, p_sb.data_ptr(), so.ctypes.data,
+                                       p_cb.data_ptr(), co.ctypes.data, 5.0, 1.0, args.max_b_rows, args.r,
+                                       p_out.data_ptr(), oo.ctypes.data, p_len.data_ptr(), p_st.data_ptr())
+            if rc != 0:
+                raise RuntimeError(f"npore_align_batch: {rc} {_lib.last_error()}")
+            return ctx.timing()
+        host_step()                                   # warm-up: staging buffers allocated
+        barrier()
+        tp = time.perf_counter()
+        tms = [host_step() for _ in range(args.pcie_steps)]
+        barrier()
+        dtp = time.perf_counter() - tp
+        _, mx = reduce_counters({}, {"e": dtp}, device=dev if backend == "nccl" else None)
+        dtp = mx["e"]
+        assert np.array_equal(p_len.numpy(), out_len) and np.array_equal(p_out.numpy()[:int(oo[-1])], out_host[:int(oo[-1])]), \
+            "host-buffer entry point and device-resident entry point disagree"
+        pcie = {"value": round(n * world * args.pcie_steps / dtp, 1), "unit": "reads/s", "steps": args.pcie_steps,
+                "ms_per_step": round(dtp / args.pcie_steps * 1e3, 2),
+                "h2d_ms": round(float(np.mean([x["h2d_ms"] for x in tms])), 3),
+                "d2h_ms": round(float(np.mean([x["d2h_ms"] for x in tms])), 3),
+                "h2d_bytes": int(ro[-1] + so[-1] + co[-1] + 4 * 8 * (n + 1)), "d2h_bytes": int(oo[-1] + 12 * n),
+                "note": "npore_align_batch on page-locked host buffers: H2D of bases + CIGARs, the whole path, D2H of the strings"}
+
+    # ---- 5. sustained leg
+    sustained = None
+    if args.sustain > 0:
+        per = max(1, args.steps)
+        barrier()
+        ts = time.perf_counter()
+        done = 0
+        while True:
+            run_steps(per)
+            done += per
+            torch.cuda.synchronize()
+            go = torch.tensor([1.0 if time.perf_counter() - ts < args.sustain else 0.0], dtype=torch.float64)
+            if use_dist:      # every rank stops after the same number of steps
+                go = go.to(dev) if backend == "nccl" else go
+                dist.all_reduce(go, op=dist.ReduceOp.MAX)
+            if float(go.item()) == 0.0:
+                break
+        barrier()
+        dts = time.perf_counter() - ts
+        _, mx = reduce_counters({}, {"e": dts}, device=dev if backend == "nccl" else None)
+        sustained = {"seconds": round(mx["e"], 2), "steps": done, "value": round(n * world * done / mx["e"], 1), "unit": "reads/s"}
 
     # ---- roofline of the dominant kernel (fill): algorithmic bytes per launch / measured duration
-    out_len = d_len.cpu().numpy()
     W = 2 * args.r + 1
     bytes_alg = sum(4 * (len(s) + len(r_) + 1) * W + 2 * (len(s) + len(r_)) + int(ol)
                     for s, r_, ol in zip(seqs, refs, out_len))
@@ -210,54 +411,62 @@ def main():
         assert np.array_equal(out_len, out_len[np.arange(n) % n_uniq]), "copies of one read differ in length"
         for k in np.random.default_rng(0).integers(n_uniq, n, 256):
             a, b = int(oo[k]), int(oo[k % n_uniq])
-            assert torch.equal(d_out[a:a + int(out_len[k])], d_out[b:b + int(out_len[k])]), "copies of one read differ"
+            assert np.array_equal(out_host[a:a + int(out_len[k])], out_host[b:b + int(out_len[k])]), "copies of one read differ"
     fill_avg_ms = float(np.mean(fill_ms))
     achieved = bytes_alg / (fill_avg_ms * 1e-3) / 1e9
-    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same default command
-    # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, KB -> bytes); null for other workloads
-    traffic = None
-    prof = os.path.join(REPO, "profiles", "r01_fill_pmc_summary.json")
-    if (n, args.ref_len, args.r, args.max_b_rows, args.base_seed) == (1000, 10_000, 100, 20000, 2) and os.path.exists(prof):
+    shape = ctx.fill_shape(args.r)
+    rows_total = sum(len(s) + len(r_) + 1 for s, r_ in zip(seqs, refs))
+    try:
+        clock_ghz = torch.cuda.get_device_properties(dev).clock_rate / 1e6
+    except AttributeError:
+        clock_ghz = 2.4
+    # the kernel's own ceiling: a chunk is a chain of dependent anti-diagonals; `resident_chunks` of them advance
+    # side by side, so kernel time ~ (sum of rows / resident chunks) x time per anti-diagonal
+    ns_per_row = fill_avg_ms * 1e6 * min(shape["resident_chunks"], max(1, n)) / max(1, rows_total)
+    practical = {"ns_per_antidiagonal": round(ns_per_row, 1), "cycles_per_antidiagonal": round(ns_per_row * clock_ghz, 0),
+                 "waves_per_chunk": shape["waves_per_chunk"], "resident_waves_per_cu": shape["resident_waves_per_cu"],
+                 "resident_chunks": shape["resident_chunks"], "lds_bytes_per_workgroup": shape["lds_bytes"],
+                 "clock_ghz": round(clock_ghz, 3)}
+    # PMC-derived figures (HBM traffic, VALU instructions per launch) cannot be collected from inside this
+    # process; they come from the committed rocprofv3 --pmc summary of this same default command, and only while
+    # that summary was taken from the kernel sources this library was built from (csrc digest); else null
+    traffic, valu, pmc_src = None, None, None
+    prof = os.path.join(REPO, "profiles", "r02_fill_pmc_summary.json")
+    if os.path.exists(prof):
         pm = json.load(open(prof))
-        traffic = int((2 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024)
+        same_cmd = (n, args.ref_len, args.r, args.max_b_rows, args.base_seed, args.mixed) == \
+                   (pm.get("reads"), pm.get("ref_len"), pm.get("r"), pm.get("max_b_rows"), pm.get("base_seed"), bool(pm.get("mixed")))
+        if same_cmd and pm.get("csrc_sha") == csrc_sha():
+            traffic = int((2 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024)      # gfx950: FETCH_SIZE counts 64 B as 32
+            insts = float(pm["SQ_INSTS_VALU"])
+            peak = N_SIMD * clock_ghz / 4.0                                       # G wave-instructions / s
+            ach = insts / (fill_avg_ms * 1e-3) / 1e9
+            wave_steps = float(pm.get("wave_steps") or 0)
+            valu = {"bound": "valu_issue", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
+                    "frac": round(ach / peak, 4), "insts_valu_per_launch": int(insts),
+                    "valu_per_wave_step": round(insts / wave_steps, 1) if wave_steps else None}
+            pmc_src = f"profiles/r02_fill_pmc_summary.json (csrc {pm['csrc_sha']})"
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "kernel": "fill_kernel", "kernel_ms": round(fill_avg_ms, 3),
-                "bytes_alg_per_launch": int(bytes_alg)}
+                "bytes_alg_per_launch": int(bytes_alg), "valu_issue": valu, "practical": practical, "pmc_source": pmc_src}
 
-    # ---- CPU baseline: the oracle (plain-C port of the reference DP), bounded sample of the same batch:
-    # one host core on the first --cpu-sample reads, then --cpu-threads cores on the whole batch (every read is
-    # independent: the reference's own parallelism is a process pool over reads); every string is compared
-    # with the GPU output
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:      # reported at N=1 only
-        import oracle
-        oracle.build()
-        out_host = d_out.cpu().numpy()
-        n_chk = min(n, max(args.cpu_sample, 10_000_000 // max(1, args.ref_len)))
-        got_all = [out_host[oo[i]:oo[i] + out_len[i]].tobytes().decode() for i in range(n_chk)]
-        k = min(args.cpu_sample, n)
-        tc = time.perf_counter()
-        want, st = oracle.align_batch(refs[:k], seqs[:k], cigs[:k], sub, nps, max_b_rows=args.max_b_rows, r=args.r)
-        dt1 = time.perf_counter() - tc
-        if got_all[:k] != want:
-            raise RuntimeError("bench.py: GPU output differs from the oracle on the CPU sample")
-        cpu = {"value": round(k / dt1, 3), "unit": "reads/s", "cores": 1, "kind": "port",
-               "sample": f"first {k} reads of the same batch, oracle/npore_oracle.c single thread, "
-                         f"checked equal to the GPU output; host has {os.cpu_count()} cores"}
-        nt = min(args.cpu_threads, os.cpu_count() or 1)
-        if nt > 1:
-            tc = time.perf_counter()
-            # bounded: about 10 M bases of reads (1 000 reads of 10 kb) keep this leg within ~15 s
-            m = max(1, min(n, 10_000_000 // max(1, args.ref_len)))
-            want, st = oracle.align_batch_procs(refs[:m], seqs[:m], cigs[:m], sub, nps, nt,
-                                                max_b_rows=args.max_b_rows, r=args.r)
-            dtn = time.perf_counter() - tc
-            if got_all[:m] != want:
-                raise RuntimeError("bench.py: GPU output differs from the oracle on the whole batch")
-            cpu["all_reads"] = {"value": round(m / dtn, 2), "unit": "reads/s", "cores": nt,
-                                "sample": f"{'all' if m == n else 'first'} {m} reads of the batch on {nt} worker processes (the reference's own "
-                                          f"parallelism: a pool over reads), every string equal to the GPU output"}
+    # ---- 6. every CPU string against the GPU's
+    if cpu is not None:
+        for i, w in cpu_want.items():
+            g = out_host[oo[i]:oo[i] + out_len[i]].tobytes().decode()
+            if g != w:
+                raise RuntimeError(f"bench.py: GPU output differs from the oracle on read {i}")
+        cpu["strings_compared"] = len(cpu_want)
+        base1 = cpu["value"]
+        sp = {"vs_port_1core": round(value / base1, 1)}
+        if "all_reads" in cpu:
+            sp["vs_port_all_cores"] = round(value / cpu["all_reads"]["value"], 1)
+        if "cython_equivalent" in cpu:
+            sp["vs_cython_equivalent_1core"] = round(value / cpu["cython_equivalent"]["value"], 1)
+            if "all_reads" in cpu:
+                sp["vs_cython_equivalent_all_cores"] = round(value / cpu["all_reads"]["cython_equivalent"], 1)
+        cpu["gpu_speedup"] = sp
 
     if rank == 0:
         line = {
@@ -270,8 +479,10 @@ def main():
                                    f"(SURVEY 8d generator{', mixed p_np' if args.mixed else ''}, base_seed={args.base_seed}"
                                    f"{f', {n_uniq} distinct reads repeated' if n_uniq < n else ''})",
                        "reads_per_gpu": n, "ref_len": args.ref_len, "r": args.r, "parallelism": f"reads x{world}",
-                       "batches_in_flight": n_ctx},
+                       "batches_in_flight": n_ctx, "devices_visible": n_dev,
+                       "reduction_backend": {"nccl": "rccl", "gloo": "gloo (ranks share a device)", None: "none"}[backend]},
             "roofline": roofline, "cpu_baseline": cpu,
+            "value_pcie_inclusive": pcie, "sustained": sustained,
             "stage_ms": {"fill": round(fill_avg_ms, 2), "traceback_gather": round(float(np.mean(tb_ms)), 2),
                          "prep": round(float(np.mean(prep_ms)), 2)},
             "bad_reads": n_bad,
@@ -279,7 +490,8 @@ def main():
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()
-    ctx.close()
+    for c in ctxs:
+        c.close()
 
 
 if __name__ == "__main__":

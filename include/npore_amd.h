@@ -63,7 +63,11 @@ int npore_device_count(void);
  *   sub_scores f32[5][5], np_scores f32[max_n][max_l+1][max_l+1]: the outputs of
  *   calc_score_matrices (reference src/aln.pyx:62-96), which align() receives as
  *   arguments (src/aln.pyx:380).  max_n/max_l replace the reads of
- *   cfg.args.max_n / cfg.args.max_l (src/aln.pyx:436-437).
+ *   cfg.args.max_n / cfg.args.max_l (src/aln.pyx:436-437).  Limits: 1 <= max_n <= 6, 2 <= max_l <= 127.
+ *   sub_scores == np_scores == NULL makes an annotation-only context: npore_get_np_info and
+ *   npore_np_regions work on it (the reference's get_np_info takes no tables, src/aln.pyx:179;
+ *   its callers src/bed.py:62 and src/bam.pyx:381 never call align() first), the align entry
+ *   points return NPORE_E_INVALID.
  * Returns NULL on failure.
  */
 npore_ctx *npore_ctx_create(const float *sub_scores, const float *np_scores,
@@ -110,7 +114,9 @@ int npore_align_batch_device(npore_ctx *ctx, int64_t n_reads,
 
 /*
  * get_np_info (reference src/aln.pyx:179-251): n-polymer annotation of one
- * sequence.  out is int32[len][2][max_n] ([pos][0=L,1=L_IDX][n-1]).
+ * sequence (len < 2^30).  out is int32[len][2][max_n] ([pos][0=L,1=L_IDX][n-1]).
+ * One kernel launch per period over as many workgroups as the sequence has
+ * 64-base windows; work buffers are kept in the context.
  */
 int npore_get_np_info(npore_ctx *ctx, const uint8_t *seq, int64_t len, int32_t *out);
 
@@ -154,9 +160,8 @@ int npore_standardize_ops_batch(int64_t n_reads, const char *alns, const int64_t
  */
 int npore_last_timing(npore_ctx *ctx, double *ms, int n);
 
-/* Tunables: key in {"tb_budget_mb","force_chunks","traceback_kernel","host_threads"} (traceback budget in MiB,
- * chunks per workgroup, 1 = windowed / 2 = row-per-hop traceback; 0 = automatic).  "force_nw" / "force_ng" are still accepted with their automatic values
- * (0, resp. 0 or 1): waves per chunk follow from the band width, one band column per lane is the only layout. */
+/* Tunables: key in {"tb_budget_mb","force_chunks","traceback_kernel"} (traceback budget in MiB,
+ * chunks per workgroup, 1 = windowed / 2 = row-per-hop traceback; 0 = automatic). */
 int npore_ctx_set(npore_ctx *ctx, const char *key, int64_t value);
 
 /* Batch sizing.  The DP of a chunk (at most max_b_rows anti-diagonals of a read; reference src/aln.pyx:344-358,
@@ -167,6 +172,10 @@ int npore_ctx_set(npore_ctx *ctx, const char *key, int64_t value);
  * Returns the chunks per round, 0 for a band the kernels do not cover (r > 255).  Replaces nothing in the
  * reference (its pool has no such granularity, src/realign.py:110-114). */
 int64_t npore_round_chunks(npore_ctx *ctx, int r);
+/* Launch geometry of the fill kernel at band half-width r, for reports (bench.py's "practical bound"):
+ * out[0] wavefronts per chunk, [1] chunks per workgroup, [2] workgroups per CU, [3] workgroups resident on the
+ * GPU, [4] LDS bytes per workgroup (up to n entries are written). */
+int npore_fill_shape(npore_ctx *ctx, int r, int32_t *out, int n);
 
 /* ---------------------------------------------------------------------------------------------
  * BAM ingest / SAM emit around the batched align(): the host side of realign_read

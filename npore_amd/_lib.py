@@ -35,6 +35,7 @@ SIGNATURES = {
     "npore_last_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "npore_ctx_set": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "npore_round_chunks": (C.c_int64, [C.c_void_p, C.c_int]),
+    "npore_fill_shape": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "npore_bam_open": (C.c_void_p, [C.c_char_p, C.c_int]),
     "npore_bam_close": (None, [C.c_void_p]),
     "npore_bam_n_records": (C.c_int64, [C.c_void_p]),

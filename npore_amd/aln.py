@@ -16,7 +16,8 @@ import numpy as np
 
 from . import _lib, cfg
 
-_CTX = {}   # (device, tables id) -> Context
+_CTX = {}      # (device, max_n, max_l, digest of the tables) -> Context: one live table set at a time
+_NP_CTX = {}   # (device, max_n, max_l) -> annotation-only Context (get_np_info before any align())
 
 
 class NporeError(RuntimeError):
@@ -43,19 +44,30 @@ def device_count():
 
 
 class Context:
-    """One per GPU: owns the device copy of the penalty tables and work buffers."""
+    """One per GPU: owns the device copy of the penalty tables and work buffers.
+    sub_scores = np_scores = None makes an annotation-only context (get_np_info / np_regions)."""
 
     def __init__(self, sub_scores, np_scores, max_n=None, max_l=None, device=0):
         self.lib = _lib.load()
         self.max_n = int(cfg.args.max_n if max_n is None else max_n)
         self.max_l = int(cfg.args.max_l if max_l is None else max_l)
-        sub = np.ascontiguousarray(sub_scores, dtype=np.float32)
-        nps = np.ascontiguousarray(np_scores, dtype=np.float32)
-        if sub.shape != (5, 5):
-            raise ValueError("sub_scores must be float32[5,5]")
-        if nps.shape != (self.max_n, self.max_l + 1, self.max_l + 1):
-            raise ValueError(f"np_scores must be float32[{self.max_n},{self.max_l + 1},{self.max_l + 1}]")
-        self.handle = self.lib.npore_ctx_create(sub.ctypes.data, nps.ctypes.data, self.max_n, self.max_l, device)
+        if sub_scores is None and np_scores is None:
+            self.handle = self.lib.npore_ctx_create(None, None, self.max_n, self.max_l, device)
+        else:
+            sub = np.ascontiguousarray(sub_scores, dtype=np.float32)
+            nps = np.asarray(np_scores, dtype=np.float32)
+            if sub.shape != (5, 5):
+                raise ValueError("sub_scores must be float32[5,5]")
+            want = (self.max_n, self.max_l + 1, self.max_l + 1)
+            if nps.ndim == 3 and all(a >= b for a, b in zip(nps.shape, want)):
+                # the reference hands align() the shipped [6,101,101] table whatever --max_n / --max_l say and
+                # np_score clamps its indices at max_l - 1 (src/aln.pyx:257-274 as called): the part beyond
+                # [max_n, max_l+1, max_l+1] is never read
+                nps = nps[:want[0], :want[1], :want[2]]
+            if nps.shape != want:
+                raise ValueError(f"np_scores must be float32[{want[0]},{want[1]},{want[2]}] (or larger)")
+            nps = np.ascontiguousarray(nps)
+            self.handle = self.lib.npore_ctx_create(sub.ctypes.data, nps.ctypes.data, self.max_n, self.max_l, device)
         if not self.handle:
             raise NporeError(f"npore_ctx_create failed: {_lib.last_error()}")
         self.device = device
@@ -78,6 +90,15 @@ class Context:
         """Chunks (units of at most max_b_rows anti-diagonals) the GPU works on at a time at band half-width r:
         batches whose full-size chunks fill whole rounds run at the best rate (include/npore_amd.h)."""
         return int(self.lib.npore_round_chunks(self.handle, int(r)))
+
+    def fill_shape(self, r=30):
+        """Launch geometry of the fill kernel at band half-width r (npore_fill_shape)."""
+        v = (C.c_int32 * 5)()
+        _check(self.lib.npore_fill_shape(self.handle, int(r), v, 5))
+        nw, cpg, wg_cu, res_wg, lds = list(v)
+        return {"waves_per_chunk": nw, "chunks_per_workgroup": cpg, "workgroups_per_cu": wg_cu,
+                "resident_workgroups": res_wg, "resident_chunks": res_wg * cpg,
+                "resident_waves_per_cu": nw * cpg * wg_cu, "lds_bytes": lds}
 
     def timing(self):
         t = (C.c_double * 8)()
@@ -146,13 +167,22 @@ class Context:
 
 
 def _context_for(sub_scores, np_scores, device=0):
-    key = (device, id(sub_scores), id(np_scores), int(cfg.args.max_n), int(cfg.args.max_l))
+    """The context holding these tables: keyed on their CONTENT (a caller that rebuilds equal arrays per call,
+    as src/bam.pyx does per process, keeps its context; 245 KB hash per call, ~0.1 ms)."""
+    import hashlib
+    h = hashlib.blake2b(digest_size=16)
+    for a in (sub_scores, np_scores):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        h.update(repr(a.shape).encode())
+        h.update(a.data)
+    key = (device, int(cfg.args.max_n), int(cfg.args.max_l), h.digest())
     ctx = _CTX.get(key)
     if ctx is None:
         ctx = Context(sub_scores, np_scores, device=device)
-        _CTX.clear()          # one live table set at a time, like cfg.args.*_scores
+        for old in _CTX.values():     # one live table set at a time, like cfg.args.*_scores
+            old.close()
+        _CTX.clear()
         _CTX[key] = ctx
-        ctx._keepalive = (sub_scores, np_scores)
     return ctx
 
 
@@ -171,10 +201,14 @@ def align(full_ref, full_seq, cigar, sub_scores, np_scores, indel_start=5, indel
 
 
 def get_np_info(seq):
-    """Reference src/aln.pyx:179-251: int32 [len(seq), 2, max_n], [pos, L=0 / L_IDX=1, n-1]."""
-    if not _CTX:
-        raise NporeError("get_np_info() needs a context: call align()/Context() first, or Context.get_np_info")
-    return next(iter(_CTX.values())).get_np_info(seq)
+    """Reference src/aln.pyx:179-251: int32 [len(seq), 2, max_n], [pos, L=0 / L_IDX=1, n-1].
+    Needs no tables and no prior align() (callers: src/bed.py:62, src/bam.pyx:381): it runs on an
+    annotation-only context for the current cfg.args.max_n / max_l, made on first use."""
+    key = (0, int(cfg.args.max_n), int(cfg.args.max_l))
+    ctx = _NP_CTX.get(key)
+    if ctx is None:
+        ctx = _NP_CTX[key] = Context(None, None, device=0)
+    return ctx.get_np_info(seq)
 
 
 def fix_matrix_properties(scores, delta=0.01):

@@ -381,13 +381,17 @@ class NativeBam:
         rid = np.array([ids.get(c, -2) for c, _, _ in regions], np.int32)
         beg = np.array([s for _, s, _ in regions], np.int64)
         end = np.array([e for _, _, e in regions], np.int64)
-        out = np.zeros(max(self.n_records * max(len(regions), 1), 1), np.int64)
-        k = self._lib.npore_bam_select(self.handle, len(regions), rid.ctypes.data, beg.ctypes.data, end.ctypes.data,
-                                       int(max_reads or 0), out.ctypes.data, len(out))
+        # two calls: the count first (cap = 0 writes nothing), then exactly that many entries -- a read overlapping
+        # several regions is listed once per region, so n_records * n_regions is the only a-priori bound
+        args = (self.handle, len(regions), rid.ctypes.data, beg.ctypes.data, end.ctypes.data, int(max_reads or 0))
+        k = self._lib.npore_bam_select(*args, None, 0)
         if k < 0:
             from . import _lib
             raise RuntimeError(_lib.last_error())
-        return out[:k].copy()
+        out = np.zeros(max(int(k), 1), np.int64)
+        k2 = self._lib.npore_bam_select(*args, out.ctypes.data, len(out))
+        assert k2 == k
+        return out[:k]
 
     def fasta_map(self, fasta):
         """int32[n_refs]: index of each BAM reference in the FASTA (-1 if absent)."""

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <future>
+#include <memory>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -30,6 +31,13 @@ int fail(int code, const std::string &msg)
     g_err = msg;
     return code;
 }
+// No C++ exception may cross the C ABI: the entry points that allocate are function-try-blocks ending in one of these.
+#define NPORE_CATCH_INT                                                                             \
+    catch (const std::bad_alloc &) { return fail(NPORE_E_NOMEM, "out of host memory"); }           \
+    catch (const std::exception &e) { return fail(NPORE_E_INVALID, std::string("internal: ") + e.what()); }
+#define NPORE_CATCH_PTR                                                                             \
+    catch (const std::bad_alloc &) { fail(NPORE_E_NOMEM, "out of host memory"); return nullptr; }  \
+    catch (const std::exception &e) { fail(NPORE_E_INVALID, std::string("internal: ") + e.what()); return nullptr; }
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
@@ -108,7 +116,7 @@ struct npore_ctx {
     int max_n = 6, max_l = 100;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
-    float *d_sub = nullptr, *d_np = nullptr;
+    float *d_sub = nullptr, *d_np = nullptr;   // NULL in an annotation-only context (created without tables)
     // tunables
     int64_t tb_budget_mb = 0;   // 0 = auto
     int tb_kernel = 0;          // 0 = by batch size, 1 = windowed traceback, 2 = row per hop
@@ -133,6 +141,8 @@ struct npore_ctx {
 };
 
 namespace {
+
+std::atomic<int> g_live_ctx[16];   // contexts alive per device (they share its memory: run_core's budget)
 
 // waves per chunk: the smallest count whose 64 * nw lanes cover the band (the kernel relies on band
 // column 2r lying in the last wave); 0 if the band is too wide
@@ -447,6 +457,7 @@ int collect_group_timing(npore_ctx *ctx, int64_t cells)
 int run_core(npore_ctx *ctx, const AlignArgs &a, const OutTarget &ot, hipStream_t s)
 {
     if (a.n_reads < 0) return fail(NPORE_E_INVALID, "n_reads < 0");
+    if (!ctx->d_sub || !ctx->d_np) return fail(NPORE_E_INVALID, "this context was created without penalty tables (annotation only)");
     if (a.r < 1) return fail(NPORE_E_INVALID, "r must be >= 1");
     if (a.max_b_rows < 2) return fail(NPORE_E_INVALID, "max_b_rows must be >= 2");
     if (a.max_b_rows > 60000)
@@ -456,24 +467,37 @@ int run_core(npore_ctx *ctx, const AlignArgs &a, const OutTarget &ot, hipStream_
     std::fill(ctx->timing, ctx->timing + 8, 0.0);
     if (a.n_reads == 0) return NPORE_OK;
 
-    // groups of consecutive reads whose traceback words fit the budget
+    // groups of consecutive reads whose traceback words fit the budget.  The automatic budget is this context's
+    // share of the device (contexts of one device run side by side: the file pipeline's peer, bench --inflight):
+    // 60 % of the memory divided by the live contexts, and never more than what is free now plus what this
+    // context already holds.
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const int64_t budget = ctx->tb_budget_mb > 0 ? ctx->tb_budget_mb * (int64_t)1048576
-                                                 : (int64_t)((double)(free_b + ctx->tb.cap) * 0.6);
+    const int live = std::max(1, g_live_ctx[ctx->device & 15].load());
+    const int64_t budget = ctx->tb_budget_mb > 0
+                               ? ctx->tb_budget_mb * (int64_t)1048576
+                               : (int64_t)std::min(0.6 * (double)total_b / live, 0.9 * (double)(free_b + ctx->tb.cap));
     const int tbs = tb_stride(a.r);
     int64_t g0 = 0;
+    int64_t max_group = a.n_reads;       // halved when a group's buffers do not fit after all
     while (g0 < a.n_reads) {
         int64_t g1 = g0, acc = 0, cells = 0;
-        while (g1 < a.n_reads) {
+        while (g1 < a.n_reads && g1 - g0 < max_group) {
             const int64_t cl = a.h_cig_off[g1 + 1] - a.h_cig_off[g1];
-            const int64_t need = (2 * cl + chunk_bound(cl, a.max_b_rows)) * tbs * 4;
+            // traceback words + the per-step / per-base side arrays (steps, inss, refw, refl, seqw, runs: < 48 B per op)
+            const int64_t need = (2 * cl + chunk_bound(cl, a.max_b_rows)) * tbs * 4 + 48 * cl;
             if (g1 > g0 && acc + need > budget) break;
             acc += need;
             cells += (a.h_seq_off[g1 + 1] - a.h_seq_off[g1] + a.h_ref_off[g1 + 1] - a.h_ref_off[g1] + 1) * (2 * a.r + 1);
             g1++;
         }
-        if (int rc = run_group(ctx, a, g0, g1, ot, s, shape)) return rc;
+        if (int rc = run_group(ctx, a, g0, g1, ot, s, shape)) {
+            if (rc == NPORE_E_NOMEM && g1 - g0 > 1) {          // another context got there first: smaller groups
+                max_group = (g1 - g0) / 2;
+                continue;
+            }
+            return rc;
+        }
         // work buffers are reused by the next group (and the events by its timing)
         HIP_TRY(hipStreamSynchronize(s));
         if (int rc = collect_group_timing(ctx, cells)) return rc;
@@ -506,9 +530,10 @@ int npore_device_count(void)
 }
 
 npore_ctx *npore_ctx_create(const float *sub_scores, const float *np_scores, int max_n, int max_l, int device_id)
-{
-    if (!sub_scores || !np_scores || max_n < 1 || max_n > MAX_PERIOD || max_l < 2 || max_l > 127) {   // repeat counts travel in 7-bit fields (layout.hpp, annotate planes)
-        fail(NPORE_E_INVALID, "npore_ctx_create: need tables, 1 <= max_n <= 6, 2 <= max_l <= 255");
+try {
+    const bool tables = sub_scores && np_scores;
+    if ((!tables && (sub_scores || np_scores)) || max_n < 1 || max_n > MAX_PERIOD || max_l < 2 || max_l > 127) {   // repeat counts travel in 7-bit fields (layout.hpp, annotate planes)
+        fail(NPORE_E_INVALID, "npore_ctx_create: need both tables (or neither: annotation-only context), 1 <= max_n <= 6, 2 <= max_l <= 127");
         return nullptr;
     }
     int n = 0;
@@ -523,18 +548,21 @@ npore_ctx *npore_ctx_create(const float *sub_scores, const float *np_scores, int
         return nullptr;
     }
     auto *ctx = new npore_ctx();
+    g_live_ctx[device_id & 15]++;
     ctx->device = device_id;
     ctx->n_cus = pr.multiProcessorCount;
     ctx->max_n = max_n;
     ctx->max_l = max_l;
     const size_t np_elems = (size_t)max_n * (max_l + 1) * (max_l + 1);
-    ctx->h_sub.assign(sub_scores, sub_scores + 25);
-    ctx->h_np.assign(np_scores, np_scores + np_elems);
-    bool ok = hipSetDevice(device_id) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipMalloc((void **)&ctx->d_sub, 25 * sizeof(float)) == hipSuccess &&
-              hipMalloc((void **)&ctx->d_np, np_elems * sizeof(float)) == hipSuccess &&
-              hipMemcpy(ctx->d_sub, sub_scores, 25 * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(ctx->d_np, np_scores, np_elems * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+    bool ok = hipSetDevice(device_id) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
+    if (tables) {
+        ctx->h_sub.assign(sub_scores, sub_scores + 25);
+        ctx->h_np.assign(np_scores, np_scores + np_elems);
+        ok = ok && hipMalloc((void **)&ctx->d_sub, 25 * sizeof(float)) == hipSuccess &&
+             hipMalloc((void **)&ctx->d_np, np_elems * sizeof(float)) == hipSuccess &&
+             hipMemcpy(ctx->d_sub, sub_scores, 25 * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(ctx->d_np, np_scores, np_elems * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+    }
     for (auto &e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     if (!ok) {
         fail(NPORE_E_HIP, "npore_ctx_create: HIP initialisation failed");
@@ -543,10 +571,12 @@ npore_ctx *npore_ctx_create(const float *sub_scores, const float *np_scores, int
     }
     return ctx;
 }
+NPORE_CATCH_PTR
 
 void npore_ctx_destroy(npore_ctx *ctx)
 {
     if (!ctx) return;
+    g_live_ctx[ctx->device & 15]--;
     npore_ctx_destroy(ctx->peer);
     (void)hipSetDevice(ctx->device);
     for (DevBuf *b : {&ctx->in_refs, &ctx->in_seqs, &ctx->in_cigs, &ctx->in_off, &ctx->rd_i32, &ctx->rd_i64, &ctx->tiles, &ctx->cwoff,
@@ -568,7 +598,7 @@ int npore_align_batch(npore_ctx *ctx, int64_t n_reads, const uint8_t *refs, cons
                       const uint8_t *seqs, const int64_t *seq_off, const char *cigars, const int64_t *cig_off,
                       float indel_start, float indel_extend, int max_b_rows, int r, char *out,
                       const int64_t *out_off, int64_t *out_len, int32_t *status)
-{
+try {
     if (!ctx) return fail(NPORE_E_INVALID, "null context");
     if (n_reads < 0) return fail(NPORE_E_INVALID, "n_reads < 0");
     if (n_reads == 0) return NPORE_OK;
@@ -615,13 +645,14 @@ int npore_align_batch(npore_ctx *ctx, int64_t n_reads, const uint8_t *refs, cons
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7])); ctx->timing[4] = ms;
     return NPORE_OK;
 }
+NPORE_CATCH_INT
 
 int npore_align_batch_device(npore_ctx *ctx, int64_t n_reads, const uint8_t *d_refs, const int64_t *d_ref_off,
                              const uint8_t *d_seqs, const int64_t *d_seq_off, const char *d_cigars,
                              const int64_t *d_cig_off, float indel_start, float indel_extend, int max_b_rows,
                              int r, char *d_out, const int64_t *d_out_off, int64_t *d_out_len,
                              int32_t *d_status, void *stream, int sync)
-{
+try {
     if (!ctx) return fail(NPORE_E_INVALID, "null context");
     if (n_reads < 0) return fail(NPORE_E_INVALID, "n_reads < 0");
     if (n_reads == 0) return NPORE_OK;
@@ -645,47 +676,46 @@ int npore_align_batch_device(npore_ctx *ctx, int64_t n_reads, const uint8_t *d_r
     (void)sync;   // run_core synchronises the stream after every group (work buffers are shared)
     return run_core(ctx, a, ot, s);
 }
+NPORE_CATCH_INT
 
 int npore_get_np_info(npore_ctx *ctx, const uint8_t *seq, int64_t len, int32_t *out)
-{
+try {
     if (!ctx || (len > 0 && (!seq || !out))) return fail(NPORE_E_INVALID, "null argument");
     if (len <= 0) return NPORE_OK;
     if (len > (1ll << 30)) return fail(NPORE_E_UNSUPPORTED, "sequence too long");
     HIP_TRY(hipSetDevice(ctx->device));
     const int mn = ctx->max_n;
-    DevBuf dseq, dent, dL, dI;
     const int pstride = (int)((len + 15) & ~(int64_t)15);
-    int rc = dseq.ensure(len + 16);
-    if (!rc) rc = dent.ensure((size_t)pstride * 7 + 16);
-    if (!rc) rc = dL.ensure((size_t)len * mn * 4);
-    if (!rc) rc = dI.ensure((size_t)len * mn * 4);
-    std::vector<int32_t> L((size_t)len * mn), I((size_t)len * mn);
-    hipError_t e = hipSuccess;
-    if (!rc) {
-        e = hipMemcpy(dseq.p, seq, len, hipMemcpyHostToDevice);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(np_info_kernel, dim3(1), dim3(1024), 0, ctx->stream, dseq.as<uint8_t>(), (int)len, mn,
-                               ctx->max_l, dent.as<uint8_t>(), pstride, dL.as<int32_t>(), dI.as<int32_t>());
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e == hipSuccess) e = hipMemcpy(L.data(), dL.p, L.size() * 4, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(I.data(), dI.p, I.size() * 4, hipMemcpyDeviceToHost);
-    }
-    dseq.release(); dent.release(); dL.release(); dI.release();
-    if (rc) return rc;
-    if (e != hipSuccess) return fail(NPORE_E_HIP, std::string("np_info: ") + hipGetErrorString(e));
-    for (int64_t p = 0; p < len; p++)
-        for (int n = 0; n < mn; n++) {
-            out[(p * 2 + 0) * mn + n] = L[p * mn + n];
-            out[(p * 2 + 1) * mn + n] = I[p * mn + n];
-        }
+    const size_t out_bytes = (size_t)len * 2 * mn * 4;
+    // work buffers of the align path are reused (nothing else runs on this context meanwhile): grow-only, kept
+    if (int rc = ctx->in_seqs.ensure((size_t)len + 16)) return rc;
+    if (int rc = ctx->seql.ensure((size_t)pstride * MAX_PERIOD + 16)) return rc;
+    if (int rc = ctx->out.ensure(out_bytes)) return rc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ctx->in_seqs.p, seq, (size_t)len, hipMemcpyHostToDevice, s));
+    const uint8_t *dseq = ctx->in_seqs.as<uint8_t>();
+    uint8_t *planes = ctx->seql.as<uint8_t>();
+    int32_t *L = ctx->out.as<int32_t>(), *I = L + mn;
+    // four waves of 64 positions per workgroup; enough workgroups for one window per wave, capped at a few per CU
+    const int64_t windows = (len + 63) / 64;
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((windows + 3) / 4, (int64_t)ctx->n_cus * 32));
+    const int ml = ctx->max_l, ilen = (int)len, os = 2 * mn;
+    if (mn >= 1) hipLaunchKernelGGL(np_info_period_kernel<1>, dim3(blocks), dim3(256), 0, s, dseq, ilen, mn, ml, planes, pstride, L, I, os);
+    if (mn >= 2) hipLaunchKernelGGL(np_info_period_kernel<2>, dim3(blocks), dim3(256), 0, s, dseq, ilen, mn, ml, planes, pstride, L, I, os);
+    if (mn >= 3) hipLaunchKernelGGL(np_info_period_kernel<3>, dim3(blocks), dim3(256), 0, s, dseq, ilen, mn, ml, planes, pstride, L, I, os);
+    if (mn >= 4) hipLaunchKernelGGL(np_info_period_kernel<4>, dim3(blocks), dim3(256), 0, s, dseq, ilen, mn, ml, planes, pstride, L, I, os);
+    if (mn >= 5) hipLaunchKernelGGL(np_info_period_kernel<5>, dim3(blocks), dim3(256), 0, s, dseq, ilen, mn, ml, planes, pstride, L, I, os);
+    if (mn >= 6) hipLaunchKernelGGL(np_info_period_kernel<6>, dim3(blocks), dim3(256), 0, s, dseq, ilen, mn, ml, planes, pstride, L, I, os);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, L, out_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return NPORE_OK;
 }
+NPORE_CATCH_INT
 
 int npore_np_regions(npore_ctx *ctx, const uint8_t *seqs, const int64_t *seq_off, int64_t n_slices, int64_t *counts,
                      const int32_t **pos, const int32_t **reps, int64_t *total)
-{
+try {
     if (!ctx || n_slices < 0 || (n_slices > 0 && (!seqs || !seq_off || !counts)) || !pos || !reps || !total)
         return fail(NPORE_E_INVALID, "null argument");
     *pos = *reps = nullptr;
@@ -742,6 +772,7 @@ int npore_np_regions(npore_ctx *ctx, const uint8_t *seqs, const int64_t *seq_off
     *total = tot;
     return NPORE_OK;
 }
+NPORE_CATCH_INT
 
 int npore_last_timing(npore_ctx *ctx, double *ms, int n)
 {
@@ -757,24 +788,34 @@ int64_t npore_round_chunks(npore_ctx *ctx, int r)
     return (int64_t)fill_round_workgroups(g, g.cmax, ctx->n_cus) * g.cmax;
 }
 
-int npore_ctx_set(npore_ctx *ctx, const char *key, int64_t value)
+int npore_fill_shape(npore_ctx *ctx, int r, int32_t *out, int n)
 {
+    FillGeom g;
+    if (!ctx || !out) return fail(NPORE_E_INVALID, "null argument");
+    if (!fill_geometry(r, g)) return fail(NPORE_E_UNSUPPORTED, "band half-width r > 255");
+    const size_t lds = fill_lds_floats(g.nw, g.cmax, g.hw, g.rwin) * sizeof(float);
+    const int wg_per_cu = std::max(1, std::min((int)((160 * 1024) / std::max<size_t>(lds, 1)), 2048 / (64 * g.nw * g.cmax)));
+    const int32_t v[5] = {g.nw, g.cmax, wg_per_cu, fill_round_workgroups(g, g.cmax, ctx->n_cus), (int32_t)lds};
+    for (int i = 0; i < n && i < 5; i++) out[i] = v[i];
+    return NPORE_OK;
+}
+
+int npore_ctx_set(npore_ctx *ctx, const char *key, int64_t value)
+try {
     if (!ctx || !key) return fail(NPORE_E_INVALID, "null argument");
     const std::string k(key);
     if (k == "tb_budget_mb") ctx->tb_budget_mb = value;
-    else if (k == "force_ng") { if (value > 1) return fail(NPORE_E_UNSUPPORTED, "one band column per lane is the only layout"); }
     else if (k == "force_chunks") ctx->force_chunks = (int)value;
     else if (k == "traceback_kernel") { if (value < 0 || value > 2) return fail(NPORE_E_INVALID, "traceback_kernel: 0, 1 or 2"); ctx->tb_kernel = (int)value; }
-    else if (k == "force_nw") { if (value > 0) return fail(NPORE_E_UNSUPPORTED, "waves per chunk follow from the band width"); }
-    else if (k == "host_threads") { /* accepted for compatibility: there is no host-side preparation any more */ }
     else return fail(NPORE_E_INVALID, "unknown key " + k);
     return NPORE_OK;
 }
+NPORE_CATCH_INT
 
 static int standardize_batch_impl(bool expanded, int64_t n_reads, const char *alns, const int64_t *aln_off, const uint8_t *refs,
                             const int64_t *ref_off, const uint8_t *seqs, const int64_t *seq_off, char *out,
                             const int64_t *out_off, int64_t *out_len, int threads)
-{
+try {
     if (n_reads < 0 || (n_reads > 0 && (!alns || !aln_off || !ref_off || !seq_off || !out || !out_off || !out_len)))
         return fail(NPORE_E_INVALID, "null argument");
     const int nt = threads > 0 ? threads : (int)std::max(1u, std::thread::hardware_concurrency());
@@ -807,6 +848,7 @@ static int standardize_batch_impl(bool expanded, int64_t n_reads, const char *al
     }
     return bad ? fail(NPORE_E_INVALID, "output slot too small") : NPORE_OK;
 }
+NPORE_CATCH_INT
 
 int npore_standardize_batch(int64_t n_reads, const char *alns, const int64_t *aln_off, const uint8_t *refs,
                             const int64_t *ref_off, const uint8_t *seqs, const int64_t *seq_off, char *out,
@@ -863,16 +905,16 @@ int npore_debug_fetch(npore_ctx *ctx, int what, void *dst, int64_t bytes)
 
 // ---- BAM ingest / SAM emit (hostio.hpp) ---------------------------------------------------------
 npore_bam *npore_bam_open(const char *path, int threads)
-{
+try {
     if (!path) { fail(NPORE_E_INVALID, "null path"); return nullptr; }
     MappedFile mf;
     if (!mf.open(path)) { fail(NPORE_E_INVALID, std::string("BAM file '") + path + "' not found"); return nullptr; }
     const ByteSpan raw{mf.p, mf.n};
-    auto *b = new npore_bam();
+    std::unique_ptr<npore_bam> hold(new npore_bam());
+    npore_bam *b = hold.get();
     std::string err;
     if (!bgzf_inflate(raw, threads, b->data_buf, b->data_size, err) || b->data_size < 12 || std::memcmp(b->data_buf.p, "BAM\1", 4) != 0) {
         fail(NPORE_E_INVALID, std::string("'") + path + "' is not a BAM file" + (err.empty() ? "" : " (" + err + ")"));
-        delete b;
         return nullptr;
     }
     b->data = reinterpret_cast<const uint8_t *>(b->data_buf.p);
@@ -881,16 +923,18 @@ npore_bam *npore_bam_open(const char *path, int threads)
     size_t p = 4;
     const int64_t l_text = rdi32(&d[p]);
     p += 4;
-    if (l_text < 0 || p + (size_t)l_text + 4 > N) { fail(NPORE_E_INVALID, "truncated BAM header"); delete b; return nullptr; }
+    if (l_text < 0 || p + (size_t)l_text + 4 > N) { fail(NPORE_E_INVALID, "truncated BAM header"); return nullptr; }
     b->text.assign(reinterpret_cast<const char *>(&d[p]), (size_t)l_text);
     while (!b->text.empty() && b->text.back() == '\0') b->text.pop_back();
     p += (size_t)l_text;
     const int32_t n_ref = rdi32(&d[p]);
     p += 4;
+    // every reference entry takes at least 9 bytes (l_name, one name byte + NUL ... l_ref)
+    if (n_ref < 0 || (size_t)n_ref > (N - p) / 9) { fail(NPORE_E_INVALID, "corrupt BAM header (n_ref)"); return nullptr; }
     for (int32_t k = 0; k < n_ref; k++) {
-        if (p + 4 > N) { fail(NPORE_E_INVALID, "truncated BAM header"); delete b; return nullptr; }
+        if (p + 4 > N) { fail(NPORE_E_INVALID, "truncated BAM header"); return nullptr; }
         const int32_t l_name = rdi32(&d[p]);
-        if (l_name < 1 || p + 8 + (size_t)l_name > N) { fail(NPORE_E_INVALID, "truncated BAM header"); delete b; return nullptr; }
+        if (l_name < 1 || p + 8 + (size_t)l_name > N) { fail(NPORE_E_INVALID, "truncated BAM header"); return nullptr; }
         b->ref_names.emplace_back(reinterpret_cast<const char *>(&d[p + 4]), (size_t)l_name - 1);
         b->ref_lens.push_back(rdi32(&d[p + 4 + (size_t)l_name]));
         p += 8 + (size_t)l_name;
@@ -902,7 +946,7 @@ npore_bam *npore_bam_open(const char *path, int threads)
     // records: offsets (one hop per record), then validation + reference spans on all cores, then the per-reference lists
     while (p + 4 <= N) {
         const int32_t bs = rdi32(&d[p]);
-        if (bs < 32 || p + 4 + (size_t)bs > N) { fail(NPORE_E_INVALID, "truncated BAM record"); delete b; return nullptr; }
+        if (bs < 32 || p + 4 + (size_t)bs > N) { fail(NPORE_E_INVALID, "truncated BAM record"); return nullptr; }
         b->rec_off.push_back((int64_t)p);
         p += 4 + (size_t)bs;
     }
@@ -921,7 +965,7 @@ npore_bam *npore_bam_open(const char *path, int threads)
             span[(size_t)i] = rec_ref_len(rec_at(*b, i));
         }
     });
-    if (corrupt) { fail(NPORE_E_INVALID, "corrupt BAM record"); delete b; return nullptr; }
+    if (corrupt) { fail(NPORE_E_INVALID, "corrupt BAM record"); return nullptr; }
     std::vector<int64_t> last_pos((size_t)n_ref, -1);
     for (int64_t i = 0; i < n_rec; i++) {
         const int32_t rid = rdi32(d + b->rec_off[(size_t)i] + 4);
@@ -934,8 +978,9 @@ npore_bam *npore_bam_open(const char *path, int threads)
             b->ref_max_len[(size_t)rid] = std::max(b->ref_max_len[(size_t)rid], span[(size_t)i]);
         }
     }
-    return b;
+    return hold.release();
 }
+NPORE_CATCH_PTR
 void npore_bam_close(npore_bam *b) { delete b; }
 int64_t npore_bam_n_records(const npore_bam *b) { return b ? (int64_t)b->rec_off.size() : 0; }
 int npore_bam_n_refs(const npore_bam *b) { return b ? (int)b->ref_names.size() : 0; }
@@ -974,14 +1019,16 @@ int64_t npore_bam_select(const npore_bam *b, int n_regions, const int32_t *ref_i
 }
 
 npore_fasta *npore_fasta_open(const char *path)
-{
+try {
     if (!path) { fail(NPORE_E_INVALID, "null path"); return nullptr; }
     MappedFile mf;
     if (!mf.open(path)) { fail(NPORE_E_INVALID, std::string("could not open FASTA '") + path + "'"); return nullptr; }
-    auto *f = new npore_fasta();
-    if (!fasta_parse(ByteSpan{mf.p, mf.n}, 0, *f)) { fail(NPORE_E_NOMEM, "FASTA: out of memory"); delete f; return nullptr; }
-    return f;
+    std::unique_ptr<npore_fasta> hold(new npore_fasta());
+    npore_fasta *f = hold.get();
+    if (!fasta_parse(ByteSpan{mf.p, mf.n}, 0, *f)) { fail(NPORE_E_NOMEM, "FASTA: out of memory"); return nullptr; }
+    return hold.release();
 }
+NPORE_CATCH_PTR
 void npore_fasta_close(npore_fasta *f) { delete f; }
 int npore_fasta_n(const npore_fasta *f) { return f ? (int)f->names.size() : 0; }
 const char *npore_fasta_name(const npore_fasta *f, int i) { return (f && i >= 0 && i < (int)f->names.size()) ? f->names[(size_t)i].c_str() : ""; }
@@ -999,7 +1046,7 @@ bool pack_args_ok(const npore_bam *b, const int64_t *idx, int64_t n)
 }  // namespace
 
 int npore_bam_pack_sizes(const npore_bam *b, const int64_t *idx, int64_t n, int64_t *ref_off, int64_t *seq_off, int64_t *cig_off)
-{
+try {
     if (!pack_args_ok(b, idx, n) || !ref_off || !seq_off || !cig_off) return fail(NPORE_E_INVALID, "bad argument");
     ref_off[0] = seq_off[0] = cig_off[0] = 0;
     for (int64_t k = 0; k < n; k++) {
@@ -1016,11 +1063,12 @@ int npore_bam_pack_sizes(const npore_bam *b, const int64_t *idx, int64_t n, int6
     }
     return NPORE_OK;
 }
+NPORE_CATCH_INT
 
 int npore_bam_pack(const npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref, const int64_t *idx, int64_t n,
                    uint8_t *refs, const int64_t *ref_off, uint8_t *seqs, const int64_t *seq_off, char *cigs,
                    const int64_t *cig_off, int threads)
-{
+try {
     if (!pack_args_ok(b, idx, n) || !fa || !fasta_of_ref || !ref_off || !seq_off || !cig_off ||
         (n > 0 && (!refs || !seqs || !cigs)))
         return fail(NPORE_E_INVALID, "bad argument");
@@ -1058,6 +1106,7 @@ int npore_bam_pack(const npore_bam *b, const npore_fasta *fa, const int32_t *fas
     });
     return bad ? fail(NPORE_E_INVALID, "a selected read lies on a contig that is not in the FASTA") : NPORE_OK;
 }
+NPORE_CATCH_INT
 
 namespace {
 int format_sam_into(const npore_bam *b, const int64_t *idx, int64_t n, const char *finals, const int64_t *final_off,
@@ -1114,12 +1163,13 @@ int format_sam_into(const npore_bam *b, const int64_t *idx, int64_t n, const cha
 
 int npore_bam_format_sam(npore_bam *b, const int64_t *idx, int64_t n, const char *finals, const int64_t *final_off,
                          const int64_t *final_len, const int32_t *status, int threads, const char **sam, int64_t *sam_len)
-{
+try {
     if (!b || !sam) return fail(NPORE_E_INVALID, "bad argument");
     const int rc = format_sam_into(b, idx, n, finals, final_off, final_len, status, threads, b->sam, sam_len);
     *sam = b->sam.p;
     return rc;
 }
+NPORE_CATCH_INT
 
 namespace {
 // pack the selected records into the slot (inputs of npore_align_batch) and size its output buffers
@@ -1174,7 +1224,7 @@ int slot_post(const npore_bam *b, const int64_t *idx, int64_t n, const int32_t *
 int npore_bam_realign_batch(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref, const int64_t *idx,
                             int64_t n, float indel_start, float indel_extend, int max_b_rows, int r, int threads,
                             const char **sam, int64_t *sam_len, int32_t *status)
-{
+try {
     if (!ctx || !b || !status || !sam || !sam_len) return fail(NPORE_E_INVALID, "null argument");
     using clk = std::chrono::steady_clock;
     auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
@@ -1196,11 +1246,12 @@ int npore_bam_realign_batch(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa,
     *sam_len = s.sam_len;
     return rc;
 }
+NPORE_CATCH_INT
 
 int npore_bam_realign_file(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref, const int64_t *idx,
                            int64_t n, int64_t batch_reads, float indel_start, float indel_extend, int max_b_rows, int r,
                            int threads, const char *out_path, int32_t *status)
-{
+try {
     if (!ctx || !b || !fa || !out_path || (n > 0 && (!idx || !status)) || batch_reads < 1) return fail(NPORE_E_INVALID, "bad argument");
     FILE *fh = std::fopen(out_path, "ab");
     if (!fh) return fail(NPORE_E_INVALID, std::string("cannot open '") + out_path + "' for appending");
@@ -1274,6 +1325,7 @@ int npore_bam_realign_file(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, 
     if (std::fclose(fh) != 0 && rc == NPORE_OK) { rc = NPORE_E_INVALID; err = "close failed"; }
     return rc == NPORE_OK ? NPORE_OK : fail(rc, err);
 }
+NPORE_CATCH_INT
 
 int npore_bam_last_timing(const npore_bam *b, double *ms, int n)
 {

@@ -375,14 +375,20 @@ __global__ __launch_bounds__(256) void sched_scatter_kernel(PrepParams p)
 // (LDS when the slice fits, else global scratch).  Optional int32 outputs
 // Lout/Iout [len][max_n] for the get_np_info() API.
 // one period (compile-time, so that the divisions by n and the shorter-period loop unroll)
-template <int n>
+// GRID = false: the windows are dealt over the waves of this workgroup (which then owns the whole sequence);
+// GRID = true: over the waves of the whole launch (one launch per period: the next period reads this one's plane).
+template <int n, bool GRID = false>
 __device__ __forceinline__ void annotate_period(const uint8_t *seq, int len, int max_n, int max_l, uint8_t *planes,
-                                                int pstride, int32_t *Lout, int32_t *Iout)
+                                                int pstride, int32_t *Lout, int32_t *Iout, int ostride = 0)
 {
     // (the wave index is wave-uniform: saying so keeps the window loops and their bounds in scalar registers)
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (GRID ? (int)blockIdx.x * wpb : 0);
+    const int64_t wstep = (int64_t)(GRID ? (int)gridDim.x * wpb : wpb) * 64;
     uint8_t *Ln = planes + (size_t)(n - 1) * pstride;
-    for (int base = wave * 64; base < len; base += nwaves * 64) {
+    for (int64_t base64 = (int64_t)wave * 64; base64 < len; base64 += wstep) {
+        const int base = (int)base64;
         const int pos = base + lane;
         auto e_at = [&](int q) { return q >= 0 && q + n < len && seq[q] == seq[q + n]; };
         const unsigned long long M0 = __builtin_amdgcn_ballot_w64(e_at(pos));
@@ -440,11 +446,13 @@ __device__ __forceinline__ void annotate_period(const uint8_t *seq, int len, int
                 if (l > stored) { stored = max_l < l ? max_l : l; idx = j; }
             }
             Ln[pos] = (uint8_t)(stored | ((stored && idx == 0) ? 128 : 0));
-            if (Lout) { Lout[(size_t)pos * max_n + (n - 1)] = stored; Iout[(size_t)pos * max_n + (n - 1)] = idx; }
+            if (Lout) { Lout[(size_t)pos * ostride + (n - 1)] = stored; Iout[(size_t)pos * ostride + (n - 1)] = idx; }
         }
     }
-    __threadfence_block();
-    __syncthreads();
+    if constexpr (!GRID) {
+        __threadfence_block();
+        __syncthreads();
+    }
 }
 
 __device__ __forceinline__ void annotate_sequence(const uint8_t *seq, int len, int max_n, int max_l,
@@ -542,11 +550,16 @@ __global__ __launch_bounds__(1024) void annotate_kernel(PrepParams p)
     }
 }
 
-// get_np_info() API: one sequence of any length, planes in global scratch, int32 outputs
-__global__ __launch_bounds__(1024) void np_info_kernel(const uint8_t *seq, int len, int max_n, int max_l,
-                                                       uint8_t *planes, int pstride, int32_t *Lout, int32_t *Iout)
+// get_np_info() API: one sequence of any length, one launch per period over as many workgroups as the sequence
+// has windows (period n reads the finished planes of the shorter periods: the launch boundary is the barrier);
+// planes in global scratch, int32 outputs straight in the API's [len][2][max_n] layout (Iout = Lout + max_n,
+// ostride = 2 * max_n)
+template <int n>
+__global__ __launch_bounds__(256) void np_info_period_kernel(const uint8_t *seq, int len, int max_n, int max_l,
+                                                             uint8_t *planes, int pstride, int32_t *Lout, int32_t *Iout,
+                                                             int ostride)
 {
-    annotate_sequence(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
+    annotate_period<n, true>(seq, len, max_n, max_l, planes, pstride, Lout, Iout, ostride);
 }
 
 // ---------------------------------------------------------------------------

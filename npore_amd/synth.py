@@ -110,3 +110,9 @@ def make_batch(base_seed, n_reads, ref_len=10_000, p_np=0.05, p_cnv=0.3, mixed=F
         r, s, c = make_pair(base_seed, first + k * stride, ref_len, p_np, p_cnv, mixed)
         refs.append(r); seqs.append(s); cigs.append(c)
     return refs, seqs, cigs
+
+
+def make_span(a):
+    """make_batch for worker pools: a = (base_seed, n_reads, ref_len, mixed, first, stride)."""
+    seed, cnt, ref_len, mixed, first, stride = a
+    return make_batch(seed, cnt, ref_len=ref_len, mixed=mixed, first=first, stride=stride)

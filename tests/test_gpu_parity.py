@@ -285,6 +285,60 @@ def test_10kb_properties(ctx, tables):
         assert got[k] == oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=100)
 
 
+def _check_alignment_properties(ref, seq, g):
+    """Size-independent properties of one output string, vectorised: the ops consume exactly the read and the
+    reference, '=' pairs equal bases and 'X' pairs different ones (src/aln.pyx:732-735)."""
+    ops = np.frombuffer(g.encode(), np.uint8)
+    uses_seq = (ops == ord("=")) | (ops == ord("X")) | (ops == ord("I"))
+    uses_ref = (ops == ord("=")) | (ops == ord("X")) | (ops == ord("D"))
+    assert (uses_seq | uses_ref).all()                       # nothing but = X I D
+    assert int(uses_seq.sum()) == len(seq) and int(uses_ref.sum()) == len(ref)
+    i = np.cumsum(uses_seq) - uses_seq                       # read / reference position each op starts at
+    j = np.cumsum(uses_ref) - uses_ref
+    eq, x = ops == ord("="), ops == ord("X")
+    assert (ref[j[eq]] == seq[i[eq]]).all() and (ref[j[x]] != seq[i[x]]).all()
+
+
+def test_c3_all_distinct_10000_reads_one_call(ctx, tables):
+    """BASELINE.json configs[2] at a tenth of its read count but full read size, ALL DISTINCT, in
+    ONE library call: 10 000 reads of 10 kb from the seed-3 mixed-density generator at r=100 (163 GB of
+    traceback words: the library splits the call into groups by its memory budget).  Size-independent properties
+    on every read, oracle equality on two of each n-polymer density."""
+    import multiprocessing as mp
+    sub, nps = tables
+    n, span = 10_000, 500
+    with mp.get_context("spawn").Pool(8) as pool:            # fresh workers: this process holds a live HIP runtime
+        parts = pool.map(synth.make_span, [(3, span, 10_000, True, k, 1) for k in range(0, n, span)])
+    refs = [x for p in parts for x in p[0]]; seqs = [x for p in parts for x in p[1]]; cigs = [x for p in parts for x in p[2]]
+    assert len(refs) == n
+    got, st = ctx.align_batch(refs, seqs, cigs, r=100, return_status=True)
+    assert not st.any() and len(got) == n
+    assert ctx.timing()["launches"] >= 1
+    for ref, seq, g in zip(refs, seqs, got):
+        _check_alignment_properties(ref, seq, g)
+    # the mixed generator draws p_np per read from {0, 0.02, 0.05, 0.15}: reads with few and with many n-polymers
+    dens = np.array([(np.diff(r_) == 0).mean() for r_ in refs[:400]])
+    pick = list(np.argsort(dens)[[0, 1, -2, -1]])
+    for k in pick:
+        assert got[k] == oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=100), k
+    # a batch is a function of its reads only: the same reads in a small call give the same strings
+    again = ctx.align_batch(refs[4990:5010], seqs[4990:5010], cigs[4990:5010], r=100)
+    assert again == got[4990:5010]
+
+
+def test_c5_256_ultralong_reads_r200(ctx, tables):
+    """BASELINE.json configs[4] at full size: 256 reads of 50 kb, r=200 (7 waves per chunk,
+    6 chunks per read, 41 GB of traceback words), properties on every read + oracle equality on two."""
+    sub, nps = tables
+    refs, seqs, cigs = synth.make_batch(5, 256, ref_len=50_000)
+    got, st = ctx.align_batch(refs, seqs, cigs, r=200, return_status=True)
+    assert not st.any()
+    for ref, seq, g in zip(refs, seqs, got):
+        _check_alignment_properties(ref, seq, g)
+    for k in (3, 200):
+        assert got[k] == oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=200), k
+
+
 def test_realign_cli_end_to_end(tmp_path):
     """BAM in -> SAM out through `python -m npore_amd.realign` == the reference's own golden
     output test/data/npore_realigned.sam (record by record; the @PG line differs by design)."""
@@ -484,6 +538,43 @@ def test_other_table_shapes(tables, max_n, max_l):
                 assert got[k] == want and st[k] == wst, (max_n, max_l, r, mbr, k)
     for seq in (pairs[0][0], pairs[3][1]):
         assert np.array_equal(c.get_np_info(seq), np.asarray(oracle.get_np_info(seq, max_n=max_n, max_l=max_l)))
+    c.close()
+
+
+def test_cli_max_l_with_shipped_table(tables, tmp_path):
+    """--max_l 50 (reference CLI flag, src/realign.py:36-37): the reference hands align() the shipped
+    [6,101,101] table whatever the flag says and clamps its indices at max_l - 1.  Context takes the full table
+    and slices it; the strings equal the oracle's on the sliced table, and the CLI runs end to end."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    sub, nps = tables
+    c = aln.Context(sub, nps, max_n=6, max_l=50, device=0)
+    refs, seqs, cigs = synth.make_batch(56, 6, ref_len=1500, p_np=0.2)
+    got = c.align_batch(refs, seqs, cigs, r=30)
+    t = np.ascontiguousarray(nps[:, :51, :51])
+    for k in range(6):
+        assert got[k] == oracle.align(refs[k], seqs[k], cigs[k], sub, t, r=30, max_l=50)
+    c.close()
+    prefix = str(tmp_path / "ml")
+    subprocess.check_call([sys.executable, "-m", "npore_amd.realign", "--bam", os.path.join(GOLDEN, "data", "reads.bam"),
+                           "--ref", os.path.join(GOLDEN, "data", "ref.fasta"), "--out_prefix", prefix,
+                           "--max_l", "50", "--max_n", "4"], cwd=REPO)
+    assert sum(1 for l in open(prefix + ".sam") if not l.startswith("@")) == 10
+
+
+def test_fill_shape_and_annotation_only_context(tables):
+    """npore_fill_shape (launch geometry for reports) and a context without tables: get_np_info works,
+    align is refused loudly."""
+    sub, nps = tables
+    c = aln.Context(None, None, max_n=6, max_l=100, device=0)
+    sh = c.fill_shape(100)
+    assert sh["waves_per_chunk"] == 4 and sh["resident_chunks"] == c.round_chunks(100)
+    assert c.fill_shape(30)["waves_per_chunk"] == 1
+    s = enc("ATATATATTTTTTAAAGCGCGC")
+    assert np.array_equal(c.get_np_info(s), oracle.get_np_info(s))
+    with pytest.raises(aln.NporeError, match="without penalty tables"):
+        c.align_batch([s], [s], ["=" * len(s)])
     c.close()
 
 

@@ -8,6 +8,7 @@ import sys
 import numpy as np
 import pytest
 
+import oracle
 from npore_amd import _lib, aln, bam, cfg, cig, dist, synth
 from conftest import load_json, GOLDEN, REPO
 
@@ -161,6 +162,28 @@ def test_sharding_and_reduction_gloo_world2():
     assert res[0][1] == [0, 2, 4] and res[1][1] == [1, 3, 5]
     for _, _, sums, maxes in res:
         assert sums["reads"] == 1001 and sums["cells"] == sum(range(1001)) and maxes["elapsed"] == 2.0
+
+
+def test_bench_cpu_baseline_leg(tables):
+    """bench.py's CPU-baseline leg on a tiny batch (no GPU involved): one core, a pool sweep, the k-scaled
+    Cython-equivalent figures, and the strings it hands back for the comparison with the GPU output."""
+    import argparse
+    import bench
+    sub, nps = tables
+    refs, seqs, cigs = synth.make_batch(2, 6, ref_len=400)
+    args = argparse.Namespace(cpu_sample=3, cpu_threads=0, max_b_rows=300, r=10)
+    cpu, want = bench.cpu_baseline(args, refs, seqs, cigs, sub, nps)
+    assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0
+    assert set(want) == set(range(6))
+    for k in range(6):
+        assert want[k] == oracle.align(refs[k], seqs[k], cigs[k], sub, nps, max_b_rows=300, r=10)
+    assert cpu["all_reads"]["cores"] >= 1 and cpu["all_reads"]["sweep"]
+    kk = cpu["k_cython_over_port"]["k"]
+    assert 0.2 < kk < 0.6                       # tests/golden/k_cython_over_port.json (measure_k.py)
+    assert abs(cpu["cython_equivalent"]["value"] - cpu["value"] * kk) < 1e-2 * cpu["value"]
+    hc = bench.host_cpus()
+    assert 1 <= hc["usable"] <= hc["cpu_count"]
+    assert len(bench.csrc_sha()) == 16
 
 
 def _parts_worker(rank, world_size, port, prefix, q):
