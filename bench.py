@@ -191,7 +191,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=1000, help="reads per GPU per step")
     ap.add_argument("--ref-len", type=int, default=10_000)
-    ap.add_argument("--r", type=int, default=100)
+    ap.add_argument("--r", "--band", dest="r", type=int, default=100,
+                    help="band half-width (--band: the spelling to use under torch.distributed.run, whose own "
+                         "argument parser rejects --r as an ambiguous abbreviation of its --rdzv-* / --role options)")
     ap.add_argument("--max-b-rows", type=int, default=20000)
     ap.add_argument("--base-seed", type=int, default=2)
     ap.add_argument("--mixed", action="store_true",

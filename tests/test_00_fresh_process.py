@@ -23,7 +23,7 @@ def test_bench_two_ranks_on_one_gpu():
     port = 29600 + os.getpid() % 200
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"),
-           "--gpus", "2", "--reads", "96", "--ref-len", "3000", "--r", "30", "--steps", "2", "--warmup", "1",
+           "--gpus", "2", "--reads", "96", "--ref-len", "3000", "--band", "30", "--steps", "2", "--warmup", "1",
            "--sustain", "0", "--pcie-steps", "1", "--no-cpu"]
     out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
