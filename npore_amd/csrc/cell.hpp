@@ -141,6 +141,10 @@ NPORE_HD int div_recip(int run, uint32_t m)
 //   Tab   step_tables(const StepInfo &)     whatever the lookups below need per anti-diagonal
 //   HistCell h_shr(Tab, uint32_t n4, int c) what the cell (i, j-n) left behind: band column
 //                                           c - (inss[b]-inss[b-n]) of anti-diagonal b-n   (n4 = 4n)
+//   auto  h_off(Tab, uint32_t n4) / HistCell h_shr_at(Tab, off, uint32_t n4, int c)   the same in two steps: where
+//                                           the record lies (a lane-table read on the device), then the record
+//   void  pin(T &...)                       device: the values are complete here and nothing that produces them is
+//                                           moved below (an empty asm with in/out operands); host: nothing
 //   HistCell h_len(Tab, uint32_t n4, int c) likewise (i-n, j): column c + n - (inss[b]-inss[b-n])
 //   uint32_t recip(Tab, uint32_t n4)        RECIP16[n]
 //   int   mer_shift(Tab, uint32_t n4)       32 - 3n (0 for n = 0)
@@ -176,26 +180,60 @@ NPORE_HD bool step_is_plain(const StepInfo &st)
            (st.ins_l + st.r <= st.drows) && (st.del_l + st.r <= st.dcols);
 }
 
-// SHR candidate straight from a column descriptor whose repeat count is < NP_LT (all lanes;
-// wave-uniform precondition): the score comes from the LDS table at an address the
-// descriptor already holds, minus the number of copies deleted so far (src/aln.pyx:642-667).
-template <bool FAST, class Env, class Tab>
-NPORE_HD void shr_small(const Env &env, const Tab &tab, const CellIn &in, int j, uint32_t dsc, bool act,
+// SHR candidate(s) straight from a column's descriptor(s) whose repeat count is < NP_LT (all lanes; wave-uniform
+// precondition): the score comes from the LDS table at an address the descriptor already holds, plus the number of
+// copies deleted so far (src/aln.pyx:642-667).  TWO = the column's second candidate in the same block.  On the GPU
+// a candidate is a chain of three dependent LDS round trips (lane tables -> history record -> score); the block is
+// written in phases -- all lane-table reads, all history reads, all score reads, then the compares in the
+// reference's order -- with env.pin() after each, which on the device keeps the compiler from sinking a read to
+// its first use (one candidate after the other: twice the chain).
+template <bool FAST, bool TWO, class Env, class Tab>
+NPORE_HD void shr_small(const Env &env, const Tab &tab, const CellIn &in, int j, bool act0, bool act1,
                         float &shrv, int &shrrun, float &shrstart)
 {
     // the descriptor itself serves as the lane-table address: the tables repeat every 8 lanes and only
     // address bits 2-7 select a lane, so the flag bits above the period do not matter
-    const int n = (int)((dsc >> 2) & 7u);
-    const HistCell h = env.h_shr(tab, dsc, in.c);
-    const bool start = (dsc & DSC_START) != 0u;
-    const float cstart = start ? h.matv : h.shrstart;                 // :649 / :662
-    const int run = start ? 0 : (int)(h.runs >> 16);
-    const int q = div_recip(run, env.recip(tab, dsc));                // indel = -(q + 1), :650 / :663
-    const float cand = cstart + env.np_small(dsc, q);
-    const bool take = act && (FAST || j - n >= 0) && cand < shrv;
-    shrv = take ? cand : shrv;
-    shrrun = take ? run + n : shrrun;                                  // :654 / :667
-    shrstart = take ? cstart : shrstart;
+    const uint32_t d0 = in.sc0, d1 = TWO ? in.sc1 : 0u;
+    auto o0 = env.h_off(tab, d0);
+    uint32_t m0 = env.recip(tab, d0);
+    auto o1 = o0;
+    uint32_t m1 = m0;
+    if constexpr (TWO) {
+        o1 = env.h_off(tab, d1);
+        m1 = env.recip(tab, d1);
+        env.pin(o0, m0, o1, m1);
+    } else {
+        env.pin(o0, m0);
+    }
+    HistCell h0 = env.h_shr_at(tab, o0, d0, in.c), h1 = h0;
+    if constexpr (TWO) {
+        h1 = env.h_shr_at(tab, o1, d1, in.c);
+        env.pin(h0.matv, h0.shrstart, h0.runs, h1.matv, h1.shrstart, h1.runs);
+    } else {
+        env.pin(h0.matv, h0.shrstart, h0.runs);
+    }
+    const int n0 = (int)((d0 >> 2) & 7u), n1 = (int)((d1 >> 2) & 7u);
+    const bool start0 = (d0 & DSC_START) != 0u, start1 = (d1 & DSC_START) != 0u;
+    const float cstart0 = start0 ? h0.matv : h0.shrstart;             // :649 / :662
+    const float cstart1 = start1 ? h1.matv : h1.shrstart;
+    const int run0 = start0 ? 0 : (int)(h0.runs >> 16), run1 = start1 ? 0 : (int)(h1.runs >> 16);
+    float s0 = env.np_small(d0, div_recip(run0, m0)), s1 = s0;        // indel = -(q + 1), :650 / :663
+    if constexpr (TWO) {
+        s1 = env.np_small(d1, div_recip(run1, m1));
+        env.pin(s0, s1);
+    }
+    const float cand0 = cstart0 + s0;
+    const bool take0 = act0 && (FAST || j - n0 >= 0) && cand0 < shrv;
+    shrv = take0 ? cand0 : shrv;
+    shrrun = take0 ? run0 + n0 : shrrun;                              // :654 / :667
+    shrstart = take0 ? cstart0 : shrstart;
+    if constexpr (TWO) {
+        const float cand1 = cstart1 + s1;
+        const bool take1 = act1 && (FAST || j - n1 >= 0) && cand1 < shrv;
+        shrv = take1 ? cand1 : shrv;
+        shrrun = take1 ? run1 + n1 : shrrun;
+        shrstart = take1 ? cstart1 : shrstart;
+    }
 }
 
 // One SHR candidate of period n (n4 = 4n; 0 = this cell has none), repeat count L of reference
@@ -221,8 +259,9 @@ NPORE_HD void shr_generic(const Env &env, const Tab &tab, const CellIn &in, int 
 }
 
 // EDGES = false: the caller patches the two band-edge cells itself (kernels.hpp patches only the
-// three values their one in-band neighbour reads).
-template <bool FAST, bool EDGES = true, class Env>
+// three values their one in-band neighbour reads).  MID = true: the caller guarantees 1 <= c <= 2r-1 for every
+// cell it passes (a middle wave of a chunk holds band-interior columns only), which drops the column tests.
+template <bool FAST, bool EDGES = true, bool MID = false, class Env>
 NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, CellOut &q)
 {
     const int r2 = 2 * st.r;
@@ -258,7 +297,7 @@ NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, 
     int lenrun = 0, shrrun = 0;
     // candidate periods: LEN needs "ref position j starts an n-polymer" and
     // "read position i-n inside one"; SHR needs "ref position j-n inside one"
-    const bool interior = (c >= 1) && (c <= r2 - 1) &&
+    const bool interior = (MID || ((c >= 1) && (c <= r2 - 1))) &&
                           (FAST || ((i >= 0) && (j >= 0) && (i <= st.drows) && (j <= st.dcols)));
     const uint32_t imask = interior ? 0xFFFFFFFFu : 0u;    // loop-invariant in the plain case
     uint32_t lm = ((in.refx & in.seqw & imask) >> FLAG_SHIFT) & 63u;
@@ -279,14 +318,10 @@ NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, 
             const bool act = sm != 0u;
             const bool has2 = (sm & DSC_HAS2) != 0u, act2 = has2;
             if (!env.any(sm >= DSC_RARE)) {
-                if (env.any(has2)) {
-                    // both in one block: the second candidate's history / table reads are independent of
-                    // the first's outcome and overlap with it
-                    shr_small<FAST>(env, tab, in, j, in.sc0, act, shrv, shrrun, shrstart);
-                    shr_small<FAST>(env, tab, in, j, in.sc1, act2, shrv, shrrun, shrstart);
-                } else {
-                    shr_small<FAST>(env, tab, in, j, in.sc0, act, shrv, shrrun, shrstart);
-                }
+                // (both in one block: the second candidate's history / table reads are independent of the first's
+                // outcome and overlap with them)
+                if (env.any(has2)) shr_small<FAST, true>(env, tab, in, j, act, act2, shrv, shrrun, shrstart);
+                else shr_small<FAST, false>(env, tab, in, j, act, false, shrv, shrrun, shrstart);
             } else {
                 // a long n-polymer (L >= NP_LT) or three or more periods in one column somewhere in the wave
                 shr_generic<FAST>(env, tab, in, j, in.sc0 & DSC_N4, (int)((in.sc0 >> 8) & 127u),

@@ -45,6 +45,7 @@ struct KParams {
     const ChunkDesc *descs;
     const int32_t *sched;   // chunk slot -> chunk index (largest chunks first)
     const int32_t *n_chunks;   // device-side count (kernels are launched over an upper bound)
+    int32_t *queue;            // next slot of the schedule to hand out (zeroed by read_scan_kernel)
     const uint8_t *steps;
     const int32_t *inss;
     const uint32_t *seqw;
@@ -59,13 +60,13 @@ struct KParams {
     int hw;                 // history records per ring row: 2r+1 columns + HIST_PAD
     int rwin;               // reference-L window entries (power of two)
     float indel_start, indel_extend;
-    int resident;           // workgroups resident at a time (a "round" of the chunk schedule)
 };
 
 // LDS floats: shared score tables + per chunk (history ring, reference-L window, exchange)
-static inline size_t chunk_lds_floats(int nw, int hw, int rwin)
+__host__ __device__ static inline size_t chunk_lds_floats(int nw, int hw, int rwin)
 {
-    return (size_t)4 * (ring_rows(nw) * hw + HIST_PAD) + 2 * (size_t)rwin + (nw > 1 ? 2 * nw * XCH_WORDS + 8 : 0);
+    // history ring + reference-L window + (several waves per chunk) exchange records, progress words, slot ring
+    return (size_t)4 * (ring_rows(nw) * hw + HIST_PAD) + 2 * (size_t)rwin + (nw > 1 ? 2 * nw * XCH_WORDS + 8 + 12 : 0);
 }
 static inline size_t fill_lds_floats(int nw, int chunks, int hw, int rwin)
 {
@@ -122,19 +123,39 @@ struct DevEnv {
     const uint4 *refw_g;      // the chunk's reference words (rare re-reads)
     int np_dim, clampv, slot, hw16, wmask, dcols;
     // tables over n, spread over the lanes: lane l holds the entry of n = l & 7
-    uint32_t t_n, t_low, t_recip, t_msh, t_mmask;
+    uint32_t t_n, t_recip, t_msh, t_mmask;
+    // lane l: byte offset from "own column, ring row 0" to column c - dI of row b-n, n = l & 7 and
+    // dI = inss[b] - inss[b-n]; kept current by the step loop with one lane shift per anti-diagonal (fill_kernel)
+    uint32_t tab_e;
+    unsigned long long n0_lanes;     // lanes holding entry 0 of the lane tables
 
-    struct Tab { uint32_t e; };   // lane l: byte offset from "own column, ring row 0" to column c - dI of row b-n, n = l & 7
-    __device__ __forceinline__ Tab step_tables(const StepInfo &st) const
-    {
-        const uint32_t dI = (uint32_t)__popc(st.hist6 & t_low);
-        const uint32_t t = (uint32_t)slot - t_n;            // row of anti-diagonal b-n in the ring
-        const uint32_t row = min(t, t + (uint32_t)NSR);     // (slot - n) mod NSR for slot - n >= -NSR
-        return Tab{__umul24(row, (uint32_t)hw16) - (dI << 4)};
-    }
+    struct Tab { uint32_t e; };
+    __device__ __forceinline__ Tab step_tables(const StepInfo &) const { return Tab{tab_e}; }
     __device__ __forceinline__ HistCell h_shr(const Tab &tab, uint32_t n4, int) const
     {
         return *reinterpret_cast<const HistCell *>(hist_c + (int)lane_table(n4, tab.e));
+    }
+    __device__ __forceinline__ uint32_t h_off(const Tab &tab, uint32_t n4) const { return lane_table(n4, tab.e); }
+    __device__ __forceinline__ HistCell h_shr_at(const Tab &, uint32_t off, uint32_t, int) const
+    {
+        return *reinterpret_cast<const HistCell *>(hist_c + (int)off);
+    }
+    // (only where a chunk is several waves in lock step: a wave on its own -- NSR == 6 -- is scheduled better
+    // without: measured +2 % fill at r = 30 with the pins, -3 % at r = 100)
+    static constexpr bool PIN = NSR != 6;
+    template <class A, class B>
+    __device__ __forceinline__ void pin(A &a, B &b) const { if constexpr (PIN) asm volatile("" : "+v"(a), "+v"(b)); }
+    template <class A, class B, class C>
+    __device__ __forceinline__ void pin(A &a, B &b, C &c) const { if constexpr (PIN) asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
+    template <class A, class B, class C, class D>
+    __device__ __forceinline__ void pin(A &a, B &b, C &c, D &d) const
+    {
+        if constexpr (PIN) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    }
+    template <class A, class B, class C, class D, class E, class F>
+    __device__ __forceinline__ void pin(A &a, B &b, C &c, D &d, E &e, F &f) const
+    {
+        if constexpr (PIN) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
     }
     __device__ __forceinline__ HistCell h_len(const Tab &tab, uint32_t n4, int) const
     {
@@ -151,9 +172,9 @@ struct DevEnv {
     __device__ __forceinline__ float np_small(uint32_t dsc, int q) const
     {
         const uint32_t a = (dsc >> 15) & 0xFFFFu;
-        // q >= L copies deleted: the call length L - 1 - q is negative -> the guard entry in front of the row
+        // q >= L copies deleted: the call length L - 1 - q is negative -> the guard entry behind the row
         const uint32_t L = (dsc >> 8) & 0xFFu;      // bits 8-14; bit 15 is clear (the address field holds a multiple of 4)
-        return lds_abs_f32(LDS_NP_BASE + a - 4u * min((uint32_t)q, L));
+        return lds_abs_f32(LDS_NP_BASE + a + 4u * min((uint32_t)q, L));
     }
     __device__ __forceinline__ int clamp() const { return clampv; }
     __device__ __forceinline__ int refl(int j, int n_idx) const { return win[(j & wmask) * 8 + n_idx]; }
@@ -179,8 +200,8 @@ struct DevEnv {
         // wait also drains the outstanding traceback stores.)
         const bool big = (unsigned)(a | b) >= (unsigned)NP_LT;     // a, b >= 0 and NP_LT == NP_CT - NP_C0 is a power of two
         const bool oot = active && big;
-        float out = lds_abs_f32(LDS_NP_BASE + 4u * (uint32_t)(((n_idx * NP_LT + (a & (NP_LT - 1))) * NP_CT) + NP_C0 +
-                                                              (b & (NP_CT - NP_C0 - 1))));
+        float out = lds_abs_f32(LDS_NP_BASE + 4u * (uint32_t)(((n_idx * NP_LT + (a & (NP_LT - 1))) * NP_CT) + (NP_LT - 1) -
+                                                              (b & (NP_LT - 1))));
         asm volatile("" : "+v"(out));   // keep this a ds_read: do not fold it with the global load below
         if (any2(active, big)) {
             if (oot) {
@@ -194,9 +215,39 @@ struct DevEnv {
     }
 };
 
-// NW waves per chunk, each owning 64 consecutive band columns.
+// value of the previous / next lane, with `edge` (a per-lane register, usually a broadcast value) kept in the lane
+// that has no neighbour (lane 0 / 63): ONE instruction where a shift and a select used to be -- the DPP move
+// leaves the destination's old contents in lanes without a valid source when bound_ctrl is off
+__device__ __forceinline__ uint32_t lane_prev_or(uint32_t edge, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t lane_next_or(uint32_t edge, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float lane_prev_or(float edge, float v)
+{
+    return __uint_as_float(lane_prev_or(__float_as_uint(edge), __float_as_uint(v)));
+}
+__device__ __forceinline__ float lane_next_or(float edge, float v)
+{
+    return __uint_as_float(lane_next_or(__float_as_uint(edge), __float_as_uint(v)));
+}
+
+// "progress word has reached target".  The words count anti-diagonals over all the chunks a group of waves has
+// worked on in one launch: bounded by the traceback words a launch can hold (4 bytes x the band per anti-diagonal
+// within the device's memory: < 2^30 anti-diagonals for every band), so a plain signed compare is safe
+__device__ __forceinline__ bool reached(int word, int target) { return word >= target; }
+
+constexpr int SLOT_RING = 8;    // chunk slots published by a group's first wave and not yet read by its last (<= NW - 1)
+
+// NW waves per chunk ("a group"), each owning 64 consecutive band columns.  PERSISTENT: the launch holds as many
+// workgroups as the GPU keeps resident, and every group of NW waves pulls its next chunk from a device-wide queue
+// (the schedule lists the chunks largest first) the moment it has finished one, until the queue is empty -- no
+// group waits for a sibling of its workgroup, no workgroup waits for a "round" to drain.
 template <int NW, int MAXT>
-__global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
+__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) void fill_kernel(KParams p)
 {
     constexpr int NSR = ring_rows(NW);
     constexpr int WPT = NW * 64;          // physical columns per chunk
@@ -210,23 +261,26 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     // issue rate while its neighbours wait for it.  (Chunk-major numbering puts all the nearly empty last
     // waves -- r=100: 9 live columns of 64 -- on one SIMD: 15 % slower; spreading each chunk over the four
     // SIMDs with mixed roles: 12 % slower, the critical wave then competes with three busy strangers.)
-    const int cpg = (int)(blockDim.x >> 6) / NW;   // chunks per workgroup
-    const int cw = wave / cpg;            // wave within the chunk
-    const int cg = wave % cpg;            // chunk within the workgroup
+    const int cpg = (int)(blockDim.x >> 6) / NW;   // chunks (groups) per workgroup
+    const int cw = wave / cpg;            // wave within the group
+    const int cg = wave % cpg;            // group within the workgroup
     // The middle waves of a chunk (all 64 lanes live, a neighbour wave on either side) are issued first when
     // several waves of the SIMD are ready: measured 1.5-2 % on the fill at NW = 3...7 (r = 70, 100, 140, 200)
     if (NW > 2 && cw != 0 && cw != NW - 1) __builtin_amdgcn_s_setprio(1);
     const int hw = p.hw;
-    float *chunk_lds = lds_sub + SUBT_ENTRIES + (size_t)cg * (4 * (NSR * hw + HIST_PAD) + 2 * p.rwin + (NW > 1 ? 2 * NW * XCH_WORDS + 8 : 0));
+    float *chunk_lds = lds_sub + SUBT_ENTRIES + (size_t)cg * chunk_lds_floats(NW, hw, p.rwin);
     HistCell *hist = reinterpret_cast<HistCell *>(chunk_lds) + HIST_PAD;     // row 0, column 0
     uint2 *win = reinterpret_cast<uint2 *>(chunk_lds + 4 * (NSR * hw + HIST_PAD));
     uint32_t *xchg = reinterpret_cast<uint32_t *>(chunk_lds + 4 * (NSR * hw + HIST_PAD) + 2 * p.rwin);   // [2][NW][XCH_WORDS]
-    int *prog = reinterpret_cast<int *>(xchg + 2 * NW * XCH_WORDS);          // [NW] anti-diagonals completed
+    int *prog = reinterpret_cast<int *>(xchg + 2 * NW * XCH_WORDS);          // [NW] anti-diagonals completed, all chunks
+    int *slotbox = prog + 8;                                                  // [SLOT_RING] + generation word
 
-    // workgroup-shared tables
+    // workgroup-shared tables.  A score row is stored with the call length DEcreasing, so that "q more copies
+    // deleted" is q entries UP from the address a column descriptor holds, and ends in one guard entry holding
+    // the constant 100 for negative call lengths (layout.hpp)
     const int np_dim = p.max_l + 1;
     for (int idx = threadIdx.x; idx < MAX_PERIOD * NP_LT * NP_CT; idx += blockDim.x) {
-        const int n = idx / (NP_LT * NP_CT), a = (idx / NP_CT) % NP_LT, b = idx % NP_CT - NP_C0;
+        const int n = idx / (NP_LT * NP_CT), a = (idx / NP_CT) % NP_LT, b = NP_LT - 1 - idx % NP_CT;
         lds_np[idx] = b < 0 ? INF_F
                             : (n < p.max_n && a < np_dim && b < np_dim) ? p.np_scores[((size_t)n * np_dim + a) * np_dim + b] : 0.0f;
     }
@@ -234,24 +288,18 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
         const int rb = idx >> 5, sb = (idx >> 2) & 7;
         lds_sub[idx] = (rb < 5 && sb < 5) ? p.sub_scores[sb * 5 + rb] : 0.0f;
     }
-    __syncthreads();
-
-    // chunk slots (largest chunks first) are dealt over the workgroups of a round (layout.hpp)
-    const int slot_id = deal_slot((int)blockIdx.x, cg, cpg, (int)gridDim.x, p.resident);
-    if (slot_id >= *p.n_chunks) return;    // hardware barriers only count waves that are still alive
-    ChunkDesc d = p.descs[uni(p.sched[slot_id])];
-    d.brk = uni(d.brk); d.nrows = uni(d.nrows); d.row0 = uni(d.row0); d.col0 = uni(d.col0);
-    d.drows = uni(d.drows); d.dcols = uni(d.dcols); d.plain_lo = uni(d.plain_lo); d.plain_hi = uni(d.plain_hi);
-    d.steps_off = uni(d.steps_off); d.seqw_off = uni(d.seqw_off); d.refw_off = uni(d.refw_off); d.tb_off = uni(d.tb_off);
     const int r = p.r;
     const int lpos = cw * 64 + lane;          // band column of this lane
     const int tcol = lpos;
-
-    const uint32_t *seqw_g = p.seqw + d.seqw_off;
-    const uint4 *refw_g = p.refw + d.refw_off;
-    const uint2 *refl_g = p.refl + d.refw_off;
-    const uint8_t *steps_g = p.steps + d.steps_off + d.brk;   // steps_g[k] = step from local row k to k+1
-    uint32_t *tb_g = p.tb + d.tb_off;
+    // history: every record starts as "no candidate can come from here" (cell.hpp).  The band edges, the columns
+    // beyond the band and the pad records either side of a row are never written and stay that way for the whole
+    // launch; the band-interior columns are reset by their own lanes before every chunk
+    for (int k = lpos - HIST_PAD; k < NSR * hw; k += WPT) hist[k] = hist_none();
+    if constexpr (NW > 1) {
+        if (lane == 0) prog[cw] = 0;
+        if (cw == 0 && lane <= SLOT_RING + 1) slotbox[lane] = 0;
+    }
+    __syncthreads();      // the only workgroup barrier: from here on the groups run on their own
 
     DevEnv<NSR> env;
     env.lds_sub = reinterpret_cast<const char *>(lds_sub);
@@ -259,303 +307,404 @@ __global__ __launch_bounds__(MAXT) void fill_kernel(KParams p)
     env.g_np = p.np_scores;
     env.win = reinterpret_cast<const uint8_t *>(win);
     env.hist_c = reinterpret_cast<const char *>(hist + tcol);
-    env.refw_g = refw_g;
     env.np_dim = np_dim;
     env.clampv = p.max_l - 1;
-    env.slot = 0;
     env.hw16 = hw * 16;
     env.wmask = p.rwin - 1;
-    env.dcols = d.dcols;
     {
         const int nl = lane & 7;
         env.t_n = (uint32_t)nl;
-        env.t_low = (1u << nl) - 1u;
         env.t_recip = recip16(nl);
         env.t_msh = nl ? 32u - 3u * (uint32_t)nl : 0u;
         env.t_mmask = (1u << (3 * nl)) - 1u;
     }
-
-    // per-cell state of the previous anti-diagonal
-    float matv = 0.0f, insv = 0.0f, delv = 0.0f, LMv = 0.0f, TMv = 0.0f;
-    uint32_t R1 = 0u, R2 = 0u;      // matrun|insrun<<16, matrun|delrun<<16
-    uint32_t LMr = 0u, TMr = 0u;    // low half: MAT.RUN of the left / top neighbour of the previous step
-    uint32_t seqw, refx, rc0, rc1;
-    {
-        const int i = r - tcol, j = tcol - r;
-        seqw = (i >= 0 && i <= d.drows) ? seqw_g[i] : SEQW_SENTINEL;
-        uint4 rw = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint4(REFW_SENTINEL, 0u, 0u, 0u);
-        refx = rw.x;
-        rc0 = rw.z;
-        rc1 = rw.w;
-    }
-    // queues of words that will enter at column 0 (read; first wave) / column WPT-1 (reference; last wave)
-    int sq_base = r + 1;              // next read index entering at column 0 is ins_l + r
-    int rq_base = WPT - r;            // next reference index entering at column WPT-1 is del_l + WPT-1 - r
-    uint32_t seq_q = SEQW_SENTINEL;
-    uint4 ref_q = make_uint4(REFW_SENTINEL, 0u, 0u, 0u);
-    if (cw == 0) {
-        const int i = sq_base + lane;
-        seq_q = (i <= d.drows) ? seqw_g[i] : SEQW_SENTINEL;
-    }
-    // reference-L window: positions [0, wfill) are resident (modulo rwin); kept by the last wave
-    int wfill = 0;
-    if (cw == NW - 1) {
-        const int j = rq_base + lane;
-        ref_q = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint4(REFW_SENTINEL, 0u, 0u, 0u);
-    }
-    while (r + 32 >= wfill) {
-        if (cw == NW - 1) {
-            const int j = wfill + lane;
-            win[j & env.wmask] = (j <= d.dcols) ? refl_g[j] : make_uint2(0u, 0u);
-        }
-        wfill += 64;
-    }
-    // history: every record starts as "no candidate can come from here" (cell.hpp); the band edges and
-    // the pad records either side of a row stay that way
-    for (int k = lpos - HIST_PAD; k < NSR * hw; k += WPT) hist[k] = hist_none();
-    if constexpr (NW > 1) {
-        if (lane == 0) prog[cw] = 0;
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-
-    StepInfo st;
-    st.r = r;
-    st.drows = d.drows;
-    st.dcols = d.dcols;
-    st.indel_start = p.indel_start;
-    st.indel_extend = p.indel_extend;
-    st.b_local = 0;
-    st.ins_l = 0;
-    st.del_l = 0;
-    st.hist6 = 0;
-    // input-path steps, 64 per coalesced load, one block prefetched (the buffer is padded)
-    unsigned long long stepmask = __builtin_amdgcn_ballot_w64(steps_g[lane] != 0);
-    unsigned long long nextmask = __builtin_amdgcn_ballot_w64(steps_g[64 + lane] != 0);
     const bool hist_lane = (tcol >= 1) && (tcol <= 2 * r - 1);     // band-interior columns leave history
+    env.n0_lanes = __builtin_amdgcn_ballot_w64((lane & 7) == 0);
     const bool tb_lane = tcol <= 2 * r;
     const uint32_t tcol4 = (uint32_t)tcol * 4u;
+    const int n_chunks = *p.n_chunks;
+    const int dealt = (int)gridDim.x * cpg;      // slots handed out without the queue: one per group
+    int pbase = 0;        // anti-diagonals of the chunks this group has finished (what prog[] counts from)
+    int gen = 0;          // chunks this group has started
 
-    // One anti-diagonal.  MODE 0: first row of the chunk (no neighbours), 1: the input path
-    // stepped 'I' (read words move one column up, "left" is the previous lane), 2: 'D'
-    // (reference words move one column down, "top" is the next lane).  The whole body is
-    // instantiated per mode so that no register shuffling is needed where the modes meet.
-    auto step = [&](auto mode_tag, auto role_tag) __attribute__((always_inline)) {
-        constexpr int MODE = decltype(mode_tag)::value;
-        // ROLE: 0 = only wave of the chunk, 1 = first, 2 = middle, 3 = last (compile-time so that the
-        // per-role code needs no joins inside the loop)
-        constexpr int ROLE = decltype(role_tag)::value;
-        constexpr bool IS_FIRST = (ROLE == 0 || ROLE == 1), IS_LAST = (ROLE == 0 || ROLE == 3);
-        const int bl = st.b_local;
-        if constexpr (NW > 1 && MODE != 0) {
-            // Per-chunk hand-shake instead of a workgroup barrier: this wave may start anti-diagonal bl
-            // once its two neighbour waves have finished bl-1 (they own the only columns it reads).
-            // LDS requests of a wave are served in order, so a neighbour's progress word becomes
-            // visible after the history / exchange words it wrote before it.
-            for (;;) {
-                // relaxed workgroup-scope atomics keep these plain LDS reads (a volatile access would
-                // become a flat system-scope load with a vmcnt(0) wait)
-                const int a = !IS_FIRST ? __hip_atomic_load(&prog[cw - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
-                const int b = !IS_LAST ? __hip_atomic_load(&prog[cw + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
-                if (uni((a < b ? a : b)) >= bl) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            asm volatile("" ::: "memory");
-        }
-        // boundary cells written by the neighbour waves at the end of the previous step
-        // (the record addresses are wave-uniform; pinning each in ONE vector register lets every word
-        // use an immediate offset instead of its own scalar-to-vector move)
-        const int xin = ((bl + 1) & 1) * (NW * XCH_WORDS);
-        CellIn in;
-        if constexpr (MODE == 1) {
-            float pm = lane_prev(matv), pd = lane_prev(delv);
-            uint32_t pr = lane_prev(R2);
-            uint32_t ps = lane_prev(seqw);
-            if constexpr (IS_FIRST) {
-                // word for row ins_l + r enters at column 0
-                if (st.ins_l + r - sq_base >= 64) {   // uniform
-                    sq_base += 64;
-                    const int i = sq_base + lane;
-                    seq_q = (i <= d.drows) ? seqw_g[i] : SEQW_SENTINEL;
-                    asm volatile("" : "+v"(seq_q));   // wait for the reload inside this rare branch (see np_full)
-                }
-                const uint32_t incoming = (uint32_t)__builtin_amdgcn_readlane((int)seq_q, (st.ins_l + r - sq_base) & 63);
-                ps = (lane == 0) ? incoming : ps;
-            } else {
-                int xi = xin + (cw - 1) * XCH_WORDS;               // last cell of the wave below (broadcast reads)
-                asm volatile("" : "+v"(xi));
-                const uint32_t *xl = xchg + xi;
-                const uint32_t x0 = xl[0], x1 = xl[1], x2 = xl[2], x3 = xl[3];
-                pm = (lane == 0) ? __uint_as_float(x0) : pm;
-                pd = (lane == 0) ? __uint_as_float(x1) : pd;
-                pr = (lane == 0) ? x2 : pr;
-                ps = (lane == 0) ? x3 : ps;
-            }
-            in.topM = matv; in.topI = insv; in.topIrun = (int)(R1 >> 16);
-            in.leftM = pm;
-            in.leftD = pd;
-            in.leftDrun = (int)(pr >> 16);
-            in.diagM = LMv;
-            in.diagMrun = (int)(LMr & 0xFFFFu);
-            LMr = pr;
-            TMr = R1;
-            seqw = ps;
-        } else if constexpr (MODE == 2) {
-            float nm = lane_next(matv), ni = lane_next(insv);
-            uint32_t nr = lane_next(R1);
-            uint32_t nx = lane_next(refx);
-            uint32_t nc0 = lane_next(rc0), nc1 = lane_next(rc1);
-            if constexpr (IS_LAST) {
-                // word for col del_l + WPT-1 - r enters at column WPT-1
-                if (st.del_l + WPT - 1 - r - rq_base >= 64) {
-                    rq_base += 64;
-                    const int j = rq_base + lane;
-                    ref_q = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint4(REFW_SENTINEL, 0u, 0u, 0u);
-                    asm volatile("" : "+v"(ref_q.x), "+v"(ref_q.z), "+v"(ref_q.w));   // wait inside the rare branch
-                }
-                const int ql = (st.del_l + WPT - 1 - r - rq_base) & 63;
-                const uint32_t inx = (uint32_t)__builtin_amdgcn_readlane((int)ref_q.x, ql);
-                const uint32_t inz = (uint32_t)__builtin_amdgcn_readlane((int)ref_q.z, ql);
-                const uint32_t inw = (uint32_t)__builtin_amdgcn_readlane((int)ref_q.w, ql);
-                nx = (lane == 63) ? inx : nx;
-                nc0 = (lane == 63) ? inz : nc0;
-                nc1 = (lane == 63) ? inw : nc1;
-            } else {
-                int xi = xin + (cw + 1) * XCH_WORDS + 5;           // first cell of the wave above
-                asm volatile("" : "+v"(xi));
-                const uint32_t *xf = xchg + xi;
-                const uint32_t x0 = xf[0], x1 = xf[1], x2 = xf[2], x3 = xf[3], x4 = xf[4], x5 = xf[5];
-                nm = (lane == 63) ? __uint_as_float(x0) : nm;
-                ni = (lane == 63) ? __uint_as_float(x1) : ni;
-                nr = (lane == 63) ? x2 : nr;
-                nx = (lane == 63) ? x3 : nx;
-                nc0 = (lane == 63) ? x4 : nc0;
-                nc1 = (lane == 63) ? x5 : nc1;
-            }
-            if (st.del_l + r + 32 >= wfill) {   // keep the L window ahead of the band (32 positions of slack)
-                if constexpr (IS_LAST) {
-                    const int j = wfill + lane;
-                    win[j & env.wmask] = (j <= d.dcols) ? refl_g[j] : make_uint2(0u, 0u);
-                }
-                wfill += 64;
-            }
-            in.leftM = matv; in.leftD = delv; in.leftDrun = (int)(R2 >> 16);
-            in.topM = nm;
-            in.topI = ni;
-            in.topIrun = (int)(nr >> 16);
-            in.diagM = TMv;
-            in.diagMrun = (int)(TMr & 0xFFFFu);
-            LMr = R2;
-            TMr = nr;
-            refx = nx;
-            rc0 = nc0;
-            rc1 = nc1;
+    for (;;) {
+        // ---- next chunk slot of the schedule.  One wave of the group asks the queue; the others read its answer
+        // from the group's slot ring in LDS (an LDS word written after another by one wave is seen after it by
+        // every other wave: requests of a wave are served in order)
+        int slot_id;
+        if (gen == 0) {
+            // the first chunk of every group is dealt like cards -- slot q of the schedule to workgroup q % grid,
+            // group q / grid -- so that the heavy chunks of a batch smaller than the launch are spread over all
+            // CUs and SIMDs instead of filling the first workgroups; the queue hands out what lies beyond
+            slot_id = cg * (int)gridDim.x + (int)blockIdx.x;
+        } else if constexpr (NW == 1) {
+            int v = 0;
+            if (lane == 0) v = atomicAdd(p.queue, 1);
+            slot_id = uni(v) + dealt;
         } else {
-            in.topM = in.topI = in.leftM = in.leftD = in.diagM = 0.0f;
-            in.topIrun = in.leftDrun = in.diagMrun = 0;
-        }
-        in.c = tcol;
-        in.seqw = seqw;
-        in.refx = refx;
-        in.sc0 = rc0;
-        in.sc1 = rc1;
-
-        CellOut o;
-        // band-edge cells (columns 0 and 2r; reference src/aln.pyx:502-507: every state = 100*(b_row+1),
-        // TYP = MAT, RUN = 0).  Only three values of an edge cell are ever read (by its one in-band
-        // neighbour), so only those are patched below; edge columns leave no history and the traceback
-        // kernel treats them as "run 0" itself.
-        if (bl >= d.plain_lo && bl < d.plain_hi) cell_update<true, false>(env, st, in, o);    // == step_is_plain(st)
-        else cell_update<false, false>(env, st, in, o);
-
-        LMv = in.leftM;
-        TMv = in.topM;
-        matv = o.matv;
-        insv = o.insv;
-        delv = o.delv;
-        R1 = (uint32_t)o.matrun | ((uint32_t)o.insrun << 16);
-        R2 = (uint32_t)o.matrun | ((uint32_t)o.delrun << 16);
-        {
-            const float e = (float)(100 * (bl + 1));
-            if constexpr (IS_FIRST) {      // column 0 is lane 0 of the first wave; read as a LEFT neighbour
-                matv = (lane == 0) ? e : matv;
-                delv = (lane == 0) ? e : delv;
-                R2 = (lane == 0) ? 0u : R2;
-            }
-            if constexpr (IS_LAST) {       // column 2r lies in the last wave (NW = ceil((2r+1)/64)); read as a TOP neighbour
-                const bool is_edge = (tcol == 2 * r);
-                matv = is_edge ? e : matv;
-                insv = is_edge ? e : insv;
-                R1 = is_edge ? 0u : R1;
-            }
-        }
-        if (hist_lane)
-            hist[env.slot * hw + tcol] =
-                HistCell{o.matv, o.lenstart, o.shrstart, (uint32_t)o.lenrun_h | ((uint32_t)o.shrrun_h << 16)};
-        if constexpr (NW > 1) {
-            // boundary cells for the neighbour waves: the last lane's cell for the wave above (it reads
-            // it as a LEFT neighbour), the first lane's for the wave below (TOP neighbour + reference words)
-            int xo = (bl & 1) * (NW * XCH_WORDS) + cw * XCH_WORDS;
-            asm volatile("" : "+v"(xo));
-            uint32_t *xout = xchg + xo;
-            if constexpr (!IS_LAST) {
-                if (lane == 63) {
-                    xout[0] = __float_as_uint(matv);
-                    xout[1] = __float_as_uint(delv);
-                    xout[2] = R2;
-                    xout[3] = seqw;
-                }
-            }
-            if constexpr (!IS_FIRST) {
+            if (cw == 0) {
+                int v = 0;
                 if (lane == 0) {
-                    xout[5] = __float_as_uint(matv);
-                    xout[6] = __float_as_uint(insv);
-                    xout[7] = R1;
-                    xout[8] = refx;
-                    xout[9] = rc0;
-                    xout[10] = rc1;
+                    v = atomicAdd(p.queue, 1) + dealt;
+                    __hip_atomic_store(&slotbox[gen & (SLOT_RING - 1)], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    asm volatile("" ::: "memory");
+                    __hip_atomic_store(&slotbox[SLOT_RING], gen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                slot_id = uni(v);
+            } else {
+                for (;;) {
+                    const int g = __hip_atomic_load(&slotbox[SLOT_RING], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (reached(uni(g), gen + 1)) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                asm volatile("" ::: "memory");
+                slot_id = uni(__hip_atomic_load(&slotbox[gen & (SLOT_RING - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            }
+        }
+        gen++;
+        if (slot_id >= n_chunks) break;     // the queue only grows: every wave of the group sees the same answer
+        ChunkDesc d = p.descs[uni(p.sched[slot_id])];
+        d.brk = uni(d.brk); d.nrows = uni(d.nrows); d.row0 = uni(d.row0); d.col0 = uni(d.col0);
+        d.drows = uni(d.drows); d.dcols = uni(d.dcols); d.plain_lo = uni(d.plain_lo); d.plain_hi = uni(d.plain_hi);
+        d.steps_off = uni(d.steps_off); d.seqw_off = uni(d.seqw_off); d.refw_off = uni(d.refw_off); d.tb_off = uni(d.tb_off);
+
+        const uint32_t *seqw_g = p.seqw + d.seqw_off;
+        const uint4 *refw_g = p.refw + d.refw_off;
+        const uint2 *refl_g = p.refl + d.refw_off;
+        const uint8_t *steps_g = p.steps + d.steps_off + d.brk;   // steps_g[k] = step from local row k to k+1
+        uint32_t *tb_g = p.tb + d.tb_off;
+        env.refw_g = refw_g;
+        env.dcols = d.dcols;
+        env.slot = 0;
+
+        // per-cell state of the previous anti-diagonal
+        float matv = 0.0f, insv = 0.0f, delv = 0.0f, LMv = 0.0f, TMv = 0.0f;
+        uint32_t R1 = 0u, R2 = 0u;      // matrun|insrun<<16, matrun|delrun<<16
+        uint32_t LMr = 0u, TMr = 0u;    // low half: MAT.RUN of the left / top neighbour of the previous step
+        uint32_t seqw, refx, rc0, rc1;
+        {
+            const int i = r - tcol, j = tcol - r;
+            seqw = (i >= 0 && i <= d.drows) ? seqw_g[i] : SEQW_SENTINEL;
+            uint4 rw = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint4(REFW_SENTINEL, 0u, 0u, 0u);
+            refx = rw.x;
+            rc0 = rw.z;
+            rc1 = rw.w;
+        }
+        // queues of words that will enter at column 0 (read; first wave) / column WPT-1 (reference; last wave)
+        int sq_base = r + 1;              // next read index entering at column 0 is ins_l + r
+        int rq_base = WPT - r;            // next reference index entering at column WPT-1 is del_l + WPT-1 - r
+        uint32_t seq_q = SEQW_SENTINEL;
+        uint4 ref_q = make_uint4(REFW_SENTINEL, 0u, 0u, 0u);
+        if (cw == 0) {
+            const int i = sq_base + lane;
+            seq_q = (i <= d.drows) ? seqw_g[i] : SEQW_SENTINEL;
+        }
+        if (cw == NW - 1) {
+            const int j = rq_base + lane;
+            ref_q = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint4(REFW_SENTINEL, 0u, 0u, 0u);
+        }
+        // input-path steps, 64 per coalesced load, one block prefetched (the buffer is padded)
+        unsigned long long stepmask = __builtin_amdgcn_ballot_w64(steps_g[lane] != 0);
+        unsigned long long nextmask = __builtin_amdgcn_ballot_w64(steps_g[64 + lane] != 0);
+        unsigned long long stepmask_peek = 0ull;
+
+        // The group's LDS (history ring, L window, exchange records) still serves its waves until all of them have
+        // finished the previous chunk, and the L window (kept by the last wave, read by every wave from its first
+        // anti-diagonals on) must be in place before any of them starts: one rendezvous per chunk.  The last wave
+        // waits for everybody's progress word, refills the window and says so; the others wait for that word.
+        int wfill = 0;
+        if constexpr (NW > 1) {
+            if (cw == NW - 1) {
+                for (;;) {
+                    const int v = lane < NW - 1 ? __hip_atomic_load(&prog[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : pbase;
+                    if (__builtin_amdgcn_ballot_w64(!reached(v, pbase)) == 0ull) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+        // reference-L window: positions [0, wfill) are resident (modulo rwin)
+        while (r + 32 >= wfill) {
+            if (cw == NW - 1) {
+                const int j = wfill + lane;
+                win[j & env.wmask] = (j <= d.dcols) ? refl_g[j] : make_uint2(0u, 0u);
+            }
+            wfill += 64;
+        }
+        if constexpr (NW > 1) {
+            if (cw == NW - 1) {
+                asm volatile("" ::: "memory");
+                if (lane == 0) __hip_atomic_store(&slotbox[SLOT_RING + 1], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                for (;;) {
+                    const int g = __hip_atomic_load(&slotbox[SLOT_RING + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (reached(uni(g), gen)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+        if (gen > 1 && hist_lane) {
+#pragma unroll
+            for (int q = 0; q < NSR; q++) hist[q * hw + tcol] = hist_none();
+        }
+        // lane table of history offsets (DevEnv::tab_e): rows before the chunk, band not moved yet
+        env.tab_e = __umul24(min((uint32_t)0 - env.t_n, (uint32_t)0 - env.t_n + (uint32_t)NSR), (uint32_t)env.hw16);
+
+        StepInfo st;
+        st.r = r;
+        st.drows = d.drows;
+        st.dcols = d.dcols;
+        st.indel_start = p.indel_start;
+        st.indel_extend = p.indel_extend;
+        st.b_local = 0;
+        st.ins_l = 0;
+        st.del_l = 0;
+        st.hist6 = 0;
+
+        // One anti-diagonal.  MODE 0: first row of the chunk (no neighbours), 1: the input path
+        // stepped 'I' (read words move one column up, "left" is the previous lane), 2: 'D'
+        // (reference words move one column down, "top" is the next lane).  The whole body is
+        // instantiated per mode so that no register shuffling is needed where the modes meet.
+        auto step = [&](auto mode_tag, auto role_tag) __attribute__((always_inline)) {
+            constexpr int MODE = decltype(mode_tag)::value;
+            // ROLE: 0 = only wave of the chunk, 1 = first, 2 = middle, 3 = last (compile-time so that the
+            // per-role code needs no joins inside the loop)
+            constexpr int ROLE = decltype(role_tag)::value;
+            constexpr bool IS_FIRST = (ROLE == 0 || ROLE == 1), IS_LAST = (ROLE == 0 || ROLE == 3);
+            const int bl = st.b_local;
+            if constexpr (NW > 1 && MODE != 0) {
+                // Per-chunk hand-shake instead of a workgroup barrier: this wave may start anti-diagonal bl
+                // once its two neighbour waves have finished bl-1 (they own the only columns it reads).
+                // LDS requests of a wave are served in order, so a neighbour's progress word becomes
+                // visible after the history / exchange words it wrote before it.
+                const int target = pbase + bl;
+                for (;;) {
+                    // relaxed workgroup-scope atomics keep these plain LDS reads (a volatile access would
+                    // become a flat system-scope load with a vmcnt(0) wait)
+                    const int a = !IS_FIRST ? __hip_atomic_load(&prog[cw - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
+                    const int b = !IS_LAST ? __hip_atomic_load(&prog[cw + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
+#if defined(NPORE_STRICT_SYNC)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+                    if (uni((a < b ? a : b)) >= target) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                asm volatile("" ::: "memory");
+            }
+            // boundary cells written by the neighbour waves at the end of the previous step
+            // (the record addresses are wave-uniform; pinning each in ONE vector register lets every word
+            // use an immediate offset instead of its own scalar-to-vector move)
+            const int xin = ((bl + 1) & 1) * (NW * XCH_WORDS);
+            CellIn in;
+            if constexpr (MODE == 1) {
+                float pm, pd;
+                uint32_t pr, ps;
+                if constexpr (IS_FIRST) {
+                    pm = lane_prev(matv); pd = lane_prev(delv); pr = lane_prev(R2);
+                    // word for row ins_l + r enters at column 0
+                    if (st.ins_l + r - sq_base >= 64) {   // uniform
+                        sq_base += 64;
+                        const int i = sq_base + lane;
+                        seq_q = (i <= d.drows) ? seqw_g[i] : SEQW_SENTINEL;
+                        asm volatile("" : "+v"(seq_q));   // wait for the reload inside this rare branch (see np_full)
+                    }
+                    const uint32_t incoming = (uint32_t)__builtin_amdgcn_readlane((int)seq_q, (st.ins_l + r - sq_base) & 63);
+                    ps = lane_prev_or(incoming, seqw);
+                } else {
+                    int xi = xin + (cw - 1) * XCH_WORDS;               // last cell of the wave below (broadcast reads)
+                    asm volatile("" : "+v"(xi));
+                    const uint32_t *xl = xchg + xi;
+                    const uint32_t x0 = xl[0], x1 = xl[1], x2 = xl[2], x3 = xl[3];
+                    // lane 0 keeps the neighbour wave's cell, the others take their previous lane's
+                    pm = lane_prev_or(__uint_as_float(x0), matv);
+                    pd = lane_prev_or(__uint_as_float(x1), delv);
+                    pr = lane_prev_or(x2, R2);
+                    ps = lane_prev_or(x3, seqw);
+                }
+                in.topM = matv; in.topI = insv; in.topIrun = (int)(R1 >> 16);
+                in.leftM = pm;
+                in.leftD = pd;
+                in.leftDrun = (int)(pr >> 16);
+                in.diagM = LMv;
+                in.diagMrun = (int)(LMr & 0xFFFFu);
+                LMr = pr;
+                TMr = R1;
+                seqw = ps;
+            } else if constexpr (MODE == 2) {
+                float nm, ni;
+                uint32_t nr, nx, nc0, nc1;
+                if constexpr (IS_LAST) {
+                    nm = lane_next(matv); ni = lane_next(insv); nr = lane_next(R1);
+                    // word for col del_l + WPT-1 - r enters at column WPT-1
+                    if (st.del_l + WPT - 1 - r - rq_base >= 64) {
+                        rq_base += 64;
+                        const int j = rq_base + lane;
+                        ref_q = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint4(REFW_SENTINEL, 0u, 0u, 0u);
+                        asm volatile("" : "+v"(ref_q.x), "+v"(ref_q.z), "+v"(ref_q.w));   // wait inside the rare branch
+                    }
+                    const int ql = (st.del_l + WPT - 1 - r - rq_base) & 63;
+                    const uint32_t inx = (uint32_t)__builtin_amdgcn_readlane((int)ref_q.x, ql);
+                    const uint32_t inz = (uint32_t)__builtin_amdgcn_readlane((int)ref_q.z, ql);
+                    const uint32_t inw = (uint32_t)__builtin_amdgcn_readlane((int)ref_q.w, ql);
+                    nx = lane_next_or(inx, refx);
+                    nc0 = lane_next_or(inz, rc0);
+                    nc1 = lane_next_or(inw, rc1);
+                } else {
+                    int xi = xin + (cw + 1) * XCH_WORDS + 5;           // first cell of the wave above
+                    asm volatile("" : "+v"(xi));
+                    const uint32_t *xf = xchg + xi;
+                    const uint32_t x0 = xf[0], x1 = xf[1], x2 = xf[2], x3 = xf[3], x4 = xf[4], x5 = xf[5];
+                    nm = lane_next_or(__uint_as_float(x0), matv);
+                    ni = lane_next_or(__uint_as_float(x1), insv);
+                    nr = lane_next_or(x2, R1);
+                    nx = lane_next_or(x3, refx);
+                    nc0 = lane_next_or(x4, rc0);
+                    nc1 = lane_next_or(x5, rc1);
+                }
+                if (st.del_l + r + 32 >= wfill) {   // keep the L window ahead of the band (32 positions of slack)
+                    if constexpr (IS_LAST) {
+                        const int j = wfill + lane;
+                        win[j & env.wmask] = (j <= d.dcols) ? refl_g[j] : make_uint2(0u, 0u);
+                    }
+                    wfill += 64;
+                }
+                in.leftM = matv; in.leftD = delv; in.leftDrun = (int)(R2 >> 16);
+                in.topM = nm;
+                in.topI = ni;
+                in.topIrun = (int)(nr >> 16);
+                in.diagM = TMv;
+                in.diagMrun = (int)(TMr & 0xFFFFu);
+                LMr = R2;
+                TMr = nr;
+                refx = nx;
+                rc0 = nc0;
+                rc1 = nc1;
+            } else {
+                in.topM = in.topI = in.leftM = in.leftD = in.diagM = 0.0f;
+                in.topIrun = in.leftDrun = in.diagMrun = 0;
+            }
+            in.c = tcol;
+            in.seqw = seqw;
+            in.refx = refx;
+            in.sc0 = rc0;
+            in.sc1 = rc1;
+
+            CellOut o;
+            // band-edge cells (columns 0 and 2r; reference src/aln.pyx:502-507: every state = 100*(b_row+1),
+            // TYP = MAT, RUN = 0).  Only three values of an edge cell are ever read (by its one in-band
+            // neighbour), so only those are patched below; edge columns leave no history and the traceback
+            // kernel treats them as "run 0" itself.  A middle wave holds band-interior columns only (MID).
+            if (bl >= d.plain_lo && bl < d.plain_hi) cell_update<true, false, ROLE == 2>(env, st, in, o);    // == step_is_plain(st)
+            else cell_update<false, false, ROLE == 2>(env, st, in, o);
+
+            LMv = in.leftM;
+            TMv = in.topM;
+            matv = o.matv;
+            insv = o.insv;
+            delv = o.delv;
+            R1 = (uint32_t)o.matrun | ((uint32_t)o.insrun << 16);
+            R2 = (uint32_t)o.matrun | ((uint32_t)o.delrun << 16);
+            {
+                const float e = (float)(100 * (bl + 1));
+                if constexpr (IS_FIRST) {      // column 0 is lane 0 of the first wave; read as a LEFT neighbour
+                    matv = (lane == 0) ? e : matv;
+                    delv = (lane == 0) ? e : delv;
+                    R2 = (lane == 0) ? 0u : R2;
+                }
+                if constexpr (IS_LAST) {       // column 2r lies in the last wave (NW = ceil((2r+1)/64)); read as a TOP neighbour
+                    const bool is_edge = (tcol == 2 * r);
+                    matv = is_edge ? e : matv;
+                    insv = is_edge ? e : insv;
+                    R1 = is_edge ? 0u : R1;
                 }
             }
-        }
-        // one traceback word per cell: uniform row base in SGPRs + per-lane byte offset, so the store
-        // costs no address arithmetic (the compiler would otherwise carry a 64-bit per-lane pointer)
-        if (tb_lane) {
-            const uint32_t *trow = tb_g + (size_t)bl * p.tbstride;
-            asm volatile("global_store_dword %0, %1, %2" : : "v"(tcol4), "v"(o.tb), "s"(trow) : "memory");
-        }
-        // publish progress after this step's LDS writes (same in-order LDS queue); never vmcnt:
-        // the traceback stores above must stay in flight
-        if constexpr (NW > 1) {
-            asm volatile("" ::: "memory");
-            if (lane == 0) __hip_atomic_store(&prog[cw], bl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    };
-
-    auto run = [&](auto role_tag) __attribute__((always_inline)) {
-        step(std::integral_constant<int, 0>{}, role_tag);
-        int left = 64;                         // steps left in stepmask
-        for (int bl = 1; bl < d.nrows; bl++) {
-            if (left == 0) {                   // step bl-1 leads from local row bl-1 to bl
-                stepmask = nextmask;
-                nextmask = __builtin_amdgcn_ballot_w64(steps_g[bl - 1 + 64 + lane] != 0);
-                left = 64;
+            if (ROLE == 2 || hist_lane)     // (a middle wave holds band-interior columns only: no lane mask)
+                hist[env.slot * hw + tcol] =
+                    HistCell{o.matv, o.lenstart, o.shrstart, (uint32_t)o.lenrun_h | ((uint32_t)o.shrrun_h << 16)};
+            if constexpr (NW > 1) {
+                // boundary cells for the neighbour waves: the last lane's cell for the wave above (it reads
+                // it as a LEFT neighbour), the first lane's for the wave below (TOP neighbour + reference words)
+                int xo = (bl & 1) * (NW * XCH_WORDS) + cw * XCH_WORDS;
+                asm volatile("" : "+v"(xo));
+                uint32_t *xout = xchg + xo;
+                if constexpr (!IS_LAST) {
+                    if (lane == 63) {
+                        xout[0] = __float_as_uint(matv);
+                        xout[1] = __float_as_uint(delv);
+                        xout[2] = R2;
+                        xout[3] = seqw;
+                    }
+                }
+                if constexpr (!IS_FIRST) {
+                    if (lane == 0) {
+                        xout[5] = __float_as_uint(matv);
+                        xout[6] = __float_as_uint(insv);
+                        xout[7] = R1;
+                        xout[8] = refx;
+                        xout[9] = rc0;
+                        xout[10] = rc1;
+                    }
+                }
             }
-            const int I = (int)(stepmask & 1ull);
-            stepmask >>= 1;
-            left--;
-            st.b_local = bl;
-            st.ins_l += I;
-            st.del_l = bl - st.ins_l;
-            st.hist6 = ((st.hist6 << 1) | (uint32_t)I) & 63u;
-            env.slot = (env.slot + 1 == NSR) ? 0 : env.slot + 1;
-            if (I) step(std::integral_constant<int, 1>{}, role_tag);
-            else step(std::integral_constant<int, 2>{}, role_tag);
-        }
-    };
-    // the wave's role within its chunk decides where annotation words and boundary cells come from
-    if constexpr (NW == 1) run(std::integral_constant<int, 0>{});
-    else if (cw == 0) run(std::integral_constant<int, 1>{});
-    else if (cw == NW - 1) run(std::integral_constant<int, 3>{});
-    else run(std::integral_constant<int, 2>{});
+            // one traceback word per cell: uniform row base in SGPRs + per-lane byte offset, so the store
+            // costs no address arithmetic (the compiler would otherwise carry a 64-bit per-lane pointer)
+            if (ROLE == 1 || ROLE == 2 || tb_lane) {     // (columns beyond the band only exist in a chunk's last wave)
+                const uint32_t *trow = tb_g + (size_t)bl * p.tbstride;
+                asm volatile("global_store_dword %0, %1, %2" : : "v"(tcol4), "v"(o.tb), "s"(trow) : "memory");
+            }
+            // publish progress after this step's LDS writes (same in-order LDS queue); never vmcnt:
+            // the traceback stores above must stay in flight
+            if constexpr (NW > 1) {
+#if defined(NPORE_STRICT_SYNC)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#else
+                asm volatile("" ::: "memory");
+#endif
+                if (lane == 0) __hip_atomic_store(&prog[cw], pbase + bl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            // lane table of history offsets for the NEXT anti-diagonal, off the neighbours' critical path: its entry n
+            // is entry n-1 of this one (same ring row), 16 bytes lower if the band moves (the next step is an 'I');
+            // entry 0 = the next anti-diagonal's own row
+            {
+                const int next_slot = (env.slot + 1 == NSR) ? 0 : env.slot + 1;
+                const uint32_t moved = lane_prev(env.tab_e) - (uint32_t)((int)(stepmask_peek & 1ull) << 4);
+                // (one v_cndmask on a lane mask held in scalar registers; left to itself the compiler branches on exec)
+                uint32_t row0 = (uint32_t)(next_slot * env.hw16);
+                asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(env.tab_e) : "v"(moved), "v"(row0), "s"(env.n0_lanes));
+            }
+        };
+
+        auto run = [&](auto role_tag) __attribute__((always_inline)) {
+            stepmask_peek = stepmask;
+            step(std::integral_constant<int, 0>{}, role_tag);
+            int left = 64;                         // steps left in stepmask
+            for (int bl = 1; bl < d.nrows; bl++) {
+                if (left == 0) {                   // step bl-1 leads from local row bl-1 to bl
+                    stepmask = nextmask;
+                    nextmask = __builtin_amdgcn_ballot_w64(steps_g[bl - 1 + 64 + lane] != 0);
+                    left = 64;
+                }
+                const int I = (int)(stepmask & 1ull);
+                stepmask >>= 1;
+                left--;
+                stepmask_peek = left ? stepmask : nextmask;     // bit 0: the step after this one
+                st.b_local = bl;
+                st.ins_l += I;
+                st.del_l = bl - st.ins_l;
+                st.hist6 = ((st.hist6 << 1) | (uint32_t)I) & 63u;
+                env.slot = (env.slot + 1 == NSR) ? 0 : env.slot + 1;
+                if (I) step(std::integral_constant<int, 1>{}, role_tag);
+                else step(std::integral_constant<int, 2>{}, role_tag);
+            }
+        };
+        // the wave's role within its chunk decides where annotation words and boundary cells come from
+        if constexpr (NW == 1) run(std::integral_constant<int, 0>{});
+        else if (cw == 0) run(std::integral_constant<int, 1>{});
+        else if (cw == NW - 1) run(std::integral_constant<int, 3>{});
+        else run(std::integral_constant<int, 2>{});
+        pbase += d.nrows;
+    }
 }
 
 // ---------------------------------------------------------------------------

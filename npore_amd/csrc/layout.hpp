@@ -34,7 +34,7 @@
 //                .y and the L window); .z: bit 6 of either word or bit 7 of .w is set ("rare column")
 //     bits 8-14  L of reference position j-n for that period
 //     bits 15-30 byte address, inside the LDS score table, of the entry for "call length L-1":
-//                ((n-1)*32 + min(L, max_l-1))*256 + (32 + L-1)*4; a deletion of q more copies reads 4q bytes lower
+//                (((n-1)*32 + min(L, max_l-1))*33 + 32 - L)*4; a deletion of q more copies reads 4q bytes higher
 //     bit  31    "first copy": start a deletion rather than continue one
 //   refl[j]  8 bytes: byte n-1 = L of reference position j for period n (0..max_l)
 //
@@ -64,28 +64,17 @@ constexpr uint32_t REFW_SENTINEL = 0x36DB6u << MER_SHIFT;  // six code-6 bases, 
 constexpr int SUBT_ENTRIES = 256;
 constexpr int MAX_PERIOD = 6;                  // kernels are specialised for max_n <= 6
 constexpr float INF_F = 100.0f;                // reference src/aln.pyx:428
-// Which slot of the chunk schedule (chunks sorted largest first) position `cg` of workgroup `block` works on.
-// The workgroups of a "round" (`resident` of them: what the GPU holds at a time) are dealt the next
-// resident * cpg slots like cards -- slot q of the round goes to workgroup q % R, position q / R -- so every
-// workgroup of the round gets its share of the heavy chunks; the last round may be shorter.
-NPORE_HD int deal_slot(int block, int cg, int cpg, int grid, int resident)
-{
-    const int R = resident < grid ? (resident > 0 ? resident : 1) : grid;
-    const int round = block / R, within = block - round * R;
-    const int Rr = (grid - round * R) < R ? (grid - round * R) : R;
-    return round * R * cpg + cg * Rr + within;
-}
-
 constexpr int HIST_PAD = 6;                    // never-written history records either side of a row (cell.hpp)
 
 constexpr uint32_t DSC_N4 = 0x1Cu, DSC_BIGL = 1u << 6, DSC_MORE = 1u << 7, DSC_START = 1u << 31;
 // summary bits, only in .z (the first candidate): the column has a second candidate / something in the
 // column needs the generic path (L >= NP_LT in either candidate, or more than two candidates)
 constexpr uint32_t DSC_HAS2 = 1u << 5, DSC_RARE = 1u << 7;
-// LDS score table: [MAX_PERIOD][NP_LT][NP_CT] floats, entry NP_C0 + call for call in [-NP_C0, NP_CT - NP_C0)
-// holding np_scores[n][L][call], and INF_F where call < 0 (np_score's "call < 0 -> 100"): one guard entry in
-// front of each row, which a candidate reaches by clamping "copies deleted so far" at the row's own L (byte 1 of
-// its descriptor).  25 KB; the odd row length also spreads the rows over the LDS banks.
+// LDS score table: [MAX_PERIOD][NP_LT][NP_CT] floats; a row holds np_scores[n][L][call] with the call length
+// DEcreasing -- entry NP_LT - 1 - call for call = NP_LT-1 ... 0 -- followed by one guard entry (NP_C0) holding INF_F
+// for call < 0 (np_score's "call < 0 -> 100"), which a candidate reaches by clamping "copies deleted so far" at the
+// row's own L (byte 1 of its descriptor): deleting q more copies is q entries up from the descriptor's address
+// (one shift-add).  25 KB; the odd row length also spreads the rows over the LDS banks.
 constexpr int NP_LT = 32, NP_CT = 33, NP_C0 = 1;
 // max_l: np_score clamps the table ROW to max_l - 1 (src/aln.pyx:257-274 as called); L itself is capped at max_l, so
 // the call length L - 1 - q never needs the clamp
@@ -94,7 +83,7 @@ NPORE_HD uint32_t make_shr_desc(int n, bool start, uint32_t L, int max_l)
     // (L <= max_l, so the clamp only bites at L == max_l: one row up.  Written as a correction of the L-only index:
     // selecting the row first made the annotate kernel 50 % slower.)
     const uint32_t over = (L >= (uint32_t)max_l) ? (uint32_t)NP_CT : 0u;
-    const uint32_t addr = L < (uint32_t)NP_LT ? ((((uint32_t)(n - 1) * NP_LT + L) * NP_CT + NP_C0 + L - 1u) - over) * 4u : 0u;
+    const uint32_t addr = L < (uint32_t)NP_LT ? ((((uint32_t)(n - 1) * NP_LT + L) * NP_CT + (uint32_t)NP_LT - L) - over) * 4u : 0u;
     return ((uint32_t)n << 2) | (L >= (uint32_t)NP_LT ? DSC_BIGL : 0u) | (L << 8) | (addr << 15) | (start ? DSC_START : 0u);
 }
 

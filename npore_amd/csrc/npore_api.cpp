@@ -169,20 +169,22 @@ bool fill_geometry(int r, FillGeom &g)
     g.nw = pick_shape(r);
     if (!g.nw) return false;
     g.hw = 2 * r + 1 + HIST_PAD;
-    g.rwin = pow2_at_least(2 * r + 101);
+    // reference-L window: the band (2r+1), 96 positions of read-ahead and the 6 positions below the band that the
+    // generic SHR path looks back on -- plus 16 of margin, because the first wave of a chunk may run NW - 2
+    // anti-diagonals behind the last one, which refills the window
+    g.rwin = pow2_at_least(2 * r + 101 + 16);
     const size_t lds_cap = 160 * 1024 / sizeof(float);
     if (fill_lds_floats(g.nw, 1, g.hw, g.rwin) > lds_cap) return false;
     g.cmax = 1;
     while ((g.cmax + 1) * g.nw * 64 <= 1024 && fill_lds_floats(g.nw, g.cmax + 1, g.hw, g.rwin) <= lds_cap) g.cmax++;
     return true;
 }
-// workgroups of `chunks` chunks that are resident together, minus a few (see launch_fill)
+// workgroups of `chunks` chunks that are resident together: the size of a persistent fill launch
 int fill_round_workgroups(const FillGeom &g, int chunks, int n_cus)
 {
     const size_t lds = fill_lds_floats(g.nw, chunks, g.hw, g.rwin) * sizeof(float);
     const int wg_per_cu = std::max(1, std::min((int)((160 * 1024) / std::max<size_t>(lds, 1)), 2048 / (64 * g.nw * chunks)));
-    const int all = std::max(1, n_cus) * wg_per_cu;
-    return std::max(1, all - std::max(1, all / 40));
+    return std::max(1, n_cus) * wg_per_cu;
 }
 
 // NW waves per chunk, `chunks` chunks per workgroup (they share the LDS score table).
@@ -207,18 +209,14 @@ hipError_t launch_fill(KParams kp, int max_chunks, int force_chunks, int n_cus, 
         return e0 != hipSuccess ? e0 : (at.sharedSizeBytes == 0 ? hipSuccess : hipErrorInvalidDeviceFunction);
     }();
     if (no_static_lds != hipSuccess) return no_static_lds;
-    // Workgroups that are resident together (one "round"): the schedule lists the chunks largest first, and the
-    // kernel deals them over the workgroups of a round like cards, so that the heavy chunks of a small batch
-    // are spread over all CUs instead of filling the first workgroups.  A round is a few workgroups short of what
-    // the GPU holds: the workgroups of later rounds (small chunks once the list is sorted) then start at once
-    // on the CUs left free and run beside the heavy round instead of after it (C2: 1 000 chunks of 20 000 rows
-    // on 250 CUs, the 1 000 chunks of ~200 rows on the other 6 meanwhile)
-    kp.resident = fill_round_workgroups(g, chunks, n_cus);
+    // A persistent launch: as many workgroups as the GPU keeps resident (or fewer, if the batch is small); their
+    // groups of NW waves pull the chunks of the schedule (largest first) from a device-side queue (kernels.hpp)
+    const int resident = fill_round_workgroups(g, chunks, n_cus);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fill_kernel<NW, MAXT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((fill_kernel<NW, MAXT>), dim3((max_chunks + chunks - 1) / chunks), dim3(64 * NW * chunks),
-                       lds, s, kp);
+    hipLaunchKernelGGL((fill_kernel<NW, MAXT>), dim3(std::min((max_chunks + chunks - 1) / chunks, resident)),
+                       dim3(64 * NW * chunks), lds, s, kp);
     return hipGetLastError();
 }
 
@@ -360,6 +358,7 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     kp.descs = pp.descs;
     kp.sched = pp.sched;
     kp.n_chunks = pp.counters;
+    kp.queue = pp.counters + 2;
     kp.steps = pp.steps;
     kp.inss = pp.inss;
     kp.seqw = pp.seqw;

@@ -53,7 +53,7 @@ struct PrepParams {
     ChunkDesc *descs;
     int32_t *sched;
     int32_t *hist;             // [max_b_rows + 2] counting sort by rows, then running positions
-    int32_t *counters;         // [0] number of chunks, [1] overflow flag
+    int32_t *counters;         // [0] number of chunks, [1] overflow flag, [2] fill kernel's queue head
     // annotation
     uint32_t *seqw;
     uint4 *refw;
@@ -196,6 +196,7 @@ __global__ __launch_bounds__(1024) void read_scan_kernel(PrepParams p)
         p.rd_chunk_first[p.n_reads] = (int32_t)(tot_c > p.max_chunks ? p.max_chunks : tot_c);
         p.counters[0] = (int32_t)(tot_c > p.max_chunks ? p.max_chunks : tot_c);
         p.counters[1] = tot_c > p.max_chunks;
+        p.counters[2] = 0;      // head of the fill kernel's chunk queue
     }
     for (int64_t k = a; k < b; k++) {
         p.rd_steps_off[k] = as;

@@ -4,6 +4,11 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from npore_amd import _lib
 _lib.LIB_PATH = os.path.abspath(sys.argv[1])
+import ctypes
+_probe = ctypes.CDLL(_lib.LIB_PATH)          # older builds lack the newest entry points: bind what is there
+for _name in list(_lib.SIGNATURES):
+    if not hasattr(_probe, _name):
+        del _lib.SIGNATURES[_name]
 from npore_amd import aln, synth
 sub, nps, _, _ = aln.load_default_tables()
 ctx = aln.Context(sub, nps)

@@ -64,6 +64,9 @@ struct ModelEnv {
         const int n = period(n4);
         return h_at(n, c - popc32(t.hist6 & ((1u << n) - 1u)));
     }
+    uint32_t h_off(const Tab &, uint32_t n4) const { return n4; }
+    HistCell h_shr_at(const Tab &t, uint32_t, uint32_t n4, int c) const { return h_shr(t, n4, c); }
+    template <class... T> void pin(T &...) const {}
     HistCell h_len(const Tab &t, uint32_t n4, int c) const
     {
         const int n = period(n4);
@@ -242,10 +245,4 @@ extern "C" void pull_model_np_info(const uint8_t *seq, int64_t len, int max_n, i
             out[(p * 2 + 0) * max_n + n] = L[p * max_n + n];
             out[(p * 2 + 1) * max_n + n] = I[p * max_n + n];
         }
-}
-
-// the fill kernel's workgroup -> schedule-slot map (layout.hpp), for the permutation test
-extern "C" int pull_model_deal_slot(int block, int cg, int cpg, int grid, int resident)
-{
-    return npore::deal_slot(block, cg, cpg, grid, resident);
 }

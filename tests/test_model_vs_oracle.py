@@ -109,22 +109,3 @@ def test_other_table_shapes(tables):
                                  return_status=True)
             b, sb = model.align(ref, seq, cig, sub, t, max_b_rows=(20000, 64)[k % 2], r=r, max_n=max_n, max_l=max_l)
             assert a == b and sa == sb, (max_n, max_l, k)
-
-
-def test_fill_slot_dealing_is_a_permutation():
-    """fill_kernel's workgroup -> schedule-slot map (layout.hpp deal_slot): every slot of the schedule is worked on
-    exactly once, whatever the grid / round sizes, and the first round gets the first (heaviest) slots."""
-    import ctypes as C
-    lib = C.CDLL(model.build())
-    f = lib.pull_model_deal_slot
-    f.argtypes = [C.c_int] * 5
-    f.restype = C.c_int
-    for cpg, grid, resident in ((4, 500, 250), (8, 250, 250), (5, 400, 250), (1, 7, 250), (13, 1231, 250),
-                                (4, 250, 250), (2, 768, 250), (3, 11, 4), (16, 1, 500), (4, 501, 1)):
-        slots = sorted(f(b, cg, cpg, grid, resident) for b in range(grid) for cg in range(cpg))
-        assert slots == list(range(grid * cpg)), (cpg, grid, resident)
-        R = min(grid, resident)
-        first = sorted(f(b, cg, cpg, grid, resident) for b in range(R) for cg in range(cpg))
-        assert first == list(range(R * cpg))
-        # position 0 of the first-round workgroups holds the R heaviest chunks
-        assert sorted(f(b, 0, cpg, grid, resident) for b in range(R)) == list(range(R))
