@@ -209,6 +209,10 @@ def main():
     ap.add_argument("--sustain", type=float, default=5.0, help="seconds of the sustained device-resident leg; 0 = skip")
     ap.add_argument("--tb-kernel", type=int, default=0,
                     help="traceback kernel: 0 = chosen by batch size, 1 = windowed, 2 = row per hop (experiments)")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="1 (default): steps are enqueued without waiting (sync=0) -- inside the context the next batch is "
+                         "prepared and the previous one traced back while the fill kernel works on the current one; the "
+                         "timed region ends when the last step has completed.  0: every step waits for its batch")
     ap.add_argument("--inflight", type=int, default=1,
                     help="batches in flight per GPU: each has its own context (stream + work buffers) and host thread, "
                          "so one batch's traceback / gather and the next one's preparation run beside a fill kernel")
@@ -279,19 +283,34 @@ def main():
              torch.zeros(n, dtype=torch.int32, device=dev)) for _ in range(n_ctx)]
     d_out, d_len, d_st = outs[0]
 
+    pipelined = bool(args.pipeline) and n_ctx == 1
+
     def step(j=0):
         o, ln, st_ = outs[j]
         rc = lib.npore_align_batch_device(
             ctxs[j].handle, n, d_rb.data_ptr(), d_ro.data_ptr(), d_sb.data_ptr(), d_so.data_ptr(),
             d_cb.data_ptr(), d_co.data_ptr(), 5.0, 1.0, args.max_b_rows, args.r,
-            o.data_ptr(), d_oo.data_ptr(), ln.data_ptr(), st_.data_ptr(), None, 1)
+            o.data_ptr(), d_oo.data_ptr(), ln.data_ptr(), st_.data_ptr(), None, 0 if pipelined else 1)
         if rc != 0:
             raise RuntimeError(f"npore_align_batch_device: {rc} {_lib.last_error()}")
 
     def run_steps(k):
-        """Exactly k steps; with several batches in flight, host thread j drives steps j, j + n_ctx, ... on its
-        own context (the library call blocks its thread and releases the GIL)."""
+        """Exactly k steps, all complete on return; the stage times (HIP events on the library's streams) of the
+        groups of reads they were made of.  Pipelined: the steps are enqueued back to back on one context.  With
+        several contexts (--inflight), host thread j drives steps j, j + n_ctx, ... on its own context (the library
+        call blocks its thread and releases the GIL)."""
+        if k == 0:
+            return []
         times = [[] for _ in range(n_ctx)]
+        if pipelined:
+            t0_ = ctx.total_timing()
+            for _ in range(k):
+                step(0)
+            ctx.wait()
+            t1_ = ctx.total_timing()
+            g = max(1.0, t1_["launches"] - t0_["launches"])
+            per = tuple((t1_[q] - t0_[q]) / g * (g / k) for q in ("fill_ms", "traceback_ms", "dev_prep_ms"))
+            return [per] * k
 
         def worker(j):
             for _ in range(j, k, n_ctx):
@@ -481,7 +500,7 @@ def main():
                                    f"(SURVEY 8d generator{', mixed p_np' if args.mixed else ''}, base_seed={args.base_seed}"
                                    f"{f', {n_uniq} distinct reads repeated' if n_uniq < n else ''})",
                        "reads_per_gpu": n, "ref_len": args.ref_len, "r": args.r, "parallelism": f"reads x{world}",
-                       "batches_in_flight": n_ctx, "devices_visible": n_dev,
+                       "batches_in_flight": n_ctx, "pipelined": pipelined, "devices_visible": n_dev,
                        "reduction_backend": {"nccl": "rccl", "gloo": "gloo (ranks share a device)", None: "none"}[backend]},
             "roofline": roofline, "cpu_baseline": cpu,
             "value_pcie_inclusive": pcie, "sustained": sustained,

@@ -17,7 +17,8 @@
  *     The reference prints "ERROR ..." and exit(1)s or silently truncates
  *     (src/aln.pyx:689-716); here the same conditions are reported per read
  *     in `status` (NPORE_ST_* bits) and the truncated string is still returned.
- *   - one context per GPU; a context is not re-entrant (one call at a time).
+ *   - one context per GPU; a context is not re-entrant (one call at a time; asynchronous batches overlap
+ *     on the device, not in the API).
  */
 #ifndef NPORE_AMD_H
 #define NPORE_AMD_H
@@ -28,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NPORE_ABI_VERSION 1
+#define NPORE_ABI_VERSION 2
 
 /* return codes */
 #define NPORE_OK 0
@@ -97,10 +98,19 @@ int npore_align_batch(npore_ctx *ctx, int64_t n_reads,
  * Device-resident variant used by bench.py and by pipelines that already hold
  * the reads in HBM: same arguments, but every pointer except ctx is a DEVICE
  * pointer (hipMalloc'ed by the caller, e.g. a torch.cuda tensor's data_ptr()).
- * `stream` is a hipStream_t passed as void* (NULL = the context's own stream, which is a
- * non-blocking stream: it is NOT ordered with work on the NULL stream, so that several contexts
- * run side by side -- the buffers must be ready when the call is made, or pass the stream that
- * produces them).  The call returns after the batch has completed.
+ * `stream` is a hipStream_t passed as void*: the batch is ordered behind the work that stream holds at
+ * the time of the call (NULL = no such order: the context's own streams are non-blocking, they are NOT
+ * ordered with work on the NULL stream, so that several contexts run side by side -- the buffers must be
+ * ready when the call is made).
+ * sync != 0: the call returns after the batch has completed.
+ * sync == 0: the call returns once the batch is enqueued; up to two batches of a context are in flight, a
+ *   third call first waits for the oldest.  A context keeps two sets of work buffers and three streams
+ *   (preparation | fill kernel | traceback + gather), so the next batch is prepared and the previous one traced
+ *   back while the fill kernel works on the current one.  Results are complete when npore_ctx_wait() returns
+ *   (and for work put on `stream` after the call, if one was passed); the input and output buffers must stay
+ *   untouched until then.  A failure found later is reported by the next call on the context.
+ * A batch too large for the traceback budget is split into groups that go through the same pipeline inside
+ * one call, whatever `sync` says.
  */
 int npore_align_batch_device(npore_ctx *ctx, int64_t n_reads,
                              const uint8_t *d_refs, const int64_t *d_ref_off,
@@ -111,6 +121,9 @@ int npore_align_batch_device(npore_ctx *ctx, int64_t n_reads,
                              char *d_out, const int64_t *d_out_off,
                              int64_t *d_out_len, int32_t *d_status,
                              void *stream, int sync);
+
+/* Wait for every batch enqueued with sync == 0; returns the first failure among them. */
+int npore_ctx_wait(npore_ctx *ctx);
 
 /*
  * get_np_info (reference src/aln.pyx:179-251): n-polymer annotation of one
@@ -159,6 +172,9 @@ int npore_standardize_ops_batch(int64_t n_reads, const char *alns, const int64_t
  *   ms[6] cells processed (count), ms[7] fill-kernel launches.
  */
 int npore_last_timing(npore_ctx *ctx, double *ms, int n);
+/* The same entries summed over every group of reads the context has completed since it was made (for a caller
+ * that keeps batches in flight: differences over a timed region). */
+int npore_total_timing(npore_ctx *ctx, double *ms, int n);
 
 /* Tunables: key in {"tb_budget_mb","force_chunks","traceback_kernel"} (traceback budget in MiB,
  * chunks per workgroup, 1 = windowed / 2 = row-per-hop traceback; 0 = automatic). */

@@ -27,6 +27,8 @@ SIGNATURES = {
     "npore_align_batch_device": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 6 +
                                  [C.c_float, C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 4 +
                                  [C.c_void_p, C.c_int]),
+    "npore_ctx_wait": (C.c_int, [C.c_void_p]),
+    "npore_total_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "npore_get_np_info": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "npore_np_regions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p),
                                    C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
@@ -95,7 +97,7 @@ def load():
             fn = getattr(lib, name)   # AttributeError if the header and the library diverge
             fn.restype = res
             fn.argtypes = args
-        if lib.npore_abi_version() != 1:
+        if lib.npore_abi_version() != 2:
             raise ImportError("libnpore_amd.so ABI version mismatch")
         _LIB = lib
     return _LIB

@@ -100,11 +100,23 @@ class Context:
                 "resident_workgroups": res_wg, "resident_chunks": res_wg * cpg,
                 "resident_waves_per_cu": nw * cpg * wg_cu, "lds_bytes": lds}
 
+    _TIMING_KEYS = ("dev_prep_ms", "fill_ms", "traceback_ms", "h2d_ms", "d2h_ms", "reserved", "cells", "launches")
+
     def timing(self):
+        """Stage times of the last completed call (npore_last_timing)."""
         t = (C.c_double * 8)()
         _check(self.lib.npore_last_timing(self.handle, t, 8))
-        keys = ("dev_prep_ms", "fill_ms", "traceback_ms", "h2d_ms", "d2h_ms", "reserved", "cells", "launches")
-        return dict(zip(keys, list(t)))
+        return dict(zip(self._TIMING_KEYS, list(t)))
+
+    def total_timing(self):
+        """Stage times summed over every group completed since the context was made (npore_total_timing)."""
+        t = (C.c_double * 8)()
+        _check(self.lib.npore_total_timing(self.handle, t, 8))
+        return dict(zip(self._TIMING_KEYS, list(t)))
+
+    def wait(self):
+        """Wait for the batches enqueued with sync=0 (npore_ctx_wait)."""
+        _check(self.lib.npore_ctx_wait(self.handle))
 
     def align_batch(self, refs, seqs, cigars, indel_start=5, indel_extend=1, max_b_rows=20000, r=30,
                     return_status=False):

@@ -110,13 +110,38 @@ struct npore_batch_slot {
     std::string err;
 };
 
+// Work buffers of one group of reads on its way through the device stages (grow-only, reused).  A context has
+// two: while the fill kernel works on one group, the next group is prepared in the other set and the previous
+// group's traceback / gather drains from it (run_core).
+struct WorkSet {
+    DevBuf rd_i32, rd_i64, steps, inss, descs, sched, hist, counters; // path + chunks
+    DevBuf tiles, cwoff;                                             // CIGAR tiles; chunk positions in the output
+    DevBuf seqw, refw, refl, seql;                                   // annotation
+    DevBuf tb, cout_, clen, cstat, cnruns;                           // fill / traceback (cout_: uint32 runs)
+    HostBuf h_cnt;                                                   // counters read back with the group
+    hipEvent_t ev[6] = {};       // prep start / end, fill start / end, traceback + gather start / end (= group done)
+    bool busy = false;           // enqueued, not collected yet
+    int64_t cells = 0, call_id = 0;
+    DevBuf *all[19] = {&rd_i32, &rd_i64, &steps, &inss, &descs, &sched, &hist, &counters, &tiles, &cwoff,
+                       &seqw, &refw, &refl, &seql, &tb, &cout_, &clen, &cstat, &cnruns};
+};
+
 struct npore_ctx {
     int device = 0;
     int n_cus = 256;
     int max_n = 6, max_l = 100;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};
+    // three non-blocking streams: preparation (also every copy), fill kernels, traceback + gather; events order
+    // the stages of a group, the streams let stages of neighbouring groups run side by side
+    hipStream_t stream = nullptr, s_fill = nullptr, s_post = nullptr;
+    hipEvent_t ev[8] = {};       // [4..7] H2D / D2H of the host-buffer entry point, [0] the caller's stream
     float *d_sub = nullptr, *d_np = nullptr;   // NULL in an annotation-only context (created without tables)
+    WorkSet ws[2];
+    int next_ws = 0;             // set the next group goes into (the older of the two)
+    WorkSet *last_ws = nullptr;  // set of the group enqueued last (npore_debug_fetch)
+    int64_t call_id = 0, timing_call = -1;
+    int deferred_rc = 0;         // failure found while collecting a group of an asynchronous call
+    std::string deferred_err;
+    double totals[8] = {};       // like timing[], summed over every group since the context was made
     // tunables
     int64_t tb_budget_mb = 0;   // 0 = auto
     int tb_kernel = 0;          // 0 = by batch size, 1 = windowed traceback, 2 = row per hop
@@ -124,11 +149,7 @@ struct npore_ctx {
     HostBuf h_offs;             // offset arrays of a device-resident batch (npore_align_batch_device)
     // device buffers (grow-only, reused across calls)
     DevBuf in_refs, in_seqs, in_cigs, in_off;                       // raw inputs (host-buffer entry point)
-    DevBuf rd_i32, rd_i64, steps, inss, descs, sched, hist, counters; // path + chunks
-    DevBuf tiles, cwoff;                                             // CIGAR tiles; chunk positions in the output
     std::vector<int32_t> regions;                                    // npore_np_regions: positions, then repeat counts
-    DevBuf seqw, refw, refl, seql;                                   // annotation
-    DevBuf tb, cout_, clen, cstat, cnruns;                           // fill / traceback (cout_: uint32 runs)
     DevBuf out, out_off, out_len, status;                            // outputs (host-buffer entry point)
     // host staging of the BAM -> SAM pipeline (npore_bam_realign_batch / _file): grow-only, reused across batches and files
     static constexpr int N_SLOTS = 6;
@@ -249,9 +270,9 @@ int64_t chunk_bound(int64_t cig_len, int max_b_rows)
 
 // Reads [g0,g1): everything from the raw bytes to the gathered output, on stream s,
 // without host synchronisation.
-int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const OutTarget &ot, hipStream_t s,
-              int shape)
+int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_t g1, const OutTarget &ot, int shape)
 {
+    hipStream_t s = ctx->stream;      // preparation; the fill and traceback stages go to their own streams below
     const int64_t nr = g1 - g0;
     const int r = a.r;
     const int tbs = tb_stride(r);
@@ -273,28 +294,28 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     for (int64_t k = g0; k < g1; k++)
         max_tiles += std::max<int64_t>(1, (a.h_cig_off[k + 1] - a.h_cig_off[k] + CIGAR_TILE - 1) / CIGAR_TILE);
     if (max_tiles > (1ll << 30)) return fail(NPORE_E_UNSUPPORTED, "too many CIGAR tiles in one group");
-    if (int rc = ctx->rd_i32.ensure((size_t)(5 * nr + 16) * 4)) return rc;
-    if (int rc = ctx->tiles.ensure((size_t)max_tiles * 24 + 64)) return rc;
-    if (int rc = ctx->cwoff.ensure((size_t)max_chunks * 8 + 64)) return rc;
-    if (int rc = ctx->rd_i64.ensure((size_t)(nr + 2) * 8)) return rc;
-    if (int rc = ctx->steps.ensure(steps_cap)) return rc;
-    if (int rc = ctx->inss.ensure((size_t)(2 * cig_bytes + nr + 16) * 4)) return rc;
-    if (int rc = ctx->descs.ensure((size_t)max_chunks * sizeof(ChunkDesc))) return rc;
-    if (int rc = ctx->sched.ensure((size_t)max_chunks * 4)) return rc;
-    if (int rc = ctx->hist.ensure((size_t)(a.max_b_rows + 2) * 4)) return rc;
-    if (int rc = ctx->counters.ensure(64)) return rc;
-    if (int rc = ctx->seqw.ensure((size_t)(S_tot + max_chunks + 16) * 4)) return rc;
+    if (int rc = w->rd_i32.ensure((size_t)(5 * nr + 16) * 4)) return rc;
+    if (int rc = w->tiles.ensure((size_t)max_tiles * 24 + 64)) return rc;
+    if (int rc = w->cwoff.ensure((size_t)max_chunks * 8 + 64)) return rc;
+    if (int rc = w->rd_i64.ensure((size_t)(nr + 2) * 8)) return rc;
+    if (int rc = w->steps.ensure(steps_cap)) return rc;
+    if (int rc = w->inss.ensure((size_t)(2 * cig_bytes + nr + 16) * 4)) return rc;
+    if (int rc = w->descs.ensure((size_t)max_chunks * sizeof(ChunkDesc))) return rc;
+    if (int rc = w->sched.ensure((size_t)max_chunks * 4)) return rc;
+    if (int rc = w->hist.ensure((size_t)(a.max_b_rows + 2) * 4)) return rc;
+    if (int rc = w->counters.ensure(64)) return rc;
+    if (int rc = w->seqw.ensure((size_t)(S_tot + max_chunks + 16) * 4)) return rc;
     {
         const size_t need = (7 * pstride <= 160 * 1024) ? 64 : (size_t)2 * max_chunks * 6 * pstride;
-        if (int rc = ctx->seql.ensure(need)) return rc;
+        if (int rc = w->seql.ensure(need)) return rc;
     }
-    if (int rc = ctx->refw.ensure((size_t)(R_tot + max_chunks + 16) * 16)) return rc;
-    if (int rc = ctx->refl.ensure((size_t)(R_tot + max_chunks + 16) * 8)) return rc;
-    if (int rc = ctx->tb.ensure((size_t)tb_words * 4 + 64)) return rc;
-    if (int rc = ctx->cout_.ensure(((size_t)(S_tot + R_tot) + 64) * 4)) return rc;
-    if (int rc = ctx->cnruns.ensure((size_t)max_chunks * 4 + 64)) return rc;
-    if (int rc = ctx->clen.ensure((size_t)max_chunks * 4 + 64)) return rc;
-    if (int rc = ctx->cstat.ensure((size_t)max_chunks * 4 + 64)) return rc;
+    if (int rc = w->refw.ensure((size_t)(R_tot + max_chunks + 16) * 16)) return rc;
+    if (int rc = w->refl.ensure((size_t)(R_tot + max_chunks + 16) * 8)) return rc;
+    if (int rc = w->tb.ensure((size_t)tb_words * 4 + 64)) return rc;
+    if (int rc = w->cout_.ensure(((size_t)(S_tot + R_tot) + 64) * 4)) return rc;
+    if (int rc = w->cnruns.ensure((size_t)max_chunks * 4 + 64)) return rc;
+    if (int rc = w->clen.ensure((size_t)max_chunks * 4 + 64)) return rc;
+    if (int rc = w->cstat.ensure((size_t)max_chunks * 4 + 64)) return rc;
 
     PrepParams pp;
     pp.n_reads = nr;
@@ -304,27 +325,28 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     pp.max_b_rows = a.max_b_rows; pp.r = r; pp.tbstride = tbs; pp.max_n = ctx->max_n; pp.max_l = ctx->max_l;
     pp.pstride = (int)pstride;
     pp.max_chunks = (int)max_chunks;
-    int32_t *i32 = ctx->rd_i32.as<int32_t>();
+    int32_t *i32 = w->rd_i32.as<int32_t>();
     pp.rd_nsteps = i32;
     pp.rd_nchunks = i32 + nr;
     pp.rd_status = i32 + 2 * nr;
     pp.rd_chunk_first = i32 + 3 * nr;   // nr + 1 entries
     pp.rd_tile_first = i32 + 4 * nr + 4;   // nr + 1 entries
-    pp.tile_cnt = ctx->tiles.as<int4>();
-    pp.tile_base = reinterpret_cast<int2 *>(ctx->tiles.as<char>() + (size_t)max_tiles * 16);
-    pp.rd_steps_off = ctx->rd_i64.as<int64_t>();
-    pp.steps = ctx->steps.as<uint8_t>();
-    pp.inss = ctx->inss.as<int32_t>();
-    pp.descs = ctx->descs.as<ChunkDesc>();
-    pp.sched = ctx->sched.as<int32_t>();
-    pp.hist = ctx->hist.as<int32_t>();
-    pp.counters = ctx->counters.as<int32_t>();
-    pp.seqw = ctx->seqw.as<uint32_t>();
-    pp.refw = ctx->refw.as<uint4>();
-    pp.refl = ctx->refl.as<uint2>();
-    pp.seql = ctx->seql.as<uint2>();
+    pp.tile_cnt = w->tiles.as<int4>();
+    pp.tile_base = reinterpret_cast<int2 *>(w->tiles.as<char>() + (size_t)max_tiles * 16);
+    pp.rd_steps_off = w->rd_i64.as<int64_t>();
+    pp.steps = w->steps.as<uint8_t>();
+    pp.inss = w->inss.as<int32_t>();
+    pp.descs = w->descs.as<ChunkDesc>();
+    pp.sched = w->sched.as<int32_t>();
+    pp.hist = w->hist.as<int32_t>();
+    pp.counters = w->counters.as<int32_t>();
+    pp.seqw = w->seqw.as<uint32_t>();
+    pp.refw = w->refw.as<uint4>();
+    pp.refl = w->refl.as<uint2>();
+    pp.seql = w->seql.as<uint2>();
 
-    HIP_TRY(hipEventRecord(ctx->ev[0], s));
+    if (int rc = w->h_cnt.ensure(64)) return rc;
+    HIP_TRY(hipEventRecord(w->ev[0], s));
     HIP_TRY(hipMemsetAsync(pp.hist, 0, (size_t)(a.max_b_rows + 2) * 4, s));
     const unsigned rd_blocks = (unsigned)((nr + 3) / 4), ch_blocks = (unsigned)((max_chunks + 255) / 256);
     const unsigned tile_blocks = (unsigned)((max_tiles + 3) / 4);
@@ -352,7 +374,11 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
         }
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ctx->ev[1], s));
+    HIP_TRY(hipEventRecord(w->ev[1], s));
+    // ---- fill: behind this group's preparation, and (same stream) behind the previous group's fill
+    s = ctx->s_fill;
+    HIP_TRY(hipStreamWaitEvent(s, w->ev[1], 0));
+    HIP_TRY(hipEventRecord(w->ev[2], s));
 
     KParams kp;
     kp.descs = pp.descs;
@@ -364,7 +390,7 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     kp.seqw = pp.seqw;
     kp.refw = pp.refw;
     kp.refl = pp.refl;
-    kp.tb = ctx->tb.as<uint32_t>();
+    kp.tb = w->tb.as<uint32_t>();
     kp.sub_scores = ctx->d_sub;
     kp.np_scores = ctx->d_np;
     kp.max_n = ctx->max_n;
@@ -387,17 +413,21 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
         default: return fail(NPORE_E_UNSUPPORTED, "unsupported waves-per-chunk count");
     }
     if (e != hipSuccess) return fail(NPORE_E_HIP, std::string("fill launch: ") + hipGetErrorString(e));
-    HIP_TRY(hipEventRecord(ctx->ev[2], s));
+    HIP_TRY(hipEventRecord(w->ev[3], s));
+    // ---- traceback + gather: behind this group's fill, beside the next group's
+    s = ctx->s_post;
+    HIP_TRY(hipStreamWaitEvent(s, w->ev[3], 0));
+    HIP_TRY(hipEventRecord(w->ev[4], s));
 
     TParams tp;
     tp.descs = pp.descs;
     tp.n_chunks = pp.counters;
     tp.tb = kp.tb;
     tp.inss = pp.inss;
-    tp.chunk_runs = ctx->cout_.as<uint32_t>();
-    tp.chunk_nruns = ctx->cnruns.as<int32_t>();
-    tp.chunk_len = ctx->clen.as<int32_t>();
-    tp.chunk_status = ctx->cstat.as<int32_t>();
+    tp.chunk_runs = w->cout_.as<uint32_t>();
+    tp.chunk_nruns = w->cnruns.as<int32_t>();
+    tp.chunk_len = w->clen.as<int32_t>();
+    tp.chunk_status = w->cstat.as<int32_t>();
     tp.r = r;
     tp.tbstride = tbs;
     // windowed traceback for small batches (about one wave per SIMD), row-per-hop for large ones (kernels.hpp)
@@ -426,7 +456,7 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
     gp.status = ot.d_status;
     gp.read_base = g0;
     gp.n_reads = nr;
-    gp.chunk_woff = ctx->cwoff.as<int64_t>();
+    gp.chunk_woff = w->cwoff.as<int64_t>();
     hipLaunchKernelGGL(gather_scan_kernel, dim3(rd_blocks), dim3(256), 0, s, gp);
     // LDS of gather_kernel: one tile of ops + (when a chunk's two base slices fit beside it) the slices
     {
@@ -438,22 +468,55 @@ int run_group(npore_ctx *ctx, const AlignArgs &a, int64_t g0, int64_t g1, const 
         hipLaunchKernelGGL(gather_kernel, dim3((unsigned)max_chunks), dim3(256), glds, s, gp);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ctx->ev[3], s));
+    HIP_TRY(hipMemcpyAsync(w->h_cnt.p, w->counters.p, 8, hipMemcpyDeviceToHost, s));    // chunk count, overflow flag
+    HIP_TRY(hipEventRecord(w->ev[5], s));
     return NPORE_OK;
 }
 
-int collect_group_timing(npore_ctx *ctx, int64_t cells)
+// Wait for a group that was enqueued into `w`, add its stage times to the context's timing and check its counters.
+int collect_group(npore_ctx *ctx, WorkSet *w)
 {
+    if (!w->busy) return NPORE_OK;
+    w->busy = false;
+    HIP_TRY(hipEventSynchronize(w->ev[5]));
+    if (w->call_id != ctx->timing_call) {       // first group of a newer call: npore_last_timing starts over
+        std::fill(ctx->timing, ctx->timing + 3, 0.0);
+        ctx->timing[6] = ctx->timing[7] = 0.0;
+        ctx->timing_call = w->call_id;
+    }
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); ctx->timing[0] += ms;
-    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2])); ctx->timing[1] += ms;
-    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->timing[2] += ms;
-    ctx->timing[6] += (double)cells;
-    ctx->timing[7] += 1;
+    for (int k = 0; k < 3; k++) {
+        HIP_TRY(hipEventElapsedTime(&ms, w->ev[2 * k], w->ev[2 * k + 1]));
+        ctx->timing[k] += ms;
+        ctx->totals[k] += ms;
+    }
+    ctx->timing[6] += (double)w->cells; ctx->totals[6] += (double)w->cells;
+    ctx->timing[7] += 1; ctx->totals[7] += 1;
+    if (w->h_cnt.as<int32_t>()[1]) return fail(NPORE_E_HIP, "internal: chunk bound exceeded");
     return NPORE_OK;
 }
 
-int run_core(npore_ctx *ctx, const AlignArgs &a, const OutTarget &ot, hipStream_t s)
+// Everything this context has in flight (asynchronous calls): collected oldest first.  Returns the first failure,
+// including one found earlier while a work set was being recycled.
+int quiesce(npore_ctx *ctx)
+{
+    int rc = ctx->deferred_rc;
+    std::string err = ctx->deferred_err;
+    for (int k = 0; k < 2; k++) {
+        WorkSet *w = &ctx->ws[(ctx->next_ws + k) & 1];
+        const int r2 = collect_group(ctx, w);
+        if (r2 && !rc) { rc = r2; err = g_err; }
+    }
+    ctx->deferred_rc = 0;
+    ctx->deferred_err.clear();
+    return rc ? fail(rc, err) : NPORE_OK;
+}
+
+// The batch, group by group, through the three-stage pipeline: the groups alternate between the two work sets, so
+// that group k+1 is prepared and group k-1 traced back while the fill kernel works on group k.  `user` (may be
+// NULL) is the caller's stream: the batch is ordered behind what it holds now.  sync = false returns once the
+// last group is enqueued (results complete when npore_ctx_wait returns, or for work put on `user` afterwards).
+int run_core(npore_ctx *ctx, const AlignArgs &a, const OutTarget &ot, hipStream_t user, bool sync)
 {
     if (a.n_reads < 0) return fail(NPORE_E_INVALID, "n_reads < 0");
     if (!ctx->d_sub || !ctx->d_np) return fail(NPORE_E_INVALID, "this context was created without penalty tables (annotation only)");
@@ -463,22 +526,28 @@ int run_core(npore_ctx *ctx, const AlignArgs &a, const OutTarget &ot, hipStream_
         return fail(NPORE_E_UNSUPPORTED, "max_b_rows > 60000: run lengths are kept in 16 bits");
     const int shape = pick_shape(a.r);
     if (!shape) return fail(NPORE_E_UNSUPPORTED, "band half-width r > 255");
-    std::fill(ctx->timing, ctx->timing + 8, 0.0);
     if (a.n_reads == 0) return NPORE_OK;
+    ctx->call_id++;
+    if (user) {
+        HIP_TRY(hipEventRecord(ctx->ev[0], user));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev[0], 0));
+    }
 
     // groups of consecutive reads whose traceback words fit the budget.  The automatic budget is this context's
-    // share of the device (contexts of one device run side by side: the file pipeline's peer, bench --inflight):
-    // 60 % of the memory divided by the live contexts, and never more than what is free now plus what this
-    // context already holds.
+    // share of the device (contexts of one device run side by side: the file pipeline's peer, bench --inflight),
+    // halved for its two work sets: 60 % of the memory divided by the live contexts, and never more than what is
+    // free now plus what the context already holds.
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const int live = std::max(1, g_live_ctx[ctx->device & 15].load());
+    const size_t held = ctx->ws[0].tb.cap + ctx->ws[1].tb.cap;
     const int64_t budget = ctx->tb_budget_mb > 0
                                ? ctx->tb_budget_mb * (int64_t)1048576
-                               : (int64_t)std::min(0.6 * (double)total_b / live, 0.9 * (double)(free_b + ctx->tb.cap));
+                               : (int64_t)(0.5 * std::min(0.6 * (double)total_b / live, 0.9 * (double)(free_b + held)));
     const int tbs = tb_stride(a.r);
     int64_t g0 = 0;
     int64_t max_group = a.n_reads;       // halved when a group's buffers do not fit after all
+    WorkSet *last = nullptr;
     while (g0 < a.n_reads) {
         int64_t g1 = g0, acc = 0, cells = 0;
         while (g1 < a.n_reads && g1 - g0 < max_group) {
@@ -490,22 +559,28 @@ int run_core(npore_ctx *ctx, const AlignArgs &a, const OutTarget &ot, hipStream_
             cells += (a.h_seq_off[g1 + 1] - a.h_seq_off[g1] + a.h_ref_off[g1 + 1] - a.h_ref_off[g1] + 1) * (2 * a.r + 1);
             g1++;
         }
-        if (int rc = run_group(ctx, a, g0, g1, ot, s, shape)) {
+        WorkSet *w = &ctx->ws[ctx->next_ws];
+        if (int rc = collect_group(ctx, w)) {        // the set's previous group (two groups back) has to be through
+            if (!ctx->deferred_rc) { ctx->deferred_rc = rc; ctx->deferred_err = g_err; }
+        }
+        if (int rc = run_group(ctx, w, a, g0, g1, ot, shape)) {
             if (rc == NPORE_E_NOMEM && g1 - g0 > 1) {          // another context got there first: smaller groups
+                (void)quiesce(ctx);
                 max_group = (g1 - g0) / 2;
                 continue;
             }
+            (void)quiesce(ctx);
             return rc;
         }
-        // work buffers are reused by the next group (and the events by its timing)
-        HIP_TRY(hipStreamSynchronize(s));
-        if (int rc = collect_group_timing(ctx, cells)) return rc;
-        int32_t cnt[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(cnt, ctx->counters.p, 8, hipMemcpyDeviceToHost, s));   // (a NULL-stream copy would wait for every other context's kernels)
-        HIP_TRY(hipStreamSynchronize(s));
-        if (cnt[1]) return fail(NPORE_E_HIP, "internal: chunk bound exceeded");
+        w->busy = true;
+        w->cells = cells;
+        w->call_id = ctx->call_id;
+        ctx->last_ws = last = w;
+        ctx->next_ws ^= 1;
         g0 = g1;
     }
+    if (sync) return quiesce(ctx);
+    if (user && last) HIP_TRY(hipStreamWaitEvent(user, last->ev[5], 0));
     return NPORE_OK;
 }
 
@@ -553,7 +628,9 @@ try {
     ctx->max_n = max_n;
     ctx->max_l = max_l;
     const size_t np_elems = (size_t)max_n * (max_l + 1) * (max_l + 1);
-    bool ok = hipSetDevice(device_id) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
+    bool ok = hipSetDevice(device_id) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&ctx->s_fill, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&ctx->s_post, hipStreamNonBlocking) == hipSuccess;
     if (tables) {
         ctx->h_sub.assign(sub_scores, sub_scores + 25);
         ctx->h_np.assign(np_scores, np_scores + np_elems);
@@ -563,6 +640,8 @@ try {
              hipMemcpy(ctx->d_np, np_scores, np_elems * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
     }
     for (auto &e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    for (auto &w : ctx->ws)
+        for (auto &e : w.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     if (!ok) {
         fail(NPORE_E_HIP, "npore_ctx_create: HIP initialisation failed");
         npore_ctx_destroy(ctx);
@@ -578,17 +657,22 @@ void npore_ctx_destroy(npore_ctx *ctx)
     g_live_ctx[ctx->device & 15]--;
     npore_ctx_destroy(ctx->peer);
     (void)hipSetDevice(ctx->device);
-    for (DevBuf *b : {&ctx->in_refs, &ctx->in_seqs, &ctx->in_cigs, &ctx->in_off, &ctx->rd_i32, &ctx->rd_i64, &ctx->tiles, &ctx->cwoff,
-                      &ctx->steps, &ctx->inss, &ctx->descs, &ctx->sched, &ctx->hist, &ctx->counters, &ctx->seqw,
-                      &ctx->refw, &ctx->refl, &ctx->seql, &ctx->tb, &ctx->cout_, &ctx->clen, &ctx->cstat, &ctx->cnruns,
-                      &ctx->out, &ctx->out_off, &ctx->out_len, &ctx->status})
+    (void)hipDeviceSynchronize();       // nothing of this context may still be running
+    for (DevBuf *b : {&ctx->in_refs, &ctx->in_seqs, &ctx->in_cigs, &ctx->in_off, &ctx->out, &ctx->out_off, &ctx->out_len, &ctx->status})
         b->release();
+    for (auto &w : ctx->ws) {
+        for (DevBuf *b : w.all) b->release();
+        w.h_cnt.release();
+        for (auto &e : w.ev)
+            if (e) (void)hipEventDestroy(e);
+    }
     ctx->h_offs.release();
     if (ctx->d_sub) (void)hipFree(ctx->d_sub);
     if (ctx->d_np) (void)hipFree(ctx->d_np);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    for (hipStream_t st : {ctx->stream, ctx->s_fill, ctx->s_post})
+        if (st) (void)hipStreamDestroy(st);
     for (auto *sp : ctx->slots) delete sp;
     delete ctx;
 }
@@ -604,6 +688,7 @@ try {
     if (!ref_off || !seq_off || !cig_off || !out_off || !out_len || !status)
         return fail(NPORE_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
+    if (int rc = quiesce(ctx)) return rc;        // (asynchronous device-resident batches still in flight)
     hipStream_t s = ctx->stream;
     const int64_t n = n_reads;
     const int64_t out_bytes = out_off[n] - out_off[0];
@@ -632,7 +717,7 @@ try {
     AlignArgs a{n, ctx->in_refs.as<uint8_t>(), d_off, ctx->in_seqs.as<uint8_t>(), d_off + (n + 1),
                 ctx->in_cigs.as<char>(), d_off + 2 * (n + 1), ro, so, co, indel_start, indel_extend, max_b_rows, r};
     OutTarget ot{ctx->out.as<uint8_t>(), d_off + 3 * (n + 1), ctx->out_len.as<int64_t>(), ctx->status.as<int32_t>()};
-    if (int rc = run_core(ctx, a, ot, s)) return rc;
+    if (int rc = run_core(ctx, a, ot, nullptr, true)) return rc;
     HIP_TRY(hipEventRecord(ctx->ev[6], s));
     HIP_TRY(hipMemcpyAsync(out + out_off[0], ctx->out.p, out_bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(out_len, ctx->out_len.p, n * 8, hipMemcpyDeviceToHost, s));
@@ -658,6 +743,7 @@ try {
     if (!d_ref_off || !d_seq_off || !d_cig_off || !d_out_off || !d_out_len || !d_status)
         return fail(NPORE_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->deferred_rc) return quiesce(ctx);   // a group of an earlier asynchronous call failed
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     // the host only needs the three offset arrays (24 bytes per read) to size work buffers
     const int64_t n = n_reads;
@@ -672,8 +758,15 @@ try {
                 offs, offs + (n + 1), offs + 2 * (n + 1),
                 indel_start, indel_extend, max_b_rows, r};
     OutTarget ot{reinterpret_cast<uint8_t *>(d_out), d_out_off, d_out_len, d_status};
-    (void)sync;   // run_core synchronises the stream after every group (work buffers are shared)
-    return run_core(ctx, a, ot, s);
+    return run_core(ctx, a, ot, (hipStream_t)stream, sync != 0);
+}
+NPORE_CATCH_INT
+
+int npore_ctx_wait(npore_ctx *ctx)
+try {
+    if (!ctx) return fail(NPORE_E_INVALID, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return quiesce(ctx);
 }
 NPORE_CATCH_INT
 
@@ -683,17 +776,18 @@ try {
     if (len <= 0) return NPORE_OK;
     if (len > (1ll << 30)) return fail(NPORE_E_UNSUPPORTED, "sequence too long");
     HIP_TRY(hipSetDevice(ctx->device));
+    if (int rc = quiesce(ctx)) return rc;
     const int mn = ctx->max_n;
     const int pstride = (int)((len + 15) & ~(int64_t)15);
     const size_t out_bytes = (size_t)len * 2 * mn * 4;
     // work buffers of the align path are reused (nothing else runs on this context meanwhile): grow-only, kept
     if (int rc = ctx->in_seqs.ensure((size_t)len + 16)) return rc;
-    if (int rc = ctx->seql.ensure((size_t)pstride * MAX_PERIOD + 16)) return rc;
+    if (int rc = ctx->ws[0].seql.ensure((size_t)pstride * MAX_PERIOD + 16)) return rc;
     if (int rc = ctx->out.ensure(out_bytes)) return rc;
     hipStream_t s = ctx->stream;
     HIP_TRY(hipMemcpyAsync(ctx->in_seqs.p, seq, (size_t)len, hipMemcpyHostToDevice, s));
     const uint8_t *dseq = ctx->in_seqs.as<uint8_t>();
-    uint8_t *planes = ctx->seql.as<uint8_t>();
+    uint8_t *planes = ctx->ws[0].seql.as<uint8_t>();
     int32_t *L = ctx->out.as<int32_t>(), *I = L + mn;
     // four waves of 64 positions per workgroup; enough workgroups for one window per wave, capped at a few per CU
     const int64_t windows = (len + 63) / 64;
@@ -727,13 +821,14 @@ try {
         if (l < 0 || l >= (1ll << 30)) return fail(NPORE_E_INVALID, "slice length out of range");
     }
     HIP_TRY(hipSetDevice(ctx->device));
+    if (int rc = quiesce(ctx)) return rc;
     const int mn = ctx->max_n;
     const size_t m = (size_t)mn * n_slices;
     // work buffers of the align path are reused (nothing else runs on this context meanwhile)
     if (int rc = ctx->in_seqs.ensure((size_t)bases + 16)) return rc;
     if (int rc = ctx->in_off.ensure((size_t)(n_slices + 1) * 8)) return rc;
-    if (int rc = ctx->seql.ensure((size_t)bases * mn + 64)) return rc;
-    if (int rc = ctx->rd_i64.ensure((m + 2) * 8)) return rc;
+    if (int rc = ctx->ws[0].seql.ensure((size_t)bases * mn + 64)) return rc;
+    if (int rc = ctx->ws[0].rd_i64.ensure((m + 2) * 8)) return rc;
     std::vector<int64_t> off((size_t)n_slices + 1);
     for (int64_t k = 0; k <= n_slices; k++) off[k] = seq_off[k] - seq_off[0];
     hipStream_t s = ctx->stream;
@@ -745,8 +840,8 @@ try {
     rp.n_slices = (int)n_slices;
     rp.max_n = mn;
     rp.max_l = ctx->max_l;
-    rp.planes = ctx->seql.as<uint8_t>();
-    rp.counts = ctx->rd_i64.as<int64_t>();
+    rp.planes = ctx->ws[0].seql.as<uint8_t>();
+    rp.counts = ctx->ws[0].rd_i64.as<int64_t>();
     rp.out_pos = rp.out_reps = nullptr;
     hipLaunchKernelGGL(region_annotate_kernel, dim3((unsigned)n_slices), dim3(1024), 0, s, rp);
     hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(1024), 0, s, rp);
@@ -777,6 +872,13 @@ int npore_last_timing(npore_ctx *ctx, double *ms, int n)
 {
     if (!ctx || !ms) return fail(NPORE_E_INVALID, "null argument");
     for (int i = 0; i < n && i < 8; i++) ms[i] = ctx->timing[i];
+    return NPORE_OK;
+}
+
+int npore_total_timing(npore_ctx *ctx, double *ms, int n)
+{
+    if (!ctx || !ms) return fail(NPORE_E_INVALID, "null argument");
+    for (int i = 0; i < n && i < 8; i++) ms[i] = ctx->totals[i];
     return NPORE_OK;
 }
 
@@ -893,7 +995,9 @@ int npore_debug_divcheck(int64_t *mismatches)
 int npore_debug_fetch(npore_ctx *ctx, int what, void *dst, int64_t bytes)
 {
     if (!ctx || !dst) return fail(NPORE_E_INVALID, "null argument");
-    DevBuf *b[] = {&ctx->steps, &ctx->inss, &ctx->descs, &ctx->seqw, &ctx->refw, &ctx->refl, &ctx->sched, &ctx->counters};
+    if (int rc = quiesce(ctx)) return rc;
+    WorkSet *w = ctx->last_ws ? ctx->last_ws : &ctx->ws[0];
+    DevBuf *b[] = {&w->steps, &w->inss, &w->descs, &w->seqw, &w->refw, &w->refl, &w->sched, &w->counters};
     if (what < 0 || what > 7) return fail(NPORE_E_INVALID, "bad selector");
     if ((size_t)bytes > b[what]->cap) return fail(NPORE_E_INVALID, "more bytes than the buffer holds");
     HIP_TRY(hipSetDevice(ctx->device));

@@ -63,3 +63,71 @@ def test_get_np_info_first_call_of_a_fresh_process():
     out = subprocess.run([sys.executable, "-c", _NP_INFO_FIRST.format(repo=REPO)], cwd=REPO,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "NP_INFO_OK 100" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+_ASYNC = r"""
+import sys, numpy as np
+sys.path.insert(0, {repo!r})
+import torch                                   # first: the library then binds to the HIP runtime torch has loaded
+dev = torch.device("cuda", 0)
+torch.zeros(1, device=dev)
+from bench import pack
+from npore_amd import _lib, aln, synth
+sub, nps, _, _ = aln.load_default_tables()
+ctx = aln.Context(sub, nps, max_n=6, max_l=100, device=0)
+lib = _lib.load()
+batches, want = [], []
+for k in range(6):
+    refs, seqs, cigs = synth.make_batch(60 + k, 40 + 7 * k, ref_len=2500 + 300 * k)
+    want.append(ctx.align_batch(refs, seqs, cigs, r=30 if k % 2 else 100))        # synchronous host-buffer path
+    rb, ro = pack(refs); sb, so = pack(seqs); cb, co = pack(cigs)
+    oo = np.zeros(len(refs) + 1, np.int64)
+    np.cumsum([len(a) + len(b) for a, b in zip(refs, seqs)], out=oo[1:])
+    t = [torch.from_numpy(x).to(dev) for x in (rb, ro, sb, so, cb, co, oo)]
+    out = torch.zeros(int(oo[-1]) + 64, dtype=torch.uint8, device=dev)
+    ln = torch.zeros(len(refs), dtype=torch.int64, device=dev)
+    st = torch.zeros(len(refs), dtype=torch.int32, device=dev)
+    batches.append((len(refs), t, out, ln, st, oo))
+torch.cuda.synchronize()
+before = ctx.total_timing()["launches"]
+for k, (n, t, out, ln, st, oo) in enumerate(batches):       # six batches enqueued back to back, two in flight
+    rc = lib.npore_align_batch_device(ctx.handle, n, *[x.data_ptr() for x in t[:6]], 5.0, 1.0, 20000, 30 if k % 2 else 100,
+                                      out.data_ptr(), t[6].data_ptr(), ln.data_ptr(), st.data_ptr(), None, 0)
+    assert rc == 0, _lib.last_error()
+ctx.wait()
+assert ctx.total_timing()["launches"] - before == 6
+for (n, t, out, ln, st, oo), w in zip(batches, want):
+    o, l = out.cpu().numpy(), ln.cpu().numpy()
+    assert not st.cpu().numpy().any()
+    assert [o[oo[i]:oo[i] + l[i]].tobytes().decode() for i in range(n)] == w
+# a stream of the caller's: the batch is ordered behind the work it holds, later work on it sees the results
+n, t, out, ln, st, oo = batches[0]
+s2 = torch.cuda.Stream(device=dev)
+with torch.cuda.stream(s2):
+    out.zero_(); ln.zero_()
+    rc = lib.npore_align_batch_device(ctx.handle, n, *[x.data_ptr() for x in t[:6]], 5.0, 1.0, 20000, 100,
+                                      out.data_ptr(), t[6].data_ptr(), ln.data_ptr(), st.data_ptr(), s2.cuda_stream, 0)
+    assert rc == 0, _lib.last_error()
+    total = ln.sum()                 # enqueued on s2 behind the batch
+s2.synchronize()
+assert int(total.item()) == sum(len(x) for x in want[0])
+ctx.wait()
+# one call, several groups: a small traceback budget splits 60 reads into groups that go through the same pipeline
+ctx.set("tb_budget_mb", 8)
+refs, seqs, cigs = synth.make_batch(70, 60, ref_len=3000)
+got = ctx.align_batch(refs, seqs, cigs, r=100)
+assert ctx.timing()["launches"] > 3
+ctx.set("tb_budget_mb", 0)
+assert got == ctx.align_batch(refs, seqs, cigs, r=100)
+ctx.close()
+print("ASYNC_OK")
+"""
+
+
+def test_async_batches_in_flight():
+    """npore_align_batch_device with sync=0 (include/npore_amd.h): batches enqueued back to back on one context
+    (two in flight, the third call recycles the first one's work buffers), results complete after npore_ctx_wait and
+    equal to the synchronous host-buffer path's; a caller's stream is honoured; a multi-group call uses the same
+    pipeline.  In its own process because torch (device buffers) has to initialise the HIP runtime first."""
+    out = subprocess.run([sys.executable, "-c", _ASYNC.format(repo=REPO)], cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ASYNC_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

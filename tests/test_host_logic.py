@@ -22,7 +22,7 @@ def test_header_symbols_exported_and_bound():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.npore_abi_version() == 1
+    assert lib.npore_abi_version() == 2
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (npore_[a-z_0-9]+)", out))
     assert declared <= exported
