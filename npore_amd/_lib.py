@@ -11,7 +11,9 @@ import subprocess
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnpore_amd.so")
+# NPORE_AMD_LIB selects another build of the same ABI (tests/tools/ab_sync.py: the -DNPORE_RELAXED_SYNC build)
+LIB_PATH = os.environ.get("NPORE_AMD_LIB") or os.path.join(_HERE, "libnpore_amd.so")
+RELAXED_LIB_PATH = os.path.join(_HERE, "libnpore_amd_relaxed.so")
 CSRC = os.path.join(_HERE, "csrc")
 _LIB = None
 
@@ -72,17 +74,20 @@ def sources():
         [os.path.join(_HERE, "..", "include", "npore_amd.h")]
 
 
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> npore_amd/libnpore_amd.so (in-tree)."""
-    if not force and os.path.exists(LIB_PATH) and \
-            all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in sources()):
-        return LIB_PATH
+def build(force=False, verbose=False, relaxed=False):
+    """hipcc --offload-arch=gfx950 -> npore_amd/libnpore_amd.so (in-tree).  relaxed=True builds
+    libnpore_amd_relaxed.so instead: the same sources with -DNPORE_RELAXED_SYNC (kernels.hpp: compiler barriers in
+    place of the workgroup release / acquire fences of the fill kernel's hand-shakes), for tests/tools/ab_sync.py."""
+    out = RELAXED_LIB_PATH if relaxed else os.path.join(_HERE, "libnpore_amd.so")
+    if not force and os.path.exists(out) and all(os.path.getmtime(s) <= os.path.getmtime(out) for s in sources()):
+        return out
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-Wall", "-Wno-unused-function", "-o", LIB_PATH, os.path.join(CSRC, "npore_api.cpp"), "-lz"]
+           "-Wall", "-Wno-unused-function"] + (["-DNPORE_RELAXED_SYNC"] if relaxed else []) + \
+          ["-o", out, os.path.join(CSRC, "npore_api.cpp"), "-lz"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return out
 
 
 def load():

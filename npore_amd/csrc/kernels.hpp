@@ -240,6 +240,20 @@ __device__ __forceinline__ float lane_next_or(float edge, float v)
 // within the device's memory: < 2^30 anti-diagonals for every band), so a plain signed compare is safe
 __device__ __forceinline__ bool reached(int word, int target) { return word >= target; }
 
+// Ordering of the LDS hand-shakes between the waves of a group (progress words, slot ring, window-ready word): a
+// workgroup-scope release fence before every publishing store, an acquire fence behind every polling load.
+// -DNPORE_RELAXED_SYNC builds the shortcut of round 1 instead -- rely on the hardware serving the LDS requests
+// of a wave in order, and only stop the COMPILER from reordering (an empty asm with a memory clobber).  Both were
+// run over the same 40 000 fuzz reads against the oracle (tests/tools/ab_sync.py: equal) and timed: the fences
+// cost nothing measurable (C2 fill 22.31 vs 22.27 ms), so they are the default.
+#if defined(NPORE_RELAXED_SYNC)
+#define NPORE_PUBLISH_FENCE() asm volatile("" ::: "memory")
+#define NPORE_OBSERVE_FENCE() asm volatile("" ::: "memory")
+#else
+#define NPORE_PUBLISH_FENCE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
+#define NPORE_OBSERVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup")
+#endif
+
 constexpr int SLOT_RING = 8;    // chunk slots published by a group's first wave and not yet read by its last (<= NW - 1)
 
 // NW waves per chunk ("a group"), each owning 64 consecutive band columns.  PERSISTENT: the launch holds as many
@@ -329,8 +343,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 
     for (;;) {
         // ---- next chunk slot of the schedule.  One wave of the group asks the queue; the others read its answer
-        // from the group's slot ring in LDS (an LDS word written after another by one wave is seen after it by
-        // every other wave: requests of a wave are served in order)
+        // from the group's slot ring in LDS (value released before the generation word, acquired behind the poll)
         int slot_id;
         if (gen == 0) {
             // the first chunk of every group is dealt like cards -- slot q of the schedule to workgroup q % grid,
@@ -347,7 +360,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 if (lane == 0) {
                     v = atomicAdd(p.queue, 1) + dealt;
                     __hip_atomic_store(&slotbox[gen & (SLOT_RING - 1)], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    asm volatile("" ::: "memory");
+                    NPORE_PUBLISH_FENCE();
                     __hip_atomic_store(&slotbox[SLOT_RING], gen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 slot_id = uni(v);
@@ -357,7 +370,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                     if (reached(uni(g), gen + 1)) break;
                     __builtin_amdgcn_s_sleep(2);
                 }
-                asm volatile("" ::: "memory");
+                NPORE_OBSERVE_FENCE();
                 slot_id = uni(__hip_atomic_load(&slotbox[gen & (SLOT_RING - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             }
         }
@@ -420,7 +433,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                     if (__builtin_amdgcn_ballot_w64(!reached(v, pbase)) == 0ull) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
-                asm volatile("" ::: "memory");
+                NPORE_OBSERVE_FENCE();
             }
         }
         // reference-L window: positions [0, wfill) are resident (modulo rwin)
@@ -433,7 +446,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         }
         if constexpr (NW > 1) {
             if (cw == NW - 1) {
-                asm volatile("" ::: "memory");
+                NPORE_PUBLISH_FENCE();
                 if (lane == 0) __hip_atomic_store(&slotbox[SLOT_RING + 1], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
                 for (;;) {
@@ -441,7 +454,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                     if (reached(uni(g), gen)) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
-                asm volatile("" ::: "memory");
+                NPORE_OBSERVE_FENCE();
             }
         }
         if (gen > 1 && hist_lane) {
@@ -476,21 +489,18 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             if constexpr (NW > 1 && MODE != 0) {
                 // Per-chunk hand-shake instead of a workgroup barrier: this wave may start anti-diagonal bl
                 // once its two neighbour waves have finished bl-1 (they own the only columns it reads).
-                // LDS requests of a wave are served in order, so a neighbour's progress word becomes
-                // visible after the history / exchange words it wrote before it.
+                // The neighbour released its history / exchange words before its progress word; the fence
+                // behind the loop acquires them.
                 const int target = pbase + bl;
                 for (;;) {
                     // relaxed workgroup-scope atomics keep these plain LDS reads (a volatile access would
                     // become a flat system-scope load with a vmcnt(0) wait)
                     const int a = !IS_FIRST ? __hip_atomic_load(&prog[cw - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
                     const int b = !IS_LAST ? __hip_atomic_load(&prog[cw + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
-#if defined(NPORE_STRICT_SYNC)
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#endif
                     if (uni((a < b ? a : b)) >= target) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
-                asm volatile("" ::: "memory");
+                NPORE_OBSERVE_FENCE();
             }
             // boundary cells written by the neighbour waves at the end of the previous step
             // (the record addresses are wave-uniform; pinning each in ONE vector register lets every word
@@ -653,14 +663,10 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 const uint32_t *trow = tb_g + (size_t)bl * p.tbstride;
                 asm volatile("global_store_dword %0, %1, %2" : : "v"(tcol4), "v"(o.tb), "s"(trow) : "memory");
             }
-            // publish progress after this step's LDS writes (same in-order LDS queue); never vmcnt:
-            // the traceback stores above must stay in flight
+            // publish progress after this step's LDS writes (workgroup release: LDS only, it does not wait for the
+            // traceback stores above, which must stay in flight)
             if constexpr (NW > 1) {
-#if defined(NPORE_STRICT_SYNC)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-#else
-                asm volatile("" ::: "memory");
-#endif
+                NPORE_PUBLISH_FENCE();
                 if (lane == 0) __hip_atomic_store(&prog[cw], pbase + bl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             // lane table of history offsets for the NEXT anti-diagonal, off the neighbours' critical path: its entry n
