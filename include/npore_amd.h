@@ -207,6 +207,11 @@ typedef struct npore_fasta npore_fasta;
  * ... not found", src/bam.pyx:22-24). */
 npore_bam *npore_bam_open(const char *path, int threads);
 void npore_bam_close(npore_bam *bam);
+/* Write the inflated BAM stream to `path` (complete or not at all: temporary file + rename).  npore_bam_open
+ * recognises such a file ("BAM\1" at offset 0) and maps it instead of inflating: with several processes per node
+ * (one per GPU) one of them inflates and the others share its copy through the page cache. */
+int npore_bam_dump_inflated(const npore_bam *bam, const char *path);
+int64_t npore_bam_inflated_size(const npore_bam *bam);
 int64_t npore_bam_n_records(const npore_bam *bam);
 int npore_bam_n_refs(const npore_bam *bam);
 const char *npore_bam_ref_name(const npore_bam *bam, int i);

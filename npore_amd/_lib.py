@@ -42,6 +42,8 @@ SIGNATURES = {
     "npore_fill_shape": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "npore_bam_open": (C.c_void_p, [C.c_char_p, C.c_int]),
     "npore_bam_close": (None, [C.c_void_p]),
+    "npore_bam_dump_inflated": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "npore_bam_inflated_size": (C.c_int64, [C.c_void_p]),
     "npore_bam_n_records": (C.c_int64, [C.c_void_p]),
     "npore_bam_n_refs": (C.c_int, [C.c_void_p]),
     "npore_bam_ref_name": (C.c_char_p, [C.c_void_p, C.c_int]),

@@ -359,10 +359,21 @@ class NativeFastaSeqs:
 class NativeBam:
     """A BAM file inflated and indexed by the library (same attributes as BamFile where realign needs them)."""
 
-    def __init__(self, path, threads=0):
+    def __init__(self, path, threads=0, share=None):
+        """share: with several processes per node (one per GPU, torch.distributed.run) the BAM is inflated ONCE --
+        by local rank 0, into a file under /dev/shm that the other local ranks map (npore_bam_dump_inflated);
+        None = do so when LOCAL_WORLD_SIZE > 1 and the inflated stream fits a quarter of the free /dev/shm."""
         from . import _lib
         self._lib = _lib.load()
-        self.handle = self._lib.npore_bam_open(os.fsencode(path), threads)
+        self._shared = None
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if share is None:
+            share = local_world > 1 and os.path.isdir("/dev/shm") and os.environ.get("NPORE_SHARE_BAM", "1") != "0"
+        open_path = path
+        if share and local_world > 1:
+            open_path = self._shared_copy(path, local_rank, threads)
+        self.handle = self._lib.npore_bam_open(os.fsencode(open_path), threads)
         if not self.handle:
             msg = _lib.last_error()
             print(f"\nERROR: BAM file '{path}' not found." if "not found" in msg else f"\nERROR: {msg}.")
@@ -371,6 +382,44 @@ class NativeBam:
         self.references = [self._lib.npore_bam_ref_name(self.handle, i).decode() for i in range(n)]
         self.lengths = [int(self._lib.npore_bam_ref_len(self.handle, i)) for i in range(n)]
         self.n_records = int(self._lib.npore_bam_n_records(self.handle))
+
+    def _shared_copy(self, path, local_rank, threads):
+        """Path to open: the inflated copy under /dev/shm (local rank 0 makes it, the others wait for it), or
+        `path` itself when sharing is not possible (no room, or the maker gave up: a `.skip` marker)."""
+        import hashlib
+        import shutil
+        import time
+        try:
+            st = os.stat(path)
+        except OSError:
+            return path
+        key = hashlib.sha1(f"{os.path.abspath(path)}:{st.st_size}:{st.st_mtime_ns}:{os.environ.get('MASTER_PORT', '')}".encode()).hexdigest()[:16]
+        raw, skip = f"/dev/shm/npore_bam_{key}.raw", f"/dev/shm/npore_bam_{key}.skip"
+        if local_rank == 0:
+            h = self._lib.npore_bam_open(os.fsencode(path), threads)
+            if not h:
+                open(skip, "w").close()
+                return path
+            ok = False
+            try:
+                size = int(self._lib.npore_bam_inflated_size(h))
+                if size * 4 <= shutil.disk_usage("/dev/shm").free:
+                    ok = self._lib.npore_bam_dump_inflated(h, os.fsencode(raw)) == 0
+            finally:
+                self._lib.npore_bam_close(h)
+            if not ok:
+                open(skip, "w").close()
+                return path
+            self._shared = (raw, skip)
+            return raw
+        t_end = time.time() + 1800
+        while time.time() < t_end:
+            if os.path.exists(raw):
+                return raw
+            if os.path.exists(skip):
+                return path
+            time.sleep(0.05)
+        return path
 
     def refs_with_reads(self):
         return {i for i in range(len(self.references)) if self._lib.npore_bam_ref_has_reads(self.handle, i)}
@@ -470,17 +519,27 @@ class NativeBam:
         if self.handle:
             self._lib.npore_bam_close(self.handle)
             self.handle = None
+        if self._shared:                 # the maker takes the shared copy away; a rank that comes later inflates itself
+            raw, skip = self._shared
+            self._shared = None
+            try:
+                open(skip, "w").close()
+                os.remove(raw)
+            except OSError:
+                pass
 
 
-def realign_native(ctx, bam, fasta, idx, out_sam, r=30, max_b_rows=20000, batch_reads=0):
+def realign_native(ctx, bam, fasta, idx, out_sam, r=30, max_b_rows=20000, batch_reads=0, threads=0):
     """realign_reads() through the library; returns the number of reads handed in.  batch_reads > 0: the whole
-    index list in overlapped batches written by the library itself; 0: one batch, text written here."""
+    index list in overlapped batches written by the library itself; 0: one batch, text written here.
+    threads: host threads of the parallel host stages (0 = all cores; one process per GPU: dist.host_threads_per_rank)."""
     if len(idx) == 0:
         return 0
     if batch_reads > 0:
-        text, status = None, bam.realign_file(ctx, fasta, idx, out_sam, batch_reads=batch_reads, r=r, max_b_rows=max_b_rows)
+        text, status = None, bam.realign_file(ctx, fasta, idx, out_sam, batch_reads=batch_reads, r=r, max_b_rows=max_b_rows,
+                                              threads=threads)
     else:
-        text, status = bam.realign_batch(ctx, fasta, idx, r=r, max_b_rows=max_b_rows)
+        text, status = bam.realign_batch(ctx, fasta, idx, r=r, max_b_rows=max_b_rows, threads=threads)
     bad = np.nonzero(status)[0]
     for k in bad:
         if status[k] & 32:

@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -204,6 +205,7 @@ inline bool bgzf_inflate(const ByteSpan &raw, int threads, RawBuf &out, size_t &
 
 // ---- handles ---------------------------------------------------------------------------------
 struct npore_bam {
+    std::unique_ptr<npore::MappedFile> raw_map;   // the file itself when it already is an inflated BAM stream
     npore::RawBuf data_buf;               // inflated stream
     const uint8_t *data = nullptr;
     size_t data_size = 0;

@@ -15,6 +15,8 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 #include "../../include/npore_amd.h"
 #include "glue.hpp"
 #include "hostio.hpp"
@@ -1010,17 +1012,25 @@ int npore_debug_fetch(npore_ctx *ctx, int what, void *dst, int64_t bytes)
 npore_bam *npore_bam_open(const char *path, int threads)
 try {
     if (!path) { fail(NPORE_E_INVALID, "null path"); return nullptr; }
-    MappedFile mf;
+    std::unique_ptr<MappedFile> mfp(new MappedFile());
+    MappedFile &mf = *mfp;
     if (!mf.open(path)) { fail(NPORE_E_INVALID, std::string("BAM file '") + path + "' not found"); return nullptr; }
     const ByteSpan raw{mf.p, mf.n};
     std::unique_ptr<npore_bam> hold(new npore_bam());
     npore_bam *b = hold.get();
     std::string err;
-    if (!bgzf_inflate(raw, threads, b->data_buf, b->data_size, err) || b->data_size < 12 || std::memcmp(b->data_buf.p, "BAM\1", 4) != 0) {
-        fail(NPORE_E_INVALID, std::string("'") + path + "' is not a BAM file" + (err.empty() ? "" : " (" + err + ")"));
-        return nullptr;
+    if (mf.n >= 12 && std::memcmp(mf.p, "BAM\1", 4) == 0) {
+        // an inflated BAM stream (npore_bam_dump_inflated: one rank of a node inflates, the others map its copy)
+        b->data = mf.p;
+        b->data_size = mf.n;
+        b->raw_map = std::move(mfp);
+    } else {
+        if (!bgzf_inflate(raw, threads, b->data_buf, b->data_size, err) || b->data_size < 12 || std::memcmp(b->data_buf.p, "BAM\1", 4) != 0) {
+            fail(NPORE_E_INVALID, std::string("'") + path + "' is not a BAM file" + (err.empty() ? "" : " (" + err + ")"));
+            return nullptr;
+        }
+        b->data = reinterpret_cast<const uint8_t *>(b->data_buf.p);
     }
-    b->data = reinterpret_cast<const uint8_t *>(b->data_buf.p);
     const uint8_t *d = b->data;
     const size_t N = b->data_size;
     size_t p = 4;
@@ -1085,6 +1095,23 @@ try {
 }
 NPORE_CATCH_PTR
 void npore_bam_close(npore_bam *b) { delete b; }
+
+int64_t npore_bam_inflated_size(const npore_bam *b) { return b ? (int64_t)b->data_size : 0; }
+
+int npore_bam_dump_inflated(const npore_bam *b, const char *path)
+try {
+    if (!b || !path) return fail(NPORE_E_INVALID, "null argument");
+    const std::string tmp = std::string(path) + ".tmp" + std::to_string((long long)::getpid());
+    FILE *fh = std::fopen(tmp.c_str(), "wb");
+    if (!fh) return fail(NPORE_E_INVALID, "cannot create '" + tmp + "'");
+    const bool ok = std::fwrite(b->data, 1, b->data_size, fh) == b->data_size;
+    if (std::fclose(fh) != 0 || !ok || std::rename(tmp.c_str(), path) != 0) {       // complete, or not there at all
+        std::remove(tmp.c_str());
+        return fail(NPORE_E_INVALID, std::string("cannot write '") + path + "'");
+    }
+    return NPORE_OK;
+}
+NPORE_CATCH_INT
 int64_t npore_bam_n_records(const npore_bam *b) { return b ? (int64_t)b->rec_off.size() : 0; }
 int npore_bam_n_refs(const npore_bam *b) { return b ? (int)b->ref_names.size() : 0; }
 const char *npore_bam_ref_name(const npore_bam *b, int i) { return (b && i >= 0 && i < (int)b->ref_names.size()) ? b->ref_names[(size_t)i].c_str() : ""; }

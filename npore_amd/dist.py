@@ -30,6 +30,41 @@ def reduce_counters(sums, maxes, device=None):
     return dict(zip(ks, ts.tolist())), dict(zip(km, tm.tolist()))
 
 
+def _append_file(out, src):
+    """Append the open file `src` to `out` inside the kernel (copy_file_range: no trip through user space, and a
+    reflink where the file system has them); plain reads and writes where that is not available."""
+    size = os.fstat(src.fileno()).st_size
+    done = 0
+    if hasattr(os, "copy_file_range"):
+        out.flush()
+        try:
+            while done < size:
+                k = os.copy_file_range(src.fileno(), out.fileno(), min(size - done, 1 << 30))
+                if k <= 0:
+                    break
+                done += k
+        except OSError:
+            pass
+        if done:
+            out.seek(0, os.SEEK_END)
+    src.seek(done)
+    while True:
+        buf = src.read(1 << 24)
+        if not buf:
+            break
+        out.write(buf)
+
+
+def host_threads_per_rank():
+    """Host threads a rank should use for the parallel host stages (BGZF inflate, packing, standardisation, SAM
+    text): the cores this process may run on, divided among the ranks of this node."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    return max(1, cores // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
+
+
 def gather_parts(final_path, out_prefix, n_local):
     """End of a multi-process realign: wait for every rank's part file, let rank 0 append them to the
     final SAM in rank order and remove them.  Returns the total number of reads (on every rank).
@@ -44,14 +79,11 @@ def gather_parts(final_path, out_prefix, n_local):
     dist.all_reduce(t, op=dist.ReduceOp.SUM)        # also the barrier: every part is complete
     if rank == 0:
         with open(final_path, "ab") as out:
+            out.flush()
             for k in range(world_size):
                 part = f"{out_prefix}.part{k}.sam"
                 with open(part, "rb") as fh:
-                    while True:
-                        buf = fh.read(1 << 24)
-                        if not buf:
-                            break
-                        out.write(buf)
+                    _append_file(out, fh)
                 os.remove(part)
     dist.barrier()
     if own_group:

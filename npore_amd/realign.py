@@ -55,10 +55,13 @@ def main():
               "(they need samtools mpileup + matplotlib); the confusion matrices in --stats_dir are used as is.")
         sys.exit(1)
     native = not cfg.args.python_io
+    # one process per GPU: the host stages of a rank use its share of the node's cores, and the BAM is inflated
+    # once per node (local rank 0; the other ranks map its copy, bam.NativeBam)
+    threads = dist_mod.host_threads_per_rank() if int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > 1 else 0
     print("> reading reference")
     ref_seqs = bam_mod.NativeFasta(cfg.args.ref) if native else bam_mod.read_fasta(cfg.args.ref)
     print("> selecting BAM regions")
-    bam = bam_mod.NativeBam(cfg.args.bam) if native else bam_mod.BamFile(cfg.args.bam)
+    bam = bam_mod.NativeBam(cfg.args.bam, threads=threads) if native else bam_mod.BamFile(cfg.args.bam)
     bam_mod.get_bam_regions(bam, ref_seqs)
 
     print("> calculating score matrices")
@@ -86,7 +89,7 @@ def main():
         idx = bam.select(cfg.args.regions, cfg.args.max_reads)
         idx = idx[rank::world]                      # reads are independent: dealt by index, no data-path collective
         print("> computing individual read realignments")
-        n += bam_mod.realign_native(ctx, bam, ref_seqs, idx, out_sam, batch_reads=cfg.args.batch_reads)
+        n += bam_mod.realign_native(ctx, bam, ref_seqs, idx, out_sam, batch_reads=cfg.args.batch_reads, threads=threads)
         bam.close()
         ref_seqs.close()
         if world > 1:

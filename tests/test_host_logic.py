@@ -256,6 +256,46 @@ def test_native_bam_matches_python_reader_on_reference_data():
     assert _native_vs_python(os.path.join(d, "reads.bam"), os.path.join(d, "ref.fasta"), [("ref", 400, 450), ("ref", 0, 30)]) > 0
 
 
+def test_inflated_bam_copy_shared_between_local_ranks(tmp_path, monkeypatch):
+    """Several processes per node: local rank 0 inflates the BAM once and leaves the stream under /dev/shm
+    (npore_bam_dump_inflated), the other local ranks map that copy (npore_bam_open recognises an inflated stream);
+    same records either way; the maker removes the copy when it closes.  Part files are appended in the kernel."""
+    from npore_amd import bam, dist
+    path = os.path.join(GOLDEN, "data", "reads.bam")
+    lib = _lib.load()
+    plain = bam.NativeBam(path, share=False)
+    raw = str(tmp_path / "copy.raw")
+    assert lib.npore_bam_dump_inflated(plain.handle, raw.encode()) == 0
+    assert os.path.getsize(raw) == lib.npore_bam_inflated_size(plain.handle) and open(raw, "rb").read(4) == b"BAM\1"
+    mapped = bam.NativeBam(raw, share=False)
+    regions = [("ref", 0, 1000)]
+    assert mapped.references == plain.references and mapped.n_records == plain.n_records
+    assert np.array_equal(mapped.select(regions), plain.select(regions))
+    mapped.close()
+    if os.path.isdir("/dev/shm"):
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+        monkeypatch.setenv("MASTER_PORT", str(40000 + os.getpid() % 20000))
+        monkeypatch.setenv("LOCAL_RANK", "0")
+        maker = bam.NativeBam(path)
+        assert maker._shared and os.path.exists(maker._shared[0])
+        monkeypatch.setenv("LOCAL_RANK", "1")
+        user = bam.NativeBam(path)                  # finds the copy at once
+        assert user._shared is None and np.array_equal(user.select(regions), plain.select(regions))
+        shared = maker._shared[0]
+        user.close(); maker.close()
+        assert not os.path.exists(shared)
+        os.remove(shared.replace(".raw", ".skip"))
+    plain.close()
+    # dist._append_file: whole files, also behind existing content
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.write_bytes(b"@HD\n"); b.write_bytes(b"x" * 100_000 + b"\n")
+    with open(a, "ab") as out, open(b, "rb") as src:
+        dist._append_file(out, src)
+        out.write(b"tail\n")
+    assert a.read_bytes() == b"@HD\n" + b"x" * 100_000 + b"\ntail\n"
+    assert dist.host_threads_per_rank() >= 1
+
+
 def test_native_bam_clips_flags_tags(tmp_path):
     """A synthetic BAM with soft/hard clips, IUPAC bases, missing qualities, HP tags of several widths,
     secondary / supplementary / unmapped records, two contigs and reads hanging over a contig end."""
