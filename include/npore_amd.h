@@ -263,6 +263,22 @@ int npore_bam_realign_file(npore_ctx *ctx, npore_bam *bam, const npore_fasta *fa
  * ms[0] pack, ms[1] npore_align_batch (incl. PCIe), ms[2] standardise, ms[3] SAM formatting. */
 int npore_bam_last_timing(const npore_bam *bam, double *ms, int n);
 
+/*
+ * The counting loop of calc_confusion_matrices (reference src/bam.pyx:351-499) for one range (ctg, start, end):
+ * the basecaller's SUB / n-polymer / INS / DEL confusion counts from pileup text.  Host code, no GPU.
+ *   lines / line_off[n_lines+1]: column 5 of `samtools mpileup -r ctg:start+1-end` (src/bam.pyx:301-316), upper-cased,
+ *     one entry per reported position, taken as positions start, start+1, ... like the reference does;
+ *   ref_codes[n_ref]: base codes of refs[ctg][start:end]; ref_text[ref_text_len]: the upper-cased contig from
+ *     `start` to its end (the n-polymer unit an insertion is compared with, :459-460);
+ *   np_info: get_np_info(refs[ctg][start:end+1]) as npore_get_np_info returns it, np_len positions.
+ * The counts are ADDED to subs[5][5], nps[max_n][max_l+1][max_l+1], inss[max_l+1], dels[max_l+1] (int64), so that
+ * ranges accumulate (the reference sums its pool's results, :183-188).  *bad_lines = lines holding a character the
+ * reference reports as unexpected (:473-476; the rest of such a line is dropped there too). */
+int npore_confusion_counts(const char *lines, const int64_t *line_off, int64_t n_lines, const uint8_t *ref_codes,
+                           int64_t n_ref, const char *ref_text, int64_t ref_text_len, const int32_t *np_info,
+                           int64_t np_len, int max_n, int max_l, int64_t *subs, int64_t *nps, int64_t *inss,
+                           int64_t *dels, int64_t *bad_lines, int threads);
+
 /* Debug self-test: out128[l] = value lane l receives from lane l-1 (l>0),
  * out128[64+l] = value from lane l+1 (l<63); checks the DPP wave-shift
  * directions the fill kernel relies on. */

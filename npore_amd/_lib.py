@@ -36,6 +36,9 @@ SIGNATURES = {
                                    C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "npore_standardize_batch": (C.c_int, [C.c_int64] + [C.c_void_p] * 9 + [C.c_int]),
     "npore_standardize_ops_batch": (C.c_int, [C.c_int64] + [C.c_void_p] * 9 + [C.c_int]),
+    "npore_confusion_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                         C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_int]),
     "npore_last_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "npore_ctx_set": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "npore_round_chunks": (C.c_int64, [C.c_void_p, C.c_int]),

@@ -552,6 +552,88 @@ def realign_native(ctx, bam, fasta, idx, out_sam, r=30, max_b_rows=20000, batch_
     return len(idx)
 
 
+# ---- confusion matrices (reference src/bam.pyx:166-200, 301-316, 351-499) ----------------------------------------
+def get_pileups(bam_path, ctg, start, end):
+    """Column 5 of `samtools mpileup -r ctg:start+1-end bam`, upper-cased, one string per reported position
+    (reference src/bam.pyx:301-316).  Needs samtools on PATH, like the reference."""
+    import shutil
+    import subprocess
+    if not shutil.which("samtools"):
+        print("\nERROR: recalculating the confusion matrices needs `samtools` (mpileup) on PATH.")
+        sys.exit(1)
+    pile = subprocess.Popen(["samtools", "mpileup", "-r", f"{ctg}:{start + 1}-{end}", bam_path],
+                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    for line in pile.stdout:
+        f = line.decode("utf-8").rstrip("\n").split("\t")
+        yield (f[4] if len(f) > 4 else "").upper().strip()
+
+
+def calc_confusion_matrices(range_tuple, pileups=None, refs=None, np_info=None, threads=0):
+    """Reference src/bam.pyx:351-499 for one range (ctg, start, end): (subs[5,5], nps[max_n,max_l+1,max_l+1],
+    inss[max_l+1], dels[max_l+1]) int64 counts of the basecaller's errors against the reference.
+    pileups: iterable of column-5 strings (default: samtools, get_pileups); refs: {contig: sequence} (default
+    cfg.args.refs); np_info: get_np_info of refs[ctg][start:end+1] (default: aln.get_np_info, on the GPU).
+    The character loop runs in the library (csrc/confusion.hpp) on all host cores."""
+    import ctypes as C
+    from . import _lib, aln
+    from .cig import bases_to_int
+    lib = _lib.load()
+    ctg, start, end = range_tuple
+    refs = cfg.args.refs if refs is None else refs
+    max_n, max_l = int(cfg.args.max_n), int(cfg.args.max_l)
+    contig = refs[ctg]
+    if pileups is None:
+        pileups = get_pileups(cfg.args.bam, ctg, start, end)
+    lines = [p.upper().strip().encode() for p in pileups]
+    if np_info is None:
+        np_info = aln.get_np_info(bases_to_int(contig[start:end + 1]))
+    np_info = np.ascontiguousarray(np_info, dtype=np.int32)
+    codes = np.ascontiguousarray(bases_to_int(contig[start:end]), dtype=np.uint8)
+    text = contig[start:].upper().encode()
+    off = np.zeros(len(lines) + 1, np.int64)
+    np.cumsum([len(x) for x in lines], out=off[1:])
+    buf = b"".join(lines) + b"\0"
+    subs = np.zeros((cfg.nbases, cfg.nbases), np.int64)
+    nps = np.zeros((max_n, max_l + 1, max_l + 1), np.int64)
+    inss = np.zeros(max_l + 1, np.int64)
+    dels = np.zeros(max_l + 1, np.int64)
+    bad = C.c_int64(0)
+    rc = lib.npore_confusion_counts(buf, off.ctypes.data, len(lines), codes.ctypes.data, len(codes), text, len(text),
+                                    np_info.ctypes.data, len(np_info), max_n, max_l, subs.ctypes.data, nps.ctypes.data,
+                                    inss.ctypes.data, dels.ctypes.data, C.byref(bad), threads)
+    if rc:
+        raise RuntimeError(_lib.last_error())
+    if bad.value:
+        print(f"ERROR: unexpected character in {bad.value} pileup line(s) of {ctg}:{start}-{end}.")   # src/bam.pyx:473-476
+    return subs, nps, inss, dels
+
+
+def get_confusion_matrices():
+    """Reference src/bam.pyx:166-200: the cached count matrices of --stats_dir, or (--recalc_cms) counted from the
+    BAM range by range (cfg.args.regions cut into --chunk_width pieces), summed and cached there."""
+    d = cfg.args.stats_dir or os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "guppy5_stats")
+    names = ("subs", "nps", "inss", "dels")
+    if not getattr(cfg.args, "recalc_cms", False):
+        print("> loading confusion matrices")
+        return tuple(np.load(os.path.join(d, f"{k}_cm.npy")) for k in names)
+    print("> calculating confusion matrices")
+    from .bed import get_ranges
+    ranges = get_ranges(cfg.args.regions, cfg.args.chunk_width)
+    total = None
+    for k, rg in enumerate(ranges):
+        res = calc_confusion_matrices(rg)
+        total = res if total is None else tuple(a + b for a, b in zip(total, res))
+        print(f"\r    {k + 1} of {len(ranges)} chunks processed.", end="", flush=True)
+    print(" ")
+    if total is None:
+        total = calc_confusion_matrices(("", 0, 0), pileups=[], refs={"": ""}, np_info=np.zeros((0, 2, int(cfg.args.max_n)), np.int32))
+    for k, m in zip(names, total):
+        np.save(os.path.join(d, f"{k}_cm"), m)
+    if getattr(cfg.args, "recalc_exit", False):
+        sys.exit(0)
+    return total
+
+
 def write_bam(path, references, records, level=6):
     """Write a BAM file (tests / benchmarks).  references: [(name, length)]; records: dicts with
     name, flag, ref_id, pos, mapq, cigar [(op, len)], seq (str over =ACMGRSVTWYHKDBN), qual (bytes or None),

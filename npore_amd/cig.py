@@ -74,77 +74,105 @@ def int_to_cig(int_cig):
     return "".join(cfg.cigars[i] for i in int_cig)
 
 
-def push_indels_left(cigar, seq, push_op):
-    """Push runs of `push_op` (1 = I, 2 = D) as far left as the sequence allows
-    (src/cig.pyx:102-159).  `cigar` (list/array of op codes M=0, I=1, D=2, '='=7,
-    X=8) is modified in place and returned; `seq` is the read (for I) or the
-    reference (for D) as codes."""
-    M, E, X = 0, 7, 8
-    n = len(cigar)
-    seq_ptr = cig_ptr = 0
-    while cig_ptr < n:
-        op = cigar[cig_ptr]
-        if op == push_op:
-            indel_len = 1
-            while cig_ptr + indel_len < n and cigar[cig_ptr + indel_len] == push_op:
-                indel_len += 1
+def to_runs(ops):
+    """[(op, length)] of an iterable of op codes (maximal runs)."""
+    runs = []
+    for op in ops:
+        if runs and runs[-1][0] == op:
+            runs[-1][1] += 1
         else:
-            cig_ptr += 1
-            if op == M or op == X or op == E:
-                seq_ptr += 1
+            runs.append([op, 1])
+    return runs
+
+
+def _push(runs, op, n):
+    if n > 0:
+        if runs and runs[-1][0] == op:
+            runs[-1][1] += n
+        else:
+            runs.append([op, n])
+
+
+def push_indels_left_runs(runs, seq, push_op):
+    """push_indels_left (reference src/cig.pyx:102-159) on RUNS [(op, length)] over M=0, I=1, D=2.
+    The reference moves a run of `push_op` one op at a time past the match ops on its left while the sequence it
+    consumes stays the same (seq[x] == seq[x + k] for a run of k); a run can only ever pass ops of the match run right
+    before it, so on runs this is: split that match run where the k-periodicity of `seq` ends, and put the indel run
+    in between.  Runs are handled left to right and each one sees the list as the previous ones left it, like the
+    in-place scan of the reference.  O(runs + positions moved)."""
+    out = []
+    p = 0                                    # position in seq of the next op (M and push_op consume it)
+    for op, k in runs:
+        if op != push_op:
+            _push(out, op, k)
+            if op == 0:
+                p += k
             continue
-        nshifts = 0
-        while (cig_ptr - nshifts > 0 and seq_ptr - nshifts > 0 and
-               seq[seq_ptr - nshifts - 1] == seq[seq_ptr - nshifts - 1 + indel_len] and
-               (cigar[cig_ptr - nshifts - 1] == E or cigar[cig_ptr - nshifts - 1] == M)):
-            nshifts += 1
-        if nshifts:
-            moved = list(cigar[cig_ptr - nshifts:cig_ptr])
-            indel = list(cigar[cig_ptr:cig_ptr + indel_len])
-            cigar[cig_ptr - nshifts:cig_ptr - nshifts + indel_len] = indel
-            cigar[cig_ptr - nshifts + indel_len:cig_ptr + indel_len] = moved
-        cig_ptr += indel_len
-        # (reference: `op == push_op` here, so the pointer of the pushed sequence advances)
-        seq_ptr += indel_len
-    return cigar
+        m = out[-1][1] if out and out[-1][0] == 0 else 0
+        s = 0
+        while s < m and seq[p - s - 1] == seq[p - s - 1 + k]:
+            s += 1
+        if s:
+            out[-1][1] -= s
+            if out[-1][1] == 0:
+                out.pop()
+        _push(out, push_op, k)
+        _push(out, 0, s)
+        p += k
+    return out
 
 
-def push_inss_thru_dels(cigar):
-    """Let insertions move left through adjacent deletions: 'DDII' -> 'IIDD'
-    (src/cig.pyx:164-192); in place."""
-    I, D = 1, 2
-    n = len(cigar)
-    for i in range(n - 1):
-        if cigar[i] == D and cigar[i + 1] == I:
-            del_idx = i - 1
-            while del_idx >= 0 and cigar[del_idx] == D:
-                del_idx -= 1
-            dels = i - del_idx
-            ins_idx = i + 1
-            while ins_idx < n and cigar[ins_idx] == I:
-                ins_idx += 1
-            inss = ins_idx - i - 1
-            for j in range(inss):
-                cigar[del_idx + 1 + j] = I
-            for j in range(dels):
-                cigar[del_idx + 1 + inss + j] = D
-    return cigar
+def inss_before_dels_runs(runs):
+    """push_inss_thru_dels (reference src/cig.pyx:164-192) on runs: its left-to-right scan swaps every 'D..D I..I'
+    it meets, which cascades until each maximal block of I / D ops reads 'I..I D..D'."""
+    out = []
+    k = 0
+    while k < len(runs):
+        if runs[k][0] == 0:
+            _push(out, 0, runs[k][1])
+            k += 1
+            continue
+        ni = nd = 0
+        while k < len(runs) and runs[k][0] != 0:
+            if runs[k][0] == 1:
+                ni += runs[k][1]
+            else:
+                nd += runs[k][1]
+            k += 1
+        _push(out, 1, ni)
+        _push(out, 2, nd)
+    return out
+
+
+def standardize_runs(aln, int_ref, int_seq):
+    """Runs [(op char, length)] of the final CIGAR: what realign_read does with align()'s string (src/bam.pyx:65-78)
+    -- X,= -> M, ONE pass of push D left / I through D / push I left / I through D (the reference's `while True`
+    always stops after one pass: its `old_cig = int_cig[:]` is a numpy view of the array the push functions modify in
+    place, so same_cigar is trivially true), then 'ID' -> 'M' (str.replace: left to right, non-overlapping; in a block
+    'I..I D..D' that is exactly one pair)."""
+    runs = to_runs(0 if c in "X=M" else (1 if c == "I" else 2) for c in aln)
+    ref = np.asarray(int_ref).tolist()
+    seq = np.asarray(int_seq).tolist()
+    runs = inss_before_dels_runs(push_indels_left_runs(runs, ref, 2))
+    runs = inss_before_dels_runs(push_indels_left_runs(runs, seq, 1))
+    out = []
+    k = 0
+    while k < len(runs):
+        op, n = runs[k]
+        if op == 1 and k + 1 < len(runs) and runs[k + 1][0] == 2:
+            _push(out, 1, n - 1)
+            _push(out, 0, 1)
+            _push(out, 2, runs[k + 1][1] - 1)
+            k += 2
+        else:
+            _push(out, op, n)
+            k += 1
+    return [("MID"[op], n) for op, n in out]
 
 
 def standardize(aln, int_ref, int_seq):
-    """What realign_read does with align()'s string (src/bam.pyx:65-78): X,= -> M, ONE
-    pass of push D left / I through D / push I left / I through D (the reference's
-    `while True` always stops after one pass: its `old_cig = int_cig[:]` is a numpy view
-    of the array the push functions modify in place, so same_cigar is trivially true),
-    then 'ID' -> 'M'.  Returns the expanded op string over 'MID'."""
-    cig = [0 if c in "X=M" else (1 if c == "I" else 2) for c in aln]
-    ref = np.asarray(int_ref).tolist()
-    seq = np.asarray(int_seq).tolist()
-    push_indels_left(cig, ref, 2)
-    push_inss_thru_dels(cig)
-    push_indels_left(cig, seq, 1)
-    push_inss_thru_dels(cig)
-    return "".join("MID"[c] for c in cig).replace("ID", "M")
+    """The expanded op string over 'MID' of standardize_runs()."""
+    return "".join(c * n for c, n in standardize_runs(aln, int_ref, int_seq))
 
 
 def standardize_batch(alns, int_refs, int_seqs, threads=0, expanded=False):

@@ -1,6 +1,6 @@
 // glue.hpp -- host-side CIGAR standardisation that realign_read applies to the string
 // align() returns (reference src/bam.pyx:65-78), in C++ because the reference's is
-// compiled Cython (src/cig.pyx:102-192).  Sequential byte scans, one read per task.
+// compiled Cython (src/cig.pyx:102-192).  One read per task.
 #pragma once
 #include <cstdint>
 #include <cstring>
@@ -9,80 +9,97 @@
 
 namespace npore {
 
-// op codes of the reference (src/cfg.py:28-32): M=0 I=1 D=2 '='=7 X=8
-enum : uint8_t { OP_M = 0, OP_I = 1, OP_D = 2, OP_E = 7, OP_X = 8 };
+// The standardisation works on RUNS (op, length) of the alignment instead of one byte per op:
+//   * push_indels_left (src/cig.pyx:102-159) moves a run of k insertions (deletions) one op at a time past the match
+//     ops on its left while the sequence it consumes stays the same, seq[x] == seq[x + k].  A run can only ever pass
+//     ops of the match run right before it, so on runs: split that match run where the k-periodicity of the sequence
+//     ends, and put the indel run in between.  Runs are taken left to right and each sees the list as the previous
+//     ones left it, like the reference's in-place scan.
+//   * push_inss_thru_dels (src/cig.pyx:164-192) swaps every 'D..D I..I' its left-to-right scan meets, which cascades
+//     until each maximal block of I / D ops reads 'I..I D..D'.
+//   * 'ID' -> 'M' (str.replace: left to right, non-overlapping) is then exactly one pair per such block.
+// O(runs + positions moved) instead of O(ops) per pass; npore_amd/cig.py holds the same formulation in Python and
+// the tests compare both with the per-op restatement of the reference (oracle/glue_literal.py) and with G4.
+enum : uint8_t { OP_M = 0, OP_I = 1, OP_D = 2 };
 
-// push_indels_left, src/cig.pyx:102-159 (in place)
-inline void push_indels_left(std::vector<uint8_t> &cigar, const uint8_t *seq, int64_t seq_len, uint8_t push_op)
+struct OpRun {
+    uint8_t op;
+    int64_t len;
+};
+
+inline void push_run(std::vector<OpRun> &runs, uint8_t op, int64_t n)
 {
-    const int64_t n = (int64_t)cigar.size();
-    int64_t seq_ptr = 0, cig_ptr = 0;
-    std::vector<uint8_t> moved;
-    while (cig_ptr < n) {
-        const uint8_t op = cigar[cig_ptr];
-        int64_t indel_len;
-        if (op == push_op) {
-            indel_len = 1;
-            while (cig_ptr + indel_len < n && cigar[cig_ptr + indel_len] == push_op) indel_len++;
-        } else {
-            cig_ptr++;
-            if (op == OP_M || op == OP_X || op == OP_E) seq_ptr++;
+    if (n <= 0) return;
+    if (!runs.empty() && runs.back().op == op) runs.back().len += n;
+    else runs.push_back(OpRun{op, n});
+}
+
+// src/cig.pyx:102-159 on runs; `seq` is what push_op consumes besides the match ops (reference for D, read for I)
+inline void push_indels_left(const std::vector<OpRun> &in, std::vector<OpRun> &out, const uint8_t *seq, int64_t seq_len,
+                             uint8_t push_op)
+{
+    out.clear();
+    int64_t p = 0;                                   // position in seq of the next op
+    for (const OpRun &r : in) {
+        if (r.op != push_op) {
+            push_run(out, r.op, r.len);
+            if (r.op == OP_M) p += r.len;
             continue;
         }
-        int64_t nshifts = 0;
-        while (cig_ptr - nshifts > 0 && seq_ptr - nshifts > 0 &&
-               seq_ptr - nshifts - 1 + indel_len < seq_len &&          // (the reference indexes unchecked)
-               seq[seq_ptr - nshifts - 1] == seq[seq_ptr - nshifts - 1 + indel_len] &&
-               (cigar[cig_ptr - nshifts - 1] == OP_E || cigar[cig_ptr - nshifts - 1] == OP_M))
-            nshifts++;
-        if (nshifts) {
-            moved.assign(cigar.begin() + (cig_ptr - nshifts), cigar.begin() + cig_ptr);
-            for (int64_t i = 0; i < indel_len; i++) cigar[cig_ptr - nshifts + i] = push_op;
-            for (int64_t i = 0; i < nshifts; i++) cigar[cig_ptr - nshifts + indel_len + i] = moved[i];
+        const int64_t k = r.len, m = (!out.empty() && out.back().op == OP_M) ? out.back().len : 0;
+        int64_t s = 0;
+        while (s < m && p - s - 1 + k < seq_len && seq[p - s - 1] == seq[p - s - 1 + k]) s++;     // (the reference indexes unchecked)
+        if (s) {
+            out.back().len -= s;
+            if (out.back().len == 0) out.pop_back();
         }
-        cig_ptr += indel_len;
-        seq_ptr += indel_len;     // op == push_op here
+        push_run(out, push_op, k);
+        push_run(out, OP_M, s);
+        p += k;
     }
 }
 
-// push_inss_thru_dels, src/cig.pyx:164-192 (in place)
-inline void push_inss_thru_dels(std::vector<uint8_t> &cigar)
+// src/cig.pyx:164-192 on runs
+inline void inss_before_dels(const std::vector<OpRun> &in, std::vector<OpRun> &out)
 {
-    const int64_t n = (int64_t)cigar.size();
-    for (int64_t i = 0; i + 1 < n; i++) {
-        if (cigar[i] == OP_D && cigar[i + 1] == OP_I) {
-            int64_t del_idx = i - 1;
-            while (del_idx >= 0 && cigar[del_idx] == OP_D) del_idx--;
-            const int64_t dels = i - del_idx;
-            int64_t ins_idx = i + 1;
-            while (ins_idx < n && cigar[ins_idx] == OP_I) ins_idx++;
-            const int64_t inss = ins_idx - i - 1;
-            for (int64_t j = 0; j < inss; j++) cigar[del_idx + 1 + j] = OP_I;
-            for (int64_t j = 0; j < dels; j++) cigar[del_idx + 1 + inss + j] = OP_D;
-        }
+    out.clear();
+    for (size_t k = 0; k < in.size();) {
+        if (in[k].op == OP_M) { push_run(out, OP_M, in[k].len); k++; continue; }
+        int64_t ni = 0, nd = 0;
+        for (; k < in.size() && in[k].op != OP_M; k++) (in[k].op == OP_I ? ni : nd) += in[k].len;
+        push_run(out, OP_I, ni);
+        push_run(out, OP_D, nd);
     }
 }
 
 // src/bam.pyx:65-78: one pass (the reference's loop always stops after one: its `old_cig` is a view of
-// the array the push functions modify), 'ID' -> 'M' (left to right, non-overlapping, like str.replace).
-// Calls emit(op) for every op of the expanded result ('M', 'I' or 'D').
+// the array the push functions modify), then 'ID' -> 'M'.  Calls emit(op, n) for every run of the result
+// ('M', 'I' or 'D'; consecutive calls never repeat an op).
 template <class Emit>
-inline void standardize_ops(const char *aln, int64_t aln_len, const uint8_t *ref, int64_t ref_len,
-                            const uint8_t *seq, int64_t seq_len, Emit emit)
+inline void standardize_runs(const char *aln, int64_t aln_len, const uint8_t *ref, int64_t ref_len,
+                             const uint8_t *seq, int64_t seq_len, Emit emit)
 {
-    std::vector<uint8_t> cig((size_t)aln_len);
+    std::vector<OpRun> a, b;
     for (int64_t i = 0; i < aln_len; i++) {
         const char c = aln[i];
-        cig[i] = (c == 'I') ? OP_I : (c == 'D') ? OP_D : OP_M;     // X,=,M -> M
+        push_run(a, (c == 'I') ? OP_I : (c == 'D') ? OP_D : OP_M, 1);     // X,=,M -> M
     }
-    push_indels_left(cig, ref, ref_len, OP_D);
-    push_inss_thru_dels(cig);
-    push_indels_left(cig, seq, seq_len, OP_I);
-    push_inss_thru_dels(cig);
-    for (int64_t i = 0; i < aln_len;) {
-        if (cig[i] == OP_I && i + 1 < aln_len && cig[i + 1] == OP_D) { emit('M'); i += 2; }
-        else { emit("MID"[cig[i]]); i += 1; }
+    push_indels_left(a, b, ref, ref_len, OP_D);
+    inss_before_dels(b, a);
+    push_indels_left(a, b, seq, seq_len, OP_I);
+    inss_before_dels(b, a);
+    b.clear();
+    for (size_t k = 0; k < a.size(); k++) {
+        if (a[k].op == OP_I && k + 1 < a.size() && a[k + 1].op == OP_D) {
+            push_run(b, OP_I, a[k].len - 1);
+            push_run(b, OP_M, 1);
+            push_run(b, OP_D, a[k + 1].len - 1);
+            k++;
+        } else {
+            push_run(b, a[k].op, a[k].len);
+        }
     }
+    for (const OpRun &r : b) emit("MID"[r.op], r.len);
 }
 
 // ... + collapse_cigar (src/cig.pyx:13-38): run-length encoded text
@@ -90,16 +107,10 @@ inline std::string standardize_collapsed(const char *aln, int64_t aln_len, const
                                          const uint8_t *seq, int64_t seq_len)
 {
     std::string out;
-    char last = 0;
-    int64_t count = 0;
-    auto flush = [&] {
-        if (count) { out += std::to_string(count); out += last; }
-    };
-    standardize_ops(aln, aln_len, ref, ref_len, seq, seq_len, [&](char op) {
-        if (op == last) count++;
-        else { flush(); last = op; count = 1; }
+    standardize_runs(aln, aln_len, ref, ref_len, seq, seq_len, [&](char op, int64_t n) {
+        out += std::to_string(n);
+        out += op;
     });
-    flush();
     return out;
 }
 
@@ -108,7 +119,10 @@ inline int64_t standardize_expanded(const char *aln, int64_t aln_len, const uint
                                     const uint8_t *seq, int64_t seq_len, char *out)
 {
     int64_t n = 0;
-    standardize_ops(aln, aln_len, ref, ref_len, seq, seq_len, [&](char op) { out[n++] = op; });
+    standardize_runs(aln, aln_len, ref, ref_len, seq, seq_len, [&](char op, int64_t len) {
+        std::memset(out + n, op, (size_t)len);
+        n += len;
+    });
     return n;
 }
 

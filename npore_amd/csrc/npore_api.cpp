@@ -18,6 +18,7 @@
 #include <unistd.h>
 
 #include "../../include/npore_amd.h"
+#include "confusion.hpp"
 #include "glue.hpp"
 #include "hostio.hpp"
 #include "kernels.hpp"
@@ -966,6 +967,53 @@ int npore_standardize_ops_batch(int64_t n_reads, const char *alns, const int64_t
 {
     return standardize_batch_impl(true, n_reads, alns, aln_off, refs, ref_off, seqs, seq_off, out, out_off, out_len, threads);
 }
+
+// ---- confusion matrices from pileup text (confusion.hpp) -------------------------------------------
+int npore_confusion_counts(const char *lines, const int64_t *line_off, int64_t n_lines, const uint8_t *ref_codes,
+                           int64_t n_ref, const char *ref_text, int64_t ref_text_len, const int32_t *np_info,
+                           int64_t np_len, int max_n, int max_l, int64_t *subs, int64_t *nps, int64_t *inss,
+                           int64_t *dels, int64_t *bad_lines, int threads)
+try {
+    if (n_lines < 0 || max_n < 1 || max_l < 1 || !subs || !nps || !inss || !dels ||
+        (n_lines > 0 && (!lines || !line_off || !ref_codes || !ref_text || !np_info)))
+        return fail(NPORE_E_INVALID, "bad argument");
+    const size_t dim = (size_t)max_l + 1, n_nps = (size_t)max_n * dim * dim;
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(threads > 0 ? threads : (int)std::thread::hardware_concurrency(),
+                                                                 (n_lines + 4095) / 4096));
+    // per-thread matrices (25 + max_n (max_l+1)^2 + 2 (max_l+1) counters), summed at the end
+    std::vector<std::vector<int64_t>> acc((size_t)nt, std::vector<int64_t>(25 + n_nps + 2 * dim, 0));
+    std::vector<int64_t> bad((size_t)nt, 0);
+    std::atomic<int64_t> next{0};
+    auto work = [&](int t) {
+        int64_t *a = acc[(size_t)t].data();
+        const ConfusionOut o{a, a + 25, a + 25 + n_nps, a + 25 + n_nps + dim};
+        for (;;) {
+            const int64_t b0 = next.fetch_add(1024);
+            if (b0 >= n_lines) break;
+            for (int64_t k = b0; k < std::min(n_lines, b0 + 1024); k++)
+                if (!confusion_count_line(lines + line_off[k], line_off[k + 1] - line_off[k], k, ref_codes, n_ref, ref_text,
+                                          ref_text_len, np_info, np_len, max_n, max_l, o))
+                    bad[(size_t)t]++;
+        }
+    };
+    if (nt == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; t++) pool.emplace_back(work, t);
+        for (auto &th : pool) th.join();
+    }
+    int64_t nbad = 0;
+    for (int t = 0; t < nt; t++) {
+        const int64_t *a = acc[(size_t)t].data();
+        for (size_t k = 0; k < 25; k++) subs[k] += a[k];
+        for (size_t k = 0; k < n_nps; k++) nps[k] += a[25 + k];
+        for (size_t k = 0; k < dim; k++) { inss[k] += a[25 + n_nps + k]; dels[k] += a[25 + n_nps + dim + k]; }
+        nbad += bad[(size_t)t];
+    }
+    if (bad_lines) *bad_lines = nbad;
+    return NPORE_OK;
+}
+NPORE_CATCH_INT
 
 // debug / self-test entries (used by tests -m gpu)
 int npore_debug_dpp(uint32_t *out128)

@@ -9,8 +9,8 @@ it in batches instead of one align() call per pool worker
 (src/realign.py:110-114).  Several GPUs: launch one process per GPU with
 `python -m torch.distributed.run --nproc-per-node N -m npore_amd.realign ...`;
 rank k realigns reads k, k+N, ... into its own part file and rank 0 appends
-the parts to the SAM (record order is arbitrary in the reference too).  --recalc_cms / --plot need samtools / matplotlib
-pipelines that are out of scope here (the shipped guppy5_stats are loaded).
+the parts to the SAM (record order is arbitrary in the reference too).
+--recalc_cms recounts the confusion matrices with `samtools mpileup` like the reference (bam.get_confusion_matrices); --plot is out of scope.
 """
 import argparse
 import os
@@ -39,8 +39,9 @@ def argparser():
     parser.add_argument("--stats_dir", default=None,
                         help="Directory with subs/nps/inss/dels _cm.npy (default: the shipped guppy5_stats).")
     parser.add_argument("--plot", action="store_true", help="(not supported in this build)")
-    parser.add_argument("--recalc_cms", action="store_true", help="(not supported in this build)")
-    parser.add_argument("--recalc_exit", action="store_true", help="(not supported in this build)")
+    parser.add_argument("--recalc_cms", action="store_true",
+                        help="Recount the confusion matrices from the BAM (needs `samtools mpileup`) instead of loading them.")
+    parser.add_argument("--recalc_exit", action="store_true", help="Exit after --recalc_cms.")
     # additions
     parser.add_argument("--batch_reads", type=int, default=2000, help="Reads per GPU batch (file to file the host stages bound the pipeline: 2 000 measured best; device-resident callers fill whole rounds, Context.round_chunks).")
     parser.add_argument("--device", type=int, default=int(os.environ.get("LOCAL_RANK", "0")), help="HIP device.")
@@ -50,9 +51,8 @@ def argparser():
 
 
 def main():
-    if cfg.args.plot or cfg.args.recalc_cms or cfg.args.recalc_exit:
-        print("\nERROR: --plot / --recalc_cms / --recalc_exit are not available in npore_amd "
-              "(they need samtools mpileup + matplotlib); the confusion matrices in --stats_dir are used as is.")
+    if cfg.args.plot:
+        print("\nERROR: --plot is not available in npore_amd (matplotlib reports are out of scope).")
         sys.exit(1)
     native = not cfg.args.python_io
     # one process per GPU: the host stages of a rank use its share of the node's cores, and the BAM is inflated
@@ -64,9 +64,16 @@ def main():
     bam = bam_mod.NativeBam(cfg.args.bam, threads=threads) if native else bam_mod.BamFile(cfg.args.bam)
     bam_mod.get_bam_regions(bam, ref_seqs)
 
-    print("> calculating score matrices")
-    cfg.args.sub_scores, cfg.args.np_scores, cfg.args.ins_scores, cfg.args.del_scores = \
-        aln.load_default_tables(cfg.args.stats_dir)
+    if cfg.args.recalc_cms:              # src/realign.py:92-95 + src/bam.pyx:166-200
+        cfg.args.refs = ref_seqs
+        subs, nps, inss, dels = bam_mod.get_confusion_matrices()
+        print("> calculating score matrices")
+        cfg.args.sub_scores, cfg.args.np_scores, cfg.args.ins_scores, cfg.args.del_scores = \
+            aln.calc_score_matrices(subs, nps, inss, dels)
+    else:
+        print("> calculating score matrices")
+        cfg.args.sub_scores, cfg.args.np_scores, cfg.args.ins_scores, cfg.args.del_scores = \
+            aln.load_default_tables(cfg.args.stats_dir)
 
     rank, world, _ = dist_mod.world()
     if world > 1 and not native:

@@ -563,6 +563,27 @@ def test_cli_max_l_with_shipped_table(tables, tmp_path):
     assert sum(1 for l in open(prefix + ".sam") if not l.startswith("@")) == 10
 
 
+def test_calc_confusion_matrices_with_device_np_info():
+    """calc_confusion_matrices (reference src/bam.pyx:351-499) with its n-polymer annotation from the GPU
+    (aln.get_np_info on the range, as the reference calls its own) == the reference's matrices (tests/golden/cms.json)."""
+    from npore_amd import bam, cfg
+    import argparse
+    g = load_json("cms.json")
+    old = cfg.args
+    cfg.args = argparse.Namespace(max_n=g["max_n"], max_l=g["max_l"])
+    try:
+        for c in g["cases"]:
+            subs, nps, inss, dels = bam.calc_confusion_matrices((c["contig"], c["start"], c["end"]), pileups=c["lines"],
+                                                                refs={c["contig"]: c["seq"]})
+            want = np.zeros_like(nps)
+            for a, b, d, v in c["nps_nonzero"]:
+                want[a, b, d] = v
+            assert subs.tolist() == c["subs"] and inss.tolist() == c["inss"] and dels.tolist() == c["dels"]
+            assert np.array_equal(nps, want)
+    finally:
+        cfg.args = old
+
+
 def test_fill_shape_and_annotation_only_context(tables):
     """npore_fill_shape (launch geometry for reports) and a context without tables: get_np_info works,
     align is refused loudly."""

@@ -103,6 +103,44 @@ def test_cpp_glue_equals_python_glue(tables):
     assert [cig._expand_cigar_np(w) for w in want] == ops == [cig.expand_cigar(w) for w in want]
 
 
+def test_run_based_glue_equals_per_op_restatement():
+    """The product's standardisation works on runs (npore_amd/cig.py, csrc/glue.hpp); oracle/glue_literal.py is the
+    per-op restatement of the reference's push_indels_left / push_inss_thru_dels / one-pass glue (src/cig.pyx:102-192,
+    src/bam.pyx:65-78).  Random edit scripts over low-complexity sequences (long periodic stretches, so that INDEL
+    runs travel far and meet), runs at both ends, adjacent I / D blocks in every order: both product forms == literal."""
+    from oracle import glue_literal
+    rng = np.random.default_rng(11)
+    alns, refs, seqs = [], [], []
+    for case in range(400):
+        alphabet = int(rng.integers(1, 4))                       # 1-3 distinct bases: everything is a repeat
+        n_ops = int(rng.integers(0, 120))
+        p = rng.dirichlet((2.0, 1.0, 1.0)) if case % 3 else np.array([0.2, 0.4, 0.4])
+        ops = rng.choice(3, size=n_ops, p=p)                     # 0 M, 1 I, 2 D
+        ref = rng.integers(1, alphabet + 1, size=int((ops != 1).sum())).astype(np.uint8)
+        ins = rng.integers(1, alphabet + 1, size=int((ops == 1).sum())).astype(np.uint8)
+        seq, i, j = [], 0, 0
+        for op in ops:
+            if op == 0:
+                seq.append(ref[j]); j += 1
+            elif op == 1:
+                seq.append(ins[i]); i += 1
+            else:
+                j += 1
+        aln = "".join("=ID"[o] if o else ("=" if rng.random() < 0.9 else "X") for o in ops)
+        alns.append(aln); refs.append(ref); seqs.append(np.array(seq, np.uint8))
+    want = [glue_literal.standardize(a, r_, s_) for a, r_, s_ in zip(alns, refs, seqs)]
+    assert [cig.standardize(a, r_, s_) for a, r_, s_ in zip(alns, refs, seqs)] == want
+    assert cig.standardize_batch(alns, refs, seqs, expanded=True) == want
+    assert cig.standardize_batch(alns, refs, seqs) == [cig.collapse_cigar(w) for w in want]
+    # the pieces on their own
+    for a, r_, s_ in list(zip(alns, refs, seqs))[:100]:
+        codes = [0 if c in "X=M" else (1 if c == "I" else 2) for c in a]
+        lit = glue_literal.push_indels_left(list(codes), r_.tolist(), 2)
+        assert cig.to_runs(lit) == cig.push_indels_left_runs(cig.to_runs(codes), r_.tolist(), 2)
+        lit2 = glue_literal.push_inss_thru_dels(list(lit))
+        assert cig.to_runs(lit2) == cig.inss_before_dels_runs(cig.to_runs(lit))
+
+
 def test_bam_reader_equals_sam():
     """reads.bam decoded with zlib+struct == reads.sam field for field (pysam-free ingest)."""
     b = bam.BamFile(os.path.join(GOLDEN, "data", "reads.bam"))
@@ -254,6 +292,35 @@ def test_native_bam_matches_python_reader_on_reference_data():
     assert _native_vs_python(os.path.join(d, "reads.bam"), os.path.join(d, "ref.fasta"), [("ref", 0, 1000)]) == 10
     assert _native_vs_python(os.path.join(d, "reads.bam"), os.path.join(d, "ref.fasta"), [("ref", 0, 1000)], max_reads=3) == 3
     assert _native_vs_python(os.path.join(d, "reads.bam"), os.path.join(d, "ref.fasta"), [("ref", 400, 450), ("ref", 0, 30)]) > 0
+
+
+def test_calc_confusion_matrices_golden():
+    """calc_confusion_matrices (reference src/bam.pyx:351-499) against tests/golden/cms.json: the count matrices the
+    reference's compiled function returns for the same pileup lines (made by tests/golden/make_golden_cms.py from the
+    reference's test reads, plus engineered lines: '^' + odd mapping qualities, '$', '*', lower case, n-polymer and
+    other INDELs, lengths beyond max_l, an unexpected character).  get_np_info comes from the oracle here (no GPU)."""
+    g = load_json("cms.json")
+    old = cfg.args
+    cfg.args = argparse.Namespace(max_n=g["max_n"], max_l=g["max_l"])
+    try:
+        for c in g["cases"]:
+            seq, start, end = c["seq"], c["start"], c["end"]
+            info = oracle.get_np_info(cig.bases_to_int(seq[start:end + 1]))
+            for threads in (1, 3):
+                subs, nps, inss, dels = bam.calc_confusion_matrices((c["contig"], start, end), pileups=c["lines"],
+                                                                    refs={c["contig"]: seq}, np_info=info, threads=threads)
+                assert subs.tolist() == c["subs"] and inss.tolist() == c["inss"] and dels.tolist() == c["dels"], (c["contig"], start)
+                want = np.zeros_like(nps)
+                for a, b, d, v in c["nps_nonzero"]:
+                    want[a, b, d] = v
+                assert np.array_equal(nps, want), (c["contig"], start, end)
+        # ranges accumulate like the reference's pool results (src/bam.pyx:183-188): counting adds into the matrices
+        c = g["cases"][1]
+        info = oracle.get_np_info(cig.bases_to_int(c["seq"][c["start"]:c["end"] + 1]))
+        a = bam.calc_confusion_matrices((c["contig"], c["start"], c["end"]), pileups=c["lines"], refs={c["contig"]: c["seq"]}, np_info=info)
+        assert int(a[0].sum()) == int(np.array(c["subs"]).sum())
+    finally:
+        cfg.args = old
 
 
 def test_inflated_bam_copy_shared_between_local_ranks(tmp_path, monkeypatch):
