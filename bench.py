@@ -447,7 +447,7 @@ def main():
     practical = {"ns_per_antidiagonal": round(ns_per_row, 1), "cycles_per_antidiagonal": round(ns_per_row * clock_ghz, 0),
                  "waves_per_chunk": shape["waves_per_chunk"], "resident_waves_per_cu": shape["resident_waves_per_cu"],
                  "resident_chunks": shape["resident_chunks"], "lds_bytes_per_workgroup": shape["lds_bytes"],
-                 "clock_ghz": round(clock_ghz, 3)}
+                 "clock_ghz": round(clock_ghz, 3), "rows_total": int(rows_total)}
     # PMC-derived figures (HBM traffic, VALU instructions per launch) cannot be collected from inside this
     # process; they come from the committed rocprofv3 --pmc summary of this same default command, and only while
     # that summary was taken from the kernel sources this library was built from (csrc digest); else null
@@ -499,7 +499,8 @@ def main():
                                    f"(band={args.r}), max_b_rows={args.max_b_rows}, guppy5_stats penalties "
                                    f"(SURVEY 8d generator{', mixed p_np' if args.mixed else ''}, base_seed={args.base_seed}"
                                    f"{f', {n_uniq} distinct reads repeated' if n_uniq < n else ''})",
-                       "reads_per_gpu": n, "ref_len": args.ref_len, "r": args.r, "parallelism": f"reads x{world}",
+                       "reads_per_gpu": n, "ref_len": args.ref_len, "r": args.r, "max_b_rows": args.max_b_rows,
+                       "base_seed": args.base_seed, "mixed": bool(args.mixed), "parallelism": f"reads x{world}",
                        "batches_in_flight": n_ctx, "pipelined": pipelined, "devices_visible": n_dev,
                        "reduction_backend": {"nccl": "rccl", "gloo": "gloo (ranks share a device)", None: "none"}[backend]},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -176,17 +176,19 @@ int npore_last_timing(npore_ctx *ctx, double *ms, int n);
  * that keeps batches in flight: differences over a timed region). */
 int npore_total_timing(npore_ctx *ctx, double *ms, int n);
 
-/* Tunables: key in {"tb_budget_mb","force_chunks","traceback_kernel"} (traceback budget in MiB,
+/* Tunables: key in {"tb_budget_mb","force_chunks","traceback_kernel"} (traceback budget in MiB per work set,
  * chunks per workgroup, 1 = windowed / 2 = row-per-hop traceback; 0 = automatic). */
 int npore_ctx_set(npore_ctx *ctx, const char *key, int64_t value);
 
 /* Batch sizing.  The DP of a chunk (at most max_b_rows anti-diagonals of a read; reference src/aln.pyx:344-358,
- * 445-456) is one unit of work of the fill kernel, and the GPU works on "rounds" of them: as many chunks as it
- * holds at a time for band half-width r.  A round takes about as long whether it is full or not, so throughput
- * is best when the full-size chunks of a batch (one per 10 kb read at max_b_rows = 20000) fill whole rounds:
- * 4 000 at r = 30, 1 000 at r = 100 on an MI355X; a batch one read over a round takes about 1.7 x as long.
- * Returns the chunks per round, 0 for a band the kernels do not cover (r > 255).  Replaces nothing in the
- * reference (its pool has no such granularity, src/realign.py:110-114). */
+ * 445-456) is one unit of work of the fill kernel: a chain of dependent anti-diagonals that a group of wavefronts
+ * works through (~1.1 us each).  The GPU holds npore_round_chunks(ctx, r) such groups at a time -- 4 096 at r = 30,
+ * 1 024 at r = 100, 512 at r = 200 on an MI355X -- and every group pulls its next chunk from a queue (largest first)
+ * the moment it has finished one, so a batch costs about ceil(full-size chunks / resident groups) chain times: at
+ * r = 30, 4 000 reads of 10 kb take 21.7 ms, 4 500 take 30.6 ms (not two full rounds), and from 6 000 reads on the
+ * rate stays within ~12 % of its maximum (profiles/r02_sweep_r30_queue.csv).  Batches enqueued with sync = 0 follow
+ * each other without a gap.  Returns the resident groups, 0 for a band the kernels do not cover (r > 255).
+ * Replaces nothing in the reference (its pool has no such granularity, src/realign.py:110-114). */
 int64_t npore_round_chunks(npore_ctx *ctx, int r);
 /* Launch geometry of the fill kernel at band half-width r, for reports (bench.py's "practical bound"):
  * out[0] wavefronts per chunk, [1] chunks per workgroup, [2] workgroups per CU, [3] workgroups resident on the
