@@ -213,6 +213,10 @@ def main():
                     help="1 (default): steps are enqueued without waiting (sync=0) -- inside the context the next batch is "
                          "prepared and the previous one traced back while the fill kernel works on the current one; the "
                          "timed region ends when the last step has completed.  0: every step waits for its batch")
+    ap.add_argument("--coresident", type=int, default=1,
+                    help="1 (default): a group of reads that overlaps another one's fill kernel is prepared and gathered "
+                         "by kernel shapes that fit beside the fill's workgroups; 0: always the stand-alone ones")
+    ap.add_argument("--force-chunks", type=int, default=0, help="chunks per fill workgroup (experiments; 0 = automatic)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="batches in flight per GPU: each has its own context (stream + work buffers) and host thread, "
                          "so one batch's traceback / gather and the next one's preparation run beside a fill kernel")
@@ -266,9 +270,12 @@ def main():
     n_ctx = max(1, args.inflight)
     ctxs = [aln.Context(sub, nps, max_n=6, max_l=100, device=dev_index) for _ in range(n_ctx)]
     ctx = ctxs[0]
-    if args.tb_kernel:
-        for c in ctxs:
+    for c in ctxs:
+        if args.tb_kernel:
             c.set("traceback_kernel", args.tb_kernel)
+        c.set("coresident", args.coresident)
+        if args.force_chunks:
+            c.set("force_chunks", args.force_chunks)
     lib = _lib.load()
 
     rb, ro = pack(refs)

@@ -1022,6 +1022,10 @@ __global__ __launch_bounds__(256) void gather_scan_kernel(GParams p)
     if (lane == 0) { p.out_len[grd] = total; p.status[grd] = st; }
 }
 
+// TILE_IN_LDS = false: no dynamic LDS -- every thread stores its ops straight to the output (uncoalesced) and reads
+// the bases from global memory: slower on its own, but a workgroup then needs 3 KB of LDS only and runs beside a
+// fill-kernel workgroup (the variant for a group whose successor's fill is already on the GPU).
+template <bool TILE_IN_LDS>
 __global__ __launch_bounds__(256) void gather_kernel(GParams p)
 {
     const int c = blockIdx.x;
@@ -1045,7 +1049,7 @@ __global__ __launch_bounds__(256) void gather_kernel(GParams p)
     const uint32_t *runs = p.chunk_runs + d.out_off;
     uint8_t *l_ops = gl;
     // bases below the chunk's end cell: seq[row0, row_end), ref[col0, col_end)
-    const bool staged = p.slice_cap > 0 && d.drows <= p.slice_cap && d.dcols <= p.slice_cap;
+    const bool staged = TILE_IN_LDS && p.slice_cap > 0 && d.drows <= p.slice_cap && d.dcols <= p.slice_cap;
     const uint8_t *seq = p.seqs + d.seq_off + d.row0, *ref = p.refs + d.ref_off + d.col0;   // local row / column 0
     if (staged) {
         uint8_t *l_seq = gl + GATHER_TILE, *l_ref = l_seq + p.slice_cap;
@@ -1107,12 +1111,15 @@ __global__ __launch_bounds__(256) void gather_kernel(GParams p)
                 } else {
                     op = (typ == T_INS || typ == T_LEN) ? 'I' : 'D';
                 }
-                l_ops[u - U0] = op;
+                if constexpr (TILE_IN_LDS) l_ops[u - U0] = op;
+                else dst[len - 1 - u] = op;
             }
         }
-        __syncthreads();
-        for (int k = t; k < U1 - U0; k += T) dst[len - 1 - U0 - k] = l_ops[k];
-        __syncthreads();
+        if constexpr (TILE_IN_LDS) {
+            __syncthreads();
+            for (int k = t; k < U1 - U0; k += T) dst[len - 1 - U0 - k] = l_ops[k];
+            __syncthreads();
+        }
     }
 }
 

@@ -149,6 +149,8 @@ struct npore_ctx {
     int64_t tb_budget_mb = 0;   // 0 = auto
     int tb_kernel = 0;          // 0 = by batch size, 1 = windowed traceback, 2 = row per hop
     int force_chunks = 0;
+    int coresident = 1;         // kernel shapes that fit beside a fill kernel for a group that overlaps another one's
+    bool fill_has_room = false; // the last fill launch left LDS for such kernels on its CUs
     HostBuf h_offs;             // offset arrays of a device-resident batch (npore_align_batch_device)
     // device buffers (grow-only, reused across calls)
     DevBuf in_refs, in_seqs, in_cigs, in_off;                       // raw inputs (host-buffer entry point)
@@ -212,8 +214,12 @@ int fill_round_workgroups(const FillGeom &g, int chunks, int n_cus)
 }
 
 // NW waves per chunk, `chunks` chunks per workgroup (they share the LDS score table).
+// leave_room: groups of reads overlap on the device (run_core), so the next group's preparation and this one's
+// gather will look for room BESIDE fill workgroups: where the fill would take (nearly) all of a CU's LDS -- r = 30:
+// 16 chunks = 159.75 KB -- a workgroup takes one chunk less (measured at r = 30, 8 000 reads per batch: 154 k
+// instead of 144 k reads/s; the scans and the gather need ~3.5 KB of LDS).
 template <int NW>
-hipError_t launch_fill(KParams kp, int max_chunks, int force_chunks, int n_cus, hipStream_t s)
+hipError_t launch_fill(KParams kp, int max_chunks, int force_chunks, int n_cus, hipStream_t s, bool leave_room, bool *has_room)
 {
     constexpr int MAXT = 1024;
     FillGeom g;
@@ -223,8 +229,16 @@ hipError_t launch_fill(KParams kp, int max_chunks, int force_chunks, int n_cus, 
     const int cmax = g.cmax;
     // few chunks: spread them over the CUs; many: pack workgroups so that the table is amortised
     int chunks = std::min(cmax, std::max(1, (max_chunks + 255) / 256));
+    if (leave_room && chunks > 1 && fill_lds_floats(NW, chunks, kp.hw, kp.rwin) * sizeof(float) + 4096 > 160 * 1024) {
+        // ... unless exactly that chunk per workgroup decides whether the batch's full-size chunks (about half of
+        // the upper bound: a read's last chunk is a short tail) are resident all at once (r = 30, 4 000 reads per
+        // batch: 142 k reads/s with 16 chunks per workgroup, 127 k with 15)
+        const int64_t big = (max_chunks + 1) / 2, wgs = fill_round_workgroups(g, chunks, n_cus);
+        if (!(big <= wgs * chunks && big > wgs * (chunks - 1))) chunks--;
+    }
     if (force_chunks > 0) chunks = std::min(cmax, force_chunks);
     const size_t lds = fill_lds_floats(NW, chunks, kp.hw, kp.rwin) * sizeof(float);
+    *has_room = lds + 4096 <= 160 * 1024;      // other kernels' light workgroups fit beside this launch's
     // the kernel addresses its score tables by absolute LDS address (kernels.hpp: lds_abs_f32): it must not
     // own any static LDS, so that the dynamic array starts at address 0
     static const hipError_t no_static_lds = [] {
@@ -273,8 +287,18 @@ int64_t chunk_bound(int64_t cig_len, int max_b_rows)
 
 // Reads [g0,g1): everything from the raw bytes to the gathered output, on stream s,
 // without host synchronisation.
-int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_t g1, const OutTarget &ot, int shape)
+int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_t g1, const OutTarget &ot, int shape,
+              bool overlapping)
 {
+    // overlapping: another group of this context is on the device.  beside_fill: ... and the fill launch it belongs to
+    // left room on its CUs (launch_fill), so kernels of light shapes can run beside it.
+    const bool beside_fill = overlapping && ctx->fill_has_room;
+    // beside_fill: another group of this context is on the device, most likely in its fill kernel, whose persistent
+    // workgroups hold nearly all the LDS and most of the vector registers of every CU until they have emptied their
+    // queue.  The preparation and gather kernels of THIS group then run in shapes that find room beside a fill
+    // workgroup instead of waiting for it to leave: 256-thread scans (one wave per SIMD), the LDS-free annotation
+    // (prep_kernels.hpp) and the gather without its LDS tile (kernels.hpp).
+    const unsigned scan_threads = beside_fill ? 256 : 1024;
     hipStream_t s = ctx->stream;      // preparation; the fill and traceback stages go to their own streams below
     const int64_t nr = g1 - g0;
     const int r = a.r;
@@ -309,7 +333,7 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     if (int rc = w->counters.ensure(64)) return rc;
     if (int rc = w->seqw.ensure((size_t)(S_tot + max_chunks + 16) * 4)) return rc;
     {
-        const size_t need = (7 * pstride <= 160 * 1024) ? 64 : (size_t)2 * max_chunks * 6 * pstride;
+        const size_t need = (7 * pstride <= 160 * 1024 && !beside_fill) ? 64 : (size_t)2 * max_chunks * 6 * pstride;
         if (int rc = w->seql.ensure(need)) return rc;
     }
     if (int rc = w->refw.ensure((size_t)(R_tot + max_chunks + 16) * 16)) return rc;
@@ -353,27 +377,30 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     HIP_TRY(hipMemsetAsync(pp.hist, 0, (size_t)(a.max_b_rows + 2) * 4, s));
     const unsigned rd_blocks = (unsigned)((nr + 3) / 4), ch_blocks = (unsigned)((max_chunks + 255) / 256);
     const unsigned tile_blocks = (unsigned)((max_tiles + 3) / 4);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, pp);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(scan_threads), 0, s, pp);
     hipLaunchKernelGGL(cigar_tile_kernel, dim3(tile_blocks), dim3(256), 0, s, pp);
     hipLaunchKernelGGL(cigar_scan_kernel, dim3(rd_blocks), dim3(256), 0, s, pp);
-    hipLaunchKernelGGL(read_scan_kernel, dim3(1), dim3(1024), 0, s, pp);
+    hipLaunchKernelGGL(read_scan_kernel, dim3(1), dim3(scan_threads), 0, s, pp);
     hipLaunchKernelGGL(expand_path_kernel, dim3(tile_blocks), dim3(256), 0, s, pp);
     hipLaunchKernelGGL(make_chunks_kernel, dim3(ch_blocks), dim3(256), 0, s, pp);
-    hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, s, pp);
+    hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(scan_threads), 0, s, pp);
     hipLaunchKernelGGL(sched_scatter_kernel, dim3(ch_blocks), dim3(256), 0, s, pp);
     {
         // slice bytes + 6 byte planes per position in LDS when that fits (it does for the default max_b_rows);
         // sized by the longest slice of the group, so that two workgroups share a CU on 10 kb reads
         const int planes_in_lds = 7 * pstride <= 160 * 1024;
         const size_t alds = planes_in_lds ? 7 * pstride : pstride;
-        if (planes_in_lds) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&annotate_kernel<true>),
+        if (beside_fill) {
+            // no LDS, 8 waves of ~30 VGPRs: fits beside the 16 waves of a fill workgroup
+            hipLaunchKernelGGL((annotate_kernel<false, false>), dim3((unsigned)(2 * max_chunks)), dim3(512), 0, s, pp);
+        } else if (planes_in_lds) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&annotate_kernel<true, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
-            hipLaunchKernelGGL(annotate_kernel<true>, dim3((unsigned)(2 * max_chunks)), dim3(1024), alds, s, pp);
+            hipLaunchKernelGGL((annotate_kernel<true, true>), dim3((unsigned)(2 * max_chunks)), dim3(1024), alds, s, pp);
         } else {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&annotate_kernel<false>),
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&annotate_kernel<false, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
-            hipLaunchKernelGGL(annotate_kernel<false>, dim3((unsigned)(2 * max_chunks)), dim3(1024), alds, s, pp);
+            hipLaunchKernelGGL((annotate_kernel<false, true>), dim3((unsigned)(2 * max_chunks)), dim3(1024), alds, s, pp);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -405,14 +432,14 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     hipError_t e = hipSuccess;
     const int mc = (int)max_chunks;
     switch (shape) {
-        case 1: e = launch_fill<1>(kp, mc, ctx->force_chunks, ctx->n_cus, s); break;
-        case 2: e = launch_fill<2>(kp, mc, ctx->force_chunks, ctx->n_cus, s); break;
-        case 3: e = launch_fill<3>(kp, mc, ctx->force_chunks, ctx->n_cus, s); break;
-        case 4: e = launch_fill<4>(kp, mc, ctx->force_chunks, ctx->n_cus, s); break;
-        case 5: e = launch_fill<5>(kp, mc, ctx->force_chunks, ctx->n_cus, s); break;
-        case 6: e = launch_fill<6>(kp, mc, ctx->force_chunks, ctx->n_cus, s); break;
-        case 7: e = launch_fill<7>(kp, mc, ctx->force_chunks, ctx->n_cus, s); break;
-        case 8: e = launch_fill<8>(kp, mc, ctx->force_chunks, ctx->n_cus, s); break;
+        case 1: e = launch_fill<1>(kp, mc, ctx->force_chunks, ctx->n_cus, s, overlapping, &ctx->fill_has_room); break;
+        case 2: e = launch_fill<2>(kp, mc, ctx->force_chunks, ctx->n_cus, s, overlapping, &ctx->fill_has_room); break;
+        case 3: e = launch_fill<3>(kp, mc, ctx->force_chunks, ctx->n_cus, s, overlapping, &ctx->fill_has_room); break;
+        case 4: e = launch_fill<4>(kp, mc, ctx->force_chunks, ctx->n_cus, s, overlapping, &ctx->fill_has_room); break;
+        case 5: e = launch_fill<5>(kp, mc, ctx->force_chunks, ctx->n_cus, s, overlapping, &ctx->fill_has_room); break;
+        case 6: e = launch_fill<6>(kp, mc, ctx->force_chunks, ctx->n_cus, s, overlapping, &ctx->fill_has_room); break;
+        case 7: e = launch_fill<7>(kp, mc, ctx->force_chunks, ctx->n_cus, s, overlapping, &ctx->fill_has_room); break;
+        case 8: e = launch_fill<8>(kp, mc, ctx->force_chunks, ctx->n_cus, s, overlapping, &ctx->fill_has_room); break;
         default: return fail(NPORE_E_UNSUPPORTED, "unsupported waves-per-chunk count");
     }
     if (e != hipSuccess) return fail(NPORE_E_HIP, std::string("fill launch: ") + hipGetErrorString(e));
@@ -464,11 +491,16 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     // LDS of gather_kernel: one tile of ops + (when a chunk's two base slices fit beside it) the slices
     {
         const int64_t rows_max = std::min<int64_t>(max_len, a.max_b_rows) + 1;    // longest slice of any chunk
-        gp.slice_cap = rows_max <= 24 * 1024 ? (int)((rows_max + 15) & ~(int64_t)15) : 0;
-        const size_t glds = (size_t)GATHER_TILE + 2 * (size_t)gp.slice_cap;
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&gather_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
-        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)max_chunks), dim3(256), glds, s, gp);
+        if (beside_fill) {
+            gp.slice_cap = 0;
+            hipLaunchKernelGGL(gather_kernel<false>, dim3((unsigned)max_chunks), dim3(256), 0, s, gp);
+        } else {
+            gp.slice_cap = rows_max <= 24 * 1024 ? (int)((rows_max + 15) & ~(int64_t)15) : 0;
+            const size_t glds = (size_t)GATHER_TILE + 2 * (size_t)gp.slice_cap;
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&gather_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));
+            hipLaunchKernelGGL(gather_kernel<true>, dim3((unsigned)max_chunks), dim3(256), glds, s, gp);
+        }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(w->h_cnt.p, w->counters.p, 8, hipMemcpyDeviceToHost, s));    // chunk count, overflow flag
@@ -566,7 +598,10 @@ int run_core(npore_ctx *ctx, const AlignArgs &a, const OutTarget &ot, hipStream_
         if (int rc = collect_group(ctx, w)) {        // the set's previous group (two groups back) has to be through
             if (!ctx->deferred_rc) { ctx->deferred_rc = rc; ctx->deferred_err = g_err; }
         }
-        if (int rc = run_group(ctx, w, a, g0, g1, ot, shape)) {
+        // (the other work set still busy: its group is in the fill or traceback stage while this one is prepared,
+        // and this group's gather will most likely run while the next one's fill is on the GPU)
+        const bool beside = ctx->coresident && ctx->ws[ctx->next_ws ^ 1].busy;
+        if (int rc = run_group(ctx, w, a, g0, g1, ot, shape, beside)) {
             if (rc == NPORE_E_NOMEM && g1 - g0 > 1) {          // another context got there first: smaller groups
                 (void)quiesce(ctx);
                 max_group = (g1 - g0) / 2;
@@ -910,6 +945,7 @@ try {
     const std::string k(key);
     if (k == "tb_budget_mb") ctx->tb_budget_mb = value;
     else if (k == "force_chunks") ctx->force_chunks = (int)value;
+    else if (k == "coresident") ctx->coresident = value != 0;
     else if (k == "traceback_kernel") { if (value < 0 || value > 2) return fail(NPORE_E_INVALID, "traceback_kernel: 0, 1 or 2"); ctx->tb_kernel = (int)value; }
     else return fail(NPORE_E_INVALID, "unknown key " + k);
     return NPORE_OK;

@@ -62,11 +62,14 @@ struct PrepParams {
 };
 
 // ---------------------------------------------------------------------------
-// exclusive scan of one value per thread over a 1024-thread workgroup (wave scans by shuffles, the 16 wave sums
-// through LDS); *total = sum over the workgroup.  s_wave: 16 entries of shared memory, reusable afterwards.
+// exclusive scan of one value per thread over the workgroup (64 ... 1024 threads; wave scans by shuffles, the wave
+// sums through LDS); *total = sum over the workgroup.  s_wave: 16 entries of shared memory, reusable afterwards.
+// (The single-workgroup scan kernels split their items over blockDim.x threads: 1 024 on a free GPU, 256 when the
+// launch has to find room beside a fill kernel -- one wave per SIMD fits next to the fill's four.)
 template <class T>
 __device__ __forceinline__ T block_scan_1024(T v, T *s_wave, T *total)
 {
+    const int nwv = blockDim.x >> 6;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     T inc = v;
 #pragma unroll
@@ -78,7 +81,7 @@ __device__ __forceinline__ T block_scan_1024(T v, T *s_wave, T *total)
     __syncthreads();
     T before = 0, tot = 0;
 #pragma unroll
-    for (int q = 0; q < 16; q++) { const T w = s_wave[q]; before += q < wave ? w : (T)0; tot += w; }
+    for (int q = 0; q < 16; q++) { const T w = q < nwv ? s_wave[q] : (T)0; before += q < wave ? w : (T)0; tot += w; }
     __syncthreads();
     *total = tot;
     return before + inc - v;
@@ -93,8 +96,8 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(PrepParams p)
 {
     __shared__ int64_t s_w[16];
     const int t = threadIdx.x;
-    const int64_t per = (p.n_reads + 1023) / 1024;
-    const int64_t a = (int64_t)t * per, b = (a + per < p.n_reads) ? a + per : p.n_reads;
+    const int64_t per = (p.n_reads + blockDim.x - 1) / blockDim.x;
+    const int64_t a = (int64_t)t * per < p.n_reads ? (int64_t)t * per : p.n_reads, b = (a + per < p.n_reads) ? a + per : p.n_reads;
     int64_t l = 0, total;
     for (int64_t k = a; k < b; k++) l += cigar_tiles(p.cig_off[k + 1] - p.cig_off[k]);
     int64_t acc = block_scan_1024(l, s_w, &total);
@@ -186,8 +189,8 @@ __global__ __launch_bounds__(1024) void read_scan_kernel(PrepParams p)
 {
     __shared__ int64_t s_w[16];
     const int t = threadIdx.x;
-    const int64_t per = (p.n_reads + 1023) / 1024;
-    const int64_t a = (int64_t)t * per, b = (a + per < p.n_reads) ? a + per : p.n_reads;
+    const int64_t per = (p.n_reads + blockDim.x - 1) / blockDim.x;
+    const int64_t a = (int64_t)t * per < p.n_reads ? (int64_t)t * per : p.n_reads, b = (a + per < p.n_reads) ? a + per : p.n_reads;
     int64_t ls = 0, lc = 0, tot_s, tot_c;
     for (int64_t k = a; k < b; k++) { ls += p.rd_nsteps[k]; lc += p.rd_nchunks[k]; }
     int64_t as = block_scan_1024(ls, s_w, &tot_s), ac = block_scan_1024(lc, s_w, &tot_c);
@@ -322,8 +325,8 @@ __global__ __launch_bounds__(1024) void chunk_scan_kernel(PrepParams p)
     __shared__ int64_t s_w[16];
     const int t = threadIdx.x;
     const int n = p.counters[0];
-    const int per = (n + 1023) / 1024;
-    const int a = t * per, b = (a + per < n) ? a + per : n;
+    const int per = (n + (int)blockDim.x - 1) / (int)blockDim.x;
+    const int a = t * per < n ? t * per : n, b = (a + per < n) ? a + per : n;
     int64_t l[4] = {0, 0, 0, 0};
     for (int k = a; k < b; k++) {
         const ChunkDesc &d = p.descs[k];
@@ -340,8 +343,8 @@ __global__ __launch_bounds__(1024) void chunk_scan_kernel(PrepParams p)
     // histogram (max_b_rows + 2 bins) -> exclusive start positions
     __shared__ int32_t hs_w[16];
     const int nb = p.max_b_rows + 2;
-    const int hper = (nb + 1023) / 1024;
-    const int ha = t * hper, hb = (ha + hper < nb) ? ha + hper : nb;
+    const int hper = (nb + (int)blockDim.x - 1) / (int)blockDim.x;
+    const int ha = t * hper < nb ? t * hper : nb, hb = (ha + hper < nb) ? ha + hper : nb;
     int32_t hl = 0, htot;
     for (int k = ha; k < hb; k++) hl += p.hist[k];
     int32_t hacc = block_scan_1024(hl, hs_w, &htot);
@@ -469,9 +472,13 @@ __device__ __forceinline__ void annotate_sequence(const uint8_t *seq, int len, i
 
 // One workgroup per (chunk, sequence).  The slice and the L planes are staged in LDS
 // (7 bytes per position) when they fit; otherwise the planes live in global scratch.
-template <bool PLANES_IN_LDS>
+// SEQ_IN_LDS = false (with the planes in global scratch too): no LDS at all -- the slice is read where it lies
+// (cache hits after the first touch).  Slower on its own, but such a workgroup finds room on a CU whose LDS a
+// fill-kernel workgroup holds: the variant for preparing the next group of reads BESIDE a running fill kernel.
+template <bool PLANES_IN_LDS, bool SEQ_IN_LDS = true>
 __global__ __launch_bounds__(1024) void annotate_kernel(PrepParams p)
 {
+    static_assert(SEQ_IN_LDS || !PLANES_IN_LDS, "planes in LDS imply the slice in LDS");
     extern __shared__ __attribute__((aligned(16))) uint8_t sbuf[];
     const int k = blockIdx.x >> 1;
     const bool is_ref = blockIdx.x & 1;
@@ -483,12 +490,15 @@ __global__ __launch_bounds__(1024) void annotate_kernel(PrepParams p)
     const int len = (int)(((int64_t)start + span + 1 < T ? (int64_t)start + span + 1 : T) - start);   // src/aln.pyx:453-454
     const uint8_t *g = (is_ref ? p.refs + p.ref_off[rd] : p.seqs + p.seq_off[rd]) + start;
     const int pstride = p.pstride;
-    uint8_t *sseq = sbuf;
+    const uint8_t *sseq = g;
     uint8_t *planes;   // a compile-time choice, so that the LDS case uses ds_* instructions rather than flat ones
     if constexpr (PLANES_IN_LDS) planes = sbuf + pstride;
     else planes = reinterpret_cast<uint8_t *>(p.seql) + ((size_t)blockIdx.x * 6) * pstride;
-    for (int q = threadIdx.x; q < len; q += blockDim.x) sseq[q] = g[q];
-    __syncthreads();
+    if constexpr (SEQ_IN_LDS) {
+        for (int q = threadIdx.x; q < len; q += blockDim.x) sbuf[q] = g[q];
+        sseq = sbuf;
+        __syncthreads();
+    }
     annotate_sequence(sseq, len, p.max_n, p.max_l, planes, pstride, nullptr, nullptr);
     auto Lat = [&](int pos, int n) -> uint32_t { return planes[(size_t)(n - 1) * pstride + pos] & 127u; };
     auto idx0 = [&](int pos, int n) -> bool { return (planes[(size_t)(n - 1) * pstride + pos] >> 7) != 0u; };
