@@ -7,6 +7,7 @@ tag=${1:-r02}; shift || true
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/prof_$tag
+rm -rf $out          # (a box is fresh, but gpurun merges into what the build container already holds)
 mkdir -p $out
 B="--no-cpu --pcie-steps 0 --sustain 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/bench.py --steps 3 --warmup 1 $B "$@" > $out/bench_trace.log 2>&1
