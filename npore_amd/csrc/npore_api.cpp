@@ -591,9 +591,18 @@ int run_core(npore_ctx *ctx, const AlignArgs &a, const OutTarget &ot, hipStream_
             const int64_t need = (2 * cl + chunk_bound(cl, a.max_b_rows)) * tbs * 4 + 48 * cl;
             if (g1 > g0 && acc + need > budget) break;
             acc += need;
-            cells += (a.h_seq_off[g1 + 1] - a.h_seq_off[g1] + a.h_ref_off[g1 + 1] - a.h_ref_off[g1] + 1) * (2 * a.r + 1);
             g1++;
         }
+        // a group that is not the last one holds a whole number of launch-fulls of full-size chunks (about one per
+        // read): its fill kernel then ends on full chains instead of a sparse tail
+        if (g1 < a.n_reads) {
+            FillGeom fg;
+            if (fill_geometry(a.r, fg)) {
+                const int64_t full = (int64_t)fill_round_workgroups(fg, fg.cmax, ctx->n_cus) * fg.cmax;
+                if (g1 - g0 > full) g1 = g0 + (g1 - g0) / full * full;
+            }
+        }
+        cells = (a.h_seq_off[g1] - a.h_seq_off[g0] + a.h_ref_off[g1] - a.h_ref_off[g0] + (g1 - g0)) * (2 * a.r + 1);
         WorkSet *w = &ctx->ws[ctx->next_ws];
         if (int rc = collect_group(ctx, w)) {        // the set's previous group (two groups back) has to be through
             if (!ctx->deferred_rc) { ctx->deferred_rc = rc; ctx->deferred_err = g_err; }
