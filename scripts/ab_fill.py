@@ -23,6 +23,8 @@ def child(lib, cases):
     import numpy as np
     sub, nps, _, _ = aln.load_default_tables()
     ctx = aln.Context(sub, nps)
+    if os.environ.get("NPORE_FORCE_CHUNKS"):
+        ctx.set("force_chunks", int(os.environ["NPORE_FORCE_CHUNKS"]))
     batches = {}
     for r, n in cases:
         if n not in batches:
