@@ -176,8 +176,10 @@ int npore_last_timing(npore_ctx *ctx, double *ms, int n);
  * that keeps batches in flight: differences over a timed region). */
 int npore_total_timing(npore_ctx *ctx, double *ms, int n);
 
-/* Tunables: key in {"tb_budget_mb","force_chunks","traceback_kernel"} (traceback budget in MiB per work set,
- * chunks per workgroup, 1 = windowed / 2 = row-per-hop traceback; 0 = automatic). */
+/* Tunables: key in {"tb_budget_mb","force_chunks","traceback_kernel","coresident"} (traceback budget in MiB per
+ * work set, chunks per fill workgroup, 1 = windowed / 2 = row-per-hop traceback; 0 = automatic.  "coresident"
+ * (default 1): a group of reads that overlaps another one on the device is prepared and gathered by kernel shapes
+ * that run beside the fill kernel's workgroups, and the fill leaves them room; 0 = always the stand-alone shapes). */
 int npore_ctx_set(npore_ctx *ctx, const char *key, int64_t value);
 
 /* Batch sizing.  The DP of a chunk (at most max_b_rows anti-diagonals of a read; reference src/aln.pyx:344-358,
