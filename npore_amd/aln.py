@@ -87,8 +87,8 @@ class Context:
         _check(self.lib.npore_ctx_set(self.handle, key.encode(), int(value)))
 
     def round_chunks(self, r=30):
-        """Chunks (units of at most max_b_rows anti-diagonals) the GPU works on at a time at band half-width r:
-        batches whose full-size chunks fill whole rounds run at the best rate (include/npore_amd.h)."""
+        """Chunks (units of at most max_b_rows anti-diagonals) the GPU works on at a time at band half-width r: a
+        batch costs about ceil(full-size chunks / this) chains of dependent anti-diagonals (include/npore_amd.h)."""
         return int(self.lib.npore_round_chunks(self.handle, int(r)))
 
     def fill_shape(self, r=30):

@@ -14,13 +14,16 @@
 //                     the band edge comes from a 64-entry queue register (first /
 //                     last wave) and crosses between waves in the exchange record.
 //                     The only per-cell HBM traffic is one 32-bit traceback word.
+//                     The launch is persistent: its groups of NW waves pull chunk
+//                     after chunk from a device-side queue.
 //   traceback_kernel  one wavefront per chunk: follows MAT.TYP/MAT.RUN words
 //                     (reference src/aln.pyx:670-742) through register windows of
 //                     the band strip around the path and records the path as
 //                     (type, length) runs.
 //   gather_scan /     per read: length and status of the output, where every chunk's ops go;
 //   gather_kernel     one workgroup per chunk: expands the chunk's runs into the op
-//                     string in the caller's output buffer (src/aln.pyx:719-742).
+//                     string in the caller's output buffer (src/aln.pyx:719-742);
+//                     <false>: without its LDS tile, to run beside a fill kernel.
 #pragma once
 #include <hip/hip_runtime.h>
 
