@@ -187,8 +187,8 @@ def cpu_baseline(args, refs, seqs, cigs, sub, nps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads", type=int, default=1000, help="reads per GPU per step")
     ap.add_argument("--ref-len", type=int, default=10_000)
     ap.add_argument("--r", "--band", dest="r", type=int, default=100,
