@@ -82,6 +82,9 @@ void npore_ctx_destroy(npore_ctx *ctx);
  *   offsets.  out: caller buffer; read i may use out[out_off[i] .. out_off[i+1]);
  *   its length goes to out_len[i] (an alignment never exceeds |ref|+|seq| ops).
  *   status[i]: NPORE_ST_* bits.
+ * A batch is worked through in groups of reads (as many as the traceback budget holds); every group uploads its
+ * slice of the inputs and downloads its slice of the results around its own kernels, so that the copies of one
+ * group run beside the kernels of its neighbours.
  * Results are bit-identical to the reference for the same
  * (read, r, max_b_rows, indel_start, indel_extend, max_n, max_l, tables).
  */
@@ -93,6 +96,22 @@ int npore_align_batch(npore_ctx *ctx, int64_t n_reads,
                       int max_b_rows, int r,
                       char *out, const int64_t *out_off,
                       int64_t *out_len, int32_t *status);
+
+/*
+ * The same, returning once the batch is enqueued: up to two groups of reads of a context are on the device at a
+ * time (uploads, kernels and downloads of neighbouring groups overlap), and the results are complete when
+ * npore_ctx_wait() returns.  ALL arrays passed in -- inputs, offsets and outputs -- must stay valid and untouched
+ * until then; page-locked host memory (hipHostMalloc / a pinned torch tensor) makes the copies truly asynchronous,
+ * pageable memory works but serialises them.  A failure found later is reported by the next call on the context.
+ */
+int npore_align_batch_async(npore_ctx *ctx, int64_t n_reads,
+                            const uint8_t *refs, const int64_t *ref_off,
+                            const uint8_t *seqs, const int64_t *seq_off,
+                            const char *cigars, const int64_t *cig_off,
+                            float indel_start, float indel_extend,
+                            int max_b_rows, int r,
+                            char *out, const int64_t *out_off,
+                            int64_t *out_len, int32_t *status);
 
 /*
  * Device-resident variant used by bench.py and by pipelines that already hold
@@ -168,7 +187,7 @@ int npore_standardize_ops_batch(int64_t n_reads, const char *alns, const int64_t
  * Timing of the stages of the last npore_align_batch* call on this context,
  * measured with HIP events on the stream the kernels ran on (milliseconds):
  *   ms[0] device prep kernels, ms[1] fill kernel(s), ms[2] traceback + gather,
- *   ms[3] H2D, ms[4] D2H (host-buffer entry point only), ms[5] unused (0),
+ *   ms[3] H2D, ms[4] D2H (host-buffer entry points only; summed over the groups), ms[5] unused (0),
  *   ms[6] cells processed (count), ms[7] fill-kernel launches.
  */
 int npore_last_timing(npore_ctx *ctx, double *ms, int n);

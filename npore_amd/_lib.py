@@ -26,6 +26,8 @@ SIGNATURES = {
     "npore_ctx_destroy": (None, [C.c_void_p]),
     "npore_align_batch": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 6 +
                           [C.c_float, C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 4),
+    "npore_align_batch_async": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 6 +
+                                [C.c_float, C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 4),
     "npore_align_batch_device": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 6 +
                                  [C.c_float, C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 4 +
                                  [C.c_void_p, C.c_int]),

@@ -114,6 +114,9 @@ class Context:
         _check(self.lib.npore_total_timing(self.handle, t, 8))
         return dict(zip(self._TIMING_KEYS, list(t)))
 
+    def total_launches(self):
+        return int(self.total_timing()["launches"])
+
     def wait(self):
         """Wait for the batches enqueued with sync=0 (npore_ctx_wait)."""
         _check(self.lib.npore_ctx_wait(self.handle))

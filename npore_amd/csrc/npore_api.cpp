@@ -122,11 +122,18 @@ struct WorkSet {
     DevBuf seqw, refw, refl, seql;                                   // annotation
     DevBuf tb, cout_, clen, cstat, cnruns;                           // fill / traceback (cout_: uint32 runs)
     HostBuf h_cnt;                                                   // counters read back with the group
+    // host-buffer entry points: the group's slice of the caller's inputs / outputs on the device, its offset
+    // arrays rebased to the slice (page-locked copy for the upload)
+    DevBuf in_refs, in_seqs, in_cigs, in_off, out, out_len, status;
+    HostBuf h_off;
+    hipEvent_t evc[4] = {};      // H2D start / end, D2H start / end of a staged group
+    bool staged = false;
     hipEvent_t ev[6] = {};       // prep start / end, fill start / end, traceback + gather start / end (= group done)
     bool busy = false;           // enqueued, not collected yet
     int64_t cells = 0, call_id = 0;
-    DevBuf *all[19] = {&rd_i32, &rd_i64, &steps, &inss, &descs, &sched, &hist, &counters, &tiles, &cwoff,
-                       &seqw, &refw, &refl, &seql, &tb, &cout_, &clen, &cstat, &cnruns};
+    DevBuf *all[26] = {&rd_i32, &rd_i64, &steps, &inss, &descs, &sched, &hist, &counters, &tiles, &cwoff,
+                       &seqw, &refw, &refl, &seql, &tb, &cout_, &clen, &cstat, &cnruns,
+                       &in_refs, &in_seqs, &in_cigs, &in_off, &out, &out_len, &status};
 };
 
 struct npore_ctx {
@@ -277,6 +284,15 @@ struct AlignArgs {
     const int64_t *h_ref_off, *h_seq_off, *h_cig_off;
     float indel_start, indel_extend;
     int max_b_rows, r;
+    // host-buffer entry points (d_* above are NULL then): every group uploads its slice of these, and downloads
+    // its slice of the results, around its own kernels -- the copies of one group overlap the kernels of its neighbours
+    const uint8_t *h_refs = nullptr, *h_seqs = nullptr;
+    const char *h_cigs = nullptr;
+    char *h_out = nullptr;
+    const int64_t *h_out_off = nullptr;
+    int64_t *h_out_len = nullptr;
+    int32_t *h_status = nullptr;
+    bool staged() const { return h_out != nullptr; }
 };
 
 int64_t chunk_bound(int64_t cig_len, int max_b_rows)
@@ -349,6 +365,38 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     pp.refs = a.d_refs; pp.ref_off = a.d_ref_off + g0;
     pp.seqs = a.d_seqs; pp.seq_off = a.d_seq_off + g0;
     pp.cigs = a.d_cigs; pp.cig_off = a.d_cig_off + g0;
+    OutTarget got = ot;                  // where the gather writes, and the index of this group's first read in it
+    int64_t out_read_base = g0;
+    w->staged = a.staged();
+    if (a.staged()) {
+        // upload the group's slice: bases + CIGAR ops as they lie, the four offset arrays rebased to the slice
+        const int64_t out_bytes = a.h_out_off[g1] - a.h_out_off[g0];
+        if (int rc = w->h_off.ensure((size_t)4 * (nr + 1) * 8)) return rc;
+        if (int rc = w->in_refs.ensure((size_t)R_tot + 64)) return rc;
+        if (int rc = w->in_seqs.ensure((size_t)S_tot + 64)) return rc;
+        if (int rc = w->in_cigs.ensure((size_t)cig_bytes + 64)) return rc;
+        if (int rc = w->in_off.ensure((size_t)4 * (nr + 1) * 8)) return rc;
+        if (int rc = w->out.ensure((size_t)out_bytes + 64)) return rc;
+        if (int rc = w->out_len.ensure((size_t)nr * 8)) return rc;
+        if (int rc = w->status.ensure((size_t)nr * 4)) return rc;
+        int64_t *ho = w->h_off.as<int64_t>(), *hro = ho, *hso = ho + (nr + 1), *hco = ho + 2 * (nr + 1), *hoo = ho + 3 * (nr + 1);
+        for (int64_t i = 0; i <= nr; i++) {
+            hro[i] = a.h_ref_off[g0 + i] - a.h_ref_off[g0]; hso[i] = a.h_seq_off[g0 + i] - a.h_seq_off[g0];
+            hco[i] = a.h_cig_off[g0 + i] - a.h_cig_off[g0]; hoo[i] = a.h_out_off[g0 + i] - a.h_out_off[g0];
+        }
+        HIP_TRY(hipEventRecord(w->evc[0], s));
+        HIP_TRY(hipMemcpyAsync(w->in_refs.p, a.h_refs + a.h_ref_off[g0], (size_t)R_tot, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(w->in_seqs.p, a.h_seqs + a.h_seq_off[g0], (size_t)S_tot, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(w->in_cigs.p, a.h_cigs + a.h_cig_off[g0], (size_t)cig_bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(w->in_off.p, ho, (size_t)4 * (nr + 1) * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(w->evc[1], s));
+        const int64_t *d_off = w->in_off.as<int64_t>();
+        pp.refs = w->in_refs.as<uint8_t>(); pp.ref_off = d_off;
+        pp.seqs = w->in_seqs.as<uint8_t>(); pp.seq_off = d_off + (nr + 1);
+        pp.cigs = w->in_cigs.as<char>(); pp.cig_off = d_off + 2 * (nr + 1);
+        got = OutTarget{w->out.as<uint8_t>(), d_off + 3 * (nr + 1), w->out_len.as<int64_t>(), w->status.as<int32_t>()};
+        out_read_base = 0;
+    }
     pp.max_b_rows = a.max_b_rows; pp.r = r; pp.tbstride = tbs; pp.max_n = ctx->max_n; pp.max_l = ctx->max_l;
     pp.pstride = (int)pstride;
     pp.max_chunks = (int)max_chunks;
@@ -478,13 +526,13 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     gp.chunk_status = tp.chunk_status;
     gp.read_status_in = pp.rd_status;
     gp.counters = pp.counters;
-    gp.seqs = a.d_seqs;
-    gp.refs = a.d_refs;
-    gp.out = ot.d_out;
-    gp.out_off = ot.d_out_off;
-    gp.out_len = ot.d_out_len;
-    gp.status = ot.d_status;
-    gp.read_base = g0;
+    gp.seqs = pp.seqs;
+    gp.refs = pp.refs;
+    gp.out = got.d_out;
+    gp.out_off = got.d_out_off;
+    gp.out_len = got.d_out_len;
+    gp.status = got.d_status;
+    gp.read_base = out_read_base;
     gp.n_reads = nr;
     gp.chunk_woff = w->cwoff.as<int64_t>();
     hipLaunchKernelGGL(gather_scan_kernel, dim3(rd_blocks), dim3(256), 0, s, gp);
@@ -503,6 +551,13 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
         }
     }
     HIP_TRY(hipGetLastError());
+    if (a.staged()) {                   // download the group's slice of the results behind its gather
+        HIP_TRY(hipEventRecord(w->evc[2], s));
+        HIP_TRY(hipMemcpyAsync(a.h_out + a.h_out_off[g0], w->out.p, (size_t)(a.h_out_off[g1] - a.h_out_off[g0]), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(a.h_out_len + g0, w->out_len.p, (size_t)nr * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(a.h_status + g0, w->status.p, (size_t)nr * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(w->evc[3], s));
+    }
     HIP_TRY(hipMemcpyAsync(w->h_cnt.p, w->counters.p, 8, hipMemcpyDeviceToHost, s));    // chunk count, overflow flag
     HIP_TRY(hipEventRecord(w->ev[5], s));
     return NPORE_OK;
@@ -515,8 +570,7 @@ int collect_group(npore_ctx *ctx, WorkSet *w)
     w->busy = false;
     HIP_TRY(hipEventSynchronize(w->ev[5]));
     if (w->call_id != ctx->timing_call) {       // first group of a newer call: npore_last_timing starts over
-        std::fill(ctx->timing, ctx->timing + 3, 0.0);
-        ctx->timing[6] = ctx->timing[7] = 0.0;
+        std::fill(ctx->timing, ctx->timing + 8, 0.0);
         ctx->timing_call = w->call_id;
     }
     float ms = 0;
@@ -525,6 +579,12 @@ int collect_group(npore_ctx *ctx, WorkSet *w)
         ctx->timing[k] += ms;
         ctx->totals[k] += ms;
     }
+    if (w->staged)
+        for (int k = 0; k < 2; k++) {
+            HIP_TRY(hipEventElapsedTime(&ms, w->evc[2 * k], w->evc[2 * k + 1]));
+            ctx->timing[3 + k] += ms;
+            ctx->totals[3 + k] += ms;
+        }
     ctx->timing[6] += (double)w->cells; ctx->totals[6] += (double)w->cells;
     ctx->timing[7] += 1; ctx->totals[7] += 1;
     if (w->h_cnt.as<int32_t>()[1]) return fail(NPORE_E_HIP, "internal: chunk bound exceeded");
@@ -687,8 +747,10 @@ try {
              hipMemcpy(ctx->d_np, np_scores, np_elems * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
     }
     for (auto &e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
-    for (auto &w : ctx->ws)
+    for (auto &w : ctx->ws) {
         for (auto &e : w.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+        for (auto &e : w.evc) ok = ok && hipEventCreate(&e) == hipSuccess;
+    }
     if (!ok) {
         fail(NPORE_E_HIP, "npore_ctx_create: HIP initialisation failed");
         npore_ctx_destroy(ctx);
@@ -710,7 +772,10 @@ void npore_ctx_destroy(npore_ctx *ctx)
     for (auto &w : ctx->ws) {
         for (DevBuf *b : w.all) b->release();
         w.h_cnt.release();
+        w.h_off.release();
         for (auto &e : w.ev)
+            if (e) (void)hipEventDestroy(e);
+        for (auto &e : w.evc)
             if (e) (void)hipEventDestroy(e);
     }
     ctx->h_offs.release();
@@ -724,57 +789,45 @@ void npore_ctx_destroy(npore_ctx *ctx)
     delete ctx;
 }
 
+static int align_batch_host(npore_ctx *ctx, int64_t n_reads, const uint8_t *refs, const int64_t *ref_off,
+                            const uint8_t *seqs, const int64_t *seq_off, const char *cigars, const int64_t *cig_off,
+                            float indel_start, float indel_extend, int max_b_rows, int r, char *out,
+                            const int64_t *out_off, int64_t *out_len, int32_t *status, bool sync)
+{
+    if (!ctx) return fail(NPORE_E_INVALID, "null context");
+    if (n_reads < 0) return fail(NPORE_E_INVALID, "n_reads < 0");
+    if (n_reads == 0) return NPORE_OK;
+    if (!refs || !seqs || !cigars || !out || !ref_off || !seq_off || !cig_off || !out_off || !out_len || !status)
+        return fail(NPORE_E_INVALID, "null argument");
+    if (out_off[n_reads] < out_off[0]) return fail(NPORE_E_INVALID, "out_off not ascending");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->deferred_rc) return quiesce(ctx);   // a group of an earlier asynchronous call failed
+    // every group of reads uploads its own slice and downloads its own results (run_group): the copies of one
+    // group run beside the kernels of its neighbours, and the caller's arrays are used as they are
+    AlignArgs a{n_reads, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ref_off, seq_off, cig_off,
+                indel_start, indel_extend, max_b_rows, r};
+    a.h_refs = refs; a.h_seqs = seqs; a.h_cigs = cigars;
+    a.h_out = out; a.h_out_off = out_off; a.h_out_len = out_len; a.h_status = status;
+    return run_core(ctx, a, OutTarget{nullptr, nullptr, nullptr, nullptr}, nullptr, sync);
+}
+
 int npore_align_batch(npore_ctx *ctx, int64_t n_reads, const uint8_t *refs, const int64_t *ref_off,
                       const uint8_t *seqs, const int64_t *seq_off, const char *cigars, const int64_t *cig_off,
                       float indel_start, float indel_extend, int max_b_rows, int r, char *out,
                       const int64_t *out_off, int64_t *out_len, int32_t *status)
 try {
-    if (!ctx) return fail(NPORE_E_INVALID, "null context");
-    if (n_reads < 0) return fail(NPORE_E_INVALID, "n_reads < 0");
-    if (n_reads == 0) return NPORE_OK;
-    if (!ref_off || !seq_off || !cig_off || !out_off || !out_len || !status)
-        return fail(NPORE_E_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(ctx->device));
-    if (int rc = quiesce(ctx)) return rc;        // (asynchronous device-resident batches still in flight)
-    hipStream_t s = ctx->stream;
-    const int64_t n = n_reads;
-    const int64_t out_bytes = out_off[n] - out_off[0];
-    if (out_bytes < 0) return fail(NPORE_E_INVALID, "out_off not ascending");
-    // rebased offsets so that only the used part of the caller's buffers is uploaded
-    std::vector<int64_t> offs(4 * (n + 1));
-    int64_t *ro = offs.data(), *so = ro + n + 1, *co = so + n + 1, *oo = co + n + 1;
-    for (int64_t i = 0; i <= n; i++) {
-        ro[i] = ref_off[i] - ref_off[0]; so[i] = seq_off[i] - seq_off[0];
-        co[i] = cig_off[i] - cig_off[0]; oo[i] = out_off[i] - out_off[0];
-    }
-    if (int rc = ctx->in_refs.ensure(ro[n] + 64)) return rc;
-    if (int rc = ctx->in_seqs.ensure(so[n] + 64)) return rc;
-    if (int rc = ctx->in_cigs.ensure(co[n] + 64)) return rc;
-    if (int rc = ctx->in_off.ensure(offs.size() * 8)) return rc;
-    if (int rc = ctx->out.ensure(out_bytes + 64)) return rc;
-    if (int rc = ctx->out_len.ensure(n * 8)) return rc;
-    if (int rc = ctx->status.ensure(n * 4)) return rc;
-    HIP_TRY(hipEventRecord(ctx->ev[4], s));
-    HIP_TRY(hipMemcpyAsync(ctx->in_refs.p, refs + ref_off[0], ro[n], hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(ctx->in_seqs.p, seqs + seq_off[0], so[n], hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(ctx->in_cigs.p, cigars + cig_off[0], co[n], hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(ctx->in_off.p, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipEventRecord(ctx->ev[5], s));
-    int64_t *d_off = ctx->in_off.as<int64_t>();
-    AlignArgs a{n, ctx->in_refs.as<uint8_t>(), d_off, ctx->in_seqs.as<uint8_t>(), d_off + (n + 1),
-                ctx->in_cigs.as<char>(), d_off + 2 * (n + 1), ro, so, co, indel_start, indel_extend, max_b_rows, r};
-    OutTarget ot{ctx->out.as<uint8_t>(), d_off + 3 * (n + 1), ctx->out_len.as<int64_t>(), ctx->status.as<int32_t>()};
-    if (int rc = run_core(ctx, a, ot, nullptr, true)) return rc;
-    HIP_TRY(hipEventRecord(ctx->ev[6], s));
-    HIP_TRY(hipMemcpyAsync(out + out_off[0], ctx->out.p, out_bytes, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(out_len, ctx->out_len.p, n * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(status, ctx->status.p, n * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipEventRecord(ctx->ev[7], s));
-    HIP_TRY(hipStreamSynchronize(s));
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5])); ctx->timing[3] = ms;
-    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7])); ctx->timing[4] = ms;
-    return NPORE_OK;
+    return align_batch_host(ctx, n_reads, refs, ref_off, seqs, seq_off, cigars, cig_off, indel_start, indel_extend,
+                            max_b_rows, r, out, out_off, out_len, status, true);
+}
+NPORE_CATCH_INT
+
+int npore_align_batch_async(npore_ctx *ctx, int64_t n_reads, const uint8_t *refs, const int64_t *ref_off,
+                            const uint8_t *seqs, const int64_t *seq_off, const char *cigars, const int64_t *cig_off,
+                            float indel_start, float indel_extend, int max_b_rows, int r, char *out,
+                            const int64_t *out_off, int64_t *out_len, int32_t *status)
+try {
+    return align_batch_host(ctx, n_reads, refs, ref_off, seqs, seq_off, cigars, cig_off, indel_start, indel_extend,
+                            max_b_rows, r, out, out_off, out_len, status, false);
 }
 NPORE_CATCH_INT
 

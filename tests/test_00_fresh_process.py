@@ -119,6 +119,33 @@ got = ctx.align_batch(refs, seqs, cigs, r=100)
 assert ctx.timing()["launches"] > 3
 ctx.set("tb_budget_mb", 0)
 assert got == ctx.align_batch(refs, seqs, cigs, r=100)
+# host buffers, asynchronously (npore_align_batch_async): page-locked arrays, three batches enqueued back to back, each
+# group uploading / downloading its own slice; results complete after the wait
+hb = []
+for k in (1, 3, 5):
+    refs, seqs, cigs = synth.make_batch(60 + k, 40 + 7 * k, ref_len=2500 + 300 * k)
+    rb, ro = pack(refs); sb, so = pack(seqs); cb, co = pack(cigs)
+    oo = np.zeros(len(refs) + 1, np.int64)
+    np.cumsum([len(a) + len(b) for a, b in zip(refs, seqs)], out=oo[1:])
+    pin = [torch.from_numpy(x).pin_memory() for x in (rb, sb, cb)]
+    out = torch.zeros(int(oo[-1]) + 64, dtype=torch.uint8).pin_memory()
+    ln = torch.zeros(len(refs), dtype=torch.int64).pin_memory()
+    st = torch.zeros(len(refs), dtype=torch.int32).pin_memory()
+    hb.append((k, len(refs), pin, (ro, so, co, oo), out, ln, st))
+ctx.set("tb_budget_mb", 16)          # several groups per batch
+for k, n, pin, offs, out, ln, st in hb:
+    rc = lib.npore_align_batch_async(ctx.handle, n, pin[0].data_ptr(), offs[0].ctypes.data, pin[1].data_ptr(), offs[1].ctypes.data,
+                                     pin[2].data_ptr(), offs[2].ctypes.data, 5.0, 1.0, 20000, 30 if k % 2 else 100,
+                                     out.data_ptr(), offs[3].ctypes.data, ln.data_ptr(), st.data_ptr())
+    assert rc == 0, _lib.last_error()
+ctx.wait()
+ctx.set("tb_budget_mb", 0)
+for k, n, pin, offs, out, ln, st in hb:
+    o, l, oo = out.numpy(), ln.numpy(), offs[3]
+    assert not st.numpy().any()
+    assert [o[oo[i]:oo[i] + l[i]].tobytes().decode() for i in range(n)] == want[k], k
+t = ctx.timing()
+assert t["h2d_ms"] > 0 and t["d2h_ms"] > 0
 ctx.close()
 print("ASYNC_OK")
 """
