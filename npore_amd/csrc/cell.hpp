@@ -46,6 +46,7 @@ namespace npore {
 // Wave-uniform quantities of one anti-diagonal (b-row) of one chunk.
 struct StepInfo {
     int b_local;     // 0-based b-row inside the chunk
+    float init_f;    // (float)(100 * b_local): what LEN / SHR start from (src/aln.pyx:473,476)
     int ins_l;       // inss[b] - row0 : local row of the input path on this anti-diagonal
     int del_l;       // dels[b] - col0 = b_local - ins_l
     int r;
@@ -268,7 +269,7 @@ NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, 
     const int c = in.c;
     const int i = st.ins_l + st.r - c;   // local a_row
     const int j = st.del_l - st.r + c;   // local a_col
-    const float init = (float)(100 * st.b_local);    // src/aln.pyx:473,476
+    const float init = st.init_f;                    // src/aln.pyx:473,476
     float insv, delv;
     int insrun, delrun;
     // ---- INS, src/aln.pyx:525-543 (branch-free: selects only)
@@ -301,7 +302,14 @@ NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, 
                           (FAST || ((i >= 0) && (j >= 0) && (i <= st.drows) && (j <= st.dcols)));
     const uint32_t imask = interior ? 0xFFFFFFFFu : 0u;    // loop-invariant in the plain case
     uint32_t lm = ((in.refx & in.seqw & imask) >> FLAG_SHIFT) & 63u;
-    const uint32_t sm = in.sc0 & imask & (DSC_N4 | DSC_HAS2 | DSC_RARE);   // period of the column's first SHR candidate + summary bits
+#if defined(NPORE_X_NOLEN)
+    lm = 0u;
+#endif
+#if defined(NPORE_X_NOSHR)
+    const uint32_t sm = 0u;
+#else
+    const uint32_t sm = in.sc0 & imask & (DSC_N4 | DSC_HAS2 | DSC_RARE);
+#endif   // period of the column's first SHR candidate + summary bits
 
     // ---- LEN / SHR candidates (pull form of src/aln.pyx:601-633, 642-667)
     // SHR of a cell comes from X = (i, j-n) at band column c - dI; LEN from

@@ -112,6 +112,9 @@ __device__ __forceinline__ float lds_abs_f32(uint32_t byte_addr)
 {
     return *reinterpret_cast<lds_cfloat *>(byte_addr);
 }
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 constexpr uint32_t LDS_NP_BASE = 0u;                                      // [6][NP_LT][NP_CT] floats
 constexpr uint32_t LDS_SUB_BASE = MAX_PERIOD * NP_LT * NP_CT * 4u;        // then the substitution table
 
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     float *chunk_lds = lds_sub + SUBT_ENTRIES + (size_t)cg * chunk_lds_floats(NW, hw, p.rwin);
     HistCell *hist = reinterpret_cast<HistCell *>(chunk_lds) + HIST_PAD;     // row 0, column 0
     uint2 *win = reinterpret_cast<uint2 *>(chunk_lds + 4 * (NSR * hw + HIST_PAD));
-    uint32_t *xchg = reinterpret_cast<uint32_t *>(chunk_lds + 4 * (NSR * hw + HIST_PAD) + 2 * p.rwin);   // [2][NW][XCH_WORDS]
+    uint32_t *xchg = reinterpret_cast<uint32_t *>(chunk_lds + 4 * (NSR * hw + HIST_PAD) + 2 * p.rwin);   // [NW][2][XCH_WORDS]
     int *prog = reinterpret_cast<int *>(xchg + 2 * NW * XCH_WORDS);          // [NW] anti-diagonals completed, all chunks
     int *slotbox = prog + 8;                                                  // [SLOT_RING] + generation word
 
@@ -337,8 +340,10 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     }
     const bool hist_lane = (tcol >= 1) && (tcol <= 2 * r - 1);     // band-interior columns leave history
     env.n0_lanes = __builtin_amdgcn_ballot_w64((lane & 7) == 0);
-    const bool tb_lane = tcol <= 2 * r;
     const uint32_t tcol4 = (uint32_t)tcol * 4u;
+    // (dynamic LDS starts at LDS address 0, see lds_abs_f32)
+    const uint32_t hist_c_addr = (uint32_t)(reinterpret_cast<const char *>(hist + tcol) - reinterpret_cast<const char *>(lds));
+    const uint32_t xchg_addr = (uint32_t)(reinterpret_cast<const char *>(xchg) - reinterpret_cast<const char *>(lds));
     const int n_chunks = *p.n_chunks;
     const int dealt = (int)gridDim.x * cpg;      // slots handed out without the queue: one per group
     int pbase = 0;        // anti-diagonals of the chunks this group has finished (what prog[] counts from)
@@ -409,6 +414,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         // queues of words that will enter at column 0 (read; first wave) / column WPT-1 (reference; last wave)
         int sq_base = r + 1;              // next read index entering at column 0 is ins_l + r
         int rq_base = WPT - r;            // next reference index entering at column WPT-1 is del_l + WPT-1 - r
+        int sq_idx = 0, rq_idx = 0;       // lane of seq_q / ref_q that holds it
         uint32_t seq_q = SEQW_SENTINEL;
         uint4 ref_q = make_uint4(REFW_SENTINEL, 0u, 0u, 0u);
         if (cw == 0) {
@@ -419,10 +425,15 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             const int j = rq_base + lane;
             ref_q = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint4(REFW_SENTINEL, 0u, 0u, 0u);
         }
-        // input-path steps, 64 per coalesced load, one block prefetched (the buffer is padded)
-        unsigned long long stepmask = __builtin_amdgcn_ballot_w64(steps_g[lane] != 0);
-        unsigned long long nextmask = __builtin_amdgcn_ballot_w64(steps_g[64 + lane] != 0);
-        unsigned long long stepmask_peek = 0ull;
+        // input-path steps, 64 per coalesced load: window m holds the steps that lead to anti-diagonals 64m ... 64m+63
+        // of the chunk, the one of anti-diagonal bl in bit bl & 63 (so the bit test needs no index arithmetic); one
+        // window is fetched ahead (the buffer is padded behind; nothing precedes the first step of the first read)
+        auto step_window = [&](int m) {
+            const int k = 64 * m + lane - 1;
+            return __builtin_amdgcn_ballot_w64(k >= 0 && steps_g[k] != 0);
+        };
+        unsigned long long stepmask = step_window(0);
+        unsigned long long nextmask = step_window(1);
 
         // The group's LDS (history ring, L window, exchange records) still serves its waves until all of them have
         // finished the previous chunk, and the L window (kept by the last wave, read by every wave from its first
@@ -467,6 +478,21 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         // lane table of history offsets (DevEnv::tab_e): rows before the chunk, band not moved yet
         env.tab_e = __umul24(min((uint32_t)0 - env.t_n, (uint32_t)0 - env.t_n + (uint32_t)NSR), (uint32_t)env.hw16);
 
+        // Per-step bookkeeping that is the same for every lane still lives in VECTOR registers: on this machine a
+        // scalar instruction costs a wave about twice the issue time of a vector one (measured: 16 extra s_add per
+        // step +7.7 % fill time at r=100, 16 extra v_add +3.9 %), and the scalar unit is shared by the CU's 16 waves.
+        uint32_t slot_v = 0u;                 // byte offset of this anti-diagonal's row in the history ring
+        uint32_t tboff_v = tcol4;             // byte offset of this lane's traceback word from the chunk's first
+        float e_v = 0.0f;                     // 100 * b_local, then 100 * (b_local + 1)  (exact in fp32: b_local < 2^16)
+        asm volatile("" : "+v"(slot_v), "+v"(e_v));
+        const uint32_t ring_bytes = (uint32_t)(NSR * env.hw16), tbstride4 = (uint32_t)p.tbstride * 4u;
+        uint32_t prog_v = (uint32_t)pbase;    // this wave's progress word: anti-diagonals finished, all chunks
+        // exchange records, [wave][parity][XCH_WORDS]: the record of the wave below for this anti-diagonal's parity
+        // (own record = + 2 records) and the same for the other parity (what the neighbours wrote last step: the
+        // wave below's at + 0, the wave above's at + 4 records); swapped after every step
+        uint32_t xown = xchg_addr + (uint32_t)((cw - 1) * 2) * (XCH_WORDS * 4u), xoth = xown + XCH_WORDS * 4u;
+        asm volatile("" : "+v"(prog_v), "+v"(xown), "+v"(xoth));
+
         StepInfo st;
         st.r = r;
         st.drows = d.drows;
@@ -482,34 +508,49 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         // stepped 'I' (read words move one column up, "left" is the previous lane), 2: 'D'
         // (reference words move one column down, "top" is the next lane).  The whole body is
         // instantiated per mode so that no register shuffling is needed where the modes meet.
-        auto step = [&](auto mode_tag, auto role_tag) __attribute__((always_inline)) {
+        auto step = [&](auto mode_tag, auto role_tag, auto fast_tag) __attribute__((always_inline)) {
             constexpr int MODE = decltype(mode_tag)::value;
             // ROLE: 0 = only wave of the chunk, 1 = first, 2 = middle, 3 = last (compile-time so that the
             // per-role code needs no joins inside the loop)
             constexpr int ROLE = decltype(role_tag)::value;
             constexpr bool IS_FIRST = (ROLE == 0 || ROLE == 1), IS_LAST = (ROLE == 0 || ROLE == 3);
-            const int bl = st.b_local;
+            // FASTSEL: every band cell of this anti-diagonal is an ordinary one (cell.hpp step_is_plain)
+            constexpr bool FASTSEL = decltype(fast_tag)::value;
+            if constexpr (MODE != 0) {
+                // ring row of this anti-diagonal, then the lane table of history offsets: its entry n is entry n-1
+                // of the previous anti-diagonal's (same ring row), 16 bytes lower if the band has just moved (an
+                // 'I' step); entry 0 = this anti-diagonal's own row.  Nothing here depends on the neighbour waves,
+                // so it sits in front of the hand-shake.
+                slot_v += (uint32_t)env.hw16;
+                slot_v = (slot_v == ring_bytes) ? 0u : slot_v;
+                const uint32_t moved = lane_prev(env.tab_e) - (MODE == 1 ? 16u : 0u);
+                // (one v_cndmask on a lane mask held in scalar registers; left to itself the compiler branches on exec)
+                asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(env.tab_e) : "v"(moved), "v"(slot_v), "s"(env.n0_lanes));
+                tboff_v += tbstride4;
+            }
+            st.init_f = e_v;
+            e_v += 100.0f;
+#if !defined(NPORE_X_NOPOLL)
             if constexpr (NW > 1 && MODE != 0) {
-                // Per-chunk hand-shake instead of a workgroup barrier: this wave may start anti-diagonal bl
-                // once its two neighbour waves have finished bl-1 (they own the only columns it reads).
-                // The neighbour released its history / exchange words before its progress word; the fence
-                // behind the loop acquires them.
-                const int target = pbase + bl;
+                // Per-chunk hand-shake instead of a workgroup barrier: this wave may start an anti-diagonal once
+                // its two neighbour waves have finished the previous one (they own the only columns it reads),
+                // i.e. once their progress words have reached this wave's own.  The neighbour released its
+                // history / exchange words before its progress word; the fence behind the loop acquires them.
                 for (;;) {
                     // relaxed workgroup-scope atomics keep these plain LDS reads (a volatile access would
                     // become a flat system-scope load with a vmcnt(0) wait)
                     const int a = !IS_FIRST ? __hip_atomic_load(&prog[cw - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
                     const int b = !IS_LAST ? __hip_atomic_load(&prog[cw + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
-                    if (uni((a < b ? a : b)) >= target) break;
-                    // (no s_sleep between two looks: measured -1 % at r = 64 / 100, -2 % at r = 200 against s_sleep 1;
+                    // (every lane reads the same words; a vector compare + branch on vcc instead of readfirstlane + s_cmp.
+                    // No s_sleep between two looks: measured -1 % at r = 64 / 100, -2 % at r = 200 against s_sleep 1;
                     // s_sleep 2 and 4 equal s_sleep 1)
+                    if (__builtin_amdgcn_ballot_w64((a < b ? a : b) < (int)prog_v) == 0ull) break;
                 }
                 NPORE_OBSERVE_FENCE();
             }
-            // boundary cells written by the neighbour waves at the end of the previous step
-            // (the record addresses are wave-uniform; pinning each in ONE vector register lets every word
-            // use an immediate offset instead of its own scalar-to-vector move)
-            const int xin = ((bl + 1) & 1) * (NW * XCH_WORDS);
+#endif
+            // boundary cells written by the neighbour waves at the end of the previous step: xoth = this group's
+            // exchange records of the previous anti-diagonal's parity, counted from the record of the wave below
             CellIn in;
             if constexpr (MODE == 1) {
                 float pm, pd;
@@ -517,18 +558,18 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 if constexpr (IS_FIRST) {
                     pm = lane_prev(matv); pd = lane_prev(delv); pr = lane_prev(R2);
                     // word for row ins_l + r enters at column 0
-                    if (st.ins_l + r - sq_base >= 64) {   // uniform
+                    if (sq_idx >= 64) {   // uniform
+                        sq_idx -= 64;
                         sq_base += 64;
                         const int i = sq_base + lane;
                         seq_q = (i <= d.drows) ? seqw_g[i] : SEQW_SENTINEL;
                         asm volatile("" : "+v"(seq_q));   // wait for the reload inside this rare branch (see np_full)
                     }
-                    const uint32_t incoming = (uint32_t)__builtin_amdgcn_readlane((int)seq_q, (st.ins_l + r - sq_base) & 63);
+                    const uint32_t incoming = (uint32_t)__builtin_amdgcn_readlane((int)seq_q, sq_idx);
+                    sq_idx++;
                     ps = lane_prev_or(incoming, seqw);
                 } else {
-                    int xi = xin + (cw - 1) * XCH_WORDS;               // last cell of the wave below (broadcast reads)
-                    asm volatile("" : "+v"(xi));
-                    const uint32_t *xl = xchg + xi;
+                    const lds_u32 *xl = reinterpret_cast<const lds_u32 *>(xoth);      // last cell of the wave below (broadcast reads)
                     const uint32_t x0 = xl[0], x1 = xl[1], x2 = xl[2], x3 = xl[3];
                     // lane 0 keeps the neighbour wave's cell, the others take their previous lane's
                     pm = lane_prev_or(__uint_as_float(x0), matv);
@@ -545,29 +586,29 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 LMr = pr;
                 TMr = R1;
                 seqw = ps;
+                st.ins_l++;
             } else if constexpr (MODE == 2) {
                 float nm, ni;
                 uint32_t nr, nx, nc0, nc1;
                 if constexpr (IS_LAST) {
                     nm = lane_next(matv); ni = lane_next(insv); nr = lane_next(R1);
                     // word for col del_l + WPT-1 - r enters at column WPT-1
-                    if (st.del_l + WPT - 1 - r - rq_base >= 64) {
+                    if (rq_idx >= 64) {
+                        rq_idx -= 64;
                         rq_base += 64;
                         const int j = rq_base + lane;
                         ref_q = (j >= 0 && j <= d.dcols) ? refw_g[j] : make_uint4(REFW_SENTINEL, 0u, 0u, 0u);
                         asm volatile("" : "+v"(ref_q.x), "+v"(ref_q.z), "+v"(ref_q.w));   // wait inside the rare branch
                     }
-                    const int ql = (st.del_l + WPT - 1 - r - rq_base) & 63;
-                    const uint32_t inx = (uint32_t)__builtin_amdgcn_readlane((int)ref_q.x, ql);
-                    const uint32_t inz = (uint32_t)__builtin_amdgcn_readlane((int)ref_q.z, ql);
-                    const uint32_t inw = (uint32_t)__builtin_amdgcn_readlane((int)ref_q.w, ql);
+                    const uint32_t inx = (uint32_t)__builtin_amdgcn_readlane((int)ref_q.x, rq_idx);
+                    const uint32_t inz = (uint32_t)__builtin_amdgcn_readlane((int)ref_q.z, rq_idx);
+                    const uint32_t inw = (uint32_t)__builtin_amdgcn_readlane((int)ref_q.w, rq_idx);
+                    rq_idx++;
                     nx = lane_next_or(inx, refx);
                     nc0 = lane_next_or(inz, rc0);
                     nc1 = lane_next_or(inw, rc1);
                 } else {
-                    int xi = xin + (cw + 1) * XCH_WORDS + 5;           // first cell of the wave above
-                    asm volatile("" : "+v"(xi));
-                    const uint32_t *xf = xchg + xi;
+                    const lds_u32 *xf = reinterpret_cast<const lds_u32 *>(xoth) + 4 * XCH_WORDS + 5;   // first cell of the wave above
                     const uint32_t x0 = xf[0], x1 = xf[1], x2 = xf[2], x3 = xf[3], x4 = xf[4], x5 = xf[5];
                     nm = lane_next_or(__uint_as_float(x0), matv);
                     ni = lane_next_or(__uint_as_float(x1), insv);
@@ -576,6 +617,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                     nc0 = lane_next_or(x4, rc0);
                     nc1 = lane_next_or(x5, rc1);
                 }
+                st.del_l++;
                 if (st.del_l + r + 32 >= wfill) {   // keep the L window ahead of the band (32 positions of slack)
                     if constexpr (IS_LAST) {
                         const int j = wfill + lane;
@@ -598,6 +640,32 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 in.topM = in.topI = in.leftM = in.leftD = in.diagM = 0.0f;
                 in.topIrun = in.leftDrun = in.diagMrun = 0;
             }
+#if defined(NPORE_PAD_VALU)
+            {
+                uint32_t pa = tcol4, pb = tcol4;
+#pragma unroll
+                for (int k = 0; k < NPORE_PAD_VALU / 2; k++) {
+                    asm volatile("v_add_u32 %0, %0, 1" : "+v"(pa));
+                    asm volatile("v_add_u32 %0, %0, 1" : "+v"(pb));
+                }
+            }
+#endif
+#if defined(NPORE_PAD_SALU)
+            {
+                uint32_t pa = 1u, pb = 2u, pc = 3u, pd = 4u;
+#pragma unroll
+                for (int k = 0; k < NPORE_PAD_SALU / 4; k++) {
+                    asm volatile("s_add_u32 %0, %0, 1" : "+s"(pa) : : "scc");
+                    asm volatile("s_add_u32 %0, %0, 1" : "+s"(pb) : : "scc");
+                    asm volatile("s_add_u32 %0, %0, 1" : "+s"(pc) : : "scc");
+                    asm volatile("s_add_u32 %0, %0, 1" : "+s"(pd) : : "scc");
+                }
+            }
+#endif
+#if defined(NPORE_PAD_NOP)
+#pragma unroll
+            for (int k = 0; k < NPORE_PAD_NOP; k++) asm volatile("s_nop 0");
+#endif
             in.c = tcol;
             in.seqw = seqw;
             in.refx = refx;
@@ -609,8 +677,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             // TYP = MAT, RUN = 0).  Only three values of an edge cell are ever read (by its one in-band
             // neighbour), so only those are patched below; edge columns leave no history and the traceback
             // kernel treats them as "run 0" itself.  A middle wave holds band-interior columns only (MID).
-            if (bl >= d.plain_lo && bl < d.plain_hi) cell_update<true, false, ROLE == 2>(env, st, in, o);    // == step_is_plain(st)
-            else cell_update<false, false, ROLE == 2>(env, st, in, o);
+            cell_update<FASTSEL, false, ROLE == 2>(env, st, in, o);
 
             LMv = in.leftM;
             TMv = in.topM;
@@ -620,7 +687,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             R1 = (uint32_t)o.matrun | ((uint32_t)o.insrun << 16);
             R2 = (uint32_t)o.matrun | ((uint32_t)o.delrun << 16);
             {
-                const float e = (float)(100 * (bl + 1));
+                const float e = e_v;
                 if constexpr (IS_FIRST) {      // column 0 is lane 0 of the first wave; read as a LEFT neighbour
                     matv = (lane == 0) ? e : matv;
                     delv = (lane == 0) ? e : delv;
@@ -633,15 +700,22 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                     R1 = is_edge ? 0u : R1;
                 }
             }
-            if (ROLE == 2 || hist_lane)     // (a middle wave holds band-interior columns only: no lane mask)
-                hist[env.slot * hw + tcol] =
-                    HistCell{o.matv, o.lenstart, o.shrstart, (uint32_t)o.lenrun_h | ((uint32_t)o.shrrun_h << 16)};
+            // history record and traceback word of the band-interior columns (a middle wave holds no others: no
+            // lane mask).  The traceback never looks at the words of the two edge columns (it stops there with
+            // "run < 1", like the reference on their TYP = MAT / RUN = 0), so they are not stored.  The word goes
+            // to uniform chunk base in SGPRs + per-lane byte offset, advanced by one row per step.
+            if (ROLE == 2 || hist_lane) {
+                *reinterpret_cast<lds_u32x4 *>(hist_c_addr + slot_v) =      // a HistCell
+                    u32x4{__float_as_uint(o.matv), __float_as_uint(o.lenstart), __float_as_uint(o.shrstart),
+                          (uint32_t)o.lenrun_h | ((uint32_t)o.shrrun_h << 16)};
+                asm volatile("global_store_dword %0, %1, %2" : : "v"(tboff_v), "v"(o.tb), "s"(tb_g) : "memory");
+            }
             if constexpr (NW > 1) {
                 // boundary cells for the neighbour waves: the last lane's cell for the wave above (it reads
-                // it as a LEFT neighbour), the first lane's for the wave below (TOP neighbour + reference words)
-                int xo = (bl & 1) * (NW * XCH_WORDS) + cw * XCH_WORDS;
-                asm volatile("" : "+v"(xo));
-                uint32_t *xout = xchg + xo;
+                // it as a LEFT neighbour), the first lane's for the wave below (TOP neighbour + reference words);
+                // then the progress word, after this step's LDS writes (workgroup release: LDS only, it does not
+                // wait for the traceback stores above, which must stay in flight)
+                lds_u32 *xout = reinterpret_cast<lds_u32 *>(xown) + 2 * XCH_WORDS;
                 if constexpr (!IS_LAST) {
                     if (lane == 63) {
                         xout[0] = __float_as_uint(matv);
@@ -650,8 +724,9 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                         xout[3] = seqw;
                     }
                 }
-                if constexpr (!IS_FIRST) {
-                    if (lane == 0) {
+                prog_v++;
+                if (lane == 0) {
+                    if constexpr (!IS_FIRST) {
                         xout[5] = __float_as_uint(matv);
                         xout[6] = __float_as_uint(insv);
                         xout[7] = R1;
@@ -659,53 +734,30 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                         xout[9] = rc0;
                         xout[10] = rc1;
                     }
+                    NPORE_PUBLISH_FENCE();
+                    __hip_atomic_store(&prog[cw], (int)prog_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-            }
-            // one traceback word per cell: uniform row base in SGPRs + per-lane byte offset, so the store
-            // costs no address arithmetic (the compiler would otherwise carry a 64-bit per-lane pointer)
-            if (ROLE == 1 || ROLE == 2 || tb_lane) {     // (columns beyond the band only exist in a chunk's last wave)
-                const uint32_t *trow = tb_g + (size_t)bl * p.tbstride;
-                asm volatile("global_store_dword %0, %1, %2" : : "v"(tcol4), "v"(o.tb), "s"(trow) : "memory");
-            }
-            // publish progress after this step's LDS writes (workgroup release: LDS only, it does not wait for the
-            // traceback stores above, which must stay in flight)
-            if constexpr (NW > 1) {
-                NPORE_PUBLISH_FENCE();
-                if (lane == 0) __hip_atomic_store(&prog[cw], pbase + bl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            // lane table of history offsets for the NEXT anti-diagonal, off the neighbours' critical path: its entry n
-            // is entry n-1 of this one (same ring row), 16 bytes lower if the band moves (the next step is an 'I');
-            // entry 0 = the next anti-diagonal's own row
-            {
-                const int next_slot = (env.slot + 1 == NSR) ? 0 : env.slot + 1;
-                const uint32_t moved = lane_prev(env.tab_e) - (uint32_t)((int)(stepmask_peek & 1ull) << 4);
-                // (one v_cndmask on a lane mask held in scalar registers; left to itself the compiler branches on exec)
-                uint32_t row0 = (uint32_t)(next_slot * env.hw16);
-                asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(env.tab_e) : "v"(moved), "v"(row0), "s"(env.n0_lanes));
+                asm volatile("v_swap_b32 %0, %1" : "+v"(xown), "+v"(xoth));      // the other parity's records next
             }
         };
 
+        // anti-diagonals [b0, b1) of one step window
+        auto span = [&](int b0, int b1, auto role_tag, auto fast_tag) __attribute__((always_inline)) {
+            for (int bl = b0; bl < b1; bl++) {
+                if ((stepmask >> (bl & 63)) & 1ull) step(std::integral_constant<int, 1>{}, role_tag, fast_tag);
+                else step(std::integral_constant<int, 2>{}, role_tag, fast_tag);
+            }
+        };
         auto run = [&](auto role_tag) __attribute__((always_inline)) {
-            stepmask_peek = stepmask;
-            step(std::integral_constant<int, 0>{}, role_tag);
-            int left = 64;                         // steps left in stepmask
-            for (int bl = 1; bl < d.nrows; bl++) {
-                if (left == 0) {                   // step bl-1 leads from local row bl-1 to bl
-                    stepmask = nextmask;
-                    nextmask = __builtin_amdgcn_ballot_w64(steps_g[bl - 1 + 64 + lane] != 0);
-                    left = 64;
-                }
-                const int I = (int)(stepmask & 1ull);
-                stepmask >>= 1;
-                left--;
-                stepmask_peek = left ? stepmask : nextmask;     // bit 0: the step after this one
-                st.b_local = bl;
-                st.ins_l += I;
-                st.del_l = bl - st.ins_l;
-                st.hist6 = ((st.hist6 << 1) | (uint32_t)I) & 63u;
-                env.slot = (env.slot + 1 == NSR) ? 0 : env.slot + 1;
-                if (I) step(std::integral_constant<int, 1>{}, role_tag);
-                else step(std::integral_constant<int, 2>{}, role_tag);
+            step(std::integral_constant<int, 0>{}, role_tag, std::false_type{});
+            for (int w0 = 0; w0 < d.nrows; w0 += 64) {
+                const int b0 = w0 ? w0 : 1, b1 = min(w0 + 64, d.nrows);
+                // (a window that is not plain from end to end runs the general cell update throughout: at most 126
+                // anti-diagonals of a chunk more than necessary)
+                if (b0 >= d.plain_lo && b1 <= d.plain_hi) span(b0, b1, role_tag, std::true_type{});     // == step_is_plain(st)
+                else span(b0, b1, role_tag, std::false_type{});
+                stepmask = nextmask;
+                nextmask = step_window((w0 >> 6) + 2);
             }
         };
         // the wave's role within its chunk decides where annotation words and boundary cells come from

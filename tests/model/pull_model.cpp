@@ -120,6 +120,7 @@ extern "C" int64_t pull_model_align(const uint8_t *full_ref, int64_t ref_len, co
             const int64_t b = brk + bl;
             StepInfo st;
             st.b_local = bl;
+            st.init_f = (float)(100 * bl);
             st.ins_l = path.inss[b] - row0;
             st.del_l = bl - st.ins_l;
             st.r = r;
