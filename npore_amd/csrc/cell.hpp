@@ -43,6 +43,12 @@
 
 namespace npore {
 
+#if defined(NPORE_STATS) && defined(__HIP_DEVICE_COMPILE__)
+#define NPORE_COUNT(k) env.count(k)
+#else
+#define NPORE_COUNT(k) ((void)0)
+#endif
+
 // Wave-uniform quantities of one anti-diagonal (b-row) of one chunk.
 struct StepInfo {
     int b_local;     // 0-based b-row inside the chunk
@@ -135,7 +141,8 @@ NPORE_HD int div_recip(int run, uint32_t m)
 //   float sub(uint32_t seqw, uint32_t refx)                    sub_scores[seq[i-1]][ref[j-1]] from the two words
 //   float np_full(int n_idx, int a, int b, bool active)        np_scores[n_idx][a][b] (a, b already clamped)
 //   float np_small(uint32_t dsc, int q)     np_score(L, -(q+1)) for a descriptor with L < NP_LT:
-//                                           np_scores[n-1][L][L-1-q], or INF_F if that call length is < 0
+//                                           np_scores[n-1][L][L-1-q], or INF_F if that call length is < 0;
+//                                           +infinity for the empty descriptor 0 (a column without a candidate)
 //   int   clamp()                                              max_l - 1 (see np_score_index below)
 //   int   refl(int j, int n_idx)                               L of local ref position j
 //   uint32_t refy(int j)                                       refw[j].y, 0 outside the chunk's columns
@@ -144,6 +151,8 @@ NPORE_HD int div_recip(int run, uint32_t m)
 //                                           c - (inss[b]-inss[b-n]) of anti-diagonal b-n   (n4 = 4n)
 //   auto  h_off(Tab, uint32_t n4) / HistCell h_shr_at(Tab, off, uint32_t n4, int c)   the same in two steps: where
 //                                           the record lies (a lane-table read on the device), then the record
+//   T     opaque(T x)                       x; device: through an empty asm, so that what is computed from it stays
+//                                           where it is written (not hoisted out of a rarely taken block)
 //   void  pin(T &...)                       device: the values are complete here and nothing that produces them is
 //                                           moved below (an empty asm with in/out operands); host: nothing
 //   HistCell h_len(Tab, uint32_t n4, int c) likewise (i-n, j): column c + n - (inss[b]-inss[b-n])
@@ -224,13 +233,15 @@ NPORE_HD void shr_small(const Env &env, const Tab &tab, const CellIn &in, int j,
         env.pin(s0, s1);
     }
     const float cand0 = cstart0 + s0;
-    const bool take0 = act0 && (FAST || j - n0 >= 0) && cand0 < shrv;
+    // (FAST: a lane without a candidate holds an empty descriptor, whose score is +infinity -- np_small -- so its
+    // candidate never passes the compare; what the band-edge and out-of-band lanes pick up is never read)
+    const bool take0 = (FAST || (act0 && j - n0 >= 0)) && cand0 < shrv;
     shrv = take0 ? cand0 : shrv;
     shrrun = take0 ? run0 + n0 : shrrun;                              // :654 / :667
     shrstart = take0 ? cstart0 : shrstart;
     if constexpr (TWO) {
         const float cand1 = cstart1 + s1;
-        const bool take1 = act1 && (FAST || j - n1 >= 0) && cand1 < shrv;
+        const bool take1 = (FAST || (act1 && j - n1 >= 0)) && cand1 < shrv;
         shrv = take1 ? cand1 : shrv;
         shrrun = take1 ? run1 + n1 : shrrun;
         shrstart = take1 ? cstart1 : shrstart;
@@ -316,22 +327,29 @@ NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, 
     // X = (i-n, j) at band column c + (n - dI), dI = inss[b] - inss[b-n].
     // SHR candidates are dense inside reference n-polymers, LEN candidates are rare
     // (they also need the read to repeat the same unit), so each has its own loop.
-    if (env.any((lm | sm) != 0u)) {
+    NPORE_COUNT(0);
+    // (almost every anti-diagonal of a wave has an SHR candidate somewhere -- 94 % at r=100, 99.8 % at r=30 -- and two
+    // thirds of them nothing else: the tests are ordered for that)
+    {
         const auto tab = env.step_tables(st);
         if (env.any(sm != 0u)) {
+            NPORE_COUNT(2);
             // the column's two highest periods come pre-decoded with the reference words
             // (evaluation order = the reference's: higher period first)
-            // (any2(a, b) = any(a && b) from two separate lane masks: a ballot of a compound condition
-            // would first be rebuilt as a 0/1 vector and compared again)
             const bool act = sm != 0u;
-            const bool has2 = (sm & DSC_HAS2) != 0u, act2 = has2;
-            if (!env.any(sm >= DSC_RARE)) {
+            if (!env.any(sm > DSC_N4)) {
+                // no column of the wave has a second candidate or needs the generic path
+                NPORE_COUNT(3);
+                shr_small<FAST, false>(env, tab, in, j, act, false, shrv, shrrun, shrstart);
+            } else if (!env.any(sm >= DSC_RARE)) {
                 // (both in one block: the second candidate's history / table reads are independent of the first's
                 // outcome and overlap with them)
-                if (env.any(has2)) shr_small<FAST, true>(env, tab, in, j, act, act2, shrv, shrrun, shrstart);
-                else shr_small<FAST, false>(env, tab, in, j, act, false, shrv, shrrun, shrstart);
+                NPORE_COUNT(3);
+                NPORE_COUNT(4);
+                shr_small<FAST, true>(env, tab, in, j, act, (sm & DSC_HAS2) != 0u, shrv, shrrun, shrstart);
             } else {
                 // a long n-polymer (L >= NP_LT) or three or more periods in one column somewhere in the wave
+                const bool has2 = (sm & DSC_HAS2) != 0u, act2 = has2;
                 shr_generic<FAST>(env, tab, in, j, in.sc0 & DSC_N4, (int)((in.sc0 >> 8) & 127u),
                                   (in.sc0 & DSC_START) != 0u, act, shrv, shrrun, shrstart);
                 if (env.any(has2))
@@ -354,8 +372,10 @@ NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, 
             }
         }
 
-        const uint32_t refm = in.refx >> MER_SHIFT;
         while (env.any(lm != 0u)) {
+            NPORE_COUNT(5);
+            // (opaque: formed here, in the one anti-diagonal in three that gets this far, not hoisted in front of the loop)
+            const uint32_t refm = env.opaque(in.refx) >> MER_SHIFT;
             const bool valid = lm != 0u;
             const int nm1 = top_index(lm);                 // period - 1 (32 if this lane has none left)
             lm = low_bits(lm, nm1);
@@ -376,9 +396,10 @@ NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, 
             const bool inside = FAST || i - (nm1 + 1) >= 0;
             const bool good = valid && inside && match;
             if (!(FAST ? env.any2(valid, match) : env.any(good))) continue;
+            NPORE_COUNT(6);
             const int n = nm1 + 1;
             const bool start = ((in.seqw >> (nm1 & 31)) & 1u) != 0u;
-            const int L = env.refl(j, nm1 & 7);
+            const int L = env.refl(st.del_l - st.r + env.opaque(c), nm1 & 7);      // (j, formed here: see refm)
             const HistCell h = env.h_len(tab, n4, c);
             const float cstart = start ? h.matv : h.lenstart;                  // :614 / :628
             const int run = start ? 0 : (int)(h.runs & 0xFFFFu);
@@ -398,7 +419,8 @@ NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, 
     const bool diag_ok = FAST || ((i > 0) && (j > 0));
     const float vdiag = in.diagM + env.sub(in.seqw, in.refx);
     float v = diag_ok ? vdiag : delv + 100.0f;     // else-branch: "ensure val1 isn't chosen"
-    uint32_t tr = diag_ok ? ((uint32_t)T_MAT | ((uint32_t)(in.diagMrun + 1) << 3)) : (uint32_t)T_MAT;  // typ | run<<3
+    const uint32_t tr_diag = (uint32_t)T_MAT | ((uint32_t)(in.diagMrun + 1) << 3);      // typ | run<<3
+    uint32_t tr = diag_ok ? tr_diag : (uint32_t)T_MAT;
     const bool t1 = insv < v;
     v = t1 ? insv : v;
     tr = t1 ? ((uint32_t)T_INS | ((uint32_t)insrun << 3)) : tr;
@@ -411,7 +433,10 @@ NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, 
     const bool t4 = shrv < v;
     v = t4 ? shrv : v;
     tr = t4 ? ((uint32_t)T_SHR | ((uint32_t)shrrun << 3)) : tr;
-    const bool any_taken = t1 || t2 || t3 || t4;
+    // "no INDEL state won": every other candidate carries a non-zero TYP, so the word itself says so (one vector
+    // compare; or-ing the four compare masks costs three scalar instructions, which are the dearer ones here)
+    static_assert(T_MAT == 0, "tr == tr_diag <=> MAT.TYP == MAT");
+    const bool any_taken = FAST ? tr != tr_diag : (t1 || t2 || t3 || t4);
     // band edge, src/aln.pyx:502-507: all five states = 100*(b_row+1), TYP = MAT, RUN = 0
     const bool edge = EDGES && ((c == 0) || (c == r2));
     const bool inrect = FAST || ((i >= 0) && (j >= 0) && (i <= st.drows) && (j <= st.dcols));

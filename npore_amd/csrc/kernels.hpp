@@ -118,8 +118,15 @@ typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 constexpr uint32_t LDS_NP_BASE = 0u;                                      // [6][NP_LT][NP_CT] floats
 constexpr uint32_t LDS_SUB_BASE = MAX_PERIOD * NP_LT * NP_CT * 4u;        // then the substitution table
 
+#if defined(NPORE_STATS)
+__device__ unsigned long long g_npore_stats[16];
+#endif
+
 template <int NSR>
 struct DevEnv {
+#if defined(NPORE_STATS)
+    __device__ __forceinline__ void count(int k) const { if ((threadIdx.x & 63) == 0) atomicAdd(&g_npore_stats[k], 1ull); }
+#endif
     static constexpr bool LEN_ARITH = NSR != 6;   // several waves per chunk (ring_rows): cell.hpp, LEN filter
     const char *lds_sub;      // [ref 8][seq 8][4] copy of sub_scores (layout.hpp SUBT_*)
     const char *lds_np;       // [6][NP_LT][NP_CT] floats (layout.hpp)
@@ -163,6 +170,8 @@ struct DevEnv {
     {
         if constexpr (PIN) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
     }
+    template <class T>
+    __device__ __forceinline__ T opaque(T x) const { asm volatile("" : "+v"(x)); return x; }
     __device__ __forceinline__ HistCell h_len(const Tab &tab, uint32_t n4, int) const
     {
         return *reinterpret_cast<const HistCell *>(hist_c + (int)(lane_table(n4, tab.e) + (n4 << 2)));
@@ -301,8 +310,11 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const int np_dim = p.max_l + 1;
     for (int idx = threadIdx.x; idx < MAX_PERIOD * NP_LT * NP_CT; idx += blockDim.x) {
         const int n = idx / (NP_LT * NP_CT), a = (idx / NP_CT) % NP_LT, b = NP_LT - 1 - idx % NP_CT;
-        lds_np[idx] = b < 0 ? INF_F
-                            : (n < p.max_n && a < np_dim && b < np_dim) ? p.np_scores[((size_t)n * np_dim + a) * np_dim + b] : 0.0f;
+        // (entry 0 -- period 1, L = 0, which no lookup uses: L = 0 is np_score's "100" -- is what the EMPTY column
+        // descriptor 0 points at: +infinity, so that a lane without a candidate never wins, cell.hpp shr_small)
+        lds_np[idx] = idx == 0 ? huge_f()
+                    : b < 0   ? INF_F
+                              : (n < p.max_n && a < np_dim && b < np_dim) ? p.np_scores[((size_t)n * np_dim + a) * np_dim + b] : 0.0f;
     }
     for (int idx = threadIdx.x; idx < SUBT_ENTRIES; idx += blockDim.x) {
         const int rb = idx >> 5, sb = (idx >> 2) & 7;

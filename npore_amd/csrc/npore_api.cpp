@@ -696,6 +696,15 @@ int run_core(npore_ctx *ctx, const AlignArgs &a, const OutTarget &ot, hipStream_
 extern "C" {
 
 int npore_abi_version(void) { return NPORE_ABI_VERSION; }
+#if defined(NPORE_STATS)
+extern "C" int npore_debug_stats(unsigned long long *out, int reset)
+{
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(npore::g_npore_stats), sizeof z) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(npore::g_npore_stats), z, sizeof z) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 const char *npore_last_error(void) { return g_err.c_str(); }
 
 int npore_device_count(void)

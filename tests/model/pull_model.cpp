@@ -44,7 +44,8 @@ struct ModelEnv {
     {
         const int n = (int)((dsc >> 2) & 7u), L = (int)((dsc >> 8) & 127u);
         const int call = L - 1 - q;
-        if (n == 0 || call < 0) return INF_F;
+        if (n == 0) return huge_f();      // empty descriptor: never wins
+        if (call < 0) return INF_F;
         const int row = L < max_l ? L : max_l - 1;          // np_score clamps the row to max_l - 1
         return np_scores[((size_t)(n - 1) * (max_l + 1) + row) * (max_l + 1) + call];
     }
@@ -67,6 +68,7 @@ struct ModelEnv {
     uint32_t h_off(const Tab &, uint32_t n4) const { return n4; }
     HistCell h_shr_at(const Tab &t, uint32_t, uint32_t n4, int c) const { return h_shr(t, n4, c); }
     template <class... T> void pin(T &...) const {}
+    template <class T> T opaque(T x) const { return x; }
     HistCell h_len(const Tab &t, uint32_t n4, int c) const
     {
         const int n = period(n4);
