@@ -340,6 +340,10 @@ NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, 
             if (!env.any(sm > DSC_N4)) {
                 // no column of the wave has a second candidate or needs the generic path
                 NPORE_COUNT(3);
+#if defined(NPORE_STATS)
+                if (!env.any(act && (sm & DSC_N4) != 4u)) NPORE_COUNT(7);
+                if (!env.any(act && (sm & DSC_N4) > 8u)) NPORE_COUNT(8);
+#endif
                 shr_small<FAST, false>(env, tab, in, j, act, false, shrv, shrrun, shrstart);
             } else if (!env.any(sm >= DSC_RARE)) {
                 // (both in one block: the second candidate's history / table reads are independent of the first's

@@ -113,6 +113,7 @@ __device__ __forceinline__ float lds_abs_f32(uint32_t byte_addr)
     return *reinterpret_cast<lds_cfloat *>(byte_addr);
 }
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) int lds_i32;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 constexpr uint32_t LDS_NP_BASE = 0u;                                      // [6][NP_LT][NP_CT] floats
@@ -291,8 +292,12 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     // waves -- r=100: 9 live columns of 64 -- on one SIMD: 15 % slower; spreading each chunk over the four
     // SIMDs with mixed roles: 12 % slower, the critical wave then competes with three busy strangers.)
     const int cpg = (int)(blockDim.x >> 6) / NW;   // chunks (groups) per workgroup
+#if defined(NPORE_X_CHUNKMAJOR)
+    const int cw = wave % NW, cg = wave / NW;
+#else
     const int cw = wave / cpg;            // wave within the group
     const int cg = wave % cpg;            // group within the workgroup
+#endif
     // The middle waves of a chunk (all 64 lanes live, a neighbour wave on either side) are issued first when
     // several waves of the SIMD are ready: measured 1.5-2 % on the fill at NW = 3...7 (r = 70, 100, 140, 200)
     if (NW > 2 && cw != 0 && cw != NW - 1) __builtin_amdgcn_s_setprio(1);
@@ -356,6 +361,9 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     // (dynamic LDS starts at LDS address 0, see lds_abs_f32)
     const uint32_t hist_c_addr = (uint32_t)(reinterpret_cast<const char *>(hist + tcol) - reinterpret_cast<const char *>(lds));
     const uint32_t xchg_addr = (uint32_t)(reinterpret_cast<const char *>(xchg) - reinterpret_cast<const char *>(lds));
+    // progress word of the wave below (the wave above's is two words on)
+    uint32_t pnb_addr = (uint32_t)(reinterpret_cast<const char *>(prog + (cw - 1)) - reinterpret_cast<const char *>(lds));
+    asm volatile("" : "+v"(pnb_addr));
     const int n_chunks = *p.n_chunks;
     const int dealt = (int)gridDim.x * cpg;      // slots handed out without the queue: one per group
     int pbase = 0;        // anti-diagonals of the chunks this group has finished (what prog[] counts from)
@@ -497,12 +505,13 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         uint32_t tboff_v = tcol4;             // byte offset of this lane's traceback word from the chunk's first
         float e_v = 0.0f;                     // 100 * b_local, then 100 * (b_local + 1)  (exact in fp32: b_local < 2^16)
         asm volatile("" : "+v"(slot_v), "+v"(e_v));
-        const uint32_t ring_bytes = (uint32_t)(NSR * env.hw16), tbstride4 = (uint32_t)p.tbstride * 4u;
+        uint32_t ring_bytes = (uint32_t)(NSR * env.hw16), tbstride4 = (uint32_t)p.tbstride * 4u;
         uint32_t prog_v = (uint32_t)pbase;    // this wave's progress word: anti-diagonals finished, all chunks
         // exchange records, [wave][parity][XCH_WORDS]: the record of the wave below for this anti-diagonal's parity
         // (own record = + 2 records) and the same for the other parity (what the neighbours wrote last step: the
-        // wave below's at + 0, the wave above's at + 4 records); swapped after every step
+        // wave below's at + 0, the wave above's at + 4 records); exchanged after every step
         uint32_t xown = xchg_addr + (uint32_t)((cw - 1) * 2) * (XCH_WORDS * 4u), xoth = xown + XCH_WORDS * 4u;
+        uint32_t xsum = xown + xoth;      // (not const: used as an asm operand inside the step lambda)
         asm volatile("" : "+v"(prog_v), "+v"(xown), "+v"(xoth));
 
         StepInfo st;
@@ -533,12 +542,19 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 // of the previous anti-diagonal's (same ring row), 16 bytes lower if the band has just moved (an
                 // 'I' step); entry 0 = this anti-diagonal's own row.  Nothing here depends on the neighbour waves,
                 // so it sits in front of the hand-shake.
+                // (written as in-place asm: with the plain expressions the compiler forms the new values in fresh
+                // registers and copies them back where the two step bodies meet)
                 slot_v += (uint32_t)env.hw16;
                 slot_v = (slot_v == ring_bytes) ? 0u : slot_v;
-                const uint32_t moved = lane_prev(env.tab_e) - (MODE == 1 ? 16u : 0u);
                 // (one v_cndmask on a lane mask held in scalar registers; left to itself the compiler branches on exec)
-                asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(env.tab_e) : "v"(moved), "v"(slot_v), "s"(env.n0_lanes));
-                tboff_v += tbstride4;
+                if constexpr (MODE == 1)
+                    asm("v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_add_u32 %0, -16, %0\n\t"
+                        "v_cndmask_b32 %0, %0, %1, %2" : "+v"(env.tab_e) : "v"(slot_v), "s"(env.n0_lanes));
+                else
+                    asm("v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                        "v_cndmask_b32 %0, %0, %1, %2" : "+v"(env.tab_e) : "v"(slot_v), "s"(env.n0_lanes));
+                const uint32_t ts4 = tbstride4;
+                asm("v_add_u32 %0, %1, %0" : "+v"(tboff_v) : "s"(ts4));
             }
             st.init_f = e_v;
             e_v += 100.0f;
@@ -551,8 +567,9 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 for (;;) {
                     // relaxed workgroup-scope atomics keep these plain LDS reads (a volatile access would
                     // become a flat system-scope load with a vmcnt(0) wait)
-                    const int a = !IS_FIRST ? __hip_atomic_load(&prog[cw - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
-                    const int b = !IS_LAST ? __hip_atomic_load(&prog[cw + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
+                    // (their addresses from a vector register: as wave-uniform values the compiler moves them there inside the loop)
+                    const int a = !IS_FIRST ? __hip_atomic_load(reinterpret_cast<lds_i32 *>(pnb_addr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
+                    const int b = !IS_LAST ? __hip_atomic_load(reinterpret_cast<lds_i32 *>(pnb_addr) + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
                     // (every lane reads the same words; a vector compare + branch on vcc instead of readfirstlane + s_cmp.
                     // No s_sleep between two looks: measured -1 % at r = 64 / 100, -2 % at r = 200 against s_sleep 1;
                     // s_sleep 2 and 4 equal s_sleep 1)
@@ -581,8 +598,13 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                     sq_idx++;
                     ps = lane_prev_or(incoming, seqw);
                 } else {
-                    const lds_u32 *xl = reinterpret_cast<const lds_u32 *>(xoth);      // last cell of the wave below (broadcast reads)
-                    const uint32_t x0 = xl[0], x1 = xl[1], x2 = xl[2], x3 = xl[3];
+                    // last cell of the wave below (broadcast reads)
+                    // (word by word into four free registers: a ds_read2 / ds_read_b128 lands in a register tuple, and
+                    // the shifts below, which write in place, would leave their results there to be copied out)
+                    uint32_t x0, x1, x2, x3;
+                    asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:4\n\tds_read_b32 %2, %4 offset:8\n\t"
+                                 "ds_read_b32 %3, %4 offset:12\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(xoth) : "memory");
                     // lane 0 keeps the neighbour wave's cell, the others take their previous lane's
                     pm = lane_prev_or(__uint_as_float(x0), matv);
                     pd = lane_prev_or(__uint_as_float(x1), delv);
@@ -620,8 +642,13 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                     nc0 = lane_next_or(inz, rc0);
                     nc1 = lane_next_or(inw, rc1);
                 } else {
-                    const lds_u32 *xf = reinterpret_cast<const lds_u32 *>(xoth) + 4 * XCH_WORDS + 5;   // first cell of the wave above
-                    const uint32_t x0 = xf[0], x1 = xf[1], x2 = xf[2], x3 = xf[3], x4 = xf[4], x5 = xf[5];
+                    // first cell of the wave above: record + 4 records, words 5-10
+                    uint32_t x0, x1, x2, x3, x4, x5;
+                    asm volatile("ds_read_b32 %0, %6 offset:212\n\tds_read_b32 %1, %6 offset:216\n\tds_read_b32 %2, %6 offset:220\n\t"
+                                 "ds_read_b32 %3, %6 offset:224\n\tds_read_b32 %4, %6 offset:228\n\tds_read_b32 %5, %6 offset:232\n\t"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5) : "v"(xoth) : "memory");
+                    static_assert((4 * XCH_WORDS + 5) * 4 == 212, "offsets in the asm above");
                     nm = lane_next_or(__uint_as_float(x0), matv);
                     ni = lane_next_or(__uint_as_float(x1), insv);
                     nr = lane_next_or(x2, R1);
@@ -736,7 +763,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                         xout[3] = seqw;
                     }
                 }
-                prog_v++;
+                asm("v_add_u32 %0, 1, %0" : "+v"(prog_v));
                 if (lane == 0) {
                     if constexpr (!IS_FIRST) {
                         xout[5] = __float_as_uint(matv);
@@ -749,7 +776,9 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                     NPORE_PUBLISH_FENCE();
                     __hip_atomic_store(&prog[cw], (int)prog_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                asm volatile("v_swap_b32 %0, %1" : "+v"(xown), "+v"(xoth));      // the other parity's records next
+                // the other parity's records next
+                const uint32_t xs = xsum;      // (an asm operand alone does not make the lambda capture it)
+                asm("v_sub_u32 %0, %2, %0\n\tv_sub_u32 %1, %2, %1" : "+v"(xown), "+v"(xoth) : "s"(xs));
             }
         };
 
@@ -765,7 +794,8 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             for (int w0 = 0; w0 < d.nrows; w0 += 64) {
                 const int b0 = w0 ? w0 : 1, b1 = min(w0 + 64, d.nrows);
                 // (a window that is not plain from end to end runs the general cell update throughout: at most 126
-                // anti-diagonals of a chunk more than necessary)
+                // anti-diagonals of a chunk more than necessary; three loops -- general, plain, general -- with the
+                // window test per step measured 1-5 % slower)
                 if (b0 >= d.plain_lo && b1 <= d.plain_hi) span(b0, b1, role_tag, std::true_type{});     // == step_is_plain(st)
                 else span(b0, b1, role_tag, std::false_type{});
                 stepmask = nextmask;

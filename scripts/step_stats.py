@@ -10,7 +10,7 @@ from npore_amd import _lib
 _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 from npore_amd import aln, synth
 
-NAMES = ["wave-steps", "any candidate", "any SHR", "SHR small", "SHR small TWO", "LEN filter iterations", "LEN candidate passes"]
+NAMES = ["wave-steps", "any candidate", "any SHR", "SHR small", "SHR small TWO", "LEN filter iterations", "LEN candidate passes", "single, all n=1", "single, all n<=2"]
 sub, nps, _, _ = aln.load_default_tables()
 ctx = aln.Context(sub, nps)
 lib = ctypes.CDLL(_lib.LIB_PATH)
