@@ -276,8 +276,12 @@ constexpr int SLOT_RING = 8;    // chunk slots published by a group's first wave
 // workgroups as the GPU keeps resident, and every group of NW waves pulls its next chunk from a device-wide queue
 // (the schedule lists the chunks largest first) the moment it has finished one, until the queue is empty -- no
 // group waits for a sibling of its workgroup, no workgroup waits for a "round" to drain.
+// Registers: four of these waves share a SIMD with whatever the NEXT batch runs beside them (npore_api.cpp: its
+// preparation, the previous one's traceback), so the kernel is held to 112 of the SIMD's 512 / 4 = 128 vector
+// registers -- amdgpu_num_vgpr counts in halves on this target (arch + acc registers) -- which leaves 64 for one
+// light wave per SIMD.  At 112 the spills are all in the per-chunk set-up, none in the step loop (checked in the ISA).
 template <int NW, int MAXT>
-__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4))) void fill_kernel(KParams p)
+__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amdgpu_num_vgpr(56))) void fill_kernel(KParams p)
 {
     constexpr int NSR = ring_rows(NW);
     constexpr int WPT = NW * 64;          // physical columns per chunk

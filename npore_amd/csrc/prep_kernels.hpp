@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void cigar_scan_kernel(PrepParams p)
 }
 
 // single workgroup: exclusive scans over reads
-__global__ __launch_bounds__(1024) void read_scan_kernel(PrepParams p)
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(32))) void read_scan_kernel(PrepParams p)
 {
     __shared__ int64_t s_w[16];
     const int t = threadIdx.x;
