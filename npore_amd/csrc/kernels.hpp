@@ -578,6 +578,9 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
                     // No s_sleep between two looks: measured -1 % at r = 64 / 100, -2 % at r = 200 against s_sleep 1;
                     // s_sleep 2 and 4 equal s_sleep 1)
                     if (__builtin_amdgcn_ballot_w64((a < b ? a : b) < (int)prog_v) == 0ull) break;
+#if defined(NPORE_X_POLLSLEEP)
+                    __builtin_amdgcn_s_sleep(NPORE_X_POLLSLEEP);
+#endif
                 }
                 NPORE_OBSERVE_FENCE();
             }
