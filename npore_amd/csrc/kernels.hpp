@@ -31,6 +31,7 @@
 
 #include "cell.hpp"
 #include "layout.hpp"
+#include "pad_hooks.hpp"
 
 namespace npore {
 
@@ -686,32 +687,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
                 in.topM = in.topI = in.leftM = in.leftD = in.diagM = 0.0f;
                 in.topIrun = in.leftDrun = in.diagMrun = 0;
             }
-#if defined(NPORE_PAD_VALU)
-            {
-                uint32_t pa = tcol4, pb = tcol4;
-#pragma unroll
-                for (int k = 0; k < NPORE_PAD_VALU / 2; k++) {
-                    asm volatile("v_add_u32 %0, %0, 1" : "+v"(pa));
-                    asm volatile("v_add_u32 %0, %0, 1" : "+v"(pb));
-                }
-            }
-#endif
-#if defined(NPORE_PAD_SALU)
-            {
-                uint32_t pa = 1u, pb = 2u, pc = 3u, pd = 4u;
-#pragma unroll
-                for (int k = 0; k < NPORE_PAD_SALU / 4; k++) {
-                    asm volatile("s_add_u32 %0, %0, 1" : "+s"(pa) : : "scc");
-                    asm volatile("s_add_u32 %0, %0, 1" : "+s"(pb) : : "scc");
-                    asm volatile("s_add_u32 %0, %0, 1" : "+s"(pc) : : "scc");
-                    asm volatile("s_add_u32 %0, %0, 1" : "+s"(pd) : : "scc");
-                }
-            }
-#endif
-#if defined(NPORE_PAD_NOP)
-#pragma unroll
-            for (int k = 0; k < NPORE_PAD_NOP; k++) asm volatile("s_nop 0");
-#endif
+            pad_hook(tcol4, env.n0_lanes);      // (nothing unless built with one of the NPORE_PAD_* experiment macros)
             in.c = tcol;
             in.seqw = seqw;
             in.refx = refx;

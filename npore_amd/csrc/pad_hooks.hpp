@@ -1,0 +1,87 @@
+// pad_hooks.hpp -- experiment hooks of the fill kernel's step (kernels.hpp): extra instructions of one kind per
+// anti-diagonal, to measure what an instruction of that kind costs the kernel (scripts/ab_fill.py over libraries built
+// with -DNPORE_PAD_VALU=16, -DNPORE_PAD_SALU=16, -DNPORE_PAD_NOP=16 or -DNPORE_PAD_OP=1...10;
+// DESIGN.md section 6 quotes the results).  Without those macros pad_hook() is empty.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace npore {
+
+__device__ __forceinline__ void pad_hook(uint32_t tcol4, unsigned long long lanes)
+{
+    (void)tcol4;
+    (void)lanes;
+#if defined(NPORE_PAD_VALU)
+    {
+        uint32_t pa = tcol4, pb = tcol4;
+#pragma unroll
+        for (int k = 0; k < NPORE_PAD_VALU / 2; k++) {
+            asm volatile("v_add_u32 %0, %0, 1" : "+v"(pa));
+            asm volatile("v_add_u32 %0, %0, 1" : "+v"(pb));
+        }
+    }
+#endif
+#if defined(NPORE_PAD_OP)
+    {
+        // what one more instruction of a given kind costs (16 of them, two independent chains)
+        uint32_t pa = tcol4, pb = tcol4 + 1u;
+        float fa = __uint_as_float(tcol4), fb = fa;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 qa = {fa, fb}, qb = {fb, fa};
+        unsigned long long msk = lanes;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+#if NPORE_PAD_OP == 1
+            asm volatile("v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(pa));
+            asm volatile("v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(pb));
+#elif NPORE_PAD_OP == 2
+            asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(pa) : "v"(pb), "s"(msk));
+            asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(pb) : "v"(pa), "s"(msk));
+#elif NPORE_PAD_OP == 3
+            asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(qa) : "v"(qb));
+            asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(qb) : "v"(qa));
+#elif NPORE_PAD_OP == 4
+            asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(pa) : "v"(pb));
+            asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(pb) : "v"(pa));
+#elif NPORE_PAD_OP == 5
+            asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(pa) : "v"(pb));
+            asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(pb) : "v"(pa));
+#elif NPORE_PAD_OP == 6
+            asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(pa));
+            asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(pb));
+#elif NPORE_PAD_OP == 7
+            asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(msk) : "v"(fa), "v"(fb));
+            asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(msk) : "v"(fb), "v"(fa));
+#elif NPORE_PAD_OP == 8
+            asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(pa) : "v"(pb));
+            asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(pb) : "v"(pa));
+#elif NPORE_PAD_OP == 9
+            asm volatile("ds_bpermute_b32 %0, %1, %0\n\ts_waitcnt lgkmcnt(0)" : "+v"(pa) : "v"(tcol4));
+            asm volatile("v_add_u32 %0, %0, 1" : "+v"(pb));
+#elif NPORE_PAD_OP == 10
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(fa) : "v"(fb));
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(fb) : "v"(fa));
+#endif
+        }
+    }
+#endif
+#if defined(NPORE_PAD_SALU)
+    {
+        uint32_t pa = 1u, pb = 2u, pc = 3u, pd = 4u;
+#pragma unroll
+        for (int k = 0; k < NPORE_PAD_SALU / 4; k++) {
+            asm volatile("s_add_u32 %0, %0, 1" : "+s"(pa) : : "scc");
+            asm volatile("s_add_u32 %0, %0, 1" : "+s"(pb) : : "scc");
+            asm volatile("s_add_u32 %0, %0, 1" : "+s"(pc) : : "scc");
+            asm volatile("s_add_u32 %0, %0, 1" : "+s"(pd) : : "scc");
+        }
+    }
+#endif
+#if defined(NPORE_PAD_NOP)
+#pragma unroll
+    for (int k = 0; k < NPORE_PAD_NOP; k++) asm volatile("s_nop 0");
+#endif
+}
+
+}  // namespace npore
