@@ -569,19 +569,32 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
                 // its two neighbour waves have finished the previous one (they own the only columns it reads),
                 // i.e. once their progress words have reached this wave's own.  The neighbour released its
                 // history / exchange words before its progress word; the fence behind the loop acquires them.
-                for (;;) {
-                    // relaxed workgroup-scope atomics keep these plain LDS reads (a volatile access would
-                    // become a flat system-scope load with a vmcnt(0) wait)
-                    // (their addresses from a vector register: as wave-uniform values the compiler moves them there inside the loop)
-                    const int a = !IS_FIRST ? __hip_atomic_load(reinterpret_cast<lds_i32 *>(pnb_addr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
-                    const int b = !IS_LAST ? __hip_atomic_load(reinterpret_cast<lds_i32 *>(pnb_addr) + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
-                    // (every lane reads the same words; a vector compare + branch on vcc instead of readfirstlane + s_cmp.
-                    // No s_sleep between two looks: measured -1 % at r = 64 / 100, -2 % at r = 200 against s_sleep 1;
-                    // s_sleep 2 and 4 equal s_sleep 1)
-                    if (__builtin_amdgcn_ballot_w64((a < b ? a : b) < (int)prog_v) == 0ull) break;
+                // One neighbour at a time, the wave ABOVE first: the waves of a group finish an anti-diagonal in the
+                // order first ... last (the SIMD serves the older wave first), so that is the one a look usually
+                // fails for (87 % of the failed looks of a middle wave, measured), and a look at one word is one LDS
+                // read and one compare instead of two and two.
+                // (relaxed workgroup-scope atomics keep these plain LDS reads -- a volatile access would become a
+                // flat system-scope load with a vmcnt(0) wait; their address comes from a vector register -- as a
+                // wave-uniform value the compiler moves it there inside the loop; every lane reads the same word:
+                // a vector compare + branch on vcc instead of readfirstlane + s_cmp.  No s_sleep between two looks:
+                // measured -1 % at r = 64 / 100, -2 % at r = 200 against s_sleep 1; s_sleep 2 and 4 equal s_sleep 1.)
+                if constexpr (!IS_LAST) {
+                    for (;;) {
+                        const int b = __hip_atomic_load(reinterpret_cast<lds_i32 *>(pnb_addr) + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (__builtin_amdgcn_ballot_w64(b < (int)prog_v) == 0ull) break;
 #if defined(NPORE_X_POLLSLEEP)
-                    __builtin_amdgcn_s_sleep(NPORE_X_POLLSLEEP);
+                        __builtin_amdgcn_s_sleep(NPORE_X_POLLSLEEP);
 #endif
+                    }
+                }
+                if constexpr (!IS_FIRST) {
+                    for (;;) {
+                        const int a = __hip_atomic_load(reinterpret_cast<lds_i32 *>(pnb_addr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (__builtin_amdgcn_ballot_w64(a < (int)prog_v) == 0ull) break;
+#if defined(NPORE_X_POLLSLEEP)
+                        __builtin_amdgcn_s_sleep(NPORE_X_POLLSLEEP);
+#endif
+                    }
                 }
                 NPORE_OBSERVE_FENCE();
             }
