@@ -332,7 +332,8 @@ NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, 
     // thirds of them nothing else: the tests are ordered for that)
     {
         const auto tab = env.step_tables(st);
-        if (env.any(sm != 0u)) {
+        // (a middle wave -- 64 band-interior columns -- has one practically always: no test)
+        if ((FAST && MID) || env.any(sm != 0u)) {
             NPORE_COUNT(2);
             // the column's two highest periods come pre-decoded with the reference words
             // (evaluation order = the reference's: higher period first)

@@ -286,6 +286,10 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
 {
     constexpr int NSR = ring_rows(NW);
     constexpr int WPT = NW * 64;          // physical columns per chunk
+    // reference-L window (LDS, kept by the chunk's last wave): refilled WIN_STEP positions at a time once the band
+    // comes within WIN_SLACK of its end.  Several waves: a whole wave's worth, and enough slack for the waves that
+    // run behind the last one.  One wave: it refills for itself, so little of both does (host: fill_geometry)
+    constexpr int WIN_STEP = NW == 1 ? 32 : 64, WIN_SLACK = NW == 1 ? 8 : 32;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *lds_np = lds;
     float *lds_sub = lds + MAX_PERIOD * NP_LT * NP_CT;
@@ -476,12 +480,12 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
             }
         }
         // reference-L window: positions [0, wfill) are resident (modulo rwin)
-        while (r + 32 >= wfill) {
-            if (cw == NW - 1) {
+        while (r + WIN_SLACK >= wfill) {
+            if (cw == NW - 1 && lane < WIN_STEP) {
                 const int j = wfill + lane;
                 win[j & env.wmask] = (j <= d.dcols) ? refl_g[j] : make_uint2(0u, 0u);
             }
-            wfill += 64;
+            wfill += WIN_STEP;
         }
         if constexpr (NW > 1) {
             if (cw == NW - 1) {
@@ -678,12 +682,12 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
                     nc1 = lane_next_or(x5, rc1);
                 }
                 st.del_l++;
-                if (st.del_l + r + 32 >= wfill) {   // keep the L window ahead of the band (32 positions of slack)
+                if (st.del_l + r + WIN_SLACK >= wfill) {   // keep the L window ahead of the band
                     if constexpr (IS_LAST) {
                         const int j = wfill + lane;
-                        win[j & env.wmask] = (j <= d.dcols) ? refl_g[j] : make_uint2(0u, 0u);
+                        if (WIN_STEP == 64 || lane < WIN_STEP) win[j & env.wmask] = (j <= d.dcols) ? refl_g[j] : make_uint2(0u, 0u);
                     }
-                    wfill += 64;
+                    wfill += WIN_STEP;
                 }
                 in.leftM = matv; in.leftD = delv; in.leftDrun = (int)(R2 >> 16);
                 in.topM = nm;

@@ -205,7 +205,10 @@ bool fill_geometry(int r, FillGeom &g)
     // reference-L window: the band (2r+1), 96 positions of read-ahead and the 6 positions below the band that the
     // generic SHR path looks back on -- plus 16 of margin, because the first wave of a chunk may run NW - 2
     // anti-diagonals behind the last one, which refills the window
-    g.rwin = pow2_at_least(2 * r + 101 + 16);
+    // (a chunk of ONE wave refills for itself, 32 positions at a time with 8 of slack: kernels.hpp WIN_STEP / WIN_SLACK;
+    // r <= 31 then needs 2r + 6 + 8 + 32 <= 128 entries, which leaves the CU 16 KB of LDS at r = 30 -- room for the
+    // kernels of the neighbouring batches beside 16 chunks)
+    g.rwin = g.nw == 1 ? pow2_at_least(2 * r + 6 + 8 + 32) : pow2_at_least(2 * r + 101 + 16);
     const size_t lds_cap = 160 * 1024 / sizeof(float);
     if (fill_lds_floats(g.nw, 1, g.hw, g.rwin) > lds_cap) return false;
     g.cmax = 1;
