@@ -160,6 +160,8 @@ NPORE_HD int div_recip(int run, uint32_t m)
 //   int   mer_shift(Tab, uint32_t n4)       32 - 3n (0 for n = 0)
 //   uint32_t mer_mask(Tab, uint32_t n4)     (1 << 3n) - 1
 //   static constexpr bool LEN_ARITH         how the LEN filter forms its n-mer shift (see there)
+//   static constexpr bool MIN3, float min3(a, b, c)   MAT by 3-way minima on the plain path (see there); min3 returns
+//                                           one of its operands
 //   bool  any(bool), any2(bool a, bool b)   wave-level "any lane" of x / of a && b (identity on the host)
 // Lanes without a candidate call these with n4 = 0 (or, in the LEN filter, 4*33) and ignore the result.
 // The table lookups are cross-lane reads on the device: call them where all lanes are active
@@ -426,18 +428,32 @@ NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, 
     float v = diag_ok ? vdiag : delv + 100.0f;     // else-branch: "ensure val1 isn't chosen"
     const uint32_t tr_diag = (uint32_t)T_MAT | ((uint32_t)(in.diagMrun + 1) << 3);      // typ | run<<3
     uint32_t tr = diag_ok ? tr_diag : (uint32_t)T_MAT;
-    const bool t1 = insv < v;
-    v = t1 ? insv : v;
-    tr = t1 ? ((uint32_t)T_INS | ((uint32_t)insrun << 3)) : tr;
-    const bool t2 = lenv < v;
-    v = t2 ? lenv : v;
-    tr = t2 ? ((uint32_t)T_LEN | ((uint32_t)lenrun << 3)) : tr;
-    const bool t3 = delv < v;
-    v = t3 ? delv : v;
-    tr = t3 ? ((uint32_t)T_DEL | ((uint32_t)delrun << 3)) : tr;
-    const bool t4 = shrv < v;
-    v = t4 ? shrv : v;
-    tr = t4 ? ((uint32_t)T_SHR | ((uint32_t)shrrun << 3)) : tr;
+    bool t1 = false, t2 = false, t3 = false, t4 = false;
+    if constexpr (FAST && Env::MIN3) {
+        // The chain of strict '<' below picks the FIRST candidate, in the order MAT, INS, LEN, DEL, SHR, that attains
+        // the minimum.  The same from two 3-way minima (which return one of their operands bit for bit: no NaNs
+        // here, denormals are kept) and one equality test per candidate, applied last to first -- 2 selects fewer
+        const float vmin = env.min3(env.min3(vdiag, insv, lenv), delv, shrv);
+        tr = (uint32_t)T_SHR | ((uint32_t)shrrun << 3);
+        tr = (delv == vmin) ? ((uint32_t)T_DEL | ((uint32_t)delrun << 3)) : tr;
+        tr = (lenv == vmin) ? ((uint32_t)T_LEN | ((uint32_t)lenrun << 3)) : tr;
+        tr = (insv == vmin) ? ((uint32_t)T_INS | ((uint32_t)insrun << 3)) : tr;
+        tr = (vdiag == vmin) ? tr_diag : tr;
+        v = vmin;
+    } else {
+        t1 = insv < v;
+        v = t1 ? insv : v;
+        tr = t1 ? ((uint32_t)T_INS | ((uint32_t)insrun << 3)) : tr;
+        t2 = lenv < v;
+        v = t2 ? lenv : v;
+        tr = t2 ? ((uint32_t)T_LEN | ((uint32_t)lenrun << 3)) : tr;
+        t3 = delv < v;
+        v = t3 ? delv : v;
+        tr = t3 ? ((uint32_t)T_DEL | ((uint32_t)delrun << 3)) : tr;
+        t4 = shrv < v;
+        v = t4 ? shrv : v;
+        tr = t4 ? ((uint32_t)T_SHR | ((uint32_t)shrrun << 3)) : tr;
+    }
     // "no INDEL state won": every other candidate carries a non-zero TYP, so the word itself says so (one vector
     // compare; or-ing the four compare masks costs three scalar instructions, which are the dearer ones here)
     static_assert(T_MAT == 0, "tr == tr_diag <=> MAT.TYP == MAT");

@@ -130,6 +130,13 @@ struct DevEnv {
     __device__ __forceinline__ void count(int k) const { if ((threadIdx.x & 63) == 0) atomicAdd(&g_npore_stats[k], 1ull); }
 #endif
     static constexpr bool LEN_ARITH = NSR != 6;   // several waves per chunk (ring_rows): cell.hpp, LEN filter
+    static constexpr bool MIN3 = NSR != 6;      // (chunks of several waves: -0.5 % fill at r = 64 ... 200; a lone wave: +0.5 %)
+    __device__ __forceinline__ float min3(float a, float b, float c) const
+    {
+        float r;      // (the instruction itself: fminf would first canonicalise its operands, one v_max each)
+        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+        return r;
+    }
     const char *lds_sub;      // [ref 8][seq 8][4] copy of sub_scores (layout.hpp SUBT_*)
     const char *lds_np;       // [6][NP_LT][NP_CT] floats (layout.hpp)
     const float *g_np;        // full table in global memory

@@ -29,6 +29,8 @@ struct ModelEnv {
     int W, slot;   // slot of the current row; row b-n is (slot - n) mod NS
     int refl_n;    // entries in refl_p / refw_p
     static constexpr bool LEN_ARITH = true;
+    static constexpr bool MIN3 = true;      // (the model takes the kernel's route)
+    float min3(float a, float b, float c) const { const float m = b < a ? b : a; return c < m ? c : m; }
     struct Tab { uint32_t hist6; };
     Tab step_tables(const StepInfo &st) const { return Tab{st.hist6}; }
     float sub(uint32_t seqw, uint32_t refx) const
