@@ -496,6 +496,40 @@ def test_long_polymers_and_many_periods(ctx, tables):
             assert got[k] == want and st[k] == wst, (r, k)
 
 
+@pytest.mark.parametrize("r", [3, 12, 30, 31])
+def test_narrow_band_window_over_long_deletions(ctx, tables, r):
+    """Chunks of ONE wave keep a 128-entry reference-L window that is refilled 32 positions at a time
+    (kernels.hpp WIN_STEP / WIN_SLACK): input paths with deletions of several hundred bases -- the band runs along
+    the reference for many windows without a read step -- through repeat-rich sequence, so that LEN / generic SHR
+    passes read the window all the way (including n-polymers that straddle a refill), against the oracle."""
+    sub, nps = tables
+    rng = np.random.default_rng(40 + r)
+    A, C, G, T = 1, 2, 3, 4
+    units = [[A] * 9, [A, C] * 6, [A, C, G] * 5, [T] * 40, [C, A] * 20, [G, G, T] * 11]
+    refs, seqs, cigs = [], [], []
+    for k in range(10):
+        ref, seq, cig = [], [], []
+        for piece in range(8):
+            flank = [int(x) for x in rng.integers(1, 5, int(rng.integers(3, 40)))]
+            ref += flank; seq += flank; cig += ["="] * len(flank)
+            u = units[int(rng.integers(len(units)))]
+            ref += u; seq += u[:len(u) - (piece % 3)]; cig += ["="] * (len(u) - piece % 3) + ["D"] * (piece % 3)
+            if piece % 2 == 0:                      # a long deletion made of repeats and random bases
+                gap = []
+                while len(gap) < int(rng.integers(150, 700)):
+                    gap += units[int(rng.integers(len(units)))] if rng.random() < 0.5 else [int(x) for x in rng.integers(1, 5, 17)]
+                ref += gap; cig += ["D"] * len(gap)
+            if piece == 5:                          # ... and a long insertion for the other direction
+                ins = [int(x) for x in rng.integers(1, 5, 260)]
+                seq += ins; cig += ["I"] * len(ins)
+        refs.append(np.array(ref, np.uint8)); seqs.append(np.array(seq, np.uint8)); cigs.append("".join(cig))
+    for mbr in (20000, 333):
+        got, st = ctx.align_batch(refs, seqs, cigs, r=r, max_b_rows=mbr, return_status=True)
+        for k in range(len(refs)):
+            want, wst = oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=r, max_b_rows=mbr, return_status=True)
+            assert got[k] == want and st[k] == wst, (r, mbr, k)
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 def test_both_traceback_kernels(tables, mode):
     """The windowed traceback (small batches) and the row-per-hop one (large batches) record the same runs:
