@@ -16,6 +16,10 @@
 //                     The only per-cell HBM traffic is one 32-bit traceback word.
 //                     The launch is persistent: its groups of NW waves pull chunk
 //                     after chunk from a device-side queue.
+//                     What is the same for all lanes of a step (ring row, traceback row,
+//                     100*b, progress count, record addresses) is kept in VECTOR registers:
+//                     scalar instructions cost a wave about twice as much here, and the
+//                     kernel runs at the vector issue rate (DESIGN.md sections 4.1, 6).
 //   traceback_kernel  one wavefront per chunk: follows MAT.TYP/MAT.RUN words
 //                     (reference src/aln.pyx:670-742) through register windows of
 //                     the band strip around the path and records the path as
@@ -143,7 +147,7 @@ struct DevEnv {
     const uint8_t *win;       // LDS window of reference L bytes, 8 per position
     const char *hist_c;       // LDS: this lane's own band column in ring row 0
     const uint4 *refw_g;      // the chunk's reference words (rare re-reads)
-    int np_dim, clampv, slot, hw16, wmask, dcols;
+    int np_dim, clampv, hw16, wmask, dcols;
     // tables over n, spread over the lanes: lane l holds the entry of n = l & 7
     uint32_t t_n, t_recip, t_msh, t_mmask;
     // lane l: byte offset from "own column, ring row 0" to column c - dI of row b-n, n = l & 7 and
@@ -432,7 +436,6 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
         uint32_t *tb_g = p.tb + d.tb_off;
         env.refw_g = refw_g;
         env.dcols = d.dcols;
-        env.slot = 0;
 
         // per-cell state of the previous anti-diagonal
         float matv = 0.0f, insv = 0.0f, delv = 0.0f, LMv = 0.0f, TMv = 0.0f;
@@ -544,7 +547,9 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
         // One anti-diagonal.  MODE 0: first row of the chunk (no neighbours), 1: the input path
         // stepped 'I' (read words move one column up, "left" is the previous lane), 2: 'D'
         // (reference words move one column down, "top" is the next lane).  The whole body is
-        // instantiated per mode so that no register shuffling is needed where the modes meet.
+        // instantiated per mode: the neighbour fetch then needs no selects.  (The compiler still places 14 + 5
+        // register copies per step where the two bodies meet; ONE body with a short per-kind branch in front of a
+        // common cell update has 5 inherent copies and measured 2.6 % slower at r = 100 -- DESIGN.md section 6.)
         auto step = [&](auto mode_tag, auto role_tag, auto fast_tag) __attribute__((always_inline)) {
             constexpr int MODE = decltype(mode_tag)::value;
             // ROLE: 0 = only wave of the chunk, 1 = first, 2 = middle, 3 = last (compile-time so that the
