@@ -796,9 +796,29 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
 
         // anti-diagonals [b0, b1) of one step window
         auto span = [&](int b0, int b1, auto role_tag, auto fast_tag) __attribute__((always_inline)) {
-            for (int bl = b0; bl < b1; bl++) {
-                if ((stepmask >> (bl & 63)) & 1ull) step(std::integral_constant<int, 1>{}, role_tag, fast_tag);
-                else step(std::integral_constant<int, 2>{}, role_tag, fast_tag);
+            if constexpr (NW == 1) {
+                // A match of the input path is a 'D' step followed by an 'I' step: the two as ONE straight-line body
+                // (the register shuffle where step bodies meet then comes once per two steps).  Only where a chunk
+                // is one wave: measured -2.6 % fill at r = 30, +0.5 % at r = 100, +-0 at r = 64 / 200.
+                for (int bl = b0; bl < b1;) {
+                    const unsigned long long m = stepmask >> (bl & 63);
+                    if ((m & 3ull) == 2ull && bl + 1 < b1) {
+                        step(std::integral_constant<int, 2>{}, role_tag, fast_tag);
+                        step(std::integral_constant<int, 1>{}, role_tag, fast_tag);
+                        bl += 2;
+                    } else if (m & 1ull) {
+                        step(std::integral_constant<int, 1>{}, role_tag, fast_tag);
+                        bl++;
+                    } else {
+                        step(std::integral_constant<int, 2>{}, role_tag, fast_tag);
+                        bl++;
+                    }
+                }
+            } else {
+                for (int bl = b0; bl < b1; bl++) {
+                    if ((stepmask >> (bl & 63)) & 1ull) step(std::integral_constant<int, 1>{}, role_tag, fast_tag);
+                    else step(std::integral_constant<int, 2>{}, role_tag, fast_tag);
+                }
             }
         };
         auto run = [&](auto role_tag) __attribute__((always_inline)) {
