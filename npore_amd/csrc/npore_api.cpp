@@ -442,8 +442,10 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
         const int planes_in_lds = 7 * pstride <= 160 * 1024;
         const size_t alds = planes_in_lds ? 7 * pstride : pstride;
         if (beside_fill) {
-            // no LDS, 8 waves of ~30 VGPRs: fits beside the 16 waves of a fill workgroup
-            hipLaunchKernelGGL((annotate_kernel<false, false>), dim3((unsigned)(2 * max_chunks)), dim3(512), 0, s, pp);
+            // no LDS, waves of ~30 VGPRs: fits beside the 16 waves of a fill workgroup (two such waves per SIMD).  Four
+            // waves per workgroup: 8 000 reads at r = 30 184 k reads/s, with eight 180 k, sixteen 169 k, one 187 k (but C2
+            // 50.9 instead of 51.8 k)
+            hipLaunchKernelGGL((annotate_kernel<false, false>), dim3((unsigned)(2 * max_chunks)), dim3(256), 0, s, pp);
         } else if (planes_in_lds) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&annotate_kernel<true, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
