@@ -626,6 +626,11 @@ def test_fill_shape_and_annotation_only_context(tables):
     sh = c.fill_shape(100)
     assert sh["waves_per_chunk"] == 4 and sh["resident_chunks"] == c.round_chunks(100)
     assert c.fill_shape(30)["waves_per_chunk"] == 1
+    # single-wave chunks keep a 128-entry L window: 16 of them leave the CU the 4 KB the light kernels of the
+    # neighbouring batches need (npore_api.cpp launch_fill), and so do the 4 four-wave chunks of r = 100
+    for rr in (30, 100):
+        sh = c.fill_shape(rr)
+        assert sh["resident_waves_per_cu"] == 16 and sh["lds_bytes"] + 4096 <= 160 * 1024, (rr, sh)
     s = enc("ATATATATTTTTTAAAGCGCGC")
     assert np.array_equal(c.get_np_info(s), oracle.get_np_info(s))
     with pytest.raises(aln.NporeError, match="without penalty tables"):
