@@ -109,3 +109,27 @@ def test_other_table_shapes(tables):
                                  return_status=True)
             b, sb = model.align(ref, seq, cig, sub, t, max_b_rows=(20000, 64)[k % 2], r=r, max_n=max_n, max_l=max_l)
             assert a == b and sa == sb, (max_n, max_l, k)
+
+
+def test_ties_and_negative_scores(tables):
+    """Tables full of exact ties (every score the same; scores on a coarse grid, some negative): the MAT state picks
+    the FIRST candidate in the reference's order that attains the minimum -- cell.hpp does that on the plain path by
+    minima and equality tests (Env::MIN3), the oracle by the reference's chain of strict '<'."""
+    sub0, nps0 = tables
+    rng = np.random.default_rng(21)
+    variants = []
+    eq_sub, eq_nps = sub0.copy(), nps0.copy()
+    eq_sub[:] = 1.0; eq_nps[:] = 1.0
+    variants.append((eq_sub, eq_nps))
+    g_sub = (rng.integers(0, 24, (5, 5)) / 4.0).astype(np.float32); g_sub[0, :] = 0; g_sub[:, 0] = 0
+    g_nps = (rng.integers(-2, 40, nps0.shape) / 4.0).astype(np.float32); g_nps[:, :3, :] = 20.0
+    variants.append((g_sub, g_nps))
+    for sub, nps in variants:
+        for k in range(60):
+            ref, seq, cig = synth.make_pair(91, k, int(rng.integers(5, 500)), float(rng.choice([0.05, 0.2, 0.4])),
+                                            float(rng.choice([0.3, 0.9])))
+            r = int(rng.choice([2, 5, 12, 30, 70]))
+            ist, iex = float(rng.integers(1, 4)), float(rng.integers(0, 2))
+            a, sa = oracle.align(ref, seq, cig, sub, nps, indel_start=ist, indel_extend=iex, r=r, return_status=True)
+            b, sb = model.align(ref, seq, cig, sub, nps, indel_start=ist, indel_extend=iex, r=r)
+            assert a == b and sa == sb, (k, r)
