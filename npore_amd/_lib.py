@@ -11,7 +11,7 @@ import subprocess
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# NPORE_AMD_LIB selects another build of the same ABI (tests/tools/ab_sync.py: the -DNPORE_RELAXED_SYNC build)
+# NPORE_AMD_LIB selects another build of the same ABI (measurement builds: tests/tools/ab_sync.py, scripts/ab_fill.py)
 LIB_PATH = os.environ.get("NPORE_AMD_LIB") or os.path.join(_HERE, "libnpore_amd.so")
 RELAXED_LIB_PATH = os.path.join(_HERE, "libnpore_amd_relaxed.so")
 CSRC = os.path.join(_HERE, "csrc")
@@ -81,15 +81,21 @@ def sources():
         [os.path.join(_HERE, "..", "include", "npore_amd.h")]
 
 
-def build(force=False, verbose=False, relaxed=False):
-    """hipcc --offload-arch=gfx950 -> npore_amd/libnpore_amd.so (in-tree).  relaxed=True builds
-    libnpore_amd_relaxed.so instead: the same sources with -DNPORE_RELAXED_SYNC (kernels.hpp: compiler barriers in
-    place of the workgroup release / acquire fences of the fill kernel's hand-shakes), for tests/tools/ab_sync.py."""
-    out = RELAXED_LIB_PATH if relaxed else os.path.join(_HERE, "libnpore_amd.so")
+def build(force=False, verbose=False, relaxed=False, defines=(), out=None):
+    """hipcc --offload-arch=gfx950 -> npore_amd/libnpore_amd.so (in-tree): the product library.
+    Measurement builds (never made by __graft_entry__.build()): `defines` = experiment macros of csrc/experiments.hpp
+    (compiled with -DNPORE_EXPERIMENTS, `out` = where to put the library); relaxed=True is shorthand for
+    libnpore_amd_relaxed.so with -DNPORE_RELAXED_SYNC (tests/tools/ab_sync.py)."""
+    if relaxed:
+        defines, out = tuple(defines) + ("NPORE_RELAXED_SYNC",), out or RELAXED_LIB_PATH
+    if defines and not out:
+        raise ValueError("a measurement build needs its own output path")
+    out = out or os.path.join(_HERE, "libnpore_amd.so")
     if not force and os.path.exists(out) and all(os.path.getmtime(s) <= os.path.getmtime(out) for s in sources()):
         return out
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-Wall", "-Wno-unused-function"] + (["-DNPORE_RELAXED_SYNC"] if relaxed else []) + \
+           "-Wall", "-Wno-unused-function"] + \
+          (["-DNPORE_EXPERIMENTS"] + ["-D" + d for d in defines] if defines else []) + \
           ["-o", out, os.path.join(CSRC, "npore_api.cpp"), "-lz"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -589,7 +589,9 @@ def calc_confusion_matrices(range_tuple, pileups=None, refs=None, np_info=None, 
         np_info = aln.get_np_info(bases_to_int(contig[start:end + 1]))
     np_info = np.ascontiguousarray(np_info, dtype=np.int32)
     codes = np.ascontiguousarray(bases_to_int(contig[start:end]), dtype=np.uint8)
-    text = contig[start:].upper().encode()
+    # (the character loop only looks at ref_text[pos+1 .. pos+1+max_n) of the range's positions; Python's slice clipping
+    # at the contig end is what the reference's contig[...] slices do there)
+    text = contig[start:end + max_n + 1].upper().encode()
     off = np.zeros(len(lines) + 1, np.int64)
     np.cumsum([len(x) for x in lines], out=off[1:])
     buf = b"".join(lines) + b"\0"
@@ -610,25 +612,43 @@ def calc_confusion_matrices(range_tuple, pileups=None, refs=None, np_info=None, 
 
 def get_confusion_matrices():
     """Reference src/bam.pyx:166-200: the cached count matrices of --stats_dir, or (--recalc_cms) counted from the
-    BAM range by range (cfg.args.regions cut into --chunk_width pieces), summed and cached there."""
-    d = cfg.args.stats_dir or os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "guppy5_stats")
+    BAM range by range (cfg.args.regions cut into --chunk_width pieces), summed and cached there.
+    Loading defaults to the shipped guppy5_stats; a recount is written to --stats_dir (default ./stats, like the
+    reference) and NEVER into the package's data directory.  Several processes (torch.distributed.run): rank 0
+    recounts and writes (temp file + rename), the others wait at a barrier and load."""
+    shipped = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "guppy5_stats")
     names = ("subs", "nps", "inss", "dels")
     if not getattr(cfg.args, "recalc_cms", False):
+        d = cfg.args.stats_dir or shipped
         print("> loading confusion matrices")
         return tuple(np.load(os.path.join(d, f"{k}_cm.npy")) for k in names)
-    print("> calculating confusion matrices")
-    from .bed import get_ranges
-    ranges = get_ranges(cfg.args.regions, cfg.args.chunk_width)
+    d = cfg.args.stats_dir or "./stats"
+    if os.path.realpath(d) == os.path.realpath(shipped):
+        print("\nERROR: --recalc_cms would overwrite the shipped guppy5_stats tables; give another --stats_dir.")
+        sys.exit(1)
+    from . import dist as dist_mod
+    rank, world_size, barrier = dist_mod.barrier_file_ranks()
     total = None
-    for k, rg in enumerate(ranges):
-        res = calc_confusion_matrices(rg)
-        total = res if total is None else tuple(a + b for a, b in zip(total, res))
-        print(f"\r    {k + 1} of {len(ranges)} chunks processed.", end="", flush=True)
-    print(" ")
+    if rank == 0:
+        print("> calculating confusion matrices")
+        from .bed import get_ranges
+        ranges = get_ranges(cfg.args.regions, cfg.args.chunk_width)
+        for k, rg in enumerate(ranges):
+            res = calc_confusion_matrices(rg)
+            total = res if total is None else tuple(a + b for a, b in zip(total, res))
+            print(f"\r    {k + 1} of {len(ranges)} chunks processed.", end="", flush=True)
+        print(" ")
+        if total is None:
+            total = calc_confusion_matrices(("", 0, 0), pileups=[], refs={"": ""},
+                                            np_info=np.zeros((0, 2, int(cfg.args.max_n)), np.int32))
+        os.makedirs(d, exist_ok=True)
+        for k, m in zip(names, total):
+            tmp = os.path.join(d, f".{k}_cm.{os.getpid()}.tmp.npy")
+            np.save(tmp, m)
+            os.replace(tmp, os.path.join(d, f"{k}_cm.npy"))
+    barrier()
     if total is None:
-        total = calc_confusion_matrices(("", 0, 0), pileups=[], refs={"": ""}, np_info=np.zeros((0, 2, int(cfg.args.max_n)), np.int32))
-    for k, m in zip(names, total):
-        np.save(os.path.join(d, f"{k}_cm"), m)
+        total = tuple(np.load(os.path.join(d, f"{k}_cm.npy")) for k in names)
     if getattr(cfg.args, "recalc_exit", False):
         sys.exit(0)
     return total

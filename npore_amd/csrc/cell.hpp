@@ -43,11 +43,15 @@
 
 namespace npore {
 
-#if defined(NPORE_STATS) && defined(__HIP_DEVICE_COMPILE__)
-#define NPORE_COUNT(k) env.count(k)
+}  // namespace npore
+// measurement builds only (scripts/ab_fill.py, step_stats.py): ablation switches, instruction pads, path counters
+#if defined(NPORE_EXPERIMENTS)
+#include "experiments.hpp"
 #else
 #define NPORE_COUNT(k) ((void)0)
+namespace npore { namespace xp { constexpr bool NOLEN = false, NOSHR = false, NOPOLL = false, CHUNKMAJOR = false; constexpr int POLLSLEEP = 0; } }
 #endif
+namespace npore {
 
 // Wave-uniform quantities of one anti-diagonal (b-row) of one chunk.
 struct StepInfo {
@@ -315,14 +319,9 @@ NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, 
                           (FAST || ((i >= 0) && (j >= 0) && (i <= st.drows) && (j <= st.dcols)));
     const uint32_t imask = interior ? 0xFFFFFFFFu : 0u;    // loop-invariant in the plain case
     uint32_t lm = ((in.refx & in.seqw & imask) >> FLAG_SHIFT) & 63u;
-#if defined(NPORE_X_NOLEN)
-    lm = 0u;
-#endif
-#if defined(NPORE_X_NOSHR)
-    const uint32_t sm = 0u;
-#else
-    const uint32_t sm = in.sc0 & imask & (DSC_N4 | DSC_HAS2 | DSC_RARE);
-#endif   // period of the column's first SHR candidate + summary bits
+    if constexpr (xp::NOLEN) lm = 0u;
+    // period of the column's first SHR candidate + summary bits
+    const uint32_t sm = xp::NOSHR ? 0u : in.sc0 & imask & (DSC_N4 | DSC_HAS2 | DSC_RARE);
 
     // ---- LEN / SHR candidates (pull form of src/aln.pyx:601-633, 642-667)
     // SHR of a cell comes from X = (i, j-n) at band column c - dI; LEN from
@@ -343,10 +342,6 @@ NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, 
             if (!env.any(sm > DSC_N4)) {
                 // no column of the wave has a second candidate or needs the generic path
                 NPORE_COUNT(3);
-#if defined(NPORE_STATS)
-                if (!env.any(act && (sm & DSC_N4) != 4u)) NPORE_COUNT(7);
-                if (!env.any(act && (sm & DSC_N4) > 8u)) NPORE_COUNT(8);
-#endif
                 shr_small<FAST, false>(env, tab, in, j, act, false, shrv, shrrun, shrstart);
             } else if (!env.any(sm >= DSC_RARE)) {
                 // (both in one block: the second candidate's history / table reads are independent of the first's

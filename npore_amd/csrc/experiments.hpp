@@ -1,12 +1,55 @@
-// pad_hooks.hpp -- experiment hooks of the fill kernel's step (kernels.hpp): extra instructions of one kind per
-// anti-diagonal, to measure what an instruction of that kind costs the kernel (scripts/ab_fill.py over libraries built
-// with -DNPORE_PAD_VALU=16, -DNPORE_PAD_SALU=16, -DNPORE_PAD_NOP=16 or -DNPORE_PAD_OP=1...10;
-// DESIGN.md section 6 quotes the results).  Without those macros pad_hook() is empty.
+// experiments.hpp -- measurement instruments of the fill kernel.  NOT part of the product build: kernels.hpp /
+// cell.hpp include this file only under -DNPORE_EXPERIMENTS (scripts/ab_fill.py, scripts/step_stats.py,
+// tests/tools/ab_sync.py build such libraries); the default library never sees it.
+//   -DNPORE_PAD_VALU=16 / NPORE_PAD_SALU=16 / NPORE_PAD_NOP=16 / NPORE_PAD_OP=1...10   extra instructions of one kind per
+//                      anti-diagonal: what an instruction of that kind costs the kernel (LABNOTES.md)
+//   -DNPORE_X_NOLEN / NPORE_X_NOSHR / NPORE_X_NOPOLL / NPORE_X_CHUNKMAJOR / NPORE_X_POLLSLEEP=k   ablations (wrong
+//                      strings, timing only) and placement / poll variants
+//   -DNPORE_STATS      per-path counters of the cell update (npore_debug_stats)
+//   -DNPORE_RELAXED_SYNC   compiler barriers instead of the workgroup release / acquire fences of the hand-shakes
 #pragma once
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
+#if defined(NPORE_STATS) && defined(__HIP_DEVICE_COMPILE__)
+#define NPORE_COUNT(k) env.count(k)
+#else
+#define NPORE_COUNT(k) ((void)0)
+#endif
+
 namespace npore {
+
+namespace xp {
+#if defined(NPORE_X_NOLEN)
+constexpr bool NOLEN = true;
+#else
+constexpr bool NOLEN = false;
+#endif
+#if defined(NPORE_X_NOSHR)
+constexpr bool NOSHR = true;
+#else
+constexpr bool NOSHR = false;
+#endif
+#if defined(NPORE_X_NOPOLL)
+constexpr bool NOPOLL = true;
+#else
+constexpr bool NOPOLL = false;
+#endif
+#if defined(NPORE_X_CHUNKMAJOR)
+constexpr bool CHUNKMAJOR = true;
+#else
+constexpr bool CHUNKMAJOR = false;
+#endif
+#if defined(NPORE_X_POLLSLEEP)
+constexpr int POLLSLEEP = NPORE_X_POLLSLEEP;
+#else
+constexpr int POLLSLEEP = 0;
+#endif
+}  // namespace xp
+
+#if defined(__HIPCC__)
 
 __device__ __forceinline__ void pad_hook(uint32_t tcol4, unsigned long long lanes)
 {
@@ -83,5 +126,7 @@ __device__ __forceinline__ void pad_hook(uint32_t tcol4, unsigned long long lane
     for (int k = 0; k < NPORE_PAD_NOP; k++) asm volatile("s_nop 0");
 #endif
 }
+
+#endif  // __HIPCC__
 
 }  // namespace npore

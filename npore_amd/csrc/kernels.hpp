@@ -35,7 +35,6 @@
 
 #include "cell.hpp"
 #include "layout.hpp"
-#include "pad_hooks.hpp"
 
 namespace npore {
 
@@ -124,13 +123,16 @@ typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 constexpr uint32_t LDS_NP_BASE = 0u;                                      // [6][NP_LT][NP_CT] floats
 constexpr uint32_t LDS_SUB_BASE = MAX_PERIOD * NP_LT * NP_CT * 4u;        // then the substitution table
 
-#if defined(NPORE_STATS)
+#if defined(NPORE_EXPERIMENTS) && defined(NPORE_STATS)
 __device__ unsigned long long g_npore_stats[16];
+#endif
+#if !defined(NPORE_EXPERIMENTS)
+__device__ __forceinline__ void pad_hook(uint32_t, unsigned long long) {}      // (experiments.hpp in measurement builds)
 #endif
 
 template <int NSR>
 struct DevEnv {
-#if defined(NPORE_STATS)
+#if defined(NPORE_EXPERIMENTS) && defined(NPORE_STATS)
     __device__ __forceinline__ void count(int k) const { if ((threadIdx.x & 63) == 0) atomicAdd(&g_npore_stats[k], 1ull); }
 #endif
     static constexpr bool LEN_ARITH = NSR != 6;   // several waves per chunk (ring_rows): cell.hpp, LEN filter
@@ -270,11 +272,11 @@ __device__ __forceinline__ bool reached(int word, int target) { return word >= t
 
 // Ordering of the LDS hand-shakes between the waves of a group (progress words, slot ring, window-ready word): a
 // workgroup-scope release fence before every publishing store, an acquire fence behind every polling load.
-// -DNPORE_RELAXED_SYNC builds the shortcut of round 1 instead -- rely on the hardware serving the LDS requests
+// -DNPORE_EXPERIMENTS -DNPORE_RELAXED_SYNC builds the shortcut of round 1 instead -- rely on the hardware serving the LDS requests
 // of a wave in order, and only stop the COMPILER from reordering (an empty asm with a memory clobber).  Both were
 // run over the same 40 000 fuzz reads against the oracle (tests/tools/ab_sync.py: equal) and timed: the fences
 // cost nothing measurable (C2 fill 22.31 vs 22.27 ms), so they are the default.
-#if defined(NPORE_RELAXED_SYNC)
+#if defined(NPORE_EXPERIMENTS) && defined(NPORE_RELAXED_SYNC)
 #define NPORE_PUBLISH_FENCE() asm volatile("" ::: "memory")
 #define NPORE_OBSERVE_FENCE() asm volatile("" ::: "memory")
 #else
@@ -312,12 +314,8 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
     // waves -- r=100: 9 live columns of 64 -- on one SIMD: 15 % slower; spreading each chunk over the four
     // SIMDs with mixed roles: 12 % slower, the critical wave then competes with three busy strangers.)
     const int cpg = (int)(blockDim.x >> 6) / NW;   // chunks (groups) per workgroup
-#if defined(NPORE_X_CHUNKMAJOR)
-    const int cw = wave % NW, cg = wave / NW;
-#else
-    const int cw = wave / cpg;            // wave within the group
-    const int cg = wave % cpg;            // group within the workgroup
-#endif
+    const int cw = xp::CHUNKMAJOR ? wave % NW : wave / cpg;            // wave within the group
+    const int cg = xp::CHUNKMAJOR ? wave / NW : wave % cpg;            // group within the workgroup
     // The middle waves of a chunk (all 64 lanes live, a neighbour wave on either side) are issued first when
     // several waves of the SIMD are ready: measured 1.5-2 % on the fill at NW = 3...7 (r = 70, 100, 140, 200)
     if (NW > 2 && cw != 0 && cw != NW - 1) __builtin_amdgcn_s_setprio(1);
@@ -579,8 +577,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
             }
             st.init_f = e_v;
             e_v += 100.0f;
-#if !defined(NPORE_X_NOPOLL)
-            if constexpr (NW > 1 && MODE != 0) {
+            if constexpr (NW > 1 && MODE != 0 && !xp::NOPOLL) {
                 // Per-chunk hand-shake instead of a workgroup barrier: this wave may start an anti-diagonal once
                 // its two neighbour waves have finished the previous one (they own the only columns it reads),
                 // i.e. once their progress words have reached this wave's own.  The neighbour released its
@@ -598,23 +595,18 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
                     for (;;) {
                         const int b = __hip_atomic_load(reinterpret_cast<lds_i32 *>(pnb_addr) + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (__builtin_amdgcn_ballot_w64(b < (int)prog_v) == 0ull) break;
-#if defined(NPORE_X_POLLSLEEP)
-                        __builtin_amdgcn_s_sleep(NPORE_X_POLLSLEEP);
-#endif
+                        if constexpr (xp::POLLSLEEP > 0) __builtin_amdgcn_s_sleep(xp::POLLSLEEP);
                     }
                 }
                 if constexpr (!IS_FIRST) {
                     for (;;) {
                         const int a = __hip_atomic_load(reinterpret_cast<lds_i32 *>(pnb_addr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (__builtin_amdgcn_ballot_w64(a < (int)prog_v) == 0ull) break;
-#if defined(NPORE_X_POLLSLEEP)
-                        __builtin_amdgcn_s_sleep(NPORE_X_POLLSLEEP);
-#endif
+                        if constexpr (xp::POLLSLEEP > 0) __builtin_amdgcn_s_sleep(xp::POLLSLEEP);
                     }
                 }
                 NPORE_OBSERVE_FENCE();
             }
-#endif
             // boundary cells written by the neighbour waves at the end of the previous step: xoth = this group's
             // exchange records of the previous anti-diagonal's parity, counted from the record of the wave below
             CellIn in;
@@ -716,7 +708,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
                 in.topM = in.topI = in.leftM = in.leftD = in.diagM = 0.0f;
                 in.topIrun = in.leftDrun = in.diagMrun = 0;
             }
-            pad_hook(tcol4, env.n0_lanes);      // (nothing unless built with one of the NPORE_PAD_* experiment macros)
+            pad_hook(tcol4, env.n0_lanes);      // (empty in the product build: experiments.hpp)
             in.c = tcol;
             in.seqw = seqw;
             in.refx = refx;

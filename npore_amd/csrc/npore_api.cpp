@@ -653,7 +653,8 @@ int run_core(npore_ctx *ctx, const AlignArgs &a, const OutTarget &ot, hipStream_
         while (g1 < a.n_reads && g1 - g0 < max_group) {
             const int64_t cl = a.h_cig_off[g1 + 1] - a.h_cig_off[g1];
             // traceback words + the per-step / per-base side arrays (steps, inss, refw, refl, seqw, runs: < 48 B per op)
-            const int64_t need = (2 * cl + chunk_bound(cl, a.max_b_rows)) * tbs * 4 + 48 * cl;
+            // (+ 24 B per op: the annotation planes in global memory of a group prepared beside another one's fill)
+            const int64_t need = (2 * cl + chunk_bound(cl, a.max_b_rows)) * tbs * 4 + (ctx->coresident ? 72 : 48) * cl;
             if (g1 > g0 && acc + need > budget) break;
             acc += need;
             g1++;
@@ -676,13 +677,16 @@ int run_core(npore_ctx *ctx, const AlignArgs &a, const OutTarget &ot, hipStream_
         // and this group's gather will most likely run while the next one's fill is on the GPU)
         const bool beside = ctx->coresident && ctx->ws[ctx->next_ws ^ 1].busy;
         if (int rc = run_group(ctx, w, a, g0, g1, ot, shape, beside)) {
+            // drain what is in flight; a failure found there (an earlier group of this call, or of a previous
+            // sync = 0 call) is the older one and must not be lost: it stays deferred / is what the call returns
+            const std::string this_err = g_err;
+            const int older = quiesce(ctx);
             if (rc == NPORE_E_NOMEM && g1 - g0 > 1) {          // another context got there first: smaller groups
-                (void)quiesce(ctx);
+                if (older) { ctx->deferred_rc = older; ctx->deferred_err = g_err; }
                 max_group = (g1 - g0) / 2;
                 continue;
             }
-            (void)quiesce(ctx);
-            return rc;
+            return older ? older : fail(rc, this_err);
         }
         w->busy = true;
         w->cells = cells;
@@ -701,7 +705,7 @@ int run_core(npore_ctx *ctx, const AlignArgs &a, const OutTarget &ot, hipStream_
 extern "C" {
 
 int npore_abi_version(void) { return NPORE_ABI_VERSION; }
-#if defined(NPORE_STATS)
+#if defined(NPORE_EXPERIMENTS) && defined(NPORE_STATS)
 extern "C" int npore_debug_stats(unsigned long long *out, int reset)
 {
     unsigned long long z[16] = {0};

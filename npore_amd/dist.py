@@ -31,28 +31,45 @@ def reduce_counters(sums, maxes, device=None):
 
 
 def _append_file(out, src):
-    """Append the open file `src` to `out` inside the kernel (copy_file_range: no trip through user space, and a
-    reflink where the file system has them); plain reads and writes where that is not available."""
+    """Append the open file `src` at the current position of `out` (opened 'r+b' / 'wb', NOT in append mode:
+    copy_file_range refuses an O_APPEND destination with EBADF) inside the kernel -- no trip through user space,
+    and a reflink where the file system has them; plain reads and writes where that is not available."""
     size = os.fstat(src.fileno()).st_size
     done = 0
     if hasattr(os, "copy_file_range"):
         out.flush()
+        pos = out.tell()
         try:
             while done < size:
-                k = os.copy_file_range(src.fileno(), out.fileno(), min(size - done, 1 << 30))
+                k = os.copy_file_range(src.fileno(), out.fileno(), min(size - done, 1 << 30),
+                                       offset_src=done, offset_dst=pos + done)
                 if k <= 0:
                     break
                 done += k
         except OSError:
             pass
-        if done:
-            out.seek(0, os.SEEK_END)
+        out.seek(pos + done)
     src.seek(done)
     while True:
         buf = src.read(1 << 24)
         if not buf:
             break
         out.write(buf)
+
+
+def barrier_file_ranks():
+    """(rank, world, barrier) for host-only steps of a multi-process run: barrier() is a gloo barrier, created on
+    first use when torch.distributed is not initialised yet; a no-op in a single process."""
+    rank, world_size, _ = world()
+    if world_size == 1:
+        return rank, world_size, (lambda: None)
+
+    def barrier():
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            dist.init_process_group("gloo")
+        dist.barrier()
+    return rank, world_size, barrier
 
 
 def host_threads_per_rank():
@@ -78,8 +95,8 @@ def gather_parts(final_path, out_prefix, n_local):
     t = torch.tensor([float(n_local)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)        # also the barrier: every part is complete
     if rank == 0:
-        with open(final_path, "ab") as out:
-            out.flush()
+        with open(final_path, "r+b") as out:
+            out.seek(0, os.SEEK_END)
             for k in range(world_size):
                 part = f"{out_prefix}.part{k}.sam"
                 with open(part, "rb") as fh:

@@ -37,7 +37,8 @@ def argparser():
     parser.add_argument("--max_l", type=int, default=100, help="Maximum n-polymer repeat count considered.")
     parser.add_argument("--chunk_width", type=int, default=100000, help="(confusion-matrix recalculation only)")
     parser.add_argument("--stats_dir", default=None,
-                        help="Directory with subs/nps/inss/dels _cm.npy (default: the shipped guppy5_stats).")
+                        help="Directory with subs/nps/inss/dels _cm.npy (default: the shipped guppy5_stats; with --recalc_cms the "
+                             "recounted matrices are written here, default ./stats as in the reference).")
     parser.add_argument("--plot", action="store_true", help="(not supported in this build)")
     parser.add_argument("--recalc_cms", action="store_true",
                         help="Recount the confusion matrices from the BAM (needs `samtools mpileup`) instead of loading them.")
@@ -65,7 +66,8 @@ def main():
     bam_mod.get_bam_regions(bam, ref_seqs)
 
     if cfg.args.recalc_cms:              # src/realign.py:92-95 + src/bam.pyx:166-200
-        cfg.args.refs = ref_seqs
+        # (the pileup counter slices the contigs: the native reader only serves lengths, so take the sequences too)
+        cfg.args.refs = bam_mod.NativeFastaSeqs(cfg.args.ref) if native else ref_seqs
         subs, nps, inss, dels = bam_mod.get_confusion_matrices()
         print("> calculating score matrices")
         cfg.args.sub_scores, cfg.args.np_scores, cfg.args.ins_scores, cfg.args.del_scores = \

@@ -1,4 +1,4 @@
-"""Debug: how often each part of the cell update runs, per wave-step (library built with -DNPORE_STATS).
+"""Debug: how often each part of the cell update runs, per wave-step (library built with _lib.build(defines=("NPORE_STATS",), out=...): -DNPORE_EXPERIMENTS -DNPORE_STATS).
 usage: python scripts/step_stats.py build_exp/lib_stats.so [r:reads ...]"""
 import ctypes
 import os

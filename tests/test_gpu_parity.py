@@ -618,6 +618,53 @@ def test_calc_confusion_matrices_with_device_np_info():
         cfg.args = old
 
 
+def test_realign_cli_recalc_cms(tmp_path, monkeypatch):
+    """`realign --recalc_cms --recalc_exit` in the default native I/O mode (reference src/realign.py:81-95,
+    src/bam.pyx:166-200) with get_pileups stubbed (samtools is absent): the matrices land in --stats_dir -- never in the
+    package's data directory -- and equal calc_confusion_matrices on the same lines; without --stats_dir they go to
+    ./stats like the reference."""
+    import hashlib
+    from npore_amd import bam, cfg, realign
+    from npore_amd.bed import get_ranges
+    shipped = os.path.join(os.path.dirname(os.path.abspath(bam.__file__)), "data", "guppy5_stats")
+    digest = lambda: [hashlib.sha256(open(os.path.join(shipped, f), "rb").read()).hexdigest() for f in sorted(os.listdir(shipped))]
+    before = digest()
+    lines = {}
+
+    def fake_pileups(bam_path, ctg, start, end):
+        rng = np.random.default_rng(start + 7)
+        out = []
+        for _ in range(start, end):
+            out.append("".join(rng.choice(list(".,ACGT*"), size=int(rng.integers(0, 6)))) + ("+2AC." if rng.random() < .05 else "")
+                       + ("-1A," if rng.random() < .05 else ""))
+        lines[(ctg, start, end)] = out
+        return iter(out)
+
+    monkeypatch.setattr(bam, "get_pileups", fake_pileups)
+    monkeypatch.chdir(tmp_path)
+    old = cfg.args
+    try:
+        for extra, d in ((["--stats_dir", str(tmp_path / "st")], tmp_path / "st"), ([], tmp_path / "stats")):
+            cfg.args = realign.argparser().parse_args(
+                ["--bam", os.path.join(GOLDEN, "data", "reads.bam"), "--ref", os.path.join(GOLDEN, "data", "ref.fasta"),
+                 "--out_prefix", str(tmp_path / "o"), "--recalc_cms", "--recalc_exit", "--chunk_width", "20000"] + extra)
+            with pytest.raises(SystemExit) as ex:
+                realign.main()
+            assert ex.value.code == 0
+            got = [np.load(os.path.join(d, f"{k}_cm.npy")) for k in ("subs", "nps", "inss", "dels")]
+            refs = bam.NativeFastaSeqs(os.path.join(GOLDEN, "data", "ref.fasta"))
+            want = None
+            for rg in get_ranges(cfg.args.regions, cfg.args.chunk_width):
+                res = bam.calc_confusion_matrices(rg, pileups=lines[tuple(rg)], refs=refs)
+                want = res if want is None else tuple(a + b for a, b in zip(want, res))
+            assert want is not None and all(np.array_equal(a, b) for a, b in zip(got, want))
+            assert got[0].sum() > 0
+            assert not [f for f in os.listdir(d) if f.endswith(".tmp.npy")]
+    finally:
+        cfg.args = old
+    assert digest() == before
+
+
 def test_fill_shape_and_annotation_only_context(tables):
     """npore_fill_shape (launch geometry for reports) and a context without tables: get_np_info works,
     align is refused loudly."""

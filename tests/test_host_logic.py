@@ -485,3 +485,33 @@ def test_experiment_builds_still_compile(tmp_path):
            "-DNPORE_X_POLLSLEEP=1", "-c", "-o", str(tmp_path / "exp.o"), src]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_append_file_copy_file_range(tmp_path):
+    """dist._append_file appends inside the kernel (copy_file_range needs a destination that is NOT O_APPEND) and
+    leaves the position at the end, also through the read/write fallback."""
+    from npore_amd import dist
+    a, b, c = tmp_path / "a", tmp_path / "b", tmp_path / "c"
+    a.write_bytes(b"header\n")
+    b.write_bytes(b"x" * 100_000)
+    c.write_bytes(b"tail")
+    with open(a, "r+b") as out:
+        out.seek(0, os.SEEK_END)
+        calls = []
+        real = getattr(os, "copy_file_range", None)
+        if real is not None:
+            def spy(*args, **kw):
+                k = real(*args, **kw)
+                calls.append(k)
+                return k
+            os.copy_file_range = spy
+        try:
+            for part in (b, c):
+                with open(part, "rb") as fh:
+                    dist._append_file(out, fh)
+        finally:
+            if real is not None:
+                os.copy_file_range = real
+    assert a.read_bytes() == b"header\n" + b"x" * 100_000 + b"tail"
+    if real is not None:
+        assert sum(calls) == 100_004        # every byte went through the in-kernel copy
