@@ -19,7 +19,8 @@ Order of business (one JSON line on rank 0 at the end):
   3. W warm-up steps, then EXACTLY K timed steps, device-resident    -> value, ms_per_step, roofline
   4. the same batch through the host-buffer entry point (pinned host memory in and out) -> value_pcie_inclusive
   5. a sustained leg: device-resident steps for >= --sustain seconds -> sustained (the GPU is busy long enough
-     for an outside sampler to see it; not part of `value`)
+     for an outside sampler to see it; not part of `value`), and `production_default`: one second of the tool's
+     default band (r=30) on 4 000 reads, whole path pipelined -- the number a user of realign.py sees per GPU
   6. every CPU string compared with the GPU's.
 """
 import argparse
@@ -47,17 +48,22 @@ def pack(seqs):
     return buf, off
 
 
-def make_reads(synth, args, count, rank, world):
-    """Reads rank, rank + world, ... of the generator; spans of them on a forked pool when there are many."""
+def make_reads(synth, args, count, rank, world, ref_len=None, mixed=None, base_seed=None):
+    """Reads rank, rank + world, ... of the generator; spans of them on a pool of SPAWNED workers when there are many
+    (fresh interpreters that only import numpy: under rocprofv3 the profiler's library has initialised the GPU in
+    this process before main() runs, and a forked child of such a process must not exist)."""
+    ref_len = args.ref_len if ref_len is None else ref_len
+    mixed = args.mixed if mixed is None else mixed
+    base_seed = args.base_seed if base_seed is None else base_seed
     if count < 2000:
-        return synth.make_batch(args.base_seed, count, ref_len=args.ref_len, mixed=args.mixed, first=rank, stride=world)
+        return synth.make_batch(base_seed, count, ref_len=ref_len, mixed=mixed, first=rank, stride=world)
     import multiprocessing as mp
     nproc = max(1, min(16, host_cpus()["usable"] // max(1, world)))
     span = 250
-    jobs = [(args.base_seed, min(span, count - k), args.ref_len, args.mixed, rank + k * world, world)
+    jobs = [(base_seed, min(span, count - k), ref_len, mixed, rank + k * world, world)
             for k in range(0, count, span)]
     refs, seqs, cigs = [], [], []
-    with mp.get_context("fork").Pool(nproc) as pool:
+    with mp.get_context("spawn").Pool(nproc) as pool:
         for r_, s_, c_ in pool.imap(synth.make_span, jobs):
             refs += r_; seqs += s_; cigs += c_
     return refs, seqs, cigs
@@ -207,6 +213,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--pcie-steps", type=int, default=10, help="steps of the host-buffer (PCIe-inclusive) leg; 0 = skip")
     ap.add_argument("--sustain", type=float, default=5.0, help="seconds of the sustained device-resident leg; 0 = skip")
+    ap.add_argument("--production", type=float, default=1.0,
+                    help="seconds of the `production_default` leg: the tool's default band (r=30, max_b_rows=20000, reference "
+                         "src/realign.py:46-51) on one full launch of the fill kernel (4 000 reads of 10 kb), pipelined; 0 = skip")
+    ap.add_argument("--production-reads", type=int, default=4000, help="reads per GPU of that leg (tests use fewer)")
     ap.add_argument("--tb-kernel", type=int, default=0,
                     help="traceback kernel: 0 = chosen by batch size, 1 = windowed, 2 = row per hop (experiments)")
     ap.add_argument("--pipeline", type=int, default=1,
@@ -239,6 +249,9 @@ def main():
         rep = [k % n_uniq for k in range(n)]
         refs = [refs[k] for k in rep]; seqs = [seqs[k] for k in rep]; cigs = [cigs[k] for k in rep]
     sub, nps, _, _ = aln.load_default_tables()
+    prod_reads = None
+    if args.production > 0:
+        prod_reads = make_reads(synth, args, args.production_reads, rank, world, ref_len=10_000, mixed=False, base_seed=2)
 
     # ---- 2. CPU baseline (forked pools: before the HIP runtime exists in this process)
     cpu, cpu_want = None, {}
@@ -438,6 +451,60 @@ def main():
         _, mx = reduce_counters({}, {"e": dts}, device=dev if backend == "nccl" else None)
         sustained = {"seconds": round(mx["e"], 2), "steps": done, "value": round(n * world * done / mx["e"], 1), "unit": "reads/s"}
 
+    # ---- 5b. the production default: r=30, one full launch of single-wave chunks, whole path pipelined
+    production = None
+    if prod_reads is not None:
+        p_refs, p_seqs, p_cigs = prod_reads
+        pn = len(p_refs)
+        prb, pro = pack(p_refs); psb, pso = pack(p_seqs); pcb, pco = pack(p_cigs)
+        poo = np.zeros(pn + 1, np.int64)
+        np.cumsum([len(a) + len(b) for a, b in zip(p_refs, p_seqs)], out=poo[1:])
+        dp = list(map(t, (prb, pro, psb, pso, pcb, pco, poo)))
+        p_out = torch.zeros(int(poo[-1]) + 64, dtype=torch.uint8, device=dev)
+        p_len = torch.zeros(pn, dtype=torch.int64, device=dev)
+        p_st = torch.zeros(pn, dtype=torch.int32, device=dev)
+
+        def prod_steps(k):
+            for _ in range(k):
+                rc = lib.npore_align_batch_device(ctx.handle, pn, dp[0].data_ptr(), dp[1].data_ptr(), dp[2].data_ptr(),
+                                                  dp[3].data_ptr(), dp[4].data_ptr(), dp[5].data_ptr(), 5.0, 1.0, 20000, 30,
+                                                  p_out.data_ptr(), dp[6].data_ptr(), p_len.data_ptr(), p_st.data_ptr(), None, 0)
+                if rc != 0:
+                    raise RuntimeError(f"npore_align_batch_device: {rc} {_lib.last_error()}")
+            ctx.wait()
+        torch.cuda.synchronize()
+        prod_steps(3)
+        barrier()
+        tt0 = ctx.total_timing()
+        tp0 = time.perf_counter()
+        done = 0
+        while True:
+            prod_steps(8)
+            done += 8
+            go = torch.tensor([1.0 if time.perf_counter() - tp0 < args.production else 0.0], dtype=torch.float64)
+            if use_dist:
+                go = go.to(dev) if backend == "nccl" else go
+                dist.all_reduce(go, op=dist.ReduceOp.MAX)
+            if float(go.item()) == 0.0:
+                break
+        barrier()
+        dtp_ = time.perf_counter() - tp0
+        tt1 = ctx.total_timing()
+        _, mx = reduce_counters({}, {"e": dtp_}, device=dev if backend == "nccl" else None)
+        g_ = max(1.0, tt1["launches"] - tt0["launches"])
+        p_fill = (tt1["fill_ms"] - tt0["fill_ms"]) / done
+        p_bytes = sum(4 * (len(s_) + len(r_) + 1) * 61 + 2 * (len(s_) + len(r_)) for s_, r_ in zip(p_seqs, p_refs)) + int(p_len.sum().item())
+        assert int((p_st != 0).sum().item()) == 0
+        production = {"workload": f"{pn} synthetic 10 kb reads per GPU (base_seed=2), r=30, max_b_rows=20000: the tool's defaults "
+                                  "(reference src/realign.py:46-51) at one full launch of the fill kernel; device-resident, pipelined",
+                      "value": round(pn * world * done / mx["e"], 1), "unit": "reads/s", "steps": done,
+                      "ms_per_step": round(mx["e"] / done * 1e3, 2),
+                      "stage_ms": {"fill": round(p_fill, 2), "traceback_gather": round((tt1["traceback_ms"] - tt0["traceback_ms"]) / done, 2),
+                                   "prep": round((tt1["dev_prep_ms"] - tt0["dev_prep_ms"]) / done, 2)},
+                      "exposed_non_fill_ms": round(mx["e"] / done * 1e3 - p_fill, 2),
+                      "roofline_frac_hbm": round(p_bytes / (p_fill * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "groups_per_step": round(g_ / done, 2)}
+        del dp, p_out
+
     # ---- roofline of the dominant kernel (fill): algorithmic bytes per launch / measured duration
     W = 2 * args.r + 1
     bytes_alg = sum(4 * (len(s) + len(r_) + 1) * W + 2 * (len(s) + len(r_)) + int(ol)
@@ -467,7 +534,7 @@ def main():
     # process; they come from the committed rocprofv3 --pmc summary of this same default command, and only while
     # that summary was taken from the kernel sources this library was built from (csrc digest); else null
     traffic, valu, pmc_src = None, None, None
-    prof = os.path.join(REPO, "profiles", "r02_fill_pmc_summary.json")
+    prof = os.path.join(REPO, "profiles", "r03_fill_pmc_summary.json")
     if os.path.exists(prof):
         pm = json.load(open(prof))
         same_cmd = (n, args.ref_len, args.r, args.max_b_rows, args.base_seed, args.mixed) == \
@@ -481,7 +548,7 @@ def main():
             valu = {"bound": "valu_issue", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
                     "frac": round(ach / peak, 4), "insts_valu_per_launch": int(insts),
                     "valu_per_wave_step": round(insts / wave_steps, 1) if wave_steps else None}
-            pmc_src = f"profiles/r02_fill_pmc_summary.json (csrc {pm['csrc_sha']})"
+            pmc_src = f"profiles/r03_fill_pmc_summary.json (csrc {pm['csrc_sha']})"
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "kernel": "fill_kernel", "kernel_ms": round(fill_avg_ms, 3),
@@ -517,9 +584,11 @@ def main():
                        "reads_per_gpu": n, "ref_len": args.ref_len, "r": args.r, "max_b_rows": args.max_b_rows,
                        "base_seed": args.base_seed, "mixed": bool(args.mixed), "parallelism": f"reads x{world}",
                        "batches_in_flight": n_ctx, "pipelined": pipelined, "devices_visible": n_dev,
+                       "value_excludes": "H2D/D2H: inputs and outputs stay in HBM across the timed region (the contract of "
+                                         "`value`); the same batch through page-locked host buffers is `value_pcie_inclusive`",
                        "reduction_backend": {"nccl": "rccl", "gloo": "gloo (ranks share a device)", None: "none"}[backend]},
             "roofline": roofline, "cpu_baseline": cpu,
-            "value_pcie_inclusive": pcie, "sustained": sustained,
+            "value_pcie_inclusive": pcie, "sustained": sustained, "production_default": production,
             "stage_ms": {"fill": round(fill_avg_ms, 2), "traceback_gather": round(float(np.mean(tb_ms)), 2),
                          "prep": round(float(np.mean(prep_ms)), 2)},
             "bad_reads": n_bad,

@@ -24,13 +24,14 @@ def test_bench_two_ranks_on_one_gpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"),
            "--gpus", "2", "--reads", "96", "--ref-len", "3000", "--band", "30", "--steps", "2", "--warmup", "1",
-           "--sustain", "0", "--pcie-steps", "1", "--no-cpu"]
+           "--sustain", "0", "--pcie-steps", "1", "--no-cpu", "--production", "0.05", "--production-reads", "64"]
     out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout                      # rank 0 prints, the other rank stays silent
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["bad_reads"] == 0
+    assert line["production_default"]["value"] > 0 and "r=30" in line["production_default"]["workload"]
     assert line["value"] > 0 and line["unit"] == "reads/s" and line["scaling"] == "weak"
     assert line["config"]["reads_per_gpu"] == 96
     assert line["roofline"]["frac"] > 0 and line["cpu_baseline"] is None      # CPU baseline is an N=1 item

@@ -326,6 +326,70 @@ def test_c3_all_distinct_10000_reads_one_call(ctx, tables):
     assert again == got[4990:5010]
 
 
+def test_c3_full_100000_reads_one_call(ctx, tables):
+    """BASELINE.json configs[2] at its FULL size: 100 000 all-distinct reads of 10 kb from the seed-3
+    mixed-density generator at r=100 in ONE library call (3.1 GB of bases + CIGARs in, 1.1 GB of strings out, 1.6 TB
+    of traceback words over the call: byte offsets beyond 2^31 and 2^32 on every per-read array, a score of groups
+    through the two work sets).  Size-independent properties on EVERY read, oracle equality on the reads of the lowest and
+    highest n-polymer density among the first 400, and a sub-batch from beyond the 4 GB mark re-run on its own."""
+    import multiprocessing as mp
+    from concurrent.futures import ThreadPoolExecutor
+    sub, nps = tables
+    n, span = 100_000, 1000
+    with mp.get_context("spawn").Pool(min(16, os.cpu_count() or 1)) as pool:   # fresh workers: this process holds a live HIP runtime
+        parts = pool.map(synth.make_span, [(3, span, 10_000, True, k, 1) for k in range(0, n, span)], chunksize=1)
+    refs = [x for p in parts for x in p[0]]; seqs = [x for p in parts for x in p[1]]; cigs = [x for p in parts for x in p[2]]
+    del parts
+    assert len(refs) == n
+    got, st = ctx.align_batch(refs, seqs, cigs, r=100, return_status=True)
+    assert not st.any() and len(got) == n
+    assert sum(len(c) for c in cigs) > (1 << 30) and sum(len(g) for g in got) > (1 << 30)
+
+    def check(lo):
+        for k in range(lo, min(lo + 500, n)):
+            _check_alignment_properties(refs[k], seqs[k], got[k])
+        return True
+    with ThreadPoolExecutor(8) as tp:          # numpy releases the GIL in the reductions
+        assert all(tp.map(check, range(0, n, 500)))
+    dens = np.array([(np.diff(r_) == 0).mean() for r_ in refs[:400]])
+    for k in list(np.argsort(dens)[[0, -1]]) + [n - 1]:
+        assert got[k] == oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=100), k
+    again = ctx.align_batch(refs[99_000:99_020], seqs[99_000:99_020], cigs[99_000:99_020], r=100)
+    assert again == got[99_000:99_020]
+
+
+def test_production_default_r30_one_full_launch(ctx, tables):
+    """The tool's default band (reference src/realign.py:46-51: r=30, max_b_rows=20000) at exactly one full launch of
+    the fill kernel (4 000 reads of 10 kb = 4 096 resident single-wave chunks): properties on every read, oracle on four."""
+    sub, nps = tables
+    refs, seqs, cigs = synth.make_batch(2, 4000)
+    got, st = ctx.align_batch(refs, seqs, cigs, r=30, return_status=True)
+    assert not st.any()
+    for ref, seq, g in zip(refs, seqs, got):
+        _check_alignment_properties(ref, seq, g)
+    for k in (0, 1333, 2666, 3999):
+        assert got[k] == oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=30), k
+
+
+def test_fuzz_time_boxed():
+    """A time-boxed leg of tests/tools/fuzz_gpu.py under the driver (fixed seeds; ~20 s over all shapes, ~25 s focused on
+    what has failed before: 4-8 waves per chunk with chunk heights of 2...64 anti-diagonals, tables with max_l < 32):
+    every string and status equal to the oracle's."""
+    import importlib.util
+    from conftest import REPO
+    spec = importlib.util.spec_from_file_location("fuzz_gpu", os.path.join(REPO, "tests", "tools", "fuzz_gpu.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    msgs = []
+    total = 0
+    for seed, focus, secs in ((301, False, 20.0), (302, True, 25.0)):
+        rounds, reads, bad = fz.fuzz(secs, seed, focus=focus, log=msgs.append)
+        assert bad == 0, msgs[:5]
+        assert rounds >= 3 and reads >= 30, (seed, rounds, reads)
+        total += reads
+    print(f"fuzz leg: {total} reads")
+
+
 def test_c5_256_ultralong_reads_r200(ctx, tables):
     """BASELINE.json configs[4] at full size: 256 reads of 50 kb, r=200 (7 waves per chunk,
     6 chunks per read, 41 GB of traceback words), properties on every read + oracle equality on two."""
