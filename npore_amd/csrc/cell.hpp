@@ -173,11 +173,12 @@ NPORE_HD int div_recip(int run, uint32_t m)
 
 // np_score, reference src/aln.pyx:257-274, split into index formation and lookup.
 // Callers pass max_l where the signature says max_n, so lengths clamp to max_l-1
-// and the `n > max_n` test is dead.  Returns true if the score is the constant 100.
-NPORE_HD bool np_score_index(int clampv, int ref_np_len, int indel_len, int &a, int &call)
+// and the `n > max_n` test reads n > max_l.  Returns true if the score is the constant 100.
+NPORE_HD bool np_score_index(int clampv, int n, int ref_np_len, int indel_len, int &a, int &call)
 {
     call = ref_np_len + indel_len;
-    const bool invalid = (ref_np_len <= 0) || (call < 0);
+    // (n > max_l: the `n > max_n` test of src/aln.pyx:265 with max_l in max_n's place -- alive when max_l < max_n)
+    const bool invalid = (ref_np_len <= 0) || (call < 0) || (n > clampv + 1);
     a = ref_np_len < 0 ? 0 : ref_np_len;
     if (a > clampv) a = clampv;
     if (call < 0) call = 0;
@@ -266,7 +267,7 @@ NPORE_HD void shr_generic(const Env &env, const Tab &tab, const CellIn &in, int 
     const int run = start ? 0 : (int)(h.runs >> 16);
     const int indel = -div_recip(run, env.recip(tab, n4)) - 1;
     int a, call;
-    const bool inval = np_score_index(env.clamp(), L, indel, a, call);
+    const bool inval = np_score_index(env.clamp(), n, L, indel, a, call);
     const bool ok = act && (FAST || j - n >= 0);
     const float score = env.np_full(n ? n - 1 : 0, a, call, ok);
     const float cand = cstart + (inval ? INF_F : score);
@@ -407,7 +408,7 @@ NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, 
             const int run = start ? 0 : (int)(h.runs & 0xFFFFu);
             const int indel = div_recip(run, env.recip(tab, n4)) + 1;          // :615 / :629
             int a, call;
-            const bool inval = np_score_index(env.clamp(), L, indel, a, call);
+            const bool inval = np_score_index(env.clamp(), n, L, indel, a, call);
             const float score = env.np_full(nm1 & 7, a, call, good);
             const float cand = cstart + (inval ? INF_F : score);
             const bool take = good && cand < lenv;

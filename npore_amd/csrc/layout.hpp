@@ -78,8 +78,14 @@ constexpr uint32_t DSC_HAS2 = 1u << 5, DSC_RARE = 1u << 7;
 constexpr int NP_LT = 32, NP_CT = 33, NP_C0 = 1;
 // max_l: np_score clamps the table ROW to max_l - 1 (src/aln.pyx:257-274 as called); L itself is capped at max_l, so
 // the call length L - 1 - q never needs the clamp
+// A period n > max_l never scores: np_score returns its constant 100 (`n > max_n` with max_l passed as max_n,
+// src/aln.pyx:265) whatever L and the copies deleted are.  Such a candidate keeps its period and start flag but
+// carries L = 0 (the generic path's "invalid" length) and the address of a guard entry, which holds that constant and
+// which the clamp at L = 0 never leaves.  (Only contexts with max_l < max_n <= 6 have such periods.)
 NPORE_HD uint32_t make_shr_desc(int n, bool start, uint32_t L, int max_l)
 {
+    if (n > max_l)
+        return ((uint32_t)n << 2) | ((((uint32_t)(n - 1) * NP_LT) * NP_CT + (uint32_t)NP_LT) * 4u << 15) | (start ? DSC_START : 0u);
     // (L <= max_l, so the clamp only bites at L == max_l: one row up.  Written as a correction of the L-only index:
     // selecting the row first made the annotate kernel 50 % slower.)
     const uint32_t over = (L >= (uint32_t)max_l) ? (uint32_t)NP_CT : 0u;

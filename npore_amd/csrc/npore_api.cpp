@@ -352,7 +352,8 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     if (int rc = w->counters.ensure(64)) return rc;
     if (int rc = w->seqw.ensure((size_t)(S_tot + max_chunks + 16) * 4)) return rc;
     {
-        const size_t need = (7 * pstride <= 160 * 1024 && !beside_fill) ? 64 : (size_t)2 * max_chunks * 6 * pstride;
+        const size_t need = (pstride + annotate_scratch_bytes((int)pstride) <= 160 * 1024 && !beside_fill)
+                                ? 64 : (size_t)2 * max_chunks * annotate_scratch_bytes((int)pstride);
         if (int rc = w->seql.ensure(need)) return rc;
     }
     if (int rc = w->refw.ensure((size_t)(R_tot + max_chunks + 16) * 16)) return rc;
@@ -439,8 +440,8 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     {
         // slice bytes + 6 byte planes per position in LDS when that fits (it does for the default max_b_rows);
         // sized by the longest slice of the group, so that two workgroups share a CU on 10 kb reads
-        const int planes_in_lds = 7 * pstride <= 160 * 1024;
-        const size_t alds = planes_in_lds ? 7 * pstride : pstride;
+        const int planes_in_lds = pstride + annotate_scratch_bytes((int)pstride) <= 160 * 1024;
+        const size_t alds = planes_in_lds ? pstride + annotate_scratch_bytes((int)pstride) : pstride;
         if (beside_fill) {
             // no LDS, waves of ~30 VGPRs: fits beside the 16 waves of a fill workgroup (two such waves per SIMD).  Four
             // waves per workgroup: 8 000 reads at r = 30 184 k reads/s, with eight 180 k, sixteen 169 k, one 187 k (but C2

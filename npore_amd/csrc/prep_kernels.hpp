@@ -381,9 +381,17 @@ __global__ __launch_bounds__(256) void sched_scatter_kernel(PrepParams p)
 // one period (compile-time, so that the divisions by n and the shorter-period loop unroll)
 // GRID = false: the windows are dealt over the waves of this workgroup (which then owns the whole sequence);
 // GRID = true: over the waves of the whole launch (one launch per period: the next period reads this one's plane).
-template <int n, bool GRID = false>
+// PRE = true: the indicator masks of all windows and periods were computed beforehand (indicator_masks below,
+// mrow = this period's row: one 64-bit word per window, nwin of them) -- a window then gets its own word and the
+// 16 before / 47 behind it in ONE coalesced read (lane l holds word w - 16 + l), and following a run into the
+// neighbouring windows is scalar work on words picked from that register; PRE = false computes every mask it looks
+// at from the bases (ballots).  All lanes of a window that reach its end are in the SAME run, so the extension is
+// wave-uniform either way.
+constexpr int MASK_BACK = 16;      // mask words held in front of the window's own (>= (max_l + 2) * 6 / 64 + 2 for max_l <= 127)
+template <int n, bool GRID = false, bool PRE = false>
 __device__ __forceinline__ void annotate_period(const uint8_t *seq, int len, int max_n, int max_l, uint8_t *planes,
-                                                int pstride, int32_t *Lout, int32_t *Iout, int ostride = 0)
+                                                int pstride, int32_t *Lout, int32_t *Iout, int ostride = 0,
+                                                const unsigned long long *mrow = nullptr)
 {
     // (the wave index is wave-uniform: saying so keeps the window loops and their bounds in scalar registers)
     const int lane = threadIdx.x & 63;
@@ -391,11 +399,27 @@ __device__ __forceinline__ void annotate_period(const uint8_t *seq, int len, int
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (GRID ? (int)blockIdx.x * wpb : 0);
     const int64_t wstep = (int64_t)(GRID ? (int)gridDim.x * wpb : wpb) * 64;
     uint8_t *Ln = planes + (size_t)(n - 1) * pstride;
+    const int nwin = (len + 63) >> 6;
     for (int64_t base64 = (int64_t)wave * 64; base64 < len; base64 += wstep) {
         const int base = (int)base64;
         const int pos = base + lane;
         auto e_at = [&](int q) { return q >= 0 && q + n < len && seq[q] == seq[q + n]; };
-        const unsigned long long M0 = __builtin_amdgcn_ballot_w64(e_at(pos));
+        unsigned long long mv = 0ull;      // PRE: lane l holds the mask word of window (base >> 6) - MASK_BACK + l
+        if constexpr (PRE) {
+            const int wi = (base >> 6) - MASK_BACK + lane;
+            if (wi >= 0 && wi < nwin) mv = mrow[wi];
+        }
+        // mask word of the window `k` windows after (k < 0: before) this one; k wave-uniform, -MASK_BACK <= k < 48
+        auto mask_at = [&](int k) -> unsigned long long {
+            if constexpr (PRE) {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mv, MASK_BACK + k);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mv >> 32), MASK_BACK + k);
+                return ((unsigned long long)hi << 32) | lo;
+            } else {
+                return __builtin_amdgcn_ballot_w64(e_at(base + 64 * k + lane));
+            }
+        };
+        const unsigned long long M0 = mask_at(0);
         // forward run from pos
         int kf;
         {
@@ -406,11 +430,16 @@ __device__ __forceinline__ void annotate_period(const uint8_t *seq, int len, int
         // has more than max_l repeats whatever kf is, and J = kb/n only matters up to max_l (below) -- so a
         // megabase run (assembly gaps of N, satellite arrays) costs a constant per window.
         const int cap = (max_l + 2) * n;
-        bool cont = (kf == 64 - lane);
-        for (int k = base + 64; k < len && k <= base + 64 + cap && __builtin_amdgcn_ballot_w64(cont) != 0ull; k += 64) {
-            const unsigned long long Mk = __builtin_amdgcn_ballot_w64(e_at(k + lane));
-            const int t = (~Mk) ? __builtin_ctzll(~Mk) : 64;
-            if (cont) { kf += t; cont = (t == 64); }
+        const bool cont = (kf == 64 - lane);
+        if (M0 >> 63) {         // the run through the window's last position goes on (every lane with `cont` is in it)
+            int ext = 0, kw = 1;
+            for (int k = base + 64; k < len && k <= base + 64 + cap; k += 64, kw++) {
+                const unsigned long long Mk = mask_at(kw);
+                const int t = (~Mk) ? __builtin_ctzll(~Mk) : 64;
+                ext += t;
+                if (t != 64) break;
+            }
+            kf += cont ? ext : 0;
         }
         // backward run ending at pos-1
         int kb = 0;
@@ -418,14 +447,24 @@ __device__ __forceinline__ void annotate_period(const uint8_t *seq, int len, int
             const unsigned long long inv = ~(M0 << (64 - lane));   // bits below are 0 after the shift -> 1 here
             kb = __builtin_clzll(inv);                              // inv != 0 because lane > 0
         }
-        bool contb = (kb == lane);
-        for (int k = base - 64; k >= 0 && k >= base - 64 - cap && __builtin_amdgcn_ballot_w64(contb) != 0ull; k -= 64) {
-            const unsigned long long Mk = __builtin_amdgcn_ballot_w64(e_at(k + lane));
-            const int t = (~Mk) ? __builtin_clzll(~Mk) : 64;
-            if (contb) { kb += t; contb = (t == 64); }
+        const bool contb = (kb == lane);
+        if (base > 0) {         // (lane 0 always looks back; the others if the run reaches the window's first position)
+            int ext = 0, kw = -1;
+            for (int k = base - 64; k >= 0 && k >= base - 64 - cap; k -= 64, kw--) {
+                const unsigned long long Mk = mask_at(kw);
+                const int t = (~Mk) ? __builtin_clzll(~Mk) : 64;
+                ext += t;
+                if (t != 64) break;
+            }
+            kb += contb ? ext : 0;
+        }
+        const int q = (int)((unsigned)kf / (unsigned)n), J = (int)((unsigned)kb / (unsigned)n);
+        // fewer than three repeats can cover any position of the window: the plane is all zero here
+        if (__builtin_amdgcn_ballot_w64(pos < len && J + q + 1 >= 3) == 0ull && !Lout) {
+            if (pos < len) Ln[pos] = 0;
+            continue;
         }
         if (pos < len) {
-            const int q = (int)((unsigned)kf / (unsigned)n), J = (int)((unsigned)kb / (unsigned)n);
             int stored = 0, idx = 0;
             // every candidate start s = pos - j*n (j <= J) lies in the run ending at pos-1, so seq[s] == seq[pos]:
             // at an N none is eligible; and starts with more than max_l repeats are all eligible (l*n > 100*n2) and
@@ -439,7 +478,7 @@ __device__ __forceinline__ void annotate_period(const uint8_t *seq, int len, int
             for (int j = jtop; j >= 0; j--) {
                 const int l = (j == 0) ? (q >= 1 ? q + 1 : 0) : j + q + 1;
                 if (stored && l <= max_l) break;
-                if (l < 3) continue;
+                if (l < 3) break;                       // (l only shrinks with j: nothing further down qualifies)
                 const int s = pos - j * n;
                 if (!seq[s]) continue;
                 bool longest = true;
@@ -459,15 +498,58 @@ __device__ __forceinline__ void annotate_period(const uint8_t *seq, int len, int
     }
 }
 
-__device__ __forceinline__ void annotate_sequence(const uint8_t *seq, int len, int max_n, int max_l,
-                                                  uint8_t *planes, int pstride, int32_t *Lout, int32_t *Iout)
+// Indicator masks of a sequence owned by this workgroup: masks[(n-1) * mstride + w] bit l = e_n[64 w + l] =
+// (seq[p] == seq[p + n]) with p + n < len, for every window w and period n <= max_n.  One pass: a position reads its
+// own base and the six behind it once for all periods.
+__device__ __forceinline__ void indicator_masks(const uint8_t *seq, int len, int max_n, unsigned long long *masks, int mstride)
 {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (int base = wave * 64; base < len; base += wpb * 64) {
+        const int pos = base + lane;
+        const int c = pos < len ? seq[pos] : -1;
+        unsigned long long mine = 0ull;
+#pragma unroll
+        for (int n = 1; n <= MAX_PERIOD; n++) {
+            const bool e = n <= max_n && pos + n < len && seq[pos + n] == c;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(e);
+            mine = (lane == n - 1) ? m : mine;
+        }
+        if (lane < max_n) masks[(size_t)lane * mstride + (base >> 6)] = mine;
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+
+// masks = nullptr: every period computes the masks it needs from the bases (callers without scratch for them)
+__device__ __forceinline__ void annotate_sequence(const uint8_t *seq, int len, int max_n, int max_l,
+                                                  uint8_t *planes, int pstride, int32_t *Lout, int32_t *Iout,
+                                                  unsigned long long *masks = nullptr, int mstride = 0)
+{
+    if (masks) {
+        indicator_masks(seq, len, max_n, masks, mstride);
+        if (max_n >= 1) annotate_period<1, false, true>(seq, len, max_n, max_l, planes, pstride, Lout, Iout, 0, masks);
+        if (max_n >= 2) annotate_period<2, false, true>(seq, len, max_n, max_l, planes, pstride, Lout, Iout, 0, masks + mstride);
+        if (max_n >= 3) annotate_period<3, false, true>(seq, len, max_n, max_l, planes, pstride, Lout, Iout, 0, masks + 2 * mstride);
+        if (max_n >= 4) annotate_period<4, false, true>(seq, len, max_n, max_l, planes, pstride, Lout, Iout, 0, masks + 3 * mstride);
+        if (max_n >= 5) annotate_period<5, false, true>(seq, len, max_n, max_l, planes, pstride, Lout, Iout, 0, masks + 4 * mstride);
+        if (max_n >= 6) annotate_period<6, false, true>(seq, len, max_n, max_l, planes, pstride, Lout, Iout, 0, masks + 5 * mstride);
+        return;
+    }
     if (max_n >= 1) annotate_period<1>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
     if (max_n >= 2) annotate_period<2>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
     if (max_n >= 3) annotate_period<3>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
     if (max_n >= 4) annotate_period<4>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
     if (max_n >= 5) annotate_period<5>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
     if (max_n >= 6) annotate_period<6>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
+}
+
+// scratch of one annotate workgroup: 6 byte planes of pstride (a multiple of 16) + 6 rows of indicator-mask words
+__host__ __device__ static inline int annotate_mask_words(int pstride) { return (pstride + 63) >> 6; }
+__host__ __device__ static inline size_t annotate_scratch_bytes(int pstride)
+{
+    return (size_t)6 * pstride + (size_t)MAX_PERIOD * 8 * annotate_mask_words(pstride);
 }
 
 // One workgroup per (chunk, sequence).  The slice and the L planes are staged in LDS
@@ -491,15 +573,22 @@ __global__ __launch_bounds__(1024) void annotate_kernel(PrepParams p)
     const uint8_t *g = (is_ref ? p.refs + p.ref_off[rd] : p.seqs + p.seq_off[rd]) + start;
     const int pstride = p.pstride;
     const uint8_t *sseq = g;
+    const int mstride = annotate_mask_words(pstride);      // indicator-mask words per period (one per 64 positions)
     uint8_t *planes;   // a compile-time choice, so that the LDS case uses ds_* instructions rather than flat ones
-    if constexpr (PLANES_IN_LDS) planes = sbuf + pstride;
-    else planes = reinterpret_cast<uint8_t *>(p.seql) + ((size_t)blockIdx.x * 6) * pstride;
+    unsigned long long *masks;
+    if constexpr (PLANES_IN_LDS) {
+        planes = sbuf + pstride;
+        masks = reinterpret_cast<unsigned long long *>(sbuf + (size_t)7 * pstride);
+    } else {
+        planes = reinterpret_cast<uint8_t *>(p.seql) + (size_t)blockIdx.x * annotate_scratch_bytes(pstride);
+        masks = reinterpret_cast<unsigned long long *>(planes + (size_t)6 * pstride);
+    }
     if constexpr (SEQ_IN_LDS) {
         for (int q = threadIdx.x; q < len; q += blockDim.x) sbuf[q] = g[q];
         sseq = sbuf;
         __syncthreads();
     }
-    annotate_sequence(sseq, len, p.max_n, p.max_l, planes, pstride, nullptr, nullptr);
+    annotate_sequence(sseq, len, p.max_n, p.max_l, planes, pstride, nullptr, nullptr, masks, mstride);
     auto Lat = [&](int pos, int n) -> uint32_t { return planes[(size_t)(n - 1) * pstride + pos] & 127u; };
     auto idx0 = [&](int pos, int n) -> bool { return (planes[(size_t)(n - 1) * pstride + pos] >> 7) != 0u; };
     if (!is_ref) {

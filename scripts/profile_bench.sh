@@ -9,7 +9,7 @@ R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/prof_$tag
 rm -rf $out          # (a box is fresh, but gpurun merges into what the build container already holds)
 mkdir -p $out
-B="--no-cpu --pcie-steps 0 --sustain 0"
+B="--no-cpu --pcie-steps 0 --sustain 0 --production 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/bench.py --steps 3 --warmup 1 $B "$@" > $out/bench_trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $out/pmc1 -- python3 $R/bench.py --steps 1 --warmup 0 $B "$@" > $out/bench_pmc1.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc2 -- python3 $R/bench.py --steps 1 --warmup 0 $B "$@" > $out/bench_pmc2.log 2>&1

@@ -618,10 +618,11 @@ def test_both_traceback_kernels(tables, mode):
     c.close()
 
 
-@pytest.mark.parametrize("max_n,max_l", [(6, 20), (4, 20), (1, 5), (6, 31), (6, 32), (3, 127)])
+@pytest.mark.parametrize("max_n,max_l", [(6, 20), (4, 20), (1, 5), (6, 31), (6, 32), (3, 127), (6, 5), (6, 3), (4, 2)])
 def test_other_table_shapes(tables, max_n, max_l):
     """Contexts with other max_n / max_l (the CLI's --max_n / --max_l): row clamp at max_l - 1 also where the
-    capped repeat count goes through the descriptor's table address (max_l < 32)."""
+    capped repeat count goes through the descriptor's table address (max_l < 32); max_l < max_n: periods above max_l
+    score np_score's constant 100 (src/aln.pyx:265 with max_l in max_n's place)."""
     from test_model_vs_oracle import polymer_pairs, small_tables
     sub, nps = tables
     t = small_tables(nps, max_n, max_l, max_l)

@@ -101,7 +101,9 @@ def test_other_table_shapes(tables):
     """max_n / max_l other than 6 / 100: np_score clamps rows and call lengths to max_l - 1, and with max_l below
     the device table's 32 rows the capped repeat count max_l itself goes through the table-address shortcut."""
     sub, nps = tables
-    for max_n, max_l in ((6, 20), (4, 20), (1, 5), (6, 31), (6, 32), (3, 127)):
+    # (6, 5), (6, 3), (4, 2): periods ABOVE max_l -- np_score's `n > max_n` test reads n > max_l (src/aln.pyx:265 as
+    # called) and such a candidate scores the constant 100
+    for max_n, max_l in ((6, 20), (4, 20), (1, 5), (6, 31), (6, 32), (3, 127), (6, 5), (6, 3), (4, 2)):
         t = small_tables(nps, max_n, max_l, max_l)
         for k, (ref, seq, cig) in enumerate(polymer_pairs(100 + max_l, 25)):
             r = (5, 30, 64)[k % 3]
@@ -133,3 +135,19 @@ def test_ties_and_negative_scores(tables):
             a, sa = oracle.align(ref, seq, cig, sub, nps, indel_start=ist, indel_extend=iex, r=r, return_status=True)
             b, sb = model.align(ref, seq, cig, sub, nps, indel_start=ist, indel_extend=iex, r=r)
             assert a == b and sa == sb, (k, r)
+
+
+def test_period_above_max_l_scores_100(tables):
+    """max_l < max_n: a 6-mer repeated five times under max_l = 5 (found by the GPU fuzz, round 3).  np_score is called
+    with max_l where its signature says max_n (src/aln.pyx:615,629,650,663), so `n > max_n` (:265) makes every
+    period-6 LEN / SHR candidate cost 100 -- the recurrence must not look its score up in the table."""
+    sub, nps = tables
+    t = small_tables(nps, 6, 5, 5)
+    enc = lambda s_: np.array(["NACGT".index(c) for c in s_], np.uint8)
+    ref, seq, cig = enc("TACATC" * 5), enc("TACCATCTACATGTTCATCTACATCTAGATC"), "===I========X=X============X==="
+    for r in (3, 10, 30):
+        for mbr in (20000, 16):
+            a, sa = oracle.align(ref, seq, cig, sub, t, max_b_rows=mbr, r=r, max_n=6, max_l=5, return_status=True)
+            b, sb = model.align(ref, seq, cig, sub, t, max_b_rows=mbr, r=r, max_n=6, max_l=5)
+            assert a == b and sa == sb, (r, mbr)
+    assert oracle.align(ref, seq, cig, sub, t, r=10, max_n=6, max_l=5) == "==I=========X=X============X==="

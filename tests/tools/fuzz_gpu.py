@@ -128,7 +128,7 @@ def fuzz(budget, seed, focus=False, log=print):
             if not ok:
                 bad += 1
                 log(f"MISMATCH seed={seed} round={rounds} read={k} r={r} mbr={mbr} gaps=({ist},{iex}) tables={kind} max_n={max_n} "
-                      f"max_l={max_l} len={len(refs[k])}/{len(seqs[k])} status={st[k]} want_status={wst}", flush=True)
+                      f"max_l={max_l} len={len(refs[k])}/{len(seqs[k])} status={st[k]} want_status={wst}")
         rounds += 1
         reads += n
     return rounds, reads, bad
