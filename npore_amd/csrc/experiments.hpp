@@ -42,6 +42,11 @@ constexpr bool CHUNKMAJOR = true;
 #else
 constexpr bool CHUNKMAJOR = false;
 #endif
+#if defined(NPORE_X_ANN)
+constexpr int ANN = NPORE_X_ANN;      // annotate ablations (timing only): 1 no packing, 2 no period passes, 3 neither
+#else
+constexpr int ANN = 0;
+#endif
 #if defined(NPORE_X_POLLSLEEP)
 constexpr int POLLSLEEP = NPORE_X_POLLSLEEP;
 #else

@@ -21,6 +21,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "cell.hpp"      // (xp:: switches of measurement builds)
 #include "layout.hpp"
 
 namespace npore {
@@ -588,7 +589,8 @@ __global__ __launch_bounds__(1024) void annotate_kernel(PrepParams p)
         sseq = sbuf;
         __syncthreads();
     }
-    annotate_sequence(sseq, len, p.max_n, p.max_l, planes, pstride, nullptr, nullptr, masks, mstride);
+    if constexpr (!(xp::ANN & 2)) annotate_sequence(sseq, len, p.max_n, p.max_l, planes, pstride, nullptr, nullptr, masks, mstride);
+    if constexpr ((xp::ANN & 1) != 0) return;
     auto Lat = [&](int pos, int n) -> uint32_t { return planes[(size_t)(n - 1) * pstride + pos] & 127u; };
     auto idx0 = [&](int pos, int n) -> bool { return (planes[(size_t)(n - 1) * pstride + pos] >> 7) != 0u; };
     if (!is_ref) {
