@@ -229,6 +229,17 @@ typedef struct npore_fasta npore_fasta;
 /* Inflate (BGZF blocks in parallel) and index a BAM file; NULL on failure (reference: "ERROR: BAM file
  * ... not found", src/bam.pyx:22-24). */
 npore_bam *npore_bam_open(const char *path, int threads);
+/* The same with the ingest mode chosen: 0 = automatic (what npore_bam_open does: STREAMED when the file is BGZF and
+ * larger than NPORE_BAM_STREAM_MB, default 1024), 1 = the whole inflated stream resident, 2 = streamed.
+ * A STREAMED handle never holds the inflated stream (reference src/bam.pyx:18-47 iterates region by region through
+ * pysam; its memory is O(one read)): it keeps the BGZF block table and 22 bytes per record (offset, reference,
+ * position, span, flag -- what npore_bam_select needs), built in one pass over windows of 256 MB, and every batch
+ * (npore_bam_pack*, _format_sam, _realign_batch, _realign_file) inflates just the blocks its records lie in.
+ * index_path (may be NULL): a record index written by npore_bam_save_index for this file; the handle then skips its
+ * indexing pass -- with one process per GPU, one process of a node indexes and the others load. */
+npore_bam *npore_bam_open_mode(const char *path, int threads, int mode, const char *index_path);
+int npore_bam_is_streamed(const npore_bam *bam);
+int npore_bam_save_index(const npore_bam *bam, const char *path);
 void npore_bam_close(npore_bam *bam);
 /* Write the inflated BAM stream to `path` (complete or not at all: temporary file + rename).  npore_bam_open
  * recognises such a file ("BAM\1" at offset 0) and maps it instead of inflating: with several processes per node

@@ -46,6 +46,9 @@ SIGNATURES = {
     "npore_round_chunks": (C.c_int64, [C.c_void_p, C.c_int]),
     "npore_fill_shape": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "npore_bam_open": (C.c_void_p, [C.c_char_p, C.c_int]),
+    "npore_bam_open_mode": (C.c_void_p, [C.c_char_p, C.c_int, C.c_int, C.c_char_p]),
+    "npore_bam_is_streamed": (C.c_int, [C.c_void_p]),
+    "npore_bam_save_index": (C.c_int, [C.c_void_p, C.c_char_p]),
     "npore_bam_close": (None, [C.c_void_p]),
     "npore_bam_dump_inflated": (C.c_int, [C.c_void_p, C.c_char_p]),
     "npore_bam_inflated_size": (C.c_int64, [C.c_void_p]),

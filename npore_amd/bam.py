@@ -359,44 +359,94 @@ class NativeFastaSeqs:
 class NativeBam:
     """A BAM file inflated and indexed by the library (same attributes as BamFile where realign needs them)."""
 
-    def __init__(self, path, threads=0, share=None):
-        """share: with several processes per node (one per GPU, torch.distributed.run) the BAM is inflated ONCE --
-        by local rank 0, into a file under /dev/shm that the other local ranks map (npore_bam_dump_inflated);
-        None = do so when LOCAL_WORLD_SIZE > 1 and the inflated stream fits a quarter of the free /dev/shm."""
+    def __init__(self, path, threads=0, share=None, stream=None):
+        """stream: None = the library decides (files above NPORE_BAM_STREAM_MB, default 1 GB, are STREAMED: no
+        inflated copy, 22 bytes of index per record, each batch inflates the blocks its reads lie in), True / False force it.
+        share: with several processes per node (one per GPU, torch.distributed.run) local rank 0 does the expensive
+        part once and leaves it under /dev/shm for the other local ranks -- the record index of a streamed file
+        (npore_bam_save_index), the inflated stream of a small one (npore_bam_dump_inflated); None = do so when
+        LOCAL_WORLD_SIZE > 1."""
         from . import _lib
         self._lib = _lib.load()
         self._shared = None
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if stream is None and os.environ.get("NPORE_BAM_STREAM") in ("0", "1"):
+            stream = os.environ["NPORE_BAM_STREAM"] == "1"
+        mode = 0 if stream is None else (2 if stream else 1)
         if share is None:
             share = local_world > 1 and os.path.isdir("/dev/shm") and os.environ.get("NPORE_SHARE_BAM", "1") != "0"
-        open_path = path
-        if share and local_world > 1:
-            open_path = self._shared_copy(path, local_rank, threads)
-        self.handle = self._lib.npore_bam_open(os.fsencode(open_path), threads)
+        will_stream = mode == 2 or (mode == 0 and self._auto_streams(path))
+        self.handle = None
+        if share and local_world > 1 and will_stream:
+            self.handle = self._open_with_shared_index(path, local_rank, threads)
+        elif share and local_world > 1:
+            path_to_open = self._shared_copy(path, local_rank, threads)
+            self.handle = self._lib.npore_bam_open_mode(os.fsencode(path_to_open), threads, 1, None)
+        if not self.handle:
+            self.handle = self._lib.npore_bam_open_mode(os.fsencode(path), threads, mode, None)
         if not self.handle:
             msg = _lib.last_error()
             print(f"\nERROR: BAM file '{path}' not found." if "not found" in msg else f"\nERROR: {msg}.")
             sys.exit(1)
+        self.streamed = bool(self._lib.npore_bam_is_streamed(self.handle))
         n = self._lib.npore_bam_n_refs(self.handle)
         self.references = [self._lib.npore_bam_ref_name(self.handle, i).decode() for i in range(n)]
         self.lengths = [int(self._lib.npore_bam_ref_len(self.handle, i)) for i in range(n)]
         self.n_records = int(self._lib.npore_bam_n_records(self.handle))
 
+    @staticmethod
+    def _auto_streams(path):
+        try:
+            with open(path, "rb") as fh:
+                gz = fh.read(2) == b"\x1f\x8b"
+            return gz and os.path.getsize(path) > int(os.environ.get("NPORE_BAM_STREAM_MB", "1024")) * (1 << 20)
+        except OSError:
+            return False
+
+    @staticmethod
+    def _shm_key(path):
+        import hashlib
+        st = os.stat(path)
+        return hashlib.sha1(f"{os.path.abspath(path)}:{st.st_size}:{st.st_mtime_ns}:{os.environ.get('MASTER_PORT', '')}".encode()).hexdigest()[:16]
+
+    def _open_with_shared_index(self, path, local_rank, threads):
+        """Streamed file, several local ranks: local rank 0 makes the record index (one pass over the file) and saves
+        it under /dev/shm; the others wait for it and open with it.  Returns a handle or None (caller opens normally)."""
+        import time
+        try:
+            key = self._shm_key(path)
+        except OSError:
+            return None
+        ix, skip = f"/dev/shm/npore_bam_{key}.idx", f"/dev/shm/npore_bam_{key}.skip"
+        if local_rank == 0:
+            h = self._lib.npore_bam_open_mode(os.fsencode(path), threads, 2, None)
+            if not h or self._lib.npore_bam_save_index(h, os.fsencode(ix)) != 0:
+                open(skip, "w").close()
+                return h or None
+            self._shared = (ix, skip)
+            return h
+        t_end = time.time() + 3600
+        while time.time() < t_end:
+            if os.path.exists(ix):
+                return self._lib.npore_bam_open_mode(os.fsencode(path), threads, 2, os.fsencode(ix)) or None
+            if os.path.exists(skip):
+                return None
+            time.sleep(0.05)
+        return None
+
     def _shared_copy(self, path, local_rank, threads):
         """Path to open: the inflated copy under /dev/shm (local rank 0 makes it, the others wait for it), or
         `path` itself when sharing is not possible (no room, or the maker gave up: a `.skip` marker)."""
-        import hashlib
         import shutil
         import time
         try:
-            st = os.stat(path)
+            key = self._shm_key(path)
         except OSError:
             return path
-        key = hashlib.sha1(f"{os.path.abspath(path)}:{st.st_size}:{st.st_mtime_ns}:{os.environ.get('MASTER_PORT', '')}".encode()).hexdigest()[:16]
         raw, skip = f"/dev/shm/npore_bam_{key}.raw", f"/dev/shm/npore_bam_{key}.skip"
         if local_rank == 0:
-            h = self._lib.npore_bam_open(os.fsencode(path), threads)
+            h = self._lib.npore_bam_open_mode(os.fsencode(path), threads, 1, None)
             if not h:
                 open(skip, "w").close()
                 return path

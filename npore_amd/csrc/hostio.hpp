@@ -18,6 +18,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
@@ -129,28 +130,61 @@ struct ByteSpan {
     const uint8_t &operator[](size_t i) const { return p[i]; }
 };
 
+struct BgzfBlock { uint64_t in_off, in_len, out_off, out_len; };    // deflate payload in the file; its place in the stream
+
+// header of the BGZF member at p[0 .. avail): payload offset / length, inflated length, member size; false = not a
+// complete BGZF member (need = bytes wanted, when more input could help)
+inline bool bgzf_member(const uint8_t *p, size_t avail, size_t &pay_off, size_t &pay_len, size_t &isize, size_t &bsize, size_t &need)
+{
+    need = 18;
+    if (avail < 18) return false;
+    if (p[0] != 31 || p[1] != 139 || p[2] != 8 || !(p[3] & 4)) { need = 0; return false; }
+    const size_t xlen = rd16(p + 10), xend = 12 + xlen;
+    need = xend;
+    if (xend > avail) return false;
+    bsize = 0;
+    for (size_t q = 12; q + 4 <= xend;) {
+        const size_t slen = rd16(p + q + 2);
+        if (p[q] == 'B' && p[q + 1] == 'C' && slen == 2 && q + 6 <= xend) bsize = (size_t)rd16(p + q + 4) + 1;
+        q += 4 + slen;
+    }
+    if (!bsize || bsize < xlen + 20) { need = 0; return false; }
+    need = bsize;
+    if (bsize > avail) return false;
+    pay_off = xend;
+    pay_len = bsize - xend - 8;
+    isize = rd32(p + bsize - 4);
+    return true;
+}
+
+inline bool inflate_block(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
+{
+    if (!out_len) return true;
+    z_stream zs;
+    std::memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<Bytef *>(in);
+    zs.avail_in = (uInt)in_len;
+    zs.next_out = out;
+    zs.avail_out = (uInt)out_len;
+    const int rc = inflate(&zs, Z_FINISH);
+    const bool ok = rc == Z_STREAM_END && zs.total_out == out_len;
+    inflateEnd(&zs);
+    return ok;
+}
+
 inline bool bgzf_inflate(const ByteSpan &raw, int threads, RawBuf &out, size_t &out_size, std::string &err)
 {
-    struct Blk { size_t in_off, in_len, out_off, out_len; };
+    typedef BgzfBlock Blk;
     std::vector<Blk> blocks;
     size_t p = 0, total = 0;
     bool is_bgzf = true;
     while (p + 18 <= raw.size()) {
-        if (raw[p] != 31 || raw[p + 1] != 139 || raw[p + 2] != 8 || !(raw[p + 3] & 4)) { is_bgzf = false; break; }
-        const size_t xlen = rd16(&raw[p + 10]);
-        size_t q = p + 12, bsize = 0;
-        const size_t xend = q + xlen;
-        if (xend > raw.size()) { is_bgzf = false; break; }
-        while (q + 4 <= xend) {
-            const size_t slen = rd16(&raw[q + 2]);
-            if (raw[q] == 'B' && raw[q + 1] == 'C' && slen == 2 && q + 6 <= xend) bsize = (size_t)rd16(&raw[q + 4]) + 1;
-            q += 4 + slen;
-        }
-        if (!bsize || p + bsize > raw.size() || bsize < xlen + 20) { is_bgzf = false; break; }
-        const size_t isize = rd32(&raw[p + bsize - 4]);
-        blocks.push_back({xend, bsize - (xend - p) - 8, total, isize});
-        total += isize;
-        p += bsize;
+        size_t po, pl, isz, bs, need;
+        if (!bgzf_member(raw.data() + p, raw.size() - p, po, pl, isz, bs, need)) { is_bgzf = false; break; }
+        blocks.push_back({p + po, pl, total, isz});
+        total += isz;
+        p += bs;
     }
     if (is_bgzf && p == raw.size()) {
         if (!out.ensure(total + 1)) { err = "out of memory"; return false; }
@@ -158,17 +192,7 @@ inline bool bgzf_inflate(const ByteSpan &raw, int threads, RawBuf &out, size_t &
         std::atomic<int> bad{0};
         parallel_for((int64_t)blocks.size(), threads, [&](int64_t i) {
             const Blk &b = blocks[(size_t)i];
-            if (!b.out_len) return;
-            z_stream zs;
-            std::memset(&zs, 0, sizeof zs);
-            if (inflateInit2(&zs, -15) != Z_OK) { bad++; return; }
-            zs.next_in = const_cast<Bytef *>(raw.data() + b.in_off);
-            zs.avail_in = (uInt)b.in_len;
-            zs.next_out = reinterpret_cast<Bytef *>(out.p) + b.out_off;
-            zs.avail_out = (uInt)b.out_len;
-            const int rc = inflate(&zs, Z_FINISH);
-            if (rc != Z_STREAM_END || zs.total_out != b.out_len) bad++;
-            inflateEnd(&zs);
+            if (!inflate_block(raw.data() + b.in_off, b.in_len, reinterpret_cast<uint8_t *>(out.p) + b.out_off, b.out_len)) bad++;
         });
         if (bad) { err = "corrupt BGZF block"; return false; }
         return true;
@@ -201,6 +225,94 @@ inline bool bgzf_inflate(const ByteSpan &raw, int threads, RawBuf &out, size_t &
     return true;
 }
 
+// A file read with pread(): the streamed BAM mode never maps the file, so that what it has read does not stay in
+// this process's resident set.
+struct PreadFile {
+    int fd = -1;
+    uint64_t size = 0;
+    PreadFile() = default;
+    PreadFile(const PreadFile &) = delete;
+    PreadFile &operator=(const PreadFile &) = delete;
+    ~PreadFile() { if (fd >= 0) ::close(fd); }
+    bool open(const char *path)
+    {
+        fd = ::open(path, O_RDONLY);
+        struct stat st;
+        if (fd < 0 || ::fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) return false;
+        size = (uint64_t)st.st_size;
+        return true;
+    }
+    bool read(uint64_t off, void *dst, size_t n) const
+    {
+        char *d = static_cast<char *>(dst);
+        while (n) {
+            const ssize_t k = ::pread(fd, d, n, (off_t)off);
+            if (k <= 0) return false;
+            d += k; off += (uint64_t)k; n -= (size_t)k;
+        }
+        return true;
+    }
+};
+
+// block table of a BGZF file, read sequentially in 8 MB pieces; false = not BGZF throughout
+inline bool bgzf_scan(const PreadFile &f, std::vector<BgzfBlock> &blocks, uint64_t &total)
+{
+    const size_t CH = 8u << 20;
+    std::vector<uint8_t> buf(CH + 65536 + 64);
+    uint64_t fp = 0;
+    size_t have = 0;            // bytes of buf in use, starting at file offset fp
+    total = 0;
+    for (;;) {
+        const size_t want = (size_t)std::min<uint64_t>(buf.size() - have, f.size - (fp + have));
+        if (want && !f.read(fp + have, buf.data() + have, want)) return false;
+        have += want;
+        size_t q = 0;
+        for (;;) {
+            size_t po, pl, isz, bs, need;
+            if (!bgzf_member(buf.data() + q, have - q, po, pl, isz, bs, need)) {
+                if (need == 0) return false;                    // not a BGZF member
+                break;                                          // incomplete: read on
+            }
+            blocks.push_back({fp + q + po, pl, total, isz});
+            total += isz;
+            q += bs;
+        }
+        if (fp + have >= f.size) return q == have;              // the file ends with a complete member
+        if (q == 0) return false;                               // a member larger than the buffer: not BGZF
+        std::memmove(buf.data(), buf.data() + q, have - q);
+        fp += q;
+        have -= q;
+    }
+}
+
+// inflate blocks [b0, b1) of the table back to back into dst (their out_off relative to blocks[b0].out_off)
+inline bool bgzf_inflate_range(const PreadFile &f, const std::vector<BgzfBlock> &blocks, size_t b0, size_t b1, uint8_t *dst, int threads)
+{
+    if (b0 >= b1) return true;
+    const uint64_t in0 = blocks[b0].in_off, in1 = blocks[b1 - 1].in_off + blocks[b1 - 1].in_len;
+    RawBuf comp;
+    if (!comp.ensure((size_t)(in1 - in0) + 1) || !f.read(in0, comp.p, (size_t)(in1 - in0))) return false;
+    std::atomic<int> bad{0};
+    const uint64_t o0 = blocks[b0].out_off;
+    const int64_t per = 8;                                      // blocks per task
+    parallel_for(((int64_t)(b1 - b0) + per - 1) / per, threads, [&](int64_t t) {
+        for (size_t i = b0 + (size_t)t * per; i < std::min(b1, b0 + (size_t)(t + 1) * per); i++) {
+            const BgzfBlock &b = blocks[i];
+            if (!inflate_block(reinterpret_cast<const uint8_t *>(comp.p) + (b.in_off - in0), b.in_len, dst + (b.out_off - o0), b.out_len)) bad++;
+        }
+    });
+    return bad == 0;
+}
+
+}  // namespace npore
+
+namespace npore {
+// The bytes of a batch of records: pointers into the resident stream, or (streamed handle) into `buf`, which holds
+// the runs of consecutive BGZF blocks the batch's records lie in, inflated for this batch (bam_fetch).
+struct RecFetch {
+    RawBuf buf;
+    std::vector<const uint8_t *> ptr;
+};
 }  // namespace npore
 
 // ---- handles ---------------------------------------------------------------------------------
@@ -213,10 +325,19 @@ struct npore_bam {
     std::vector<std::string> ref_names;
     std::vector<int64_t> ref_lens;
     std::vector<uint8_t> ref_has_reads;
-    std::vector<int64_t> rec_off;         // offset of each record's block_size field
+    // STREAMED mode (large files): the inflated stream is never held as a whole.  The handle keeps the BGZF block
+    // table and, per record, what selection needs (below); the bytes of a batch of records are inflated on demand
+    // from the blocks that hold them (RecFetch).  data == nullptr then.
+    bool streamed = false;
+    std::unique_ptr<npore::PreadFile> file;
+    std::vector<npore::BgzfBlock> blocks;
+    std::vector<int32_t> m_ref, m_pos, m_span;     // per record: reference id, position, reference span
+    std::vector<uint16_t> m_flag;
+    std::vector<int64_t> rec_off;         // offset of each record's block_size field (in the inflated stream)
     std::vector<std::vector<int64_t>> by_ref;   // record indices per reference id, file order
     std::vector<uint8_t> ref_sorted;      // ... which is ascending in position (regions then need no full scan)
     std::vector<int64_t> ref_max_len;     // longest reference span of a record on that reference
+    npore::RecFetch api_fetch;            // records of the last npore_bam_pack_sizes / _pack / _format_sam call
     npore::RawBuf sam;                    // text of the last formatted batch
     npore::RawBuf w_finals;               // final CIGARs of the last batch (work buffer, reused)
     double stage_ms[4] = {0, 0, 0, 0};    // last npore_bam_realign_batch: pack, align, standardise, format
@@ -252,10 +373,53 @@ struct RecView {
     uint32_t cig(int k) const { return rd32(cigar() + 4 * (size_t)k); }
 };
 
-inline RecView rec_at(const npore_bam &b, int64_t i)
+inline RecView rec_view(const uint8_t *q) { return RecView{q + 4, rdi32(q)}; }
+
+inline RecView rec_of(const RecFetch &f, int64_t k) { return rec_view(f.ptr[(size_t)k]); }
+
+inline bool bam_fetch(const npore_bam &b, const int64_t *idx, int64_t n, int threads, RecFetch &f, std::string &err)
 {
-    const uint8_t *q = b.data + b.rec_off[(size_t)i];
-    return RecView{q + 4, rdi32(q)};
+    f.ptr.resize((size_t)n);
+    if (!b.streamed) {
+        for (int64_t k = 0; k < n; k++) f.ptr[(size_t)k] = b.data + b.rec_off[(size_t)idx[k]];
+        return true;
+    }
+    // blocks touched by the records (a record may straddle blocks), as sorted runs of consecutive blocks
+    auto block_of = [&](uint64_t off) {      // last block with out_off <= off and out_len > 0 covering it
+        size_t lo = 0, hi = b.blocks.size();
+        while (hi - lo > 1) { const size_t mid = (lo + hi) >> 1; if (b.blocks[mid].out_off <= off) lo = mid; else hi = mid; }
+        return lo;
+    };
+    const int64_t n_rec = (int64_t)b.rec_off.size();
+    std::vector<std::pair<size_t, size_t>> need((size_t)n);      // [first, last] block of each record
+    for (int64_t k = 0; k < n; k++) {
+        const uint64_t a = (uint64_t)b.rec_off[(size_t)idx[k]];
+        const uint64_t e = idx[k] + 1 < n_rec ? (uint64_t)b.rec_off[(size_t)idx[k] + 1] : (uint64_t)b.data_size;
+        need[(size_t)k] = {block_of(a), block_of(e ? e - 1 : 0)};
+    }
+    std::vector<std::pair<size_t, size_t>> runs(need);
+    std::sort(runs.begin(), runs.end());
+    size_t m = 0;
+    for (size_t k = 0; k < runs.size(); k++) {
+        if (m && runs[k].first <= runs[m - 1].second + 1) runs[m - 1].second = std::max(runs[m - 1].second, runs[k].second);
+        else runs[m++] = runs[k];
+    }
+    runs.resize(m);
+    std::vector<uint64_t> base(m + 1, 0);
+    for (size_t k = 0; k < m; k++)
+        base[k + 1] = base[k] + (b.blocks[runs[k].second].out_off + b.blocks[runs[k].second].out_len - b.blocks[runs[k].first].out_off);
+    if (!f.buf.ensure((size_t)base[m] + 8)) { err = "out of memory"; return false; }
+    for (size_t k = 0; k < m; k++)
+        if (!bgzf_inflate_range(*b.file, b.blocks, runs[k].first, runs[k].second + 1, reinterpret_cast<uint8_t *>(f.buf.p) + base[k], threads)) {
+            err = "corrupt BGZF block";
+            return false;
+        }
+    for (int64_t k = 0; k < n; k++) {
+        const size_t r = (size_t)(std::upper_bound(runs.begin(), runs.end(), std::make_pair(need[(size_t)k].first, (size_t)-1)) - runs.begin()) - 1;
+        f.ptr[(size_t)k] = reinterpret_cast<const uint8_t *>(f.buf.p) + base[r] +
+                           ((uint64_t)b.rec_off[(size_t)idx[k]] - b.blocks[runs[r].first].out_off);
+    }
+    return true;
 }
 
 // reference length consumed: M, D, N, =, X  (pysam reference_length)

@@ -107,6 +107,7 @@ struct HostBuf {   // pinned staging
 // One batch on its way through the BAM -> SAM pipeline: host staging (page-locked where it crosses PCIe) and offsets.
 struct npore_batch_slot {
     RawBuf refs{true}, seqs{true}, cigs{true}, alns{true}, finals, sam;
+    RecFetch rf;                 // the batch's BAM records (streamed handles: inflated for the batch)
     std::vector<int64_t> ro, so, co, oo, fo, olen, flen;
     int64_t sam_len = 0;
     int rc = 0;
@@ -1174,9 +1175,198 @@ int npore_debug_fetch(npore_ctx *ctx, int what, void *dst, int64_t bytes)
 
 
 // ---- BAM ingest / SAM emit (hostio.hpp) ---------------------------------------------------------
-npore_bam *npore_bam_open(const char *path, int threads)
+namespace {
+// header of a BAM stream at d[0 .. N): text, references; *hdr_end = offset of the first record.  -1: more bytes needed
+// (streamed mode reads on), 0: corrupt, 1: ok
+int bam_parse_header(npore_bam *b, const uint8_t *d, size_t N, size_t *hdr_end)
+{
+    if (N < 12) return -1;
+    if (std::memcmp(d, "BAM\1", 4) != 0) return 0;
+    size_t p = 4;
+    const int64_t l_text = rdi32(&d[p]);
+    p += 4;
+    if (l_text < 0) return 0;
+    if (p + (size_t)l_text + 4 > N) return -1;
+    b->text.assign(reinterpret_cast<const char *>(&d[p]), (size_t)l_text);
+    while (!b->text.empty() && b->text.back() == '\0') b->text.pop_back();
+    p += (size_t)l_text;
+    const int32_t n_ref = rdi32(&d[p]);
+    p += 4;
+    if (n_ref < 0) return 0;
+    b->ref_names.clear();
+    b->ref_lens.clear();
+    for (int32_t k = 0; k < n_ref; k++) {
+        if (p + 4 > N) return -1;
+        const int32_t l_name = rdi32(&d[p]);
+        if (l_name < 1) return 0;
+        if (p + 8 + (size_t)l_name > N) return -1;
+        b->ref_names.emplace_back(reinterpret_cast<const char *>(&d[p + 4]), (size_t)l_name - 1);
+        b->ref_lens.push_back(rdi32(&d[p + 4 + (size_t)l_name]));
+        p += 8 + (size_t)l_name;
+    }
+    *hdr_end = p;
+    return 1;
+}
+
+// what selection needs of the records in d[first record .. ): validation + metadata on all cores.  `offs` = offsets of
+// the records' block_size fields relative to d; the metadata is appended to the handle's arrays.
+bool bam_index_records(npore_bam *b, const uint8_t *d, const std::vector<int64_t> &offs, int64_t global_base, int threads)
+{
+    const int64_t n = (int64_t)offs.size(), at = (int64_t)b->rec_off.size();
+    b->rec_off.resize((size_t)(at + n));
+    b->m_ref.resize((size_t)(at + n));
+    b->m_pos.resize((size_t)(at + n));
+    b->m_span.resize((size_t)(at + n));
+    b->m_flag.resize((size_t)(at + n));
+    std::atomic<int> corrupt{0};
+    const int64_t per = 256;
+    parallel_for((n + per - 1) / per, threads, [&](int64_t blk) {
+        for (int64_t i = blk * per; i < std::min(n, (blk + 1) * per); i++) {
+            // the variable-length parts the accessors will walk must lie inside the record
+            const uint8_t *q = d + offs[(size_t)i];
+            const int32_t bs = rdi32(q);
+            const uint8_t *f = q + 4;
+            const int64_t l_rn = f[8], n_cig = rd16(f + 12), l_seq = rdi32(f + 16);
+            if (l_rn < 1 || l_seq < 0 || 32 + l_rn + 4 * n_cig + (l_seq + 1) / 2 + l_seq > bs || f[32 + l_rn - 1] != 0) { corrupt++; return; }
+            const RecView r = rec_view(q);
+            const int64_t span = rec_ref_len(r);
+            b->rec_off[(size_t)(at + i)] = global_base + offs[(size_t)i];
+            b->m_ref[(size_t)(at + i)] = r.ref_id();
+            b->m_pos[(size_t)(at + i)] = r.pos();
+            b->m_span[(size_t)(at + i)] = (int32_t)std::min<int64_t>(span, INT32_MAX);
+            b->m_flag[(size_t)(at + i)] = (uint16_t)r.flag();
+        }
+    });
+    return corrupt == 0;
+}
+
+// per-reference record lists and the shortcuts of npore_bam_select, from the per-record metadata
+void bam_finish_index(npore_bam *b)
+{
+    const int32_t n_ref = (int32_t)b->ref_names.size();
+    b->ref_has_reads.assign((size_t)n_ref, 0);
+    b->by_ref.assign((size_t)n_ref, {});
+    b->ref_sorted.assign((size_t)n_ref, 1);
+    b->ref_max_len.assign((size_t)n_ref, 0);
+    std::vector<int64_t> last_pos((size_t)n_ref, -1);
+    const int64_t n_rec = (int64_t)b->rec_off.size();
+    for (int64_t i = 0; i < n_rec; i++) {
+        const int32_t rid = b->m_ref[(size_t)i];
+        if (rid >= 0 && rid < n_ref) {
+            const int64_t pos = b->m_pos[(size_t)i];
+            b->ref_has_reads[(size_t)rid] = 1;
+            b->by_ref[(size_t)rid].push_back(i);
+            if (pos < last_pos[(size_t)rid]) b->ref_sorted[(size_t)rid] = 0;
+            last_pos[(size_t)rid] = pos;
+            b->ref_max_len[(size_t)rid] = std::max<int64_t>(b->ref_max_len[(size_t)rid], b->m_span[(size_t)i]);
+        }
+    }
+}
+
+// STREAMED open: block table, then the stream in windows of `win_blocks` BGZF blocks (inflated on all cores, walked,
+// dropped); a record that straddles two windows is carried over.  Resident: one window + 22 bytes per record.
+npore_bam *bam_open_streamed(const char *path, int threads, std::unique_ptr<PreadFile> file, const char *index_path)
+{
+    std::unique_ptr<npore_bam> hold(new npore_bam());
+    npore_bam *b = hold.get();
+    b->streamed = true;
+    b->file = std::move(file);
+    uint64_t total = 0;
+    if (!bgzf_scan(*b->file, b->blocks, total)) { fail(NPORE_E_INVALID, std::string("'") + path + "' is not a BGZF file"); return nullptr; }
+    b->data_size = (size_t)total;
+    if (index_path && *index_path) {        // another process of this node has made the record index already
+        MappedFile ix;
+        const uint8_t *q = nullptr;
+        if (ix.open(index_path) && ix.n >= 32 && std::memcmp(ix.p, "NPOREIX1", 8) == 0) q = ix.p;
+        if (q) {
+            uint64_t n_rec, hdr_len, tot;
+            std::memcpy(&n_rec, q + 8, 8); std::memcpy(&hdr_len, q + 16, 8); std::memcpy(&tot, q + 24, 8);
+            size_t hdr_end = 0;
+            const size_t need = 32 + hdr_len + n_rec * 22;
+            if (tot == total && ix.n >= need && bam_parse_header(b, q + 32, (size_t)hdr_len, &hdr_end) == 1) {
+                const uint8_t *a = q + 32 + hdr_len;
+                b->rec_off.resize(n_rec); b->m_ref.resize(n_rec); b->m_pos.resize(n_rec); b->m_span.resize(n_rec); b->m_flag.resize(n_rec);
+                std::memcpy(b->rec_off.data(), a, n_rec * 8); a += n_rec * 8;
+                std::memcpy(b->m_ref.data(), a, n_rec * 4); a += n_rec * 4;
+                std::memcpy(b->m_pos.data(), a, n_rec * 4); a += n_rec * 4;
+                std::memcpy(b->m_span.data(), a, n_rec * 4); a += n_rec * 4;
+                std::memcpy(b->m_flag.data(), a, n_rec * 2);
+                bam_finish_index(b);
+                return hold.release();
+            }
+        }
+        // (an unusable index file: fall through and index the file here)
+    }
+    size_t win_blocks = 4096;               // <= 256 MB of inflated stream per window
+    if (const char *e = std::getenv("NPORE_BAM_WINDOW_BLOCKS")) win_blocks = (size_t)std::max(1, std::atoi(e));
+    RawBuf win;
+    std::vector<uint8_t> carry;             // the incomplete tail of the previous window
+    uint64_t carry_at = 0;                  // stream offset of carry[0]
+    bool have_header = false;
+    std::vector<int64_t> offs;
+    for (size_t b0 = 0; b0 < b->blocks.size();) {
+        const size_t b1 = std::min(b->blocks.size(), b0 + win_blocks);
+        const uint64_t w0 = b->blocks[b0].out_off, w1 = b->blocks[b1 - 1].out_off + b->blocks[b1 - 1].out_len;
+        if (!win.ensure(carry.size() + (size_t)(w1 - w0) + 8)) { fail(NPORE_E_NOMEM, "BAM window"); return nullptr; }
+        uint8_t *d = reinterpret_cast<uint8_t *>(win.p);
+        if (!carry.empty()) std::memcpy(d, carry.data(), carry.size());
+        if (!bgzf_inflate_range(*b->file, b->blocks, b0, b1, d + carry.size(), threads)) {
+            fail(NPORE_E_INVALID, std::string("'") + path + "': corrupt BGZF block");
+            return nullptr;
+        }
+        const uint64_t base = carry.empty() ? w0 : carry_at;      // stream offset of d[0]
+        const size_t N = carry.size() + (size_t)(w1 - w0);
+        size_t p = 0;
+        if (!have_header) {
+            size_t hdr_end = 0;
+            const int rc = bam_parse_header(b, d, N, &hdr_end);
+            if (rc == 0) { fail(NPORE_E_INVALID, std::string("'") + path + "' is not a BAM file"); return nullptr; }
+            if (rc < 0) {                                         // the header does not end in this window: read on
+                if (b1 == b->blocks.size()) { fail(NPORE_E_INVALID, "truncated BAM header"); return nullptr; }
+                carry.assign(d, d + N);
+                carry_at = base;
+                b0 = b1;
+                continue;
+            }
+            have_header = true;
+            p = hdr_end;
+        }
+        offs.clear();
+        while (p + 4 <= N) {
+            const int32_t bs = rdi32(&d[p]);
+            if (bs < 32) { fail(NPORE_E_INVALID, "truncated BAM record"); return nullptr; }
+            if (p + 4 + (size_t)bs > N) break;
+            offs.push_back((int64_t)p);
+            p += 4 + (size_t)bs;
+        }
+        if (!bam_index_records(b, d, offs, (int64_t)base, threads)) { fail(NPORE_E_INVALID, "corrupt BAM record"); return nullptr; }
+        carry.assign(d + p, d + N);
+        carry_at = base + p;
+        b0 = b1;
+    }
+    if (!have_header) { fail(NPORE_E_INVALID, std::string("'") + path + "' is not a BAM file"); return nullptr; }
+    if (!carry.empty()) { fail(NPORE_E_INVALID, "truncated BAM record"); return nullptr; }
+    bam_finish_index(b);
+    return hold.release();
+}
+}  // namespace
+
+// mode 0: automatic (streamed when the file is BGZF and larger than NPORE_BAM_STREAM_MB, default 1024 MB), 1: whole file
+// resident, 2: streamed.  index_path (may be NULL): a record index saved by npore_bam_save_index for this very file --
+// a streamed handle then skips its indexing pass (one process of a node indexes, the others load).
+npore_bam *npore_bam_open_mode(const char *path, int threads, int mode, const char *index_path)
 try {
     if (!path) { fail(NPORE_E_INVALID, "null path"); return nullptr; }
+    if (mode != 1) {
+        std::unique_ptr<PreadFile> pf(new PreadFile());
+        if (!pf->open(path)) { fail(NPORE_E_INVALID, std::string("BAM file '") + path + "' not found"); return nullptr; }
+        uint8_t magic[4] = {0, 0, 0, 0};
+        const bool gz = pf->size >= 28 && pf->read(0, magic, 4) && magic[0] == 31 && magic[1] == 139;
+        uint64_t limit_mb = 1024;
+        if (const char *e = std::getenv("NPORE_BAM_STREAM_MB")) limit_mb = (uint64_t)std::max(0ll, std::atoll(e));
+        if (gz && (mode == 2 || pf->size > limit_mb * 1048576ull)) return bam_open_streamed(path, threads, std::move(pf), index_path);
+        if (mode == 2) { fail(NPORE_E_INVALID, std::string("'") + path + "' is not a BGZF file (streamed mode)"); return nullptr; }
+    }
     std::unique_ptr<MappedFile> mfp(new MappedFile());
     MappedFile &mf = *mfp;
     if (!mf.open(path)) { fail(NPORE_E_INVALID, std::string("BAM file '") + path + "' not found"); return nullptr; }
@@ -1198,67 +1388,56 @@ try {
     }
     const uint8_t *d = b->data;
     const size_t N = b->data_size;
-    size_t p = 4;
-    const int64_t l_text = rdi32(&d[p]);
-    p += 4;
-    if (l_text < 0 || p + (size_t)l_text + 4 > N) { fail(NPORE_E_INVALID, "truncated BAM header"); return nullptr; }
-    b->text.assign(reinterpret_cast<const char *>(&d[p]), (size_t)l_text);
-    while (!b->text.empty() && b->text.back() == '\0') b->text.pop_back();
-    p += (size_t)l_text;
-    const int32_t n_ref = rdi32(&d[p]);
-    p += 4;
-    // every reference entry takes at least 9 bytes (l_name, one name byte + NUL ... l_ref)
-    if (n_ref < 0 || (size_t)n_ref > (N - p) / 9) { fail(NPORE_E_INVALID, "corrupt BAM header (n_ref)"); return nullptr; }
-    for (int32_t k = 0; k < n_ref; k++) {
-        if (p + 4 > N) { fail(NPORE_E_INVALID, "truncated BAM header"); return nullptr; }
-        const int32_t l_name = rdi32(&d[p]);
-        if (l_name < 1 || p + 8 + (size_t)l_name > N) { fail(NPORE_E_INVALID, "truncated BAM header"); return nullptr; }
-        b->ref_names.emplace_back(reinterpret_cast<const char *>(&d[p + 4]), (size_t)l_name - 1);
-        b->ref_lens.push_back(rdi32(&d[p + 4 + (size_t)l_name]));
-        p += 8 + (size_t)l_name;
-    }
-    b->ref_has_reads.assign((size_t)n_ref, 0);
-    b->by_ref.assign((size_t)n_ref, {});
-    b->ref_sorted.assign((size_t)n_ref, 1);
-    b->ref_max_len.assign((size_t)n_ref, 0);
-    // records: offsets (one hop per record), then validation + reference spans on all cores, then the per-reference lists
+    size_t p = 0;
+    if (bam_parse_header(b, d, N, &p) != 1) { fail(NPORE_E_INVALID, "truncated BAM header"); return nullptr; }
+    // records: offsets (one hop per record), then validation + metadata on all cores, then the per-reference lists
+    std::vector<int64_t> offs;
     while (p + 4 <= N) {
         const int32_t bs = rdi32(&d[p]);
         if (bs < 32 || p + 4 + (size_t)bs > N) { fail(NPORE_E_INVALID, "truncated BAM record"); return nullptr; }
-        b->rec_off.push_back((int64_t)p);
+        offs.push_back((int64_t)p);
         p += 4 + (size_t)bs;
     }
-    const int64_t n_rec = (int64_t)b->rec_off.size();
-    std::vector<int64_t> span((size_t)n_rec, 0);
-    std::atomic<int> corrupt{0};
-    const int64_t per = 256;
-    parallel_for((n_rec + per - 1) / per, threads, [&](int64_t blk) {
-        for (int64_t i = blk * per; i < std::min(n_rec, (blk + 1) * per); i++) {
-            // the variable-length parts the accessors will walk must lie inside the record
-            const uint8_t *q = d + b->rec_off[(size_t)i];
-            const int32_t bs = rdi32(q);
-            const uint8_t *f = q + 4;
-            const int64_t l_rn = f[8], n_cig = rd16(f + 12), l_seq = rdi32(f + 16);
-            if (l_rn < 1 || l_seq < 0 || 32 + l_rn + 4 * n_cig + (l_seq + 1) / 2 + l_seq > bs || f[32 + l_rn - 1] != 0) { corrupt++; return; }
-            span[(size_t)i] = rec_ref_len(rec_at(*b, i));
-        }
-    });
-    if (corrupt) { fail(NPORE_E_INVALID, "corrupt BAM record"); return nullptr; }
-    std::vector<int64_t> last_pos((size_t)n_ref, -1);
-    for (int64_t i = 0; i < n_rec; i++) {
-        const int32_t rid = rdi32(d + b->rec_off[(size_t)i] + 4);
-        if (rid >= 0 && rid < n_ref) {
-            const int64_t pos = rdi32(d + b->rec_off[(size_t)i] + 8);
-            b->ref_has_reads[(size_t)rid] = 1;
-            b->by_ref[(size_t)rid].push_back(i);
-            if (pos < last_pos[(size_t)rid]) b->ref_sorted[(size_t)rid] = 0;
-            last_pos[(size_t)rid] = pos;
-            b->ref_max_len[(size_t)rid] = std::max(b->ref_max_len[(size_t)rid], span[(size_t)i]);
-        }
-    }
+    if (!bam_index_records(b, d, offs, 0, threads)) { fail(NPORE_E_INVALID, "corrupt BAM record"); return nullptr; }
+    bam_finish_index(b);
     return hold.release();
 }
 NPORE_CATCH_PTR
+npore_bam *npore_bam_open(const char *path, int threads) { return npore_bam_open_mode(path, threads, 0, nullptr); }
+int npore_bam_is_streamed(const npore_bam *b) { return b && b->streamed ? 1 : 0; }
+
+// The record index of a handle (header + per-record offsets and metadata: 22 bytes per record), complete or not there
+// at all, for npore_bam_open_mode(..., index_path) in the other processes of a node.
+int npore_bam_save_index(const npore_bam *b, const char *path)
+try {
+    if (!b || !path) return fail(NPORE_E_INVALID, "null argument");
+    // the header as a BAM stream prefix, so that the loader parses it with the same code
+    std::string hdr("BAM\1", 4);
+    auto put32 = [&](int32_t v) { hdr.append(reinterpret_cast<const char *>(&v), 4); };
+    put32((int32_t)b->text.size());
+    hdr += b->text;
+    put32((int32_t)b->ref_names.size());
+    for (size_t k = 0; k < b->ref_names.size(); k++) {
+        put32((int32_t)b->ref_names[k].size() + 1);
+        hdr.append(b->ref_names[k].c_str(), b->ref_names[k].size() + 1);
+        put32((int32_t)b->ref_lens[k]);
+    }
+    const std::string tmp = std::string(path) + ".tmp" + std::to_string((long long)::getpid());
+    FILE *fh = std::fopen(tmp.c_str(), "wb");
+    if (!fh) return fail(NPORE_E_INVALID, "cannot create '" + tmp + "'");
+    const uint64_t n_rec = b->rec_off.size(), hdr_len = hdr.size(), tot = b->data_size;
+    bool ok = std::fwrite("NPOREIX1", 1, 8, fh) == 8 && std::fwrite(&n_rec, 8, 1, fh) == 1 && std::fwrite(&hdr_len, 8, 1, fh) == 1 &&
+              std::fwrite(&tot, 8, 1, fh) == 1 && std::fwrite(hdr.data(), 1, hdr.size(), fh) == hdr.size();
+    auto put = [&](const void *p, size_t bytes) { if (ok && bytes) ok = std::fwrite(p, 1, bytes, fh) == bytes; };
+    put(b->rec_off.data(), n_rec * 8); put(b->m_ref.data(), n_rec * 4); put(b->m_pos.data(), n_rec * 4);
+    put(b->m_span.data(), n_rec * 4); put(b->m_flag.data(), n_rec * 2);
+    if (std::fclose(fh) != 0 || !ok || std::rename(tmp.c_str(), path) != 0) {
+        std::remove(tmp.c_str());
+        return fail(NPORE_E_INVALID, std::string("cannot write '") + path + "'");
+    }
+    return NPORE_OK;
+}
+NPORE_CATCH_INT
 void npore_bam_close(npore_bam *b) { delete b; }
 
 int64_t npore_bam_inflated_size(const npore_bam *b) { return b ? (int64_t)b->data_size : 0; }
@@ -1266,6 +1445,7 @@ int64_t npore_bam_inflated_size(const npore_bam *b) { return b ? (int64_t)b->dat
 int npore_bam_dump_inflated(const npore_bam *b, const char *path)
 try {
     if (!b || !path) return fail(NPORE_E_INVALID, "null argument");
+    if (b->streamed) return fail(NPORE_E_UNSUPPORTED, "a streamed BAM handle holds no inflated stream (share its index: npore_bam_save_index)");
     const std::string tmp = std::string(path) + ".tmp" + std::to_string((long long)::getpid());
     FILE *fh = std::fopen(tmp.c_str(), "wb");
     if (!fh) return fail(NPORE_E_INVALID, "cannot create '" + tmp + "'");
@@ -1296,16 +1476,15 @@ int64_t npore_bam_select(const npore_bam *b, int n_regions, const int32_t *ref_i
             // coordinate-sorted (the usual case): skip everything that ends before the region can start
             const int64_t lo = start[g] - b->ref_max_len[(size_t)ref_id[g]];
             first = (size_t)(std::lower_bound(recs.begin(), recs.end(), lo,
-                                              [&](int64_t i, int64_t v) { return (int64_t)rec_at(*b, i).pos() < v; }) - recs.begin());
+                                              [&](int64_t i, int64_t v) { return (int64_t)b->m_pos[(size_t)i] < v; }) - recs.begin());
         }
         for (size_t q = first; q < recs.size(); q++) {
             const int64_t i = recs[q];
-            const RecView r = rec_at(*b, i);
-            if (b->ref_sorted[(size_t)ref_id[g]] && r.pos() >= stop[g]) break;
-            const int64_t rl = rec_ref_len(r);
-            if (!(r.pos() < stop[g] && r.pos() + rl > start[g])) continue;        // overlaps [start, stop)
+            const int64_t pos = b->m_pos[(size_t)i], rl = b->m_span[(size_t)i];
+            if (b->ref_sorted[(size_t)ref_id[g]] && pos >= stop[g]) break;
+            if (!(pos < stop[g] && pos + rl > start[g])) continue;                 // overlaps [start, stop)
             if (max_reads > 0 && kept >= max_reads) return kept;                   // src/bam.pyx:29-30
-            if (r.flag() & (0x100 | 0x800 | 0x4)) continue;                       // secondary / supplementary / unmapped, :31-32
+            if (b->m_flag[(size_t)i] & (0x100 | 0x800 | 0x4)) continue;           // secondary / supplementary / unmapped, :31-32
             if (kept < cap) out_idx[kept] = i;
             kept++;
         }
@@ -1340,12 +1519,18 @@ bool pack_args_ok(const npore_bam *b, const int64_t *idx, int64_t n)
 }
 }  // namespace
 
-int npore_bam_pack_sizes(const npore_bam *b, const int64_t *idx, int64_t n, int64_t *ref_off, int64_t *seq_off, int64_t *cig_off)
-try {
-    if (!pack_args_ok(b, idx, n) || !ref_off || !seq_off || !cig_off) return fail(NPORE_E_INVALID, "bad argument");
+namespace {
+int fetch_records(const npore_bam *b, const int64_t *idx, int64_t n, int threads, RecFetch &rf)
+{
+    std::string err;
+    if (!bam_fetch(*b, idx, n, threads, rf, err)) return fail(NPORE_E_INVALID, "BAM records: " + err);
+    return NPORE_OK;
+}
+void pack_sizes_of(const RecFetch &rf, int64_t n, int64_t *ref_off, int64_t *seq_off, int64_t *cig_off)
+{
     ref_off[0] = seq_off[0] = cig_off[0] = 0;
     for (int64_t k = 0; k < n; k++) {
-        const RecView r = rec_at(*b, idx[k]);
+        const RecView r = rec_of(rf, k);
         int64_t lead, trail, ops = 0;
         rec_clips(r, lead, trail);
         for (int c = 0; c < r.n_cigar(); c++) {
@@ -1356,10 +1541,24 @@ try {
         seq_off[k + 1] = seq_off[k] + std::max<int64_t>(0, (int64_t)r.l_seq() - lead - trail);
         cig_off[k + 1] = cig_off[k] + ops;
     }
+}
+}  // namespace
+
+int npore_bam_pack_sizes(const npore_bam *b, const int64_t *idx, int64_t n, int64_t *ref_off, int64_t *seq_off, int64_t *cig_off)
+try {
+    if (!pack_args_ok(b, idx, n) || !ref_off || !seq_off || !cig_off) return fail(NPORE_E_INVALID, "bad argument");
+    RecFetch &rf = const_cast<npore_bam *>(b)->api_fetch;
+    if (int rc = fetch_records(b, idx, n, 0, rf)) return rc;
+    pack_sizes_of(rf, n, ref_off, seq_off, cig_off);
     return NPORE_OK;
 }
 NPORE_CATCH_INT
 
+namespace {
+int pack_records(const npore_bam *b, const RecFetch &rf, const npore_fasta *fa, const int32_t *fasta_of_ref, int64_t n,
+                 uint8_t *refs, const int64_t *ref_off, uint8_t *seqs, const int64_t *seq_off, char *cigs,
+                 const int64_t *cig_off, int threads);
+}
 int npore_bam_pack(const npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref, const int64_t *idx, int64_t n,
                    uint8_t *refs, const int64_t *ref_off, uint8_t *seqs, const int64_t *seq_off, char *cigs,
                    const int64_t *cig_off, int threads)
@@ -1367,9 +1566,20 @@ try {
     if (!pack_args_ok(b, idx, n) || !fa || !fasta_of_ref || !ref_off || !seq_off || !cig_off ||
         (n > 0 && (!refs || !seqs || !cigs)))
         return fail(NPORE_E_INVALID, "bad argument");
+    RecFetch &rf = const_cast<npore_bam *>(b)->api_fetch;
+    if (int rc = fetch_records(b, idx, n, threads, rf)) return rc;
+    return pack_records(b, rf, fa, fasta_of_ref, n, refs, ref_off, seqs, seq_off, cigs, cig_off, threads);
+}
+NPORE_CATCH_INT
+
+namespace {
+int pack_records(const npore_bam *b, const RecFetch &rf, const npore_fasta *fa, const int32_t *fasta_of_ref, int64_t n,
+                 uint8_t *refs, const int64_t *ref_off, uint8_t *seqs, const int64_t *seq_off, char *cigs,
+                 const int64_t *cig_off, int threads)
+{
     std::atomic<int> bad{0};
     parallel_for(n, threads, [&](int64_t k) {
-        const RecView r = rec_at(*b, idx[k]);
+        const RecView r = rec_of(rf, k);
         const int32_t rid = r.ref_id();
         const int fi = (rid >= 0 && rid < (int32_t)b->ref_names.size()) ? fasta_of_ref[rid] : -1;
         if (fi < 0 || fi >= (int)fa->names.size()) { bad++; return; }
@@ -1401,19 +1611,17 @@ try {
     });
     return bad ? fail(NPORE_E_INVALID, "a selected read lies on a contig that is not in the FASTA") : NPORE_OK;
 }
-NPORE_CATCH_INT
 
-namespace {
-int format_sam_into(const npore_bam *b, const int64_t *idx, int64_t n, const char *finals, const int64_t *final_off,
+int format_sam_into(const npore_bam *b, const RecFetch &rf, int64_t n, const char *finals, const int64_t *final_off,
                     const int64_t *final_len, const int32_t *status, int threads, RawBuf &out, int64_t *sam_len)
 {
-    if (!pack_args_ok(b, idx, n) || !sam_len || (n > 0 && (!finals || !final_off || !final_len || !status)))
+    if (!b || n < 0 || !sam_len || (n > 0 && (!finals || !final_off || !final_len || !status)))
         return fail(NPORE_E_INVALID, "bad argument");
     // pass 1: line sizes; pass 2: fill (both parallel over reads)
     std::vector<int64_t> off((size_t)n + 1, 0);
     auto line = [&](int64_t k, char *dst) -> int64_t {    // returns the length; writes when dst != nullptr
         if (status[k] & NPORE_ST_BAD_INPUT) return 0;    // refused reads are not written
-        const RecView r = rec_at(*b, idx[k]);
+        const RecView r = rec_of(rf, k);
         int64_t lead, trail;
         rec_clips(r, lead, trail);
         const int64_t sl = std::max<int64_t>(0, (int64_t)r.l_seq() - lead - trail);
@@ -1459,8 +1667,9 @@ int format_sam_into(const npore_bam *b, const int64_t *idx, int64_t n, const cha
 int npore_bam_format_sam(npore_bam *b, const int64_t *idx, int64_t n, const char *finals, const int64_t *final_off,
                          const int64_t *final_len, const int32_t *status, int threads, const char **sam, int64_t *sam_len)
 try {
-    if (!b || !sam) return fail(NPORE_E_INVALID, "bad argument");
-    const int rc = format_sam_into(b, idx, n, finals, final_off, final_len, status, threads, b->sam, sam_len);
+    if (!pack_args_ok(b, idx, n) || !sam) return fail(NPORE_E_INVALID, "bad argument");
+    if (int rc = fetch_records(b, idx, n, threads, b->api_fetch)) return rc;
+    const int rc = format_sam_into(b, b->api_fetch, n, finals, final_off, final_len, status, threads, b->sam, sam_len);
     *sam = b->sam.p;
     return rc;
 }
@@ -1474,11 +1683,14 @@ int slot_pack(const npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of
     for (auto *v : {&s.ro, &s.so, &s.co, &s.oo, &s.fo}) v->assign((size_t)n + 1, 0);
     s.olen.assign((size_t)n, 0);
     s.flen.assign((size_t)n, 0);
-    if (int rc = npore_bam_pack_sizes(b, idx, n, s.ro.data(), s.so.data(), s.co.data())) return rc;
+    if (!pack_args_ok(b, idx, n)) return fail(NPORE_E_INVALID, "bad argument");
+    if (int rc = fetch_records(b, idx, n, threads, s.rf)) return rc;
+    pack_sizes_of(s.rf, n, s.ro.data(), s.so.data(), s.co.data());
     if (!s.refs.ensure((size_t)s.ro[(size_t)n] + 64) || !s.seqs.ensure((size_t)s.so[(size_t)n] + 64) || !s.cigs.ensure((size_t)s.co[(size_t)n] + 64))
         return fail(NPORE_E_NOMEM, "batch buffers");
-    if (int rc = npore_bam_pack(b, fa, fasta_of_ref, idx, n, reinterpret_cast<uint8_t *>(s.refs.p), s.ro.data(),
-                                reinterpret_cast<uint8_t *>(s.seqs.p), s.so.data(), s.cigs.p, s.co.data(), threads))
+    if (!fa || !fasta_of_ref) return fail(NPORE_E_INVALID, "bad argument");
+    if (int rc = pack_records(b, s.rf, fa, fasta_of_ref, n, reinterpret_cast<uint8_t *>(s.refs.p), s.ro.data(),
+                              reinterpret_cast<uint8_t *>(s.seqs.p), s.so.data(), s.cigs.p, s.co.data(), threads))
         return rc;
     for (int64_t k = 0; k < n; k++) {
         const int64_t cap = (s.ro[(size_t)k + 1] - s.ro[(size_t)k]) + (s.so[(size_t)k + 1] - s.so[(size_t)k]);
@@ -1511,7 +1723,8 @@ int slot_post(const npore_bam *b, const int64_t *idx, int64_t n, const int32_t *
         s.flen[(size_t)k] = (int64_t)c.size();
     });
     if (ms_std) *ms_std = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    return format_sam_into(b, idx, n, s.finals.p, s.fo.data(), s.flen.data(), status, threads, s.sam, &s.sam_len);
+    (void)idx;
+    return format_sam_into(b, s.rf, n, s.finals.p, s.fo.data(), s.flen.data(), status, threads, s.sam, &s.sam_len);
 }
 }  // namespace
 

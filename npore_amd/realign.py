@@ -96,7 +96,13 @@ def main():
     n = 0
     if native:
         idx = bam.select(cfg.args.regions, cfg.args.max_reads)
-        idx = idx[rank::world]                      # reads are independent: dealt by index, no data-path collective
+        # reads are independent: dealt by index, no data-path collective.  A resident BAM is dealt round-robin; a
+        # STREAMED one in contiguous shares, so that a rank only ever inflates the blocks that hold its own reads
+        if bam.streamed and world > 1:
+            per = (len(idx) + world - 1) // world
+            idx = idx[rank * per:(rank + 1) * per]
+        else:
+            idx = idx[rank::world]
         print("> computing individual read realignments")
         n += bam_mod.realign_native(ctx, bam, ref_seqs, idx, out_sam, batch_reads=cfg.args.batch_reads, threads=threads)
         bam.close()

@@ -488,6 +488,15 @@ def test_native_realign_batch_matches_python_pipeline(ctx, tmp_path):
         out = tmp_path / "pipe.sam"
         st2 = nb.realign_file(ctx, nf, idx, str(out), batch_reads=5, r=30)
         assert np.array_equal(st2, pst) and out.read_bytes() == text
+        # a STREAMED handle (bounded-memory ingest: every batch inflates the BGZF blocks its records lie in) writes the same
+        ns = bam.NativeBam(str(tmp_path / "s.bam"), stream=True)
+        assert ns.streamed and np.array_equal(ns.select(cfg.args.regions), idx)
+        out3 = tmp_path / "pipe_streamed.sam"
+        st3 = ns.realign_file(ctx, nf, idx, str(out3), batch_reads=5, r=30)
+        assert np.array_equal(st3, pst) and out3.read_bytes() == text
+        text4, st4 = ns.realign_batch(ctx, nf, idx[::-1], r=30)
+        assert np.array_equal(st4, pst[::-1]) and sorted(bytes(text4).splitlines()) == sorted(text.splitlines())
+        ns.close()
     finally:
         cfg.args = old
 
@@ -527,6 +536,14 @@ def test_realign_cli_two_processes(tmp_path):
     got, want = recs(prefix + ".sam"), recs(os.path.join(GOLDEN, "data", "npore_realigned.sam"))
     assert len(got) == 10 and got == want
     assert not os.path.exists(prefix + ".part0.sam") and not os.path.exists(prefix + ".part1.sam")
+    # the same with the BAM STREAMED (bounded-memory ingest): local rank 0 shares the record index, every rank takes
+    # a contiguous share of the reads and inflates only the blocks that hold it
+    env = dict(os.environ, NPORE_BAM_STREAM="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(29900 + os.getpid() % 100), "-m",
+                           "npore_amd.realign", "--bam", os.path.join(GOLDEN, "data", "reads.bam"),
+                           "--ref", os.path.join(GOLDEN, "data", "ref.fasta"), "--out_prefix", prefix + "_s"], cwd=REPO, env=env)
+    assert recs(prefix + "_s.sam") == want
 
 
 def test_long_polymers_and_many_periods(ctx, tables):

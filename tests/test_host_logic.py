@@ -255,7 +255,7 @@ def test_realign_part_files_gloo_world2(tmp_path):
 
 
 # ---- native host I/O (csrc/hostio.hpp) against the pure-Python restatement in npore_amd/bam.py ----
-def _native_vs_python(bam_path, fasta_path, regions, max_reads=0):
+def _native_vs_python(bam_path, fasta_path, regions, max_reads=0, stream=None):
     import argparse
     from npore_amd import bam, cfg
     from npore_amd.cig import bases_to_int, expand_cigar
@@ -265,7 +265,8 @@ def _native_vs_python(bam_path, fasta_path, regions, max_reads=0):
         py = bam.BamFile(bam_path)
         refs = bam.read_fasta(fasta_path)
         rds = list(bam.get_read_data(py, refs))
-        nb, nf = bam.NativeBam(bam_path, threads=3), bam.NativeFasta(fasta_path)
+        nb, nf = bam.NativeBam(bam_path, threads=3, stream=stream), bam.NativeFasta(fasta_path)
+        assert stream is None or nb.streamed == stream
         assert nb.references == py.references and nb.lengths == py.lengths
         assert nb.n_records == len(py.records) and nb.refs_with_reads() == py.refs_with_reads()
         assert list(nf) == list(refs) and all(len(nf[k]) == len(refs[k]) for k in refs)
@@ -515,3 +516,76 @@ def test_append_file_copy_file_range(tmp_path):
     assert a.read_bytes() == b"header\n" + b"x" * 100_000 + b"tail"
     if real is not None:
         assert sum(calls) == 100_004        # every byte went through the in-kernel copy
+
+
+def test_streamed_bam_equals_resident(tmp_path, monkeypatch):
+    """STREAMED ingest (npore_bam_open_mode 2: block table + 22 bytes per record, the records of a batch inflated from
+    the BGZF blocks they lie in) against the resident mode and the Python reader: a BAM of ~120 BGZF blocks indexed in
+    windows of 2 blocks (records straddle blocks and windows, the header straddles the first window), selection by
+    region, packed bases / CIGARs, SAM text, all through tiny scattered batches; the saved record index reopens the
+    file without a second pass; a file that is not BGZF is refused in that mode."""
+    from npore_amd import bam
+    rng = np.random.default_rng(12)
+    contigs = {f"c{k}_{'x' * 40}": "".join(rng.choice(list("ACGT"), 60_000)) for k in range(3)}
+    fa = tmp_path / "r.fa"
+    fa.write_text("".join(f">{n}\n" + "\n".join(s_[i:i + 70] for i in range(0, len(s_), 70)) + "\n" for n, s_ in contigs.items()))
+    names = list(contigs)
+    recs = []
+    for k in range(900):
+        rid = int(rng.integers(0, 3))
+        L = int(rng.choice([30, 200, 3000, 9000]))
+        cig = [(0, L // 2), (1, 2), (2, 3), (7, L - L // 2 - 2)]
+        if k % 3 == 0: cig = [(4, 5)] + cig
+        if k % 7 == 0: cig = cig + [(4, 4), (5, 6)]
+        qlen = sum(n for op, n in cig if op in (0, 1, 4, 7, 8))
+        rlen = sum(n for op, n in cig if op in (0, 2, 3, 7, 8))
+        pos = int(rng.integers(0, 60_000 - rlen))
+        recs.append(dict(name=f"read{k}", flag=[0, 16, 0x100, 0, 4, 0x800][k % 6], ref_id=rid, pos=pos, mapq=int(rng.integers(0, 61)),
+                         cigar=cig, seq="".join(rng.choice(list("ACGT"), qlen)),
+                         qual=None if k % 5 == 0 else rng.integers(0, 42, qlen).astype(np.uint8).tobytes(), hp=None if k % 4 == 1 else k % 3))
+    recs.sort(key=lambda r_: (r_["ref_id"], r_["pos"]))
+    bp = str(tmp_path / "big.bam")
+    # (+ 2 500 read-less contigs in the header: ~300 KB, so the header itself spans several windows)
+    bam.write_bam(bp, [(n, len(s_)) for n, s_ in contigs.items()] + [(f"unplaced_scaffold_{k:05d}_{'y' * 30}", 1000 + k) for k in range(2500)],
+                  recs, level=1)
+    monkeypatch.setenv("NPORE_BAM_WINDOW_BLOCKS", "2")
+    regions = [(names[0], 0, 59_999), (names[2], 10_000, 30_000), (names[1], 0, 59_999)]
+    n1 = _native_vs_python(bp, str(fa), regions, stream=True)
+    assert n1 == _native_vs_python(bp, str(fa), regions, stream=False) and n1 > 300
+    assert _native_vs_python(bp, str(fa), regions, max_reads=17, stream=True) == 17
+    a, b = bam.NativeBam(bp, stream=False), bam.NativeBam(bp, stream=True)
+    lib = _lib.load()
+    assert lib.npore_bam_inflated_size(a.handle) == lib.npore_bam_inflated_size(b.handle)
+    ia = a.select(regions)
+    assert np.array_equal(ia, b.select(regions))
+    nf = bam.NativeFasta(str(fa))
+    for sub in (ia[::37], ia[5:9], ia[-3:][::-1], ia[:0]):         # scattered, adjacent, reversed, empty batches
+        pa, pb = a.pack(nf, sub), b.pack(nf, sub)
+        assert all(np.array_equal(x, y) for x, y in zip(pa, pb))
+        fin, st = ["5M"] * len(sub), np.zeros(len(sub), np.int32)
+        assert a.format_sam(sub, fin, st) == b.format_sam(sub, fin, st)
+    # the record index of a streamed handle, saved and loaded by another handle (what the other ranks of a node do)
+    ix = str(tmp_path / "big.idx")
+    assert lib.npore_bam_save_index(b.handle, os.fsencode(ix)) == 0 and os.path.getsize(ix) < 400_000 + 22 * b.n_records
+    h = lib.npore_bam_open_mode(os.fsencode(bp), 2, 2, os.fsencode(ix))
+    assert h and lib.npore_bam_n_records(h) == b.n_records and lib.npore_bam_is_streamed(h) == 1
+    lib.npore_bam_close(h)
+    assert lib.npore_bam_dump_inflated(b.handle, os.fsencode(str(tmp_path / "no.raw"))) != 0      # nothing to dump
+    raw = str(tmp_path / "copy.raw")
+    assert lib.npore_bam_dump_inflated(a.handle, os.fsencode(raw)) == 0
+    assert not lib.npore_bam_open_mode(os.fsencode(raw), 1, 2, None) and "BGZF" in _lib.last_error()
+    # several local ranks: rank 0 indexes and shares the index, rank 1 loads it
+    if os.path.isdir("/dev/shm"):
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+        monkeypatch.setenv("MASTER_PORT", str(41000 + os.getpid() % 20000))
+        monkeypatch.setenv("LOCAL_RANK", "0")
+        maker = bam.NativeBam(bp, stream=True)
+        assert maker._shared and maker._shared[0].endswith(".idx") and os.path.exists(maker._shared[0])
+        monkeypatch.setenv("LOCAL_RANK", "1")
+        user = bam.NativeBam(bp, stream=True)
+        assert user.streamed and np.array_equal(user.select(regions), ia)
+        shared = maker._shared[0]
+        user.close(); maker.close()
+        assert not os.path.exists(shared)
+        os.remove(shared.replace(".idx", ".skip"))
+    a.close(); b.close(); nf.close()
