@@ -42,6 +42,11 @@ constexpr bool CHUNKMAJOR = true;
 #else
 constexpr bool CHUNKMAJOR = false;
 #endif
+#if defined(NPORE_X_NOASM)
+constexpr bool NOASM = true;        // the plain steps through the compiled C++ body instead of fill_step_asm.inc (A/B)
+#else
+constexpr bool NOASM = false;
+#endif
 #if defined(NPORE_X_ANN)
 constexpr int ANN = NPORE_X_ANN;      // annotate ablations (timing only): 1 no packing, 2 no period passes, 3 neither
 #else

@@ -1,0 +1,709 @@
+#!/usr/bin/env python3
+"""Generator of fill_step_asm.inc: the plain ("FAST") anti-diagonal loop of fill_kernel as hand-scheduled gfx950
+assembly, one text per wave role (0 = only wave of a chunk, 1 = first, 2 = middle, 3 = last of several).
+
+Why assembly: the compiler places 15 ... 31 register copies per step where the bodies of the two step kinds ('I' / 'D'
+of the input path) meet -- a fifth of the step's vector instructions -- and no source-level
+formulation removed them.  Here every loop-carried value has ONE register for the whole loop (the asm operands), both
+step kinds update it in place, and the temporaries are fixed scratch registers (v91 ... v111, declared clobbered).
+
+What the text does is exactly the `step` lambda of kernels.hpp for FASTSEL = true (cell.hpp cell_update<FAST>), for as
+many steps of one 64-step window as it can take: it returns with status 1 in front of a step that needs one of the
+rare paths (a column descriptor with DSC_RARE, a word queue or the L window about to run out) -- nothing of that step
+is done yet -- and the caller runs that one step through the C++ body and comes back.
+
+    python npore_amd/csrc/gen_fill_asm.py        # rewrites fill_step_asm.inc next to this file
+
+Hazards of gfx940-class hardware that the assembler does not resolve for inline text are handled by `fix_hazards`
+(VALU-written SGPR / VCC read by a VALU within 2 issue slots, a VGPR written by a VALU read by a DPP move within 2 or by
+v_readlane within 1): it inserts s_nop where the written schedule does not already keep the distance.
+"""
+import os
+import re
+
+# ---- scratch registers (clobbered) ---------------------------------------------------------------------------------
+X0, X1, X2, X3, X4, X5 = "v91", "v92", "v93", "v94", "v95", "v96"      # neighbour cell / exchange words, then scratch
+SD, SE, SF = "v97", "v98", "v99"
+P0, P1, PP = "v100", "v101", "v[100:101]"
+SUBV, DRUN, NINSR, NDELR = "v102", "v103", "v104", "v105"
+SHRV, SHRRUN, SHRST, LENV, LENRUN, LENST = "v106", "v107", "v108", "v109", "v110", "v111"
+SCRATCH = ["v%d" % k for k in range(91, 112)]
+
+LDS_SUB_BASE = 6 * 32 * 33 * 4      # kernels.hpp LDS_SUB_BASE
+XCH_WORDS = 12                      # kernels.hpp
+
+
+def O(name):
+    return "%[" + name + "]"
+
+
+class Text:
+    def __init__(self):
+        self.lines = []
+
+    def __call__(self, s):
+        for ln in s.strip("\n").split("\n"):
+            ln = ln.strip()
+            if ln:
+                self.lines.append(ln)
+
+    def label(self, name):
+        self.lines.append(name + "_%=:")
+
+
+def L(name):
+    return name + "_%="
+
+
+def core(t, mode, first, last, multi):
+    """Cell update + stores + hand-over of one step.  mode 'I': top = own cell, left = neighbour (X0 X1 X2);
+    'D': left = own cell, top = neighbour."""
+    mid = multi and not first and not last
+    own_m, own_i, own_d, r1, r2 = O("matv"), O("insv"), O("delv"), O("R1"), O("R2")
+    if mode == "I":
+        topM, topI, topR, leftM, leftD, leftR, diagM = own_m, own_i, r1, X0, X1, O("LMr"), O("LMv")
+    else:
+        topM, topI, topR, leftM, leftD, leftR, diagM = X0, X1, O("TMr"), own_m, own_d, r2, O("TMv")
+    sfx = "_" + mode
+    # ---- substitution score on its way; LEN / SHR state
+    t(f"""
+        v_alignbit_b32 {SUBV}, {O('refx')}, {O('seqw')}, 25
+        v_and_b32 {SUBV}, 0x3fc, {SUBV}
+        ds_read_b32 {SUBV}, {SUBV} offset:{LDS_SUB_BASE}
+    """)
+    if mode == "I":                      # (the 'I' prologue left sm = rc0 & summary bits in SHRST: rc0 does not move)
+        smr = SHRST
+    else:
+        t(f"v_and_b32 {X3}, 0xbc, {O('rc0')}")
+        if not mid:
+            t(f"v_cndmask_b32 {X3}, 0, {X3}, {O('mhist')}")
+        smr = X3
+    t(f"""
+        v_mov_b32 {LENV}, {O('ev')}
+        v_mov_b32 {LENRUN}, 0
+        v_mov_b32 {LENST}, 0x7f800000
+    """)
+    # ---- SHR candidates of the column (cell.hpp shr_small)
+    if not mid:
+        t(f"""
+            v_cmp_ne_u32 vcc, 0, {smr}
+            s_cbranch_vccnz {L('shr_some' + sfx)}
+            v_mov_b32 {SHRV}, {O('ev')}
+            v_mov_b32 {SHRRUN}, 0
+            v_mov_b32 {SHRST}, 0x7f800000
+            s_branch {L('shr_done' + sfx)}
+        """)
+        t.label("shr_some" + sfx)
+    t(f"""
+        v_cmp_lt_u32 vcc, 28, {smr}
+        s_cbranch_vccnz {L('shr_two' + sfx)}
+    """)
+    # one candidate per column
+    t(f"""
+        v_and_b32 {X3}, 28, {O('rc0')}
+        ds_bpermute_b32 {X4}, {X3}, {O('tab')}
+        ds_bpermute_b32 {X5}, {X3}, {O('trecip')}
+        v_cmp_gt_i32 vcc, 0, {O('rc0')}
+        v_bfe_u32 {SE}, {O('rc0')}, 15, 16
+        v_bfe_u32 {SF}, {O('rc0')}, 2, 3
+        s_waitcnt lgkmcnt(0)
+        v_add_u32 {X4}, {O('hca')}, {X4}
+        ds_read_b32 {SD}, {X4}
+        ds_read_b64 {PP}, {X4} offset:8
+        s_waitcnt lgkmcnt(0)
+        v_lshrrev_b32 {P1}, 16, {P1}
+        v_cndmask_b32 {P1}, {P1}, 0, vcc
+        v_cndmask_b32 {SD}, {P0}, {SD}, vcc
+        v_mul_u32_u24 {X5}, {P1}, {X5}
+        v_min_u32_sdwa {X5}, {X5}, {O('rc0')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_1
+        v_lshl_add_u32 {SE}, {X5}, 2, {SE}
+        ds_read_b32 {SE}, {SE}
+        s_waitcnt lgkmcnt(0)
+        v_add_f32 {SE}, {SD}, {SE}
+        v_cmp_lt_f32 vcc, {SE}, {O('ev')}
+        v_add_u32 {P1}, {P1}, {SF}
+        v_cndmask_b32 {SHRV}, {O('ev')}, {SE}, vcc
+        v_cndmask_b32 {SHRRUN}, 0, {P1}, vcc
+        v_cndmask_b32 {SHRST}, {O('inf')}, {SD}, vcc
+        s_branch {L('shr_done' + sfx)}
+    """)
+    # two candidates (second in rc1): all lane-table reads, all history reads, all score reads, then the compares in
+    # the reference's order.  NINSR / NDELR are free here (INS / DEL come after the passes)
+    t.label("shr_two" + sfx)
+    t(f"""
+        v_and_b32 {X3}, 28, {O('rc0')}
+        v_and_b32 {NINSR}, 28, {O('rc1')}
+        ds_bpermute_b32 {X4}, {X3}, {O('tab')}
+        ds_bpermute_b32 {X5}, {X3}, {O('trecip')}
+        ds_bpermute_b32 {SD}, {NINSR}, {O('tab')}
+        ds_bpermute_b32 {NDELR}, {NINSR}, {O('trecip')}
+        v_cmp_gt_i32 vcc, 0, {O('rc0')}
+        v_cmp_gt_i32 {O('sa')}, 0, {O('rc1')}
+        s_waitcnt lgkmcnt(0)
+        v_add_u32 {X4}, {O('hca')}, {X4}
+        v_add_u32 {SD}, {O('hca')}, {SD}
+        ds_read_b32 {X3}, {X4}
+        ds_read_b64 {PP}, {X4} offset:8
+        ds_read_b32 {NINSR}, {SD}
+        ds_read_b64 v[98:99], {SD} offset:8
+        s_waitcnt lgkmcnt(0)
+        v_lshrrev_b32 {P1}, 16, {P1}
+        v_lshrrev_b32 {SF}, 16, {SF}
+        v_cndmask_b32 {P1}, {P1}, 0, vcc
+        v_cndmask_b32 {SF}, {SF}, 0, {O('sa')}
+        v_cndmask_b32 {X3}, {P0}, {X3}, vcc
+        v_cndmask_b32 {NINSR}, {SE}, {NINSR}, {O('sa')}
+        v_mul_u32_u24 {X5}, {P1}, {X5}
+        v_mul_u32_u24 {NDELR}, {SF}, {NDELR}
+        v_bfe_u32 {X4}, {O('rc0')}, 15, 16
+        v_bfe_u32 {SD}, {O('rc1')}, 15, 16
+        v_min_u32_sdwa {X5}, {X5}, {O('rc0')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_1
+        v_min_u32_sdwa {NDELR}, {NDELR}, {O('rc1')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_1
+        v_lshl_add_u32 {X4}, {X5}, 2, {X4}
+        v_lshl_add_u32 {SD}, {NDELR}, 2, {SD}
+        ds_read_b32 {X4}, {X4}
+        ds_read_b32 {SD}, {SD}
+        v_bfe_u32 {X5}, {O('rc0')}, 2, 3
+        v_bfe_u32 {NDELR}, {O('rc1')}, 2, 3
+        v_add_u32 {P1}, {P1}, {X5}
+        v_add_u32 {SF}, {SF}, {NDELR}
+        s_waitcnt lgkmcnt(0)
+        v_add_f32 {X4}, {X3}, {X4}
+        v_add_f32 {SD}, {NINSR}, {SD}
+        v_cmp_lt_f32 vcc, {X4}, {O('ev')}
+        v_cndmask_b32 {SHRV}, {O('ev')}, {X4}, vcc
+        v_cndmask_b32 {SHRRUN}, 0, {P1}, vcc
+        v_cndmask_b32 {SHRST}, {O('inf')}, {X3}, vcc
+        v_cmp_lt_f32 vcc, {SD}, {SHRV}
+        v_cndmask_b32 {SHRV}, {SHRV}, {SD}, vcc
+        v_cndmask_b32 {SHRRUN}, {SHRRUN}, {SF}, vcc
+        v_cndmask_b32 {SHRST}, {SHRST}, {NINSR}, vcc
+    """)
+    t.label("shr_done" + sfx)
+    # ---- LEN candidates (cell.hpp, LEN loop; LEN_ARITH form)
+    t(f"""
+        v_and_b32 {X3}, {O('refx')}, {O('seqw')}
+        v_bfe_u32 {X3}, {X3}, 8, 6
+    """)
+    if not mid:
+        t(f"v_cndmask_b32 {X3}, 0, {X3}, {O('mhist')}")
+    t.label("len_top" + sfx)
+    t(f"""
+        v_cmp_ne_u32 vcc, 0, {X3}
+        s_cbranch_vccz {L('len_done' + sfx)}
+        s_mov_b64 {O('sa')}, vcc
+        v_ffbh_u32 {X4}, {X3}
+        v_sub_u32 {X4}, 31, {X4}
+        v_bfe_u32 {X3}, {X3}, 0, {X4}
+        v_mul_u32_u24 {X5}, 3, {X4}
+        v_sub_u32 {X5}, 29, {X5}
+        v_lshrrev_b32 {SD}, 14, {O('refx')}
+        v_lshrrev_b32 {SE}, {X5}, {O('seqw')}
+        v_xor_b32 {SE}, {SE}, {SD}
+        v_lshlrev_b32 {SE}, {X5}, {SE}
+        v_cmp_eq_u32 {O('sb')}, 0, {SE}
+        s_and_b64 {O('sb')}, {O('sb')}, {O('sa')}
+        s_cbranch_scc0 {L('len_top' + sfx)}
+        v_add_u32 {SF}, 1, {X4}
+        v_lshlrev_b32 {NINSR}, 2, {SF}
+        ds_bpermute_b32 {NDELR}, {NINSR}, {O('tab')}
+        ds_bpermute_b32 {X5}, {NINSR}, {O('trecip')}
+        v_bfe_u32 {SD}, {O('seqw')}, {X4}, 1
+        v_cmp_ne_u32 {O('sc')}, 0, {SD}
+        v_add_u32 {SD}, {O('sdel')}, {O('lanej')}
+        v_and_b32 {SD}, {O('wmask')}, {SD}
+        v_and_b32 {X4}, 7, {X4}
+        v_lshl_add_u32 {SD}, {SD}, 3, {X4}
+        v_add_u32 {SD}, {O('winaddr')}, {SD}
+        ds_read_u8 {SD}, {SD}
+        s_waitcnt lgkmcnt(0)
+        v_lshl_add_u32 {NDELR}, {NINSR}, 2, {NDELR}
+        v_add_u32 {NDELR}, {O('hca')}, {NDELR}
+        ds_read_b64 {PP}, {NDELR}
+        ds_read_b32 {NINSR}, {NDELR} offset:12
+        v_cmp_ne_u32 {O('sa')}, 0, {SD}
+        v_cmp_ge_u32 vcc, {O('clamp1')}, {SF}
+        s_and_b64 {O('sa')}, {O('sa')}, vcc
+        s_waitcnt lgkmcnt(0)
+        v_cndmask_b32 {P0}, {P1}, {P0}, {O('sc')}
+        v_and_b32 {NINSR}, 0xffff, {NINSR}
+        v_cndmask_b32 {NINSR}, {NINSR}, 0, {O('sc')}
+        v_mul_u32_u24 {P1}, {NINSR}, {X5}
+        v_lshrrev_b32 {P1}, 16, {P1}
+        v_add3_u32 {P1}, {SD}, {P1}, 1
+        v_min_u32 {SD}, {O('clampv')}, {SD}
+        v_min_u32 {P1}, {O('clampv')}, {P1}
+        v_or_b32 {SE}, {SD}, {P1}
+        v_cmp_lt_u32 vcc, 31, {SE}
+        v_and_b32 {SE}, 31, {SD}
+        v_lshl_or_b32 {SE}, {X4}, 5, {SE}
+        v_mul_u32_u24 {SE}, 33, {SE}
+        v_and_b32 {X5}, 31, {P1}
+        v_sub_u32 {SE}, {SE}, {X5}
+        v_add_u32 {SE}, 31, {SE}
+        v_lshlrev_b32 {SE}, 2, {SE}
+        ds_read_b32 {SE}, {SE}
+        s_and_b64 vcc, vcc, {O('sb')}
+        s_cbranch_vccz {L('len_lds' + sfx)}
+        s_waitcnt lgkmcnt(0)
+        s_mov_b64 exec, vcc
+        v_mul_lo_u32 {X5}, {X4}, {O('npdim')}
+        v_add_u32 {X5}, {X5}, {SD}
+        v_mul_lo_u32 {X5}, {X5}, {O('npdim')}
+        v_add_u32 {X5}, {X5}, {P1}
+        v_lshlrev_b32 {X5}, 2, {X5}
+        global_load_dword {SE}, {X5}, {O('gnp')}
+        s_waitcnt vmcnt(0)
+        s_mov_b64 exec, -1
+    """)
+    t.label("len_lds" + sfx)
+    t(f"""
+        s_waitcnt lgkmcnt(0)
+        s_mov_b64 vcc, {O('sa')}
+        v_cndmask_b32 {SE}, {O('c100')}, {SE}, vcc
+        v_add_f32 {SE}, {P0}, {SE}
+        v_add_u32 {NINSR}, {NINSR}, {SF}
+        v_cmp_lt_f32 vcc, {SE}, {LENV}
+        s_and_b64 vcc, vcc, {O('sb')}
+        v_cndmask_b32 {LENV}, {LENV}, {SE}, vcc
+        v_cndmask_b32 {LENRUN}, {LENRUN}, {NINSR}, vcc
+        v_cndmask_b32 {LENST}, {LENST}, {P0}, vcc
+        s_branch {L('len_top' + sfx)}
+    """)
+    t.label("len_done" + sfx)
+    # ---- INS / DEL (src/aln.pyx:525-565), MAT by two 3-way minima and equality tests (cell.hpp, Env::MIN3)
+    t(f"""
+        v_add_f32 {SD}, {O('istart')}, {topM}
+        v_add_f32 {SE}, {O('iext')}, {topI}
+        v_add_f32 {SF}, {O('istart')}, {leftM}
+        v_add_f32 {X3}, {O('iext')}, {leftD}
+        v_add_u32_sdwa {NINSR}, {topR}, {O('one')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD
+        v_add_u32_sdwa {NDELR}, {leftR}, {O('one')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD
+        v_cmp_lt_f32 vcc, {SE}, {SD}
+        v_cmp_lt_f32 {O('sa')}, {X3}, {SF}
+        s_waitcnt lgkmcnt(0)
+        v_add_f32 {SUBV}, {diagM}, {SUBV}
+        v_cndmask_b32 {own_i}, {SD}, {SE}, vcc
+        v_cndmask_b32 {NINSR}, 1, {NINSR}, vcc
+        v_cndmask_b32 {own_d}, {SF}, {X3}, {O('sa')}
+        v_cndmask_b32 {NDELR}, 1, {NDELR}, {O('sa')}
+    """)
+    # the neighbour's MAT value becomes the diagonal of a later step
+    t(f"v_mov_b32 {O('LMv') if mode == 'I' else O('TMv')}, {X0}")
+    t(f"""
+        v_min3_f32 {SD}, {SUBV}, {own_i}, {LENV}
+        v_min3_f32 {own_m}, {SD}, {own_d}, {SHRV}
+        v_lshl_or_b32 {SE}, {SHRRUN}, 3, 4
+        v_lshl_or_b32 {SF}, {NDELR}, 3, 3
+        v_lshl_or_b32 {X3}, {LENRUN}, 3, 2
+        v_lshl_or_b32 {X4}, {NINSR}, 3, 1
+        v_lshl_add_u32 {X5}, {DRUN}, 3, 8
+        v_cmp_eq_f32 vcc, {own_d}, {own_m}
+        v_cmp_eq_f32 {O('sa')}, {LENV}, {own_m}
+        v_cmp_eq_f32 {O('sb')}, {own_i}, {own_m}
+        v_cmp_eq_f32 {O('sc')}, {SUBV}, {own_m}
+        v_cndmask_b32 {SE}, {SE}, {SF}, vcc
+        v_add_u32 {SD}, 1, {DRUN}
+        v_cndmask_b32 {SE}, {SE}, {X3}, {O('sa')}
+        v_lshl_or_b32 {SF}, {SHRRUN}, 16, {LENRUN}
+        v_cndmask_b32 {SE}, {SE}, {X4}, {O('sb')}
+        v_cndmask_b32 {SD}, 0, {SD}, {O('sc')}
+        v_cndmask_b32 {SE}, {SE}, {X5}, {O('sc')}
+        v_lshl_or_b32 {r1}, {NINSR}, 16, {SD}
+        v_lshl_or_b32 {r2}, {NDELR}, 16, {SD}
+        v_add_u32 {X3}, {O('hca')}, {O('slot')}
+    """)
+    # history record + traceback word of the band-interior columns (a middle wave holds no others)
+    if not mid:
+        t(f"s_mov_b64 exec, {O('mhist')}")
+    t(f"""
+        ds_write2_b32 {X3}, {own_m}, {LENST} offset1:1
+        ds_write2_b32 {X3}, {SHRST}, {SF} offset0:2 offset1:3
+        global_store_dword {O('tboff')}, {SE}, {O('tbg')}
+    """)
+    if not mid:
+        t("s_mov_b64 exec, -1")
+    # band-edge cells (src/aln.pyx:502-507): the three values their one in-band neighbour reads
+    if first or last:
+        t(f"v_add_f32 {SD}, 0x42c80000, {O('ev')}")
+    if first:
+        t(f"""
+            v_cndmask_b32 {own_m}, {own_m}, {SD}, {O('ml0')}
+            v_cndmask_b32 {own_d}, {own_d}, {SD}, {O('ml0')}
+            v_cndmask_b32 {r2}, {r2}, 0, {O('ml0')}
+        """)
+    if last:
+        t(f"""
+            v_cndmask_b32 {own_m}, {own_m}, {SD}, {O('medge')}
+            v_cndmask_b32 {own_i}, {own_i}, {SD}, {O('medge')}
+            v_cndmask_b32 {r1}, {r1}, 0, {O('medge')}
+        """)
+    # hand-over to the neighbour waves, progress word (workgroup release: this wave's LDS writes first)
+    if multi:
+        if not last:
+            t(f"""
+                s_mov_b64 exec, {O('ml63')}
+                ds_write_b32 {O('xown')}, {own_m} offset:{2 * XCH_WORDS * 4}
+                ds_write_b32 {O('xown')}, {own_d} offset:{2 * XCH_WORDS * 4 + 4}
+                ds_write_b32 {O('xown')}, {r2} offset:{2 * XCH_WORDS * 4 + 8}
+                ds_write_b32 {O('xown')}, {O('seqw')} offset:{2 * XCH_WORDS * 4 + 12}
+                s_mov_b64 exec, -1
+            """)
+        t(f"v_add_u32 {O('prog')}, 1, {O('prog')}")
+        t(f"s_mov_b64 exec, {O('ml0')}")
+        if not first:
+            b = 2 * XCH_WORDS * 4 + 20
+            t(f"""
+                ds_write_b32 {O('xown')}, {own_m} offset:{b}
+                ds_write_b32 {O('xown')}, {own_i} offset:{b + 4}
+                ds_write_b32 {O('xown')}, {r1} offset:{b + 8}
+                ds_write_b32 {O('xown')}, {O('refx')} offset:{b + 12}
+                ds_write_b32 {O('xown')}, {O('rc0')} offset:{b + 16}
+                ds_write_b32 {O('xown')}, {O('rc1')} offset:{b + 20}
+            """)
+        t(f"""
+            s_waitcnt lgkmcnt(0)
+            ds_write_b32 {O('progaddr')}, {O('prog')}
+            s_mov_b64 exec, -1
+            v_sub_u32 {O('xown')}, {O('xsum')}, {O('xown')}
+            v_sub_u32 {O('xoth')}, {O('xsum')}, {O('xoth')}
+        """)
+    t(f"""
+        v_add_f32 {O('ev')}, 0x42c80000, {O('ev')}
+        s_add_i32 {O('bl')}, {O('bl')}, 1
+        s_cmp_lt_i32 {O('bl')}, {O('b1')}
+        s_cbranch_scc1 {L('top')}
+        s_branch {L('done')}
+    """)
+
+
+def polls(t, first, last, sfx):
+    if not last:
+        t.label("pa" + sfx)
+        t(f"""
+            ds_read_b32 {X3}, {O('pnb')} offset:8
+            s_waitcnt lgkmcnt(0)
+            v_cmp_lt_i32 vcc, {X3}, {O('prog')}
+            s_cbranch_vccnz {L('pa' + sfx)}
+        """)
+    if not first:
+        t.label("pb" + sfx)
+        t(f"""
+            ds_read_b32 {X3}, {O('pnb')}
+            s_waitcnt lgkmcnt(0)
+            v_cmp_lt_i32 vcc, {X3}, {O('prog')}
+            s_cbranch_vccnz {L('pb' + sfx)}
+        """)
+
+
+def book(t, mode):
+    """ring row of this anti-diagonal, lane table of history offsets, traceback row"""
+    t(f"""
+        v_add_u32 {O('slot')}, {O('hw16')}, {O('slot')}
+        v_cmp_ne_u32 vcc, {O('ringb')}, {O('slot')}
+        v_mov_b32_dpp {O('tab')}, {O('tab')} wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+        v_add_u32 {O('tboff')}, {O('tbs4')}, {O('tboff')}
+        v_cndmask_b32 {O('slot')}, 0, {O('slot')}, vcc
+    """)
+    if mode == "I":
+        t(f"v_add_u32 {O('tab')}, -16, {O('tab')}")
+    t(f"v_cndmask_b32 {O('tab')}, {O('tab')}, {O('slot')}, {O('n0')}")
+
+
+def gen_role(role):
+    multi = role != 0
+    first = role in (0, 1)
+    last = role in (0, 3)
+    mid = role == 2
+    t = Text()
+    t.label("top")
+    t(f"""
+        s_bitcmp1_b64 {O('mask')}, {O('bl')}
+        s_cbranch_scc0 {L('mode_d')}
+    """)
+    # ================= 'I' step: read words move one column up, "left" is the previous lane
+    if first:
+        t(f"""
+            s_cmp_ge_i32 {O('sqidx')}, 64
+            s_cbranch_scc1 {L('exit')}
+        """)
+    t(f"v_and_b32 {SHRST}, 0xbc, {O('rc0')}")
+    if not mid:
+        t(f"v_cndmask_b32 {SHRST}, 0, {SHRST}, {O('mhist')}")
+    t(f"""
+        v_cmp_lt_u32 vcc, 0x7f, {SHRST}
+        s_cbranch_vccnz {L('exit')}
+    """)
+    if multi:
+        polls(t, first, last, "_i")
+    if not first:
+        t(f"""
+            ds_read_b32 {X0}, {O('xoth')}
+            ds_read_b32 {X1}, {O('xoth')} offset:4
+            ds_read_b32 {X2}, {O('xoth')} offset:8
+            ds_read_b32 {X3}, {O('xoth')} offset:12
+        """)
+    t(f"""
+        v_mov_b32 {O('TMv')}, {O('matv')}
+        v_mov_b32 {O('TMr')}, {O('R1')}
+    """)
+    book(t, "I")
+    if not first:
+        t(f"""
+            s_waitcnt lgkmcnt(0)
+            v_mov_b32_dpp {X0}, {O('matv')} wave_shr:1 row_mask:0xf bank_mask:0xf
+            v_mov_b32_dpp {X1}, {O('delv')} wave_shr:1 row_mask:0xf bank_mask:0xf
+            v_mov_b32_dpp {X2}, {O('R2')} wave_shr:1 row_mask:0xf bank_mask:0xf
+            v_mov_b32_dpp {X3}, {O('seqw')} wave_shr:1 row_mask:0xf bank_mask:0xf
+            v_and_b32 {DRUN}, 0xffff, {O('LMr')}
+            v_mov_b32 {O('seqw')}, {X3}
+            v_mov_b32 {O('LMr')}, {X2}
+        """)
+    else:
+        t(f"""
+            v_readlane_b32 {O('sx')}, {O('seqq')}, {O('sqidx')}
+            s_add_i32 {O('sqidx')}, {O('sqidx')}, 1
+            v_mov_b32_dpp {X0}, {O('matv')} wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+            v_mov_b32_dpp {X1}, {O('delv')} wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+            v_mov_b32_dpp {X2}, {O('R2')} wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+            v_mov_b32_dpp {O('seqw')}, {O('seqw')} wave_shr:1 row_mask:0xf bank_mask:0xf
+            v_and_b32 {DRUN}, 0xffff, {O('LMr')}
+            v_mov_b32 {O('LMr')}, {X2}
+            v_writelane_b32 {O('seqw')}, {O('sx')}, 0
+        """)
+    core(t, "I", first, last, multi)
+    # ================= 'D' step: reference words move one column down, "top" is the next lane
+    t.label("mode_d")
+    if last:
+        t(f"""
+            s_cmp_ge_i32 {O('rqidx')}, 64
+            s_cbranch_scc1 {L('exit')}
+            s_cmp_ge_i32 {O('sdel')}, {O('dlim')}
+            s_cbranch_scc1 {L('exit')}
+        """)
+    if multi:
+        polls(t, first, last, "_d")
+    if not last:
+        b = (4 * XCH_WORDS + 5) * 4
+        t(f"""
+            ds_read_b32 {X0}, {O('xoth')} offset:{b}
+            ds_read_b32 {X1}, {O('xoth')} offset:{b + 4}
+            ds_read_b32 {X2}, {O('xoth')} offset:{b + 8}
+            ds_read_b32 {X3}, {O('xoth')} offset:{b + 12}
+            ds_read_b32 {X4}, {O('xoth')} offset:{b + 16}
+            ds_read_b32 {X5}, {O('xoth')} offset:{b + 20}
+            s_waitcnt lgkmcnt(0)
+            v_or_b32 {SD}, {O('rc0')}, {X4}
+        """)
+    else:
+        t(f"""
+            v_readlane_b32 {O('sx')}, {O('rqz')}, {O('rqidx')}
+            v_or_b32 {SD}, {O('sx')}, {O('rc0')}
+        """)
+    t(f"""
+        v_and_b32 {SD}, 0x80, {SD}
+        v_cmp_ne_u32 vcc, 0, {SD}
+        s_cbranch_vccnz {L('exit')}
+        s_add_i32 {O('sdel')}, {O('sdel')}, 1
+        v_mov_b32 {O('LMv')}, {O('matv')}
+        v_mov_b32 {O('LMr')}, {O('R2')}
+    """)
+    book(t, "D")
+    if not last:
+        t(f"""
+            v_mov_b32_dpp {X0}, {O('matv')} wave_shl:1 row_mask:0xf bank_mask:0xf
+            v_mov_b32_dpp {X1}, {O('insv')} wave_shl:1 row_mask:0xf bank_mask:0xf
+            v_mov_b32_dpp {X2}, {O('R1')} wave_shl:1 row_mask:0xf bank_mask:0xf
+            v_mov_b32_dpp {X3}, {O('refx')} wave_shl:1 row_mask:0xf bank_mask:0xf
+            v_mov_b32_dpp {X4}, {O('rc0')} wave_shl:1 row_mask:0xf bank_mask:0xf
+            v_mov_b32_dpp {X5}, {O('rc1')} wave_shl:1 row_mask:0xf bank_mask:0xf
+            v_and_b32 {DRUN}, 0xffff, {O('TMr')}
+            v_mov_b32 {O('refx')}, {X3}
+            v_mov_b32 {O('rc0')}, {X4}
+            v_mov_b32 {O('rc1')}, {X5}
+            v_mov_b32 {O('TMr')}, {X2}
+        """)
+    else:
+        t(f"""
+            v_mov_b32_dpp {X0}, {O('matv')} wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+            v_mov_b32_dpp {X1}, {O('insv')} wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+            v_mov_b32_dpp {X2}, {O('R1')} wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+            v_mov_b32_dpp {O('rc0')}, {O('rc0')} wave_shl:1 row_mask:0xf bank_mask:0xf
+            v_writelane_b32 {O('rc0')}, {O('sx')}, 63
+            v_readlane_b32 {O('sx')}, {O('rqx')}, {O('rqidx')}
+            v_mov_b32_dpp {O('refx')}, {O('refx')} wave_shl:1 row_mask:0xf bank_mask:0xf
+            v_and_b32 {DRUN}, 0xffff, {O('TMr')}
+            v_writelane_b32 {O('refx')}, {O('sx')}, 63
+            v_readlane_b32 {O('sx')}, {O('rqw')}, {O('rqidx')}
+            v_mov_b32_dpp {O('rc1')}, {O('rc1')} wave_shl:1 row_mask:0xf bank_mask:0xf
+            v_mov_b32 {O('TMr')}, {X2}
+            s_add_i32 {O('rqidx')}, {O('rqidx')}, 1
+            v_writelane_b32 {O('rc1')}, {O('sx')}, 63
+        """)
+    core(t, "D", first, last, multi)
+    t.label("exit")
+    t(f"s_mov_b32 {O('status')}, 1")
+    t(f"s_branch {L('end')}")
+    t.label("done")
+    t(f"s_mov_b32 {O('status')}, 0")
+    t.label("end")
+    return fix_hazards(t.lines)
+
+
+# ---- hazards -------------------------------------------------------------------------------------------------------
+_SREG = re.compile(r"%\[(\w+)\]|\b(vcc|exec)\b")
+_VREG = re.compile(r"\bv(\d+)\b|v\[(\d+):(\d+)\]|%\[(\w+)\]")
+
+
+def _regs(tok):
+    """registers named by one operand token: set of strings ('v97', '%matv', 'vcc', ...)"""
+    tok = tok.strip()
+    out = set()
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return {"v%d" % k for k in range(int(m.group(1)), int(m.group(2)) + 1)}
+    if re.fullmatch(r"v\d+", tok):
+        return {tok}
+    m = re.fullmatch(r"%\[(\w+)\]", tok)
+    if m:
+        return {"%" + m.group(1)}
+    if tok in ("vcc", "exec"):
+        return {tok}
+    return out
+
+
+def _split(ins):
+    parts = ins.split(None, 1)
+    op = parts[0]
+    ops = []
+    if len(parts) > 1:
+        body = re.split(r"\s+(?:offset|offset0|offset1|dst_sel|row_mask|wave_shr|wave_shl|bound_ctrl)\b", parts[1])[0]
+        ops = [o.strip() for o in body.split(",")]
+    return op, ops
+
+
+def fix_hazards(lines):
+    """Insert s_nop so that (a) a VALU that reads an SGPR / VCC written by a VALU comes at least 2 issue slots later,
+    (b) a DPP move reads no VGPR written by a VALU less than 2 slots before, (c) v_readlane reads no VGPR written by
+    the previous VALU, (d) v_readlane / v_writelane use no lane-select SGPR written by a VALU within 4 slots.
+    Conservative across labels (distances are kept along the fall-through path; a taken branch costs more than these)."""
+    out = []
+    wrote_s = {}     # SGPR-like name -> index (in `out`) of the VALU that wrote it
+    wrote_v = {}     # VGPR-like name -> index of the VALU that wrote it
+    for ins in lines:
+        if ins.endswith(":"):
+            out.append(ins)
+            continue
+        op, ops = _split(ins)
+        is_valu = op.startswith("v_")
+        need = 0
+        here = len(out)
+        if is_valu:
+            srcs = ops[1:] if ops else []
+            dpp = "wave_sh" in ins or "row_sh" in ins
+            for tok in srcs:
+                for r in _regs(tok):
+                    if r in wrote_s:        # VALU-written SGPR / VCC read by a VALU
+                        need = max(need, 2 - (here - wrote_s[r] - 1))
+                    if dpp and r in wrote_v:
+                        need = max(need, 2 - (here - wrote_v[r] - 1))
+                    if op.startswith("v_readlane") and r in wrote_v:
+                        need = max(need, 1 - (here - wrote_v[r] - 1))
+            if op.startswith("v_readlane") or op.startswith("v_writelane"):
+                for r in _regs(ops[-1]):
+                    if r in wrote_s:
+                        need = max(need, 4 - (here - wrote_s[r] - 1))
+            if dpp:                          # (an in-place DPP move also reads its destination)
+                for r in _regs(ops[0]):
+                    if r in wrote_v:
+                        need = max(need, 2 - (here - wrote_v[r] - 1))
+        if need > 0:
+            out.append("s_nop %d" % (need - 1))
+        if is_valu and ops:
+            dst = ops[0]
+            writes_s = op.startswith("v_cmp") or op.startswith("v_readlane") or op.startswith("v_readfirstlane")
+            for r in _regs(dst):
+                if writes_s:
+                    wrote_s[r] = len(out)
+                else:
+                    wrote_v[r] = len(out)
+            if op.startswith("v_cmp") and not dst.startswith("%") and dst != "vcc":
+                pass
+        elif not is_valu and ops and op.startswith("s_") and not op.startswith("s_cbranch") and not op.startswith("s_waitcnt"):
+            for r in _regs(ops[0]):          # rewritten by the scalar unit: no VALU-write hazard left on it
+                wrote_s.pop(r, None)
+        if op.startswith("ds_read") or op.startswith("global_load") or op.startswith("ds_bpermute"):
+            for r in _regs(ops[0]):
+                wrote_v.pop(r, None)
+        out.append(ins)
+    return out
+
+
+# ---- operand lists ---------------------------------------------------------------------------------------------------
+def operands(role):
+    multi, first, last = role != 0, role in (0, 1), role in (0, 3)
+    outs = [("matv", "+v", "matv"), ("insv", "+v", "insv"), ("delv", "+v", "delv"), ("LMv", "+v", "LMv"), ("TMv", "+v", "TMv"),
+            ("R1", "+v", "R1"), ("R2", "+v", "R2"), ("LMr", "+v", "LMr"), ("TMr", "+v", "TMr"), ("seqw", "+v", "seqw"),
+            ("refx", "+v", "refx"), ("rc0", "+v", "rc0"), ("rc1", "+v", "rc1"), ("tab", "+v", "env.tab_e"),
+            ("slot", "+v", "slot_v"), ("tboff", "+v", "tboff_v"), ("ev", "+v", "e_v"),
+            ("bl", "+s", "a_bl"), ("sdel", "+s", "a_sdel"), ("status", "=&s", "a_status"),
+            ("sa", "=&s", "a_sa"), ("sb", "=&s", "a_sb"), ("sc", "=&s", "a_sc")]
+    if multi:
+        outs += [("prog", "+v", "prog_v"), ("xown", "+v", "xown"), ("xoth", "+v", "xoth")]
+    if first:
+        outs += [("sqidx", "+s", "a_sq")]
+    if last:
+        outs += [("rqidx", "+s", "a_rq")]
+    if first or last:
+        outs += [("sx", "=&s", "a_sx")]
+    ins = [("mask", "s", "stepmask"), ("b1", "s", "a_b1"), ("hw16", "s", "a_hw16"), ("ringb", "s", "ring_bytes"),
+           ("tbs4", "s", "tbstride4"), ("n0", "s", "env.n0_lanes"), ("tbg", "s", "tb_g"), ("istart", "s", "a_istart"),
+           ("iext", "s", "a_iext"), ("winaddr", "s", "a_winaddr"), ("wmask", "s", "a_wmask"), ("clampv", "s", "a_clampv"),
+           ("clamp1", "s", "a_clamp1"), ("npdim", "s", "a_npdim"), ("gnp", "s", "env.g_np"),
+           ("hca", "v", "hist_c_addr"), ("trecip", "v", "env.t_recip"), ("one", "v", "a_one"), ("lanej", "v", "a_lanej"),
+           ("inf", "v", "a_inf"), ("c100", "v", "a_c100")]
+    if role != 2:
+        ins += [("mhist", "s", "a_mhist")]
+    if multi:
+        ins += [("xsum", "s", "xsum"), ("pnb", "v", "pnb_addr"), ("progaddr", "v", "a_progaddr"), ("ml0", "s", "a_ml0")]
+        if not last:
+            ins += [("ml63", "s", "a_ml63")]
+    elif first:
+        ins += [("ml0", "s", "a_ml0")]
+    if last:
+        ins += [("medge", "s", "a_medge"), ("dlim", "s", "a_dlim"), ("rqx", "v", "ref_q.x"), ("rqz", "v", "ref_q.z"),
+                ("rqw", "v", "ref_q.w")]
+    if first:
+        ins += [("seqq", "v", "seq_q")]
+    return outs, ins
+
+
+def main():
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = ["// fill_step_asm.inc -- GENERATED by gen_fill_asm.py (do not edit): the plain-step loop of fill_kernel as gfx950",
+           "// assembly, one text per wave role, with the operand lists that bind it to the variables of kernels.hpp.", ""]
+    for role in range(4):
+        lines = gen_role(role)
+        outs, ins = operands(role)
+        used = set(re.findall(r"%\[(\w+)\]", "\n".join(lines)))
+        declared = {n for n, _, _ in outs + ins}
+        assert used <= declared, (role, sorted(used - declared))
+        outs = [o for o in outs if o[0] in used or o[1].startswith("+")]
+        ins = [i for i in ins if i[0] in used]
+        out.append(f"#define NPORE_FILL_ASM_TEXT_{role} \\")
+        for ln in lines:
+            out.append('    "' + ln + '\\n\\t" \\')
+        out.append('    ""')
+        out.append(f"#define NPORE_FILL_ASM_OUTS_{role} " + ", ".join(f'[{n}] "{c}"({e})' for n, c, e in outs))
+        out.append(f"#define NPORE_FILL_ASM_INS_{role} " + ", ".join(f'[{n}] "{c}"({e})' for n, c, e in ins))
+        out.append("")
+    out.append("#define NPORE_FILL_ASM_CLOBBERS \"memory\", \"vcc\", \"scc\", " + ", ".join('"%s"' % r for r in SCRATCH))
+    with open(os.path.join(here, "fill_step_asm.inc"), "w") as fh:
+        fh.write("\n".join(out) + "\n")
+    for role in range(4):
+        n = gen_role(role)
+        print("role", role, "lines", len(n), "nops", sum(1 for x in n if x.startswith("s_nop")))
+
+
+if __name__ == "__main__":
+    main()

@@ -34,6 +34,7 @@
 #include <type_traits>
 
 #include "cell.hpp"
+#include "fill_step_asm.inc"
 #include "layout.hpp"
 
 namespace npore {
@@ -813,6 +814,55 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
                 }
             }
         };
+        // The plain anti-diagonals [b0, b1) of one step window through the hand-scheduled loop (fill_step_asm.inc,
+        // generated by gen_fill_asm.py: the same step as `step` with FASTSEL, every loop-carried value in ONE register
+        // for both step kinds).  The text stops in front of a step that needs a rare path (a column descriptor
+        // with DSC_RARE, a word queue or the L window about to run out); that one step goes through the C++ body.
+        auto plain_span = [&](int b0, int b1, auto role_tag) __attribute__((always_inline)) {
+            constexpr int ROLE = decltype(role_tag)::value;
+            int a_bl = b0, a_sdel = uni(st.del_l);      // (uni: the compiler does not always see that these are wave-uniform)
+            const int a_b1 = b1;
+            const uint32_t a_hw16 = (uint32_t)env.hw16, a_wmask = (uint32_t)env.wmask, a_clampv = (uint32_t)env.clampv,
+                           a_clamp1 = (uint32_t)env.clampv + 1u, a_npdim = (uint32_t)env.np_dim;
+            const float a_istart = st.indel_start, a_iext = st.indel_extend;
+            const uint32_t a_winaddr = (uint32_t)(reinterpret_cast<const char *>(win) - reinterpret_cast<const char *>(lds));
+            const unsigned long long a_mhist = __builtin_amdgcn_ballot_w64(hist_lane), a_ml0 = 1ull, a_ml63 = 1ull << 63,
+                                     a_medge = __builtin_amdgcn_ballot_w64(tcol == 2 * r);
+            uint32_t a_one = 1u, a_lanej = (uint32_t)(tcol - r);
+            uint32_t a_progaddr = (uint32_t)(reinterpret_cast<const char *>(prog + cw) - reinterpret_cast<const char *>(lds));
+            float a_inf = huge_f(), a_c100 = INF_F;          // (a literal and VCC do not fit one v_cndmask: constants in registers)
+            asm volatile("" : "+v"(a_one), "+v"(a_lanej), "+v"(a_progaddr), "+v"(a_inf), "+v"(a_c100));
+            (void)a_mhist; (void)a_ml0; (void)a_ml63; (void)a_medge; (void)a_progaddr;
+            for (;;) {
+                int a_status, a_sx;
+                unsigned long long a_sa, a_sb, a_sc;
+                const int a_dlim = uni(wfill) - r - WIN_SLACK - 1;  // (the 'D' step that would make the window refill)
+                const int bl_in = a_bl;
+                int a_sq = uni(sq_idx), a_rq = uni(rq_idx);
+                (void)a_dlim; (void)a_sx; (void)a_sq; (void)a_rq;
+                if constexpr (ROLE == 0)
+                    asm volatile(NPORE_FILL_ASM_TEXT_0 : NPORE_FILL_ASM_OUTS_0 : NPORE_FILL_ASM_INS_0 : NPORE_FILL_ASM_CLOBBERS);
+                else if constexpr (ROLE == 1)
+                    asm volatile(NPORE_FILL_ASM_TEXT_1 : NPORE_FILL_ASM_OUTS_1 : NPORE_FILL_ASM_INS_1 : NPORE_FILL_ASM_CLOBBERS);
+                else if constexpr (ROLE == 2)
+                    asm volatile(NPORE_FILL_ASM_TEXT_2 : NPORE_FILL_ASM_OUTS_2 : NPORE_FILL_ASM_INS_2 : NPORE_FILL_ASM_CLOBBERS);
+                else
+                    asm volatile(NPORE_FILL_ASM_TEXT_3 : NPORE_FILL_ASM_OUTS_3 : NPORE_FILL_ASM_INS_3 : NPORE_FILL_ASM_CLOBBERS);
+                sq_idx = a_sq;
+                rq_idx = a_rq;
+                // the scalar bookkeeping the text does not carry: local row / column of the input path
+                const int done = a_bl - bl_in;
+                const unsigned long long took = done >= 64 ? ~0ull : (((1ull << done) - 1ull) << (bl_in & 63));
+                st.ins_l += __popcll(stepmask & took);
+                st.del_l = a_sdel;
+                if (!a_status) break;
+                if ((stepmask >> (a_bl & 63)) & 1ull) step(std::integral_constant<int, 1>{}, role_tag, std::true_type{});
+                else step(std::integral_constant<int, 2>{}, role_tag, std::true_type{});
+                a_bl++;
+                a_sdel = uni(st.del_l);
+                if (a_bl >= b1) break;
+            }
+        };
         auto run = [&](auto role_tag) __attribute__((always_inline)) {
             step(std::integral_constant<int, 0>{}, role_tag, std::false_type{});
             for (int w0 = 0; w0 < d.nrows; w0 += 64) {
@@ -820,7 +870,10 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
                 // (a window that is not plain from end to end runs the general cell update throughout: at most 126
                 // anti-diagonals of a chunk more than necessary; three loops -- general, plain, general -- with the
                 // window test per step measured 1-5 % slower)
-                if (b0 >= d.plain_lo && b1 <= d.plain_hi) span(b0, b1, role_tag, std::true_type{});     // == step_is_plain(st)
+                if (b0 >= d.plain_lo && b1 <= d.plain_hi) {      // == step_is_plain(st) for every step of the window
+                    if constexpr (xp::NOASM) span(b0, b1, role_tag, std::true_type{});
+                    else plain_span(b0, b1, role_tag);
+                }
                 else span(b0, b1, role_tag, std::false_type{});
                 stepmask = nextmask;
                 nextmask = step_window((w0 >> 6) + 2);
