@@ -27,7 +27,7 @@ SD, SE, SF = "v97", "v98", "v99"
 P0, P1, PP = "v100", "v101", "v[100:101]"
 SUBV, DRUN, NINSR, NDELR = "v102", "v103", "v104", "v105"
 SHRV, SHRRUN, SHRST, LENV, LENRUN, LENST = "v106", "v107", "v108", "v109", "v110", "v111"
-SCRATCH = ["v%d" % k for k in range(91, 112)]
+SCRATCH = ["v%d" % k for k in range(89, 112)]
 
 LDS_SUB_BASE = 6 * 32 * 33 * 4      # kernels.hpp LDS_SUB_BASE
 XCH_WORDS = 12                      # kernels.hpp
@@ -55,35 +55,69 @@ def L(name):
     return name + "_%="
 
 
-def core(t, mode, first, last, multi):
-    """Cell update + stores + hand-over of one step.  mode 'I': top = own cell, left = neighbour (X0 X1 X2);
-    'D': left = own cell, top = neighbour."""
-    mid = multi and not first and not last
-    own_m, own_i, own_d, r1, r2 = O("matv"), O("insv"), O("delv"), O("R1"), O("R2")
-    if mode == "I":
-        topM, topI, topR, leftM, leftD, leftR, diagM = own_m, own_i, r1, X0, X1, O("LMr"), O("LMv")
-    else:
-        topM, topI, topR, leftM, leftD, leftR, diagM = X0, X1, O("TMr"), own_m, own_d, r2, O("TMv")
-    sfx = "_" + mode
-    # ---- substitution score on its way; LEN / SHR state
+# more scratch: lane-table results of the first SHR candidate, fetched before the hand-shake poll
+E0, E1 = "v89", "v90"
+OPT = {"relaxed": False}          # relaxed: no lgkmcnt wait in front of the progress store (LDS serves a wave in order)
+
+
+def shr_tables(t, tmp=X3):
+    """lane tables of the column's first SHR candidate (cell.hpp shr_small): where its source record lies, 1/n.
+    tmp: a register with NO load on its way (a VALU write to a register an LDS read is still going to fill races)"""
+    t(f"""
+        v_and_b32 {tmp}, 28, {O('rc0')}
+        ds_bpermute_b32 {E0}, {tmp}, {O('tab')}
+        ds_bpermute_b32 {E1}, {tmp}, {O('trecip')}
+    """)
+
+
+def shr_hist(t):
+    t(f"""
+        v_add_u32 {E0}, {O('hca')}, {E0}
+        ds_read_b32 {SD}, {E0}
+        ds_read_b64 {PP}, {E0} offset:8
+    """)
+
+
+def sub_read(t):
     t(f"""
         v_alignbit_b32 {SUBV}, {O('refx')}, {O('seqw')}, 25
         v_and_b32 {SUBV}, 0x3fc, {SUBV}
         ds_read_b32 {SUBV}, {SUBV} offset:{LDS_SUB_BASE}
     """)
-    if mode == "I":                      # (the 'I' prologue left sm = rc0 & summary bits in SHRST: rc0 does not move)
-        smr = SHRST
+
+
+def ins_del(t, mode, tmp=None):
+    """INS / DEL (src/aln.pyx:525-565): new values straight into the own registers, runs into NINSR / NDELR.
+    tmp: four free registers (default X3 X4 X5 SF; SD SE P0 P1 E0 E1 may hold SHR candidates in flight)."""
+    A, B, C, D = tmp or (X3, X4, X5, SF)
+    own_m, own_i, own_d, r1, r2 = O("matv"), O("insv"), O("delv"), O("R1"), O("R2")
+    if mode == "I":
+        topM, topI, topR, leftM, leftD, leftR = own_m, own_i, r1, X0, X1, O("LMr")
     else:
-        t(f"v_and_b32 {X3}, 0xbc, {O('rc0')}")
-        if not mid:
-            t(f"v_cndmask_b32 {X3}, 0, {X3}, {O('mhist')}")
-        smr = X3
+        topM, topI, topR, leftM, leftD, leftR = X0, X1, O("TMr"), own_m, own_d, r2
     t(f"""
+        v_add_f32 {A}, {O('istart')}, {topM}
+        v_add_f32 {B}, {O('iext')}, {topI}
+        v_add_f32 {C}, {O('istart')}, {leftM}
+        v_add_f32 {D}, {O('iext')}, {leftD}
+        v_add_u32_sdwa {NINSR}, {topR}, {O('one')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD
+        v_add_u32_sdwa {NDELR}, {leftR}, {O('one')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD
+        v_cmp_lt_f32 {O('sb')}, {B}, {A}
+        v_cmp_lt_f32 {O('sc')}, {D}, {C}
         v_mov_b32 {LENV}, {O('ev')}
         v_mov_b32 {LENRUN}, 0
+        v_cndmask_b32 {own_i}, {A}, {B}, {O('sb')}
+        v_cndmask_b32 {NINSR}, 1, {NINSR}, {O('sb')}
+        v_cndmask_b32 {own_d}, {C}, {D}, {O('sc')}
+        v_cndmask_b32 {NDELR}, 1, {NDELR}, {O('sc')}
         v_mov_b32 {LENST}, 0x7f800000
     """)
-    # ---- SHR candidates of the column (cell.hpp shr_small)
+
+
+def shr_pass(t, mode, mid, sfx, smr):
+    """SHR candidates of the column (cell.hpp shr_small<FAST>).  On entry: the first candidate's lane-table results in
+    E0 (offset, hca already added) / E1 and its source record in SD (matv), P0 (shrstart), P1 (runs) -- all fetched;
+    INS / DEL are computed in the shadow of the score read."""
     if not mid:
         t(f"""
             v_cmp_ne_u32 vcc, 0, {smr}
@@ -91,100 +125,104 @@ def core(t, mode, first, last, multi):
             v_mov_b32 {SHRV}, {O('ev')}
             v_mov_b32 {SHRRUN}, 0
             v_mov_b32 {SHRST}, 0x7f800000
-            s_branch {L('shr_done' + sfx)}
         """)
+        ins_del(t, mode)
+        t(f"s_branch {L('shr_done' + sfx)}")
         t.label("shr_some" + sfx)
     t(f"""
         v_cmp_lt_u32 vcc, 28, {smr}
         s_cbranch_vccnz {L('shr_two' + sfx)}
     """)
-    # one candidate per column
+    # ---- one candidate per column
     t(f"""
-        v_and_b32 {X3}, 28, {O('rc0')}
-        ds_bpermute_b32 {X4}, {X3}, {O('tab')}
-        ds_bpermute_b32 {X5}, {X3}, {O('trecip')}
         v_cmp_gt_i32 vcc, 0, {O('rc0')}
-        v_bfe_u32 {SE}, {O('rc0')}, 15, 16
-        v_bfe_u32 {SF}, {O('rc0')}, 2, 3
-        s_waitcnt lgkmcnt(0)
-        v_add_u32 {X4}, {O('hca')}, {X4}
-        ds_read_b32 {SD}, {X4}
-        ds_read_b64 {PP}, {X4} offset:8
-        s_waitcnt lgkmcnt(0)
         v_lshrrev_b32 {P1}, 16, {P1}
+        v_bfe_u32 {SE}, {O('rc0')}, 15, 16
         v_cndmask_b32 {P1}, {P1}, 0, vcc
         v_cndmask_b32 {SD}, {P0}, {SD}, vcc
-        v_mul_u32_u24 {X5}, {P1}, {X5}
-        v_min_u32_sdwa {X5}, {X5}, {O('rc0')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_1
-        v_lshl_add_u32 {SE}, {X5}, 2, {SE}
+        v_mul_u32_u24 {E1}, {P1}, {E1}
+        v_bfe_u32 {E0}, {O('rc0')}, 2, 3
+        v_min_u32_sdwa {E1}, {E1}, {O('rc0')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_1
+        v_add_u32 {P1}, {P1}, {E0}
+        v_lshl_add_u32 {SE}, {E1}, 2, {SE}
         ds_read_b32 {SE}, {SE}
+    """)
+    ins_del(t, mode)
+    t(f"""
         s_waitcnt lgkmcnt(0)
         v_add_f32 {SE}, {SD}, {SE}
         v_cmp_lt_f32 vcc, {SE}, {O('ev')}
-        v_add_u32 {P1}, {P1}, {SF}
+        v_and_b32 {X3}, {O('refx')}, {O('seqw')}
+        v_bfe_u32 {X3}, {X3}, 8, 6
         v_cndmask_b32 {SHRV}, {O('ev')}, {SE}, vcc
         v_cndmask_b32 {SHRRUN}, 0, {P1}, vcc
         v_cndmask_b32 {SHRST}, {O('inf')}, {SD}, vcc
-        s_branch {L('shr_done' + sfx)}
+        s_branch {L('shr_done2' + sfx)}
     """)
-    # two candidates (second in rc1): all lane-table reads, all history reads, all score reads, then the compares in
-    # the reference's order.  NINSR / NDELR are free here (INS / DEL come after the passes)
+    # ---- two candidates (second in rc1): its lane tables and record now, then both scores, then the compares in
+    # the reference's order
     t.label("shr_two" + sfx)
     t(f"""
-        v_and_b32 {X3}, 28, {O('rc0')}
-        v_and_b32 {NINSR}, 28, {O('rc1')}
+        v_and_b32 {X3}, 28, {O('rc1')}
         ds_bpermute_b32 {X4}, {X3}, {O('tab')}
         ds_bpermute_b32 {X5}, {X3}, {O('trecip')}
-        ds_bpermute_b32 {SD}, {NINSR}, {O('tab')}
-        ds_bpermute_b32 {NDELR}, {NINSR}, {O('trecip')}
         v_cmp_gt_i32 vcc, 0, {O('rc0')}
         v_cmp_gt_i32 {O('sa')}, 0, {O('rc1')}
+        v_lshrrev_b32 {P1}, 16, {P1}
+        v_bfe_u32 {SE}, {O('rc0')}, 15, 16
+        v_cndmask_b32 {P1}, {P1}, 0, vcc
+        v_cndmask_b32 {SD}, {P0}, {SD}, vcc
+        v_mul_u32_u24 {E1}, {P1}, {E1}
+        v_bfe_u32 {E0}, {O('rc0')}, 2, 3
+        v_min_u32_sdwa {E1}, {E1}, {O('rc0')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_1
+        v_add_u32 {P1}, {P1}, {E0}
+        v_lshl_add_u32 {E0}, {E1}, 2, {SE}
         s_waitcnt lgkmcnt(0)
         v_add_u32 {X4}, {O('hca')}, {X4}
-        v_add_u32 {SD}, {O('hca')}, {SD}
-        ds_read_b32 {X3}, {X4}
-        ds_read_b64 {PP}, {X4} offset:8
-        ds_read_b32 {NINSR}, {SD}
-        ds_read_b64 v[98:99], {SD} offset:8
+        ds_read_b32 {E1}, {X4}
+        ds_read_b64 v[98:99], {X4} offset:8
+        ds_read_b32 {E0}, {E0}
+    """)
+    ins_del(t, mode, (X3, SHRST, SHRV, SHRRUN))     # (X4 X5 SE SF E0 E1 SD P0 P1 are in use)
+    t(f"""
         s_waitcnt lgkmcnt(0)
-        v_lshrrev_b32 {P1}, 16, {P1}
         v_lshrrev_b32 {SF}, 16, {SF}
-        v_cndmask_b32 {P1}, {P1}, 0, vcc
         v_cndmask_b32 {SF}, {SF}, 0, {O('sa')}
-        v_cndmask_b32 {X3}, {P0}, {X3}, vcc
-        v_cndmask_b32 {NINSR}, {SE}, {NINSR}, {O('sa')}
-        v_mul_u32_u24 {X5}, {P1}, {X5}
-        v_mul_u32_u24 {NDELR}, {SF}, {NDELR}
-        v_bfe_u32 {X4}, {O('rc0')}, 15, 16
-        v_bfe_u32 {SD}, {O('rc1')}, 15, 16
-        v_min_u32_sdwa {X5}, {X5}, {O('rc0')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_1
-        v_min_u32_sdwa {NDELR}, {NDELR}, {O('rc1')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_1
+        v_cndmask_b32 {E1}, {SE}, {E1}, {O('sa')}
+        v_mul_u32_u24 {X5}, {SF}, {X5}
+        v_bfe_u32 {X4}, {O('rc1')}, 15, 16
+        v_min_u32_sdwa {X5}, {X5}, {O('rc1')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_1
+        v_bfe_u32 {X3}, {O('rc1')}, 2, 3
         v_lshl_add_u32 {X4}, {X5}, 2, {X4}
-        v_lshl_add_u32 {SD}, {NDELR}, 2, {SD}
         ds_read_b32 {X4}, {X4}
-        ds_read_b32 {SD}, {SD}
-        v_bfe_u32 {X5}, {O('rc0')}, 2, 3
-        v_bfe_u32 {NDELR}, {O('rc1')}, 2, 3
-        v_add_u32 {P1}, {P1}, {X5}
-        v_add_u32 {SF}, {SF}, {NDELR}
-        s_waitcnt lgkmcnt(0)
-        v_add_f32 {X4}, {X3}, {X4}
-        v_add_f32 {SD}, {NINSR}, {SD}
-        v_cmp_lt_f32 vcc, {X4}, {O('ev')}
-        v_cndmask_b32 {SHRV}, {O('ev')}, {X4}, vcc
+        v_add_u32 {SF}, {SF}, {X3}
+        v_add_f32 {E0}, {SD}, {E0}
+        v_cmp_lt_f32 vcc, {E0}, {O('ev')}
+        v_and_b32 {X3}, {O('refx')}, {O('seqw')}
+        v_bfe_u32 {X3}, {X3}, 8, 6
+        v_cndmask_b32 {SHRV}, {O('ev')}, {E0}, vcc
         v_cndmask_b32 {SHRRUN}, 0, {P1}, vcc
-        v_cndmask_b32 {SHRST}, {O('inf')}, {X3}, vcc
-        v_cmp_lt_f32 vcc, {SD}, {SHRV}
-        v_cndmask_b32 {SHRV}, {SHRV}, {SD}, vcc
+        v_cndmask_b32 {SHRST}, {O('inf')}, {SD}, vcc
+        s_waitcnt lgkmcnt(0)
+        v_add_f32 {X4}, {E1}, {X4}
+        v_cmp_lt_f32 vcc, {X4}, {SHRV}
+        s_nop 1
+        v_cndmask_b32 {SHRV}, {SHRV}, {X4}, vcc
         v_cndmask_b32 {SHRRUN}, {SHRRUN}, {SF}, vcc
-        v_cndmask_b32 {SHRST}, {SHRST}, {NINSR}, vcc
+        v_cndmask_b32 {SHRST}, {SHRST}, {E1}, vcc
+        s_branch {L('shr_done2' + sfx)}
     """)
     t.label("shr_done" + sfx)
-    # ---- LEN candidates (cell.hpp, LEN loop; LEN_ARITH form)
     t(f"""
         v_and_b32 {X3}, {O('refx')}, {O('seqw')}
         v_bfe_u32 {X3}, {X3}, 8, 6
     """)
+    t.label("shr_done2" + sfx)
+
+
+def len_pass(t, mid, sfx):
+    """LEN candidates (cell.hpp, LEN loop; LEN_ARITH form).  On entry X3 = the six "read position i-n in an n-polymer
+    and reference position j starts one" bits.  Free: X4 X5 SD SE SF P0 P1 E0 E1."""
     if not mid:
         t(f"v_cndmask_b32 {X3}, 0, {X3}, {O('mhist')}")
     t.label("len_top" + sfx)
@@ -205,9 +243,9 @@ def core(t, mode, first, last, multi):
         s_and_b64 {O('sb')}, {O('sb')}, {O('sa')}
         s_cbranch_scc0 {L('len_top' + sfx)}
         v_add_u32 {SF}, 1, {X4}
-        v_lshlrev_b32 {NINSR}, 2, {SF}
-        ds_bpermute_b32 {NDELR}, {NINSR}, {O('tab')}
-        ds_bpermute_b32 {X5}, {NINSR}, {O('trecip')}
+        v_lshlrev_b32 {E0}, 2, {SF}
+        ds_bpermute_b32 {E1}, {E0}, {O('tab')}
+        ds_bpermute_b32 {X5}, {E0}, {O('trecip')}
         v_bfe_u32 {SD}, {O('seqw')}, {X4}, 1
         v_cmp_ne_u32 {O('sc')}, 0, {SD}
         v_add_u32 {SD}, {O('sdel')}, {O('lanej')}
@@ -217,18 +255,18 @@ def core(t, mode, first, last, multi):
         v_add_u32 {SD}, {O('winaddr')}, {SD}
         ds_read_u8 {SD}, {SD}
         s_waitcnt lgkmcnt(0)
-        v_lshl_add_u32 {NDELR}, {NINSR}, 2, {NDELR}
-        v_add_u32 {NDELR}, {O('hca')}, {NDELR}
-        ds_read_b64 {PP}, {NDELR}
-        ds_read_b32 {NINSR}, {NDELR} offset:12
+        v_lshl_add_u32 {E1}, {E0}, 2, {E1}
+        v_add_u32 {E1}, {O('hca')}, {E1}
+        ds_read_b64 {PP}, {E1}
+        ds_read_b32 {E0}, {E1} offset:12
         v_cmp_ne_u32 {O('sa')}, 0, {SD}
         v_cmp_ge_u32 vcc, {O('clamp1')}, {SF}
         s_and_b64 {O('sa')}, {O('sa')}, vcc
         s_waitcnt lgkmcnt(0)
         v_cndmask_b32 {P0}, {P1}, {P0}, {O('sc')}
-        v_and_b32 {NINSR}, 0xffff, {NINSR}
-        v_cndmask_b32 {NINSR}, {NINSR}, 0, {O('sc')}
-        v_mul_u32_u24 {P1}, {NINSR}, {X5}
+        v_and_b32 {E0}, 0xffff, {E0}
+        v_cndmask_b32 {E0}, {E0}, 0, {O('sc')}
+        v_mul_u32_u24 {P1}, {E0}, {X5}
         v_lshrrev_b32 {P1}, 16, {P1}
         v_add3_u32 {P1}, {SD}, {P1}, 1
         v_min_u32 {SD}, {O('clampv')}, {SD}
@@ -262,42 +300,32 @@ def core(t, mode, first, last, multi):
         s_mov_b64 vcc, {O('sa')}
         v_cndmask_b32 {SE}, {O('c100')}, {SE}, vcc
         v_add_f32 {SE}, {P0}, {SE}
-        v_add_u32 {NINSR}, {NINSR}, {SF}
+        v_add_u32 {E0}, {E0}, {SF}
         v_cmp_lt_f32 vcc, {SE}, {LENV}
         s_and_b64 vcc, vcc, {O('sb')}
         v_cndmask_b32 {LENV}, {LENV}, {SE}, vcc
-        v_cndmask_b32 {LENRUN}, {LENRUN}, {NINSR}, vcc
+        v_cndmask_b32 {LENRUN}, {LENRUN}, {E0}, vcc
         v_cndmask_b32 {LENST}, {LENST}, {P0}, vcc
         s_branch {L('len_top' + sfx)}
     """)
     t.label("len_done" + sfx)
-    # ---- INS / DEL (src/aln.pyx:525-565), MAT by two 3-way minima and equality tests (cell.hpp, Env::MIN3)
+
+
+def tail(t, mode, first, last, multi):
+    """MAT by two 3-way minima and equality tests (cell.hpp, Env::MIN3), stores, hand-over, loop"""
+    mid = multi and not first and not last
+    own_m, own_i, own_d, r1, r2 = O("matv"), O("insv"), O("delv"), O("R1"), O("R2")
+    diagM = O("LMv") if mode == "I" else O("TMv")
     t(f"""
-        v_add_f32 {SD}, {O('istart')}, {topM}
-        v_add_f32 {SE}, {O('iext')}, {topI}
-        v_add_f32 {SF}, {O('istart')}, {leftM}
-        v_add_f32 {X3}, {O('iext')}, {leftD}
-        v_add_u32_sdwa {NINSR}, {topR}, {O('one')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD
-        v_add_u32_sdwa {NDELR}, {leftR}, {O('one')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD
-        v_cmp_lt_f32 vcc, {SE}, {SD}
-        v_cmp_lt_f32 {O('sa')}, {X3}, {SF}
         s_waitcnt lgkmcnt(0)
         v_add_f32 {SUBV}, {diagM}, {SUBV}
-        v_cndmask_b32 {own_i}, {SD}, {SE}, vcc
-        v_cndmask_b32 {NINSR}, 1, {NINSR}, vcc
-        v_cndmask_b32 {own_d}, {SF}, {X3}, {O('sa')}
-        v_cndmask_b32 {NDELR}, 1, {NDELR}, {O('sa')}
-    """)
-    # the neighbour's MAT value becomes the diagonal of a later step
-    t(f"v_mov_b32 {O('LMv') if mode == 'I' else O('TMv')}, {X0}")
-    t(f"""
-        v_min3_f32 {SD}, {SUBV}, {own_i}, {LENV}
-        v_min3_f32 {own_m}, {SD}, {own_d}, {SHRV}
         v_lshl_or_b32 {SE}, {SHRRUN}, 3, 4
         v_lshl_or_b32 {SF}, {NDELR}, 3, 3
+        v_min3_f32 {SD}, {SUBV}, {own_i}, {LENV}
+        v_mov_b32 {diagM}, {X0}
+        v_min3_f32 {own_m}, {SD}, {own_d}, {SHRV}
         v_lshl_or_b32 {X3}, {LENRUN}, 3, 2
         v_lshl_or_b32 {X4}, {NINSR}, 3, 1
-        v_lshl_add_u32 {X5}, {DRUN}, 3, 8
         v_cmp_eq_f32 vcc, {own_d}, {own_m}
         v_cmp_eq_f32 {O('sa')}, {LENV}, {own_m}
         v_cmp_eq_f32 {O('sb')}, {own_i}, {own_m}
@@ -305,23 +333,24 @@ def core(t, mode, first, last, multi):
         v_cndmask_b32 {SE}, {SE}, {SF}, vcc
         v_add_u32 {SD}, 1, {DRUN}
         v_cndmask_b32 {SE}, {SE}, {X3}, {O('sa')}
-        v_lshl_or_b32 {SF}, {SHRRUN}, 16, {LENRUN}
+        v_lshl_add_u32 {X5}, {DRUN}, 3, 8
         v_cndmask_b32 {SE}, {SE}, {X4}, {O('sb')}
         v_cndmask_b32 {SD}, 0, {SD}, {O('sc')}
         v_cndmask_b32 {SE}, {SE}, {X5}, {O('sc')}
+        v_lshl_or_b32 {SF}, {SHRRUN}, 16, {LENRUN}
         v_lshl_or_b32 {r1}, {NINSR}, 16, {SD}
         v_lshl_or_b32 {r2}, {NDELR}, 16, {SD}
         v_add_u32 {X3}, {O('hca')}, {O('slot')}
     """)
-    # history record + traceback word of the band-interior columns (a middle wave holds no others)
+    # history record of the band-interior columns (a middle wave holds no others)
     if not mid:
         t(f"s_mov_b64 exec, {O('mhist')}")
     t(f"""
         ds_write2_b32 {X3}, {own_m}, {LENST} offset1:1
         ds_write2_b32 {X3}, {SHRST}, {SF} offset0:2 offset1:3
-        global_store_dword {O('tboff')}, {SE}, {O('tbg')}
     """)
     if not mid:
+        t(f"global_store_dword {O('tboff')}, {SE}, {O('tbg')}")
         t("s_mov_b64 exec, -1")
     # band-edge cells (src/aln.pyx:502-507): the three values their one in-band neighbour reads
     if first or last:
@@ -338,8 +367,9 @@ def core(t, mode, first, last, multi):
             v_cndmask_b32 {own_i}, {own_i}, {SD}, {O('medge')}
             v_cndmask_b32 {r1}, {r1}, 0, {O('medge')}
         """)
-    # hand-over to the neighbour waves, progress word (workgroup release: this wave's LDS writes first)
+    # hand-over to the neighbour waves, then the progress word (workgroup release: behind this wave's LDS writes)
     if multi:
+        t(f"v_add_u32 {O('prog')}, 1, {O('prog')}")
         if not last:
             t(f"""
                 s_mov_b64 exec, {O('ml63')}
@@ -347,9 +377,7 @@ def core(t, mode, first, last, multi):
                 ds_write_b32 {O('xown')}, {own_d} offset:{2 * XCH_WORDS * 4 + 4}
                 ds_write_b32 {O('xown')}, {r2} offset:{2 * XCH_WORDS * 4 + 8}
                 ds_write_b32 {O('xown')}, {O('seqw')} offset:{2 * XCH_WORDS * 4 + 12}
-                s_mov_b64 exec, -1
             """)
-        t(f"v_add_u32 {O('prog')}, 1, {O('prog')}")
         t(f"s_mov_b64 exec, {O('ml0')}")
         if not first:
             b = 2 * XCH_WORDS * 4 + 20
@@ -361,13 +389,16 @@ def core(t, mode, first, last, multi):
                 ds_write_b32 {O('xown')}, {O('rc0')} offset:{b + 16}
                 ds_write_b32 {O('xown')}, {O('rc1')} offset:{b + 20}
             """)
+        if not OPT["relaxed"]:
+            t("s_waitcnt lgkmcnt(0)")
         t(f"""
-            s_waitcnt lgkmcnt(0)
             ds_write_b32 {O('progaddr')}, {O('prog')}
             s_mov_b64 exec, -1
             v_sub_u32 {O('xown')}, {O('xsum')}, {O('xown')}
             v_sub_u32 {O('xoth')}, {O('xsum')}, {O('xoth')}
         """)
+    if mid:
+        t(f"global_store_dword {O('tboff')}, {SE}, {O('tbg')}")
     t(f"""
         v_add_f32 {O('ev')}, 0x42c80000, {O('ev')}
         s_add_i32 {O('bl')}, {O('bl')}, 1
@@ -421,12 +452,15 @@ def gen_role(role):
         s_bitcmp1_b64 {O('mask')}, {O('bl')}
         s_cbranch_scc0 {L('mode_d')}
     """)
-    # ================= 'I' step: read words move one column up, "left" is the previous lane
+    # ================= 'I' step: read words move one column up, "left" is the previous lane.  The column
+    # descriptors do not move, so everything about the SHR candidate that does not depend on the neighbour waves --
+    # the summary bits, the lane-table reads -- is done in front of the hand-shake poll.
     if first:
         t(f"""
             s_cmp_ge_i32 {O('sqidx')}, 64
-            s_cbranch_scc1 {L('exit')}
+            s_cbranch_scc1 {L('fill_sq')}
         """)
+        t.label("sq_ok")
     t(f"v_and_b32 {SHRST}, 0xbc, {O('rc0')}")
     if not mid:
         t(f"v_cndmask_b32 {SHRST}, 0, {SHRST}, {O('mhist')}")
@@ -434,6 +468,18 @@ def gen_role(role):
         v_cmp_lt_u32 vcc, 0x7f, {SHRST}
         s_cbranch_vccnz {L('exit')}
     """)
+    book(t, "I")
+    shr_tables(t)
+    t(f"""
+        v_and_b32 {DRUN}, 0xffff, {O('LMr')}
+        v_mov_b32 {O('TMv')}, {O('matv')}
+        v_mov_b32 {O('TMr')}, {O('R1')}
+    """)
+    if first:
+        t(f"""
+            v_readlane_b32 {O('sx')}, {O('seqq')}, {O('sqidx')}
+            s_add_i32 {O('sqidx')}, {O('sqidx')}, 1
+        """)
     if multi:
         polls(t, first, last, "_i")
     if not first:
@@ -443,104 +489,196 @@ def gen_role(role):
             ds_read_b32 {X2}, {O('xoth')} offset:8
             ds_read_b32 {X3}, {O('xoth')} offset:12
         """)
-    t(f"""
-        v_mov_b32 {O('TMv')}, {O('matv')}
-        v_mov_b32 {O('TMr')}, {O('R1')}
-    """)
-    book(t, "I")
+    else:
+        t("s_waitcnt lgkmcnt(0)")
+    shr_hist(t)
     if not first:
         t(f"""
-            s_waitcnt lgkmcnt(0)
+            s_waitcnt lgkmcnt(2)
+            v_mov_b32_dpp {X3}, {O('seqw')} wave_shr:1 row_mask:0xf bank_mask:0xf
             v_mov_b32_dpp {X0}, {O('matv')} wave_shr:1 row_mask:0xf bank_mask:0xf
             v_mov_b32_dpp {X1}, {O('delv')} wave_shr:1 row_mask:0xf bank_mask:0xf
             v_mov_b32_dpp {X2}, {O('R2')} wave_shr:1 row_mask:0xf bank_mask:0xf
-            v_mov_b32_dpp {X3}, {O('seqw')} wave_shr:1 row_mask:0xf bank_mask:0xf
-            v_and_b32 {DRUN}, 0xffff, {O('LMr')}
             v_mov_b32 {O('seqw')}, {X3}
             v_mov_b32 {O('LMr')}, {X2}
         """)
     else:
         t(f"""
-            v_readlane_b32 {O('sx')}, {O('seqq')}, {O('sqidx')}
-            s_add_i32 {O('sqidx')}, {O('sqidx')}, 1
+            v_mov_b32_dpp {O('seqw')}, {O('seqw')} wave_shr:1 row_mask:0xf bank_mask:0xf
             v_mov_b32_dpp {X0}, {O('matv')} wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
             v_mov_b32_dpp {X1}, {O('delv')} wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
             v_mov_b32_dpp {X2}, {O('R2')} wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
-            v_mov_b32_dpp {O('seqw')}, {O('seqw')} wave_shr:1 row_mask:0xf bank_mask:0xf
-            v_and_b32 {DRUN}, 0xffff, {O('LMr')}
-            v_mov_b32 {O('LMr')}, {X2}
             v_writelane_b32 {O('seqw')}, {O('sx')}, 0
+            v_mov_b32 {O('LMr')}, {X2}
         """)
-    core(t, "I", first, last, multi)
-    # ================= 'D' step: reference words move one column down, "top" is the next lane
+    sub_read(t)
+    t("s_waitcnt lgkmcnt(1)")          # the candidate's source record (the substitution score may still be on its way)
+    shr_pass(t, "I", mid, "_I", SHRST)
+    len_pass(t, mid, "_I")
+    tail(t, "I", first, last, multi)
+    # ================= 'D' step: reference words (and the column descriptors) move one column down, "top" is the
+    # next lane.  Last wave of a chunk: the word entering at its last lane comes from its own queue, so the step is
+    # laid out like an 'I' step; the other waves learn it from the wave above, behind the poll.
     t.label("mode_d")
     if last:
         t(f"""
             s_cmp_ge_i32 {O('rqidx')}, 64
-            s_cbranch_scc1 {L('exit')}
-            s_cmp_ge_i32 {O('sdel')}, {O('dlim')}
-            s_cbranch_scc1 {L('exit')}
+            s_cbranch_scc1 {L('fill_rq')}
         """)
-    if multi:
-        polls(t, first, last, "_d")
-    if not last:
-        b = (4 * XCH_WORDS + 5) * 4
+        t.label("rq_ok")
         t(f"""
-            ds_read_b32 {X0}, {O('xoth')} offset:{b}
-            ds_read_b32 {X1}, {O('xoth')} offset:{b + 4}
-            ds_read_b32 {X2}, {O('xoth')} offset:{b + 8}
-            ds_read_b32 {X3}, {O('xoth')} offset:{b + 12}
-            ds_read_b32 {X4}, {O('xoth')} offset:{b + 16}
-            ds_read_b32 {X5}, {O('xoth')} offset:{b + 20}
-            s_waitcnt lgkmcnt(0)
-            v_or_b32 {SD}, {O('rc0')}, {X4}
+            s_cmp_ge_i32 {O('sdel')}, {O('dlim')}
+            s_cbranch_scc1 {L('fill_win')}
         """)
-    else:
+        t.label("win_ok")
         t(f"""
             v_readlane_b32 {O('sx')}, {O('rqz')}, {O('rqidx')}
             v_or_b32 {SD}, {O('sx')}, {O('rc0')}
+            v_and_b32 {SD}, 0x80, {SD}
+            v_cmp_ne_u32 vcc, 0, {SD}
+            s_cbranch_vccnz {L('exit')}
         """)
+    book(t, "D")
     t(f"""
-        v_and_b32 {SD}, 0x80, {SD}
-        v_cmp_ne_u32 vcc, 0, {SD}
-        s_cbranch_vccnz {L('exit')}
         s_add_i32 {O('sdel')}, {O('sdel')}, 1
+        v_and_b32 {DRUN}, 0xffff, {O('TMr')}
         v_mov_b32 {O('LMv')}, {O('matv')}
         v_mov_b32 {O('LMr')}, {O('R2')}
     """)
-    book(t, "D")
-    if not last:
+    if last:
         t(f"""
-            v_mov_b32_dpp {X0}, {O('matv')} wave_shl:1 row_mask:0xf bank_mask:0xf
-            v_mov_b32_dpp {X1}, {O('insv')} wave_shl:1 row_mask:0xf bank_mask:0xf
-            v_mov_b32_dpp {X2}, {O('R1')} wave_shl:1 row_mask:0xf bank_mask:0xf
-            v_mov_b32_dpp {X3}, {O('refx')} wave_shl:1 row_mask:0xf bank_mask:0xf
-            v_mov_b32_dpp {X4}, {O('rc0')} wave_shl:1 row_mask:0xf bank_mask:0xf
-            v_mov_b32_dpp {X5}, {O('rc1')} wave_shl:1 row_mask:0xf bank_mask:0xf
-            v_and_b32 {DRUN}, 0xffff, {O('TMr')}
-            v_mov_b32 {O('refx')}, {X3}
-            v_mov_b32 {O('rc0')}, {X4}
-            v_mov_b32 {O('rc1')}, {X5}
-            v_mov_b32 {O('TMr')}, {X2}
-        """)
-    else:
-        t(f"""
-            v_mov_b32_dpp {X0}, {O('matv')} wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
-            v_mov_b32_dpp {X1}, {O('insv')} wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
-            v_mov_b32_dpp {X2}, {O('R1')} wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
             v_mov_b32_dpp {O('rc0')}, {O('rc0')} wave_shl:1 row_mask:0xf bank_mask:0xf
+            v_mov_b32_dpp {X0}, {O('matv')} wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
             v_writelane_b32 {O('rc0')}, {O('sx')}, 63
             v_readlane_b32 {O('sx')}, {O('rqx')}, {O('rqidx')}
             v_mov_b32_dpp {O('refx')}, {O('refx')} wave_shl:1 row_mask:0xf bank_mask:0xf
-            v_and_b32 {DRUN}, 0xffff, {O('TMr')}
+            v_mov_b32_dpp {X1}, {O('insv')} wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+            v_mov_b32_dpp {X2}, {O('R1')} wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
             v_writelane_b32 {O('refx')}, {O('sx')}, 63
             v_readlane_b32 {O('sx')}, {O('rqw')}, {O('rqidx')}
             v_mov_b32_dpp {O('rc1')}, {O('rc1')} wave_shl:1 row_mask:0xf bank_mask:0xf
             v_mov_b32 {O('TMr')}, {X2}
             s_add_i32 {O('rqidx')}, {O('rqidx')}, 1
+            v_and_b32 {SHRST}, 0xbc, {O('rc0')}
             v_writelane_b32 {O('rc1')}, {O('sx')}, 63
+            v_cndmask_b32 {SHRST}, 0, {SHRST}, {O('mhist')}
         """)
-    core(t, "D", first, last, multi)
+        shr_tables(t)
+        if multi:
+            polls(t, first, last, "_d")
+        else:
+            t("s_waitcnt lgkmcnt(0)")
+        shr_hist(t)
+        sub_read(t)
+        t("s_waitcnt lgkmcnt(1)")
+    else:
+        polls(t, first, last, "_d")
+        b = (4 * XCH_WORDS + 5) * 4
+        t(f"""
+            ds_read_b32 {X4}, {O('xoth')} offset:{b + 16}
+            ds_read_b32 {X0}, {O('xoth')} offset:{b}
+            ds_read_b32 {X1}, {O('xoth')} offset:{b + 4}
+            ds_read_b32 {X2}, {O('xoth')} offset:{b + 8}
+            ds_read_b32 {X3}, {O('xoth')} offset:{b + 12}
+            ds_read_b32 {X5}, {O('xoth')} offset:{b + 20}
+            s_waitcnt lgkmcnt(5)
+            v_or_b32 {SD}, {O('rc0')}, {X4}
+            v_and_b32 {SD}, 0x80, {SD}
+            v_cmp_ne_u32 vcc, 0, {SD}
+            s_cbranch_vccnz {L('exit2')}
+            v_mov_b32_dpp {X4}, {O('rc0')} wave_shl:1 row_mask:0xf bank_mask:0xf
+            v_mov_b32 {O('rc0')}, {X4}
+        """)
+        shr_tables(t, SF)          # (X3 is waiting for its exchange word)
+        t(f"""
+            v_and_b32 {SHRST}, 0xbc, {O('rc0')}
+            s_waitcnt lgkmcnt(2)
+            v_mov_b32_dpp {X3}, {O('refx')} wave_shl:1 row_mask:0xf bank_mask:0xf
+            v_mov_b32_dpp {X5}, {O('rc1')} wave_shl:1 row_mask:0xf bank_mask:0xf
+            v_mov_b32_dpp {X0}, {O('matv')} wave_shl:1 row_mask:0xf bank_mask:0xf
+            v_mov_b32_dpp {X1}, {O('insv')} wave_shl:1 row_mask:0xf bank_mask:0xf
+            v_mov_b32_dpp {X2}, {O('R1')} wave_shl:1 row_mask:0xf bank_mask:0xf
+            v_mov_b32 {O('refx')}, {X3}
+            v_mov_b32 {O('rc1')}, {X5}
+            v_mov_b32 {O('TMr')}, {X2}
+        """)
+        if not mid:
+            t(f"v_cndmask_b32 {SHRST}, 0, {SHRST}, {O('mhist')}")
+        sub_read(t)
+        t("s_waitcnt lgkmcnt(1)")
+        shr_hist(t)
+        t("s_waitcnt lgkmcnt(0)")
+    shr_pass(t, "D", mid, "_D", SHRST)
+    len_pass(t, mid, "_D")
+    tail(t, "D", first, last, multi)
+    # ---- refills (rare: once per 64 steps of a kind).  They wait for vmcnt(0), which also drains the traceback stores
+    if first:
+        # read words entering at column 0: the next 64 (SEQW_SENTINEL behind the chunk's last row)
+        t.label("fill_sq")
+        t(f"""
+            s_sub_i32 {O('sqidx')}, {O('sqidx')}, 64
+            s_add_i32 {O('sqbase')}, {O('sqbase')}, 64
+            v_add_u32 {X3}, {O('sqbase')}, {O('laneid')}
+            v_mov_b32 {O('seqq')}, 0xffffc000
+            v_cmp_ge_i32 vcc, {O('drows')}, {X3}
+            v_lshlrev_b32 {X3}, 2, {X3}
+            s_and_saveexec_b64 {O('sa')}, vcc
+            global_load_dword {O('seqq')}, {X3}, {O('seqwg')}
+            s_waitcnt vmcnt(0)
+            s_mov_b64 exec, -1
+            s_branch {L('sq_ok')}
+        """)
+    if last:
+        # reference words entering at the last column: the next 64 (REFW_SENTINEL outside the chunk's columns)
+        t.label("fill_rq")
+        t(f"""
+            s_sub_i32 {O('rqidx')}, {O('rqidx')}, 64
+            s_add_i32 {O('rqbase')}, {O('rqbase')}, 64
+            v_add_u32 {X5}, {O('rqbase')}, {O('laneid')}
+            v_mov_b32 {O('rqx')}, 0xdb6d8000
+            v_mov_b32 {O('rqz')}, 0
+            v_mov_b32 {O('rqw')}, 0
+            v_cmp_le_i32 vcc, 0, {X5}
+            v_cmp_ge_i32 {O('sa')}, {O('dcols')}, {X5}
+            v_lshlrev_b32 {X5}, 4, {X5}
+            s_and_b64 vcc, vcc, {O('sa')}
+            s_and_saveexec_b64 {O('sa')}, vcc
+            global_load_dwordx4 v[92:95], {X5}, {O('refwg')}
+            s_waitcnt vmcnt(0)
+            v_mov_b32 {O('rqx')}, v92
+            v_mov_b32 {O('rqz')}, v94
+            v_mov_b32 {O('rqw')}, v95
+            s_mov_b64 exec, -1
+            s_branch {L('rq_ok')}
+        """)
+        # reference-L window (LDS): the next WIN_STEP positions, ahead of the band
+        ws = 32 if role == 0 else 64
+        t.label("fill_win")
+        t(f"""
+            v_add_u32 {X5}, {O('wfill')}, {O('laneid')}
+            v_mov_b32 {P0}, 0
+            v_mov_b32 {P1}, 0
+            v_cmp_gt_u32 vcc, {ws}, {O('laneid')}
+            v_cmp_ge_i32 {O('sa')}, {O('dcols')}, {X5}
+            v_lshlrev_b32 {X4}, 3, {X5}
+            s_and_b64 {O('sa')}, {O('sa')}, vcc
+            s_mov_b64 exec, {O('sa')}
+            global_load_dwordx2 {PP}, {X4}, {O('reflg')}
+            s_waitcnt vmcnt(0)
+            s_mov_b64 exec, vcc
+            v_and_b32 {X5}, {O('wmask')}, {X5}
+            v_lshlrev_b32 {X5}, 3, {X5}
+            v_add_u32 {X5}, {O('winaddr')}, {X5}
+            ds_write_b64 {X5}, {PP}
+            s_mov_b64 exec, -1
+            s_add_i32 {O('wfill')}, {O('wfill')}, {ws}
+            s_add_i32 {O('dlim')}, {O('dlim')}, {ws}
+            s_branch {L('win_ok')}
+        """)
+    t.label("exit2")
+    t("s_waitcnt lgkmcnt(0)")      # (exchange words still on their way into scratch registers the caller may reuse)
+    t(f"s_mov_b32 {O('status')}, 2")
+    t(f"s_branch {L('end')}")
     t.label("exit")
     t(f"s_mov_b32 {O('status')}, 1")
     t(f"s_branch {L('end')}")
@@ -651,9 +789,10 @@ def operands(role):
     if multi:
         outs += [("prog", "+v", "prog_v"), ("xown", "+v", "xown"), ("xoth", "+v", "xoth")]
     if first:
-        outs += [("sqidx", "+s", "a_sq")]
+        outs += [("sqidx", "+s", "a_sq"), ("sqbase", "+s", "a_sqb"), ("seqq", "+v", "seq_q")]
     if last:
-        outs += [("rqidx", "+s", "a_rq")]
+        outs += [("rqidx", "+s", "a_rq"), ("rqbase", "+s", "a_rqb"), ("rqx", "+v", "ref_q.x"), ("rqz", "+v", "ref_q.z"),
+                 ("rqw", "+v", "ref_q.w"), ("wfill", "+s", "a_wfill"), ("dlim", "+s", "a_dlim")]
     if first or last:
         outs += [("sx", "=&s", "a_sx")]
     ins = [("mask", "s", "stepmask"), ("b1", "s", "a_b1"), ("hw16", "s", "a_hw16"), ("ringb", "s", "ring_bytes"),
@@ -671,10 +810,11 @@ def operands(role):
     elif first:
         ins += [("ml0", "s", "a_ml0")]
     if last:
-        ins += [("medge", "s", "a_medge"), ("dlim", "s", "a_dlim"), ("rqx", "v", "ref_q.x"), ("rqz", "v", "ref_q.z"),
-                ("rqw", "v", "ref_q.w")]
+        ins += [("medge", "s", "a_medge"), ("dcols", "s", "a_dcols"), ("refwg", "s", "refw_g"), ("reflg", "s", "refl_g")]
     if first:
-        ins += [("seqq", "v", "seq_q")]
+        ins += [("drows", "s", "a_drows"), ("seqwg", "s", "seqw_g")]
+    if first or last:
+        ins += [("laneid", "v", "a_laneid")]
     return outs, ins
 
 

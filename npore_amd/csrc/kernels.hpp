@@ -549,15 +549,18 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
         // instantiated per mode: the neighbour fetch then needs no selects.  (The compiler still places 14 + 5
         // register copies per step where the two bodies meet; ONE body with a short per-kind branch in front of a
         // common cell update has 5 inherent copies and measured 2.6 % slower at r = 100 -- DESIGN.md section 6.)
-        auto step = [&](auto mode_tag, auto role_tag, auto fast_tag) __attribute__((always_inline)) {
+        // book_tag = false: ring row, lane table of history offsets and traceback row of this anti-diagonal have been
+        // advanced already (a 'D' step that the assembly loop handed over behind its poll, plain_span below)
+        auto step4 = [&](auto mode_tag, auto role_tag, auto fast_tag, auto book_tag) __attribute__((always_inline)) {
             constexpr int MODE = decltype(mode_tag)::value;
+            constexpr bool BOOK = decltype(book_tag)::value;
             // ROLE: 0 = only wave of the chunk, 1 = first, 2 = middle, 3 = last (compile-time so that the
             // per-role code needs no joins inside the loop)
             constexpr int ROLE = decltype(role_tag)::value;
             constexpr bool IS_FIRST = (ROLE == 0 || ROLE == 1), IS_LAST = (ROLE == 0 || ROLE == 3);
             // FASTSEL: every band cell of this anti-diagonal is an ordinary one (cell.hpp step_is_plain)
             constexpr bool FASTSEL = decltype(fast_tag)::value;
-            if constexpr (MODE != 0) {
+            if constexpr (MODE != 0 && BOOK) {
                 // ring row of this anti-diagonal, then the lane table of history offsets: its entry n is entry n-1
                 // of the previous anti-diagonal's (same ring row), 16 bytes lower if the band has just moved (an
                 // 'I' step); entry 0 = this anti-diagonal's own row.  Nothing here depends on the neighbour waves,
@@ -787,6 +790,10 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
             }
         };
 
+        auto step = [&](auto mode_tag, auto role_tag, auto fast_tag) __attribute__((always_inline)) {
+            step4(mode_tag, role_tag, fast_tag, std::true_type{});
+        };
+
         // anti-diagonals [b0, b1) of one step window
         auto span = [&](int b0, int b1, auto role_tag, auto fast_tag) __attribute__((always_inline)) {
             if constexpr (NW == 1) {
@@ -831,15 +838,19 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
             uint32_t a_one = 1u, a_lanej = (uint32_t)(tcol - r);
             uint32_t a_progaddr = (uint32_t)(reinterpret_cast<const char *>(prog + cw) - reinterpret_cast<const char *>(lds));
             float a_inf = huge_f(), a_c100 = INF_F;          // (a literal and VCC do not fit one v_cndmask: constants in registers)
-            asm volatile("" : "+v"(a_one), "+v"(a_lanej), "+v"(a_progaddr), "+v"(a_inf), "+v"(a_c100));
+            uint32_t a_laneid = (uint32_t)lane;
+            const int a_drows = d.drows, a_dcols = d.dcols;
+            asm volatile("" : "+v"(a_one), "+v"(a_lanej), "+v"(a_progaddr), "+v"(a_inf), "+v"(a_c100), "+v"(a_laneid));
+            (void)a_laneid; (void)a_drows; (void)a_dcols;
             (void)a_mhist; (void)a_ml0; (void)a_ml63; (void)a_medge; (void)a_progaddr;
             for (;;) {
                 int a_status, a_sx;
                 unsigned long long a_sa, a_sb, a_sc;
-                const int a_dlim = uni(wfill) - r - WIN_SLACK - 1;  // (the 'D' step that would make the window refill)
+                int a_wfill = uni(wfill);
+                int a_dlim = a_wfill - r - WIN_SLACK - 1;       // (the 'D' step that makes the L window refill)
                 const int bl_in = a_bl;
-                int a_sq = uni(sq_idx), a_rq = uni(rq_idx);
-                (void)a_dlim; (void)a_sx; (void)a_sq; (void)a_rq;
+                int a_sq = uni(sq_idx), a_rq = uni(rq_idx), a_sqb = uni(sq_base), a_rqb = uni(rq_base);
+                (void)a_dlim; (void)a_sx; (void)a_sq; (void)a_rq; (void)a_sqb; (void)a_rqb; (void)a_wfill;
                 if constexpr (ROLE == 0)
                     asm volatile(NPORE_FILL_ASM_TEXT_0 : NPORE_FILL_ASM_OUTS_0 : NPORE_FILL_ASM_INS_0 : NPORE_FILL_ASM_CLOBBERS);
                 else if constexpr (ROLE == 1)
@@ -848,15 +859,19 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
                     asm volatile(NPORE_FILL_ASM_TEXT_2 : NPORE_FILL_ASM_OUTS_2 : NPORE_FILL_ASM_INS_2 : NPORE_FILL_ASM_CLOBBERS);
                 else
                     asm volatile(NPORE_FILL_ASM_TEXT_3 : NPORE_FILL_ASM_OUTS_3 : NPORE_FILL_ASM_INS_3 : NPORE_FILL_ASM_CLOBBERS);
-                sq_idx = a_sq;
-                rq_idx = a_rq;
+                sq_idx = a_sq; sq_base = a_sqb;
+                rq_idx = a_rq; rq_base = a_rqb;
+                if constexpr (ROLE == 0 || ROLE == 3) wfill = a_wfill;
                 // the scalar bookkeeping the text does not carry: local row / column of the input path
                 const int done = a_bl - bl_in;
                 const unsigned long long took = done >= 64 ? ~0ull : (((1ull << done) - 1ull) << (bl_in & 63));
                 st.ins_l += __popcll(stepmask & took);
                 st.del_l = a_sdel;
                 if (!a_status) break;
-                if ((stepmask >> (a_bl & 63)) & 1ull) step(std::integral_constant<int, 1>{}, role_tag, std::true_type{});
+                if (a_status == 2) {       // a 'D' step, stopped behind its poll: bookkeeping and column count already advanced
+                    st.del_l = a_sdel - 1;
+                    step4(std::integral_constant<int, 2>{}, role_tag, std::true_type{}, std::false_type{});
+                } else if ((stepmask >> (a_bl & 63)) & 1ull) step(std::integral_constant<int, 1>{}, role_tag, std::true_type{});
                 else step(std::integral_constant<int, 2>{}, role_tag, std::true_type{});
                 a_bl++;
                 a_sdel = uni(st.del_l);
