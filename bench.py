@@ -125,8 +125,9 @@ def csrc_sha():
     h = hashlib.sha256()
     d = os.path.join(REPO, "npore_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        h.update(f.encode())
-        h.update(open(os.path.join(d, f), "rb").read())
+        if os.path.isfile(os.path.join(d, f)):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 

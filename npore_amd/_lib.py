@@ -80,7 +80,7 @@ SIGNATURES = {
 
 
 def sources():
-    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + \
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if os.path.isfile(os.path.join(CSRC, f))] + \
         [os.path.join(_HERE, "..", "include", "npore_amd.h")]
 
 

@@ -25,9 +25,10 @@ import re
 X0, X1, X2, X3, X4, X5 = "v91", "v92", "v93", "v94", "v95", "v96"      # neighbour cell / exchange words, then scratch
 SD, SE, SF = "v97", "v98", "v99"
 P0, P1, PP = "v100", "v101", "v[100:101]"
-SUBV, DRUN, NINSR, NDELR = "v102", "v103", "v104", "v105"
-SHRV, SHRRUN, SHRST, LENV, LENRUN, LENST = "v106", "v107", "v108", "v109", "v110", "v111"
-SCRATCH = ["v%d" % k for k in range(89, 112)]
+SUBV, DRUN, NINSR, NDELR = "v102", "v103", "v87", "v88"
+SHRV, SHRRUN, LENV, LENRUN = "v104", "v105", "v106", "v107"
+Q0, LENST, SHRST, QRUNS, QQ = "v108", "v109", "v110", "v111", "v[108:111]"      # the history record: one ds_write_b128
+SCRATCH = ["v%d" % k for k in range(87, 112)]
 
 LDS_SUB_BASE = 6 * 32 * 33 * 4      # kernels.hpp LDS_SUB_BASE
 XCH_WORDS = 12                      # kernels.hpp
@@ -38,8 +39,17 @@ def O(name):
 
 
 class Text:
+    """main = the path most steps take (falls through from label to label); ool = rare blocks, emitted behind it"""
     def __init__(self):
         self.lines = []
+        self.main = self.lines
+        self.ool = []
+
+    def rare(self):
+        self.lines = self.ool
+
+    def common(self):
+        self.lines = self.main
 
     def __call__(self, s):
         for ln in s.strip("\n").split("\n"):
@@ -86,49 +96,63 @@ def sub_read(t):
     """)
 
 
-def ins_del(t, mode, tmp=None):
-    """INS / DEL (src/aln.pyx:525-565): new values straight into the own registers, runs into NINSR / NDELR.
-    tmp: four free registers (default X3 X4 X5 SF; SD SE P0 P1 E0 E1 may hold SHR candidates in flight)."""
-    A, B, C, D = tmp or (X3, X4, X5, SF)
-    own_m, own_i, own_d, r1, r2 = O("matv"), O("insv"), O("delv"), O("R1"), O("R2")
+def ins_part(t, mode, A, B, msk):
+    """INS (src/aln.pyx:525-543): new value straight into the own register, run into NINSR.  A, B: free registers"""
     if mode == "I":
-        topM, topI, topR, leftM, leftD, leftR = own_m, own_i, r1, X0, X1, O("LMr")
+        topM, topI, topR = O("matv"), O("insv"), O("R1")
     else:
-        topM, topI, topR, leftM, leftD, leftR = X0, X1, O("TMr"), own_m, own_d, r2
+        topM, topI, topR = X0, X1, O("TMr")
     t(f"""
         v_add_f32 {A}, {O('istart')}, {topM}
         v_add_f32 {B}, {O('iext')}, {topI}
-        v_add_f32 {C}, {O('istart')}, {leftM}
-        v_add_f32 {D}, {O('iext')}, {leftD}
         v_add_u32_sdwa {NINSR}, {topR}, {O('one')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD
-        v_add_u32_sdwa {NDELR}, {leftR}, {O('one')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD
-        v_cmp_lt_f32 {O('sb')}, {B}, {A}
-        v_cmp_lt_f32 {O('sc')}, {D}, {C}
+        v_cmp_lt_f32 {msk}, {B}, {A}
         v_mov_b32 {LENV}, {O('ev')}
         v_mov_b32 {LENRUN}, 0
-        v_cndmask_b32 {own_i}, {A}, {B}, {O('sb')}
-        v_cndmask_b32 {NINSR}, 1, {NINSR}, {O('sb')}
-        v_cndmask_b32 {own_d}, {C}, {D}, {O('sc')}
-        v_cndmask_b32 {NDELR}, 1, {NDELR}, {O('sc')}
-        v_mov_b32 {LENST}, 0x7f800000
+        v_cndmask_b32 {O('insv')}, {A}, {B}, {msk}
+        v_cndmask_b32 {NINSR}, 1, {NINSR}, {msk}
     """)
 
 
-def shr_pass(t, mode, mid, sfx, smr):
+def del_part(t, mode, A, B, msk):
+    """DEL (src/aln.pyx:547-565)"""
+    if mode == "I":
+        leftM, leftD, leftR = X0, X1, O("LMr")
+    else:
+        leftM, leftD, leftR = O("matv"), O("delv"), O("R2")
+    t(f"""
+        v_add_f32 {A}, {O('istart')}, {leftM}
+        v_add_f32 {B}, {O('iext')}, {leftD}
+        v_add_u32_sdwa {NDELR}, {leftR}, {O('one')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD
+        v_cmp_lt_f32 {msk}, {B}, {A}
+        v_mov_b32 {LENST}, 0x7f800000
+        v_and_b32 {X3}, {O('refx')}, {O('seqw')}
+        v_cndmask_b32 {O('delv')}, {A}, {B}, {msk}
+        v_cndmask_b32 {NDELR}, 1, {NDELR}, {msk}
+    """)
+
+
+def shr_pass(t, mid, sfx, smr, shadow, shadow2):
     """SHR candidates of the column (cell.hpp shr_small<FAST>).  On entry: the first candidate's lane-table results in
-    E0 (offset, hca already added) / E1 and its source record in SD (matv), P0 (shrstart), P1 (runs) -- all fetched;
-    INS / DEL are computed in the shadow of the score read."""
+    E0 (address of its source record) / E1 (1/n) and the record itself in SD (matv), P0 (shrstart), P1 (runs).
+    shadow(): work issued in the shadow of the score read (free registers X4 X5 SF); shadow2(): the same for the
+    two-candidate block (free registers SHRV SHRRUN).  Leaves X3 = refx & seqw (shadow's last act) for the LEN test.
+    The single-candidate case falls through; "no candidate in the wave" and "two candidates" are out of line."""
     if not mid:
         t(f"""
             v_cmp_ne_u32 vcc, 0, {smr}
-            s_cbranch_vccnz {L('shr_some' + sfx)}
+            s_cbranch_vccz {L('shr_none' + sfx)}
+        """)
+        t.rare()
+        t.label("shr_none" + sfx)
+        t(f"""
             v_mov_b32 {SHRV}, {O('ev')}
             v_mov_b32 {SHRRUN}, 0
             v_mov_b32 {SHRST}, 0x7f800000
         """)
-        ins_del(t, mode)
+        shadow()
         t(f"s_branch {L('shr_done' + sfx)}")
-        t.label("shr_some" + sfx)
+        t.common()
     t(f"""
         v_cmp_lt_u32 vcc, 28, {smr}
         s_cbranch_vccnz {L('shr_two' + sfx)}
@@ -147,20 +171,21 @@ def shr_pass(t, mode, mid, sfx, smr):
         v_lshl_add_u32 {SE}, {E1}, 2, {SE}
         ds_read_b32 {SE}, {SE}
     """)
-    ins_del(t, mode)
+    shadow()
     t(f"""
         s_waitcnt lgkmcnt(0)
         v_add_f32 {SE}, {SD}, {SE}
         v_cmp_lt_f32 vcc, {SE}, {O('ev')}
-        v_and_b32 {X3}, {O('refx')}, {O('seqw')}
         v_bfe_u32 {X3}, {X3}, 8, 6
+        s_nop 0
         v_cndmask_b32 {SHRV}, {O('ev')}, {SE}, vcc
         v_cndmask_b32 {SHRRUN}, 0, {P1}, vcc
         v_cndmask_b32 {SHRST}, {O('inf')}, {SD}, vcc
-        s_branch {L('shr_done2' + sfx)}
     """)
+    t.label("shr_done2" + sfx)
     # ---- two candidates (second in rc1): its lane tables and record now, then both scores, then the compares in
     # the reference's order
+    t.rare()
     t.label("shr_two" + sfx)
     t(f"""
         v_and_b32 {X3}, 28, {O('rc1')}
@@ -183,7 +208,7 @@ def shr_pass(t, mode, mid, sfx, smr):
         ds_read_b64 v[98:99], {X4} offset:8
         ds_read_b32 {E0}, {E0}
     """)
-    ins_del(t, mode, (X3, SHRST, SHRV, SHRRUN))     # (X4 X5 SE SF E0 E1 SD P0 P1 are in use)
+    shadow2()                # (X4 X5 SE SF E0 E1 SD P0 P1 are in use; leaves X3 = refx & seqw)
     t(f"""
         s_waitcnt lgkmcnt(0)
         v_lshrrev_b32 {SF}, 16, {SF}
@@ -192,14 +217,14 @@ def shr_pass(t, mode, mid, sfx, smr):
         v_mul_u32_u24 {X5}, {SF}, {X5}
         v_bfe_u32 {X4}, {O('rc1')}, 15, 16
         v_min_u32_sdwa {X5}, {X5}, {O('rc1')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_1
-        v_bfe_u32 {X3}, {O('rc1')}, 2, 3
+        v_bfe_u32 {SE}, {O('rc1')}, 2, 3
         v_lshl_add_u32 {X4}, {X5}, 2, {X4}
         ds_read_b32 {X4}, {X4}
-        v_add_u32 {SF}, {SF}, {X3}
+        v_add_u32 {SF}, {SF}, {SE}
         v_add_f32 {E0}, {SD}, {E0}
         v_cmp_lt_f32 vcc, {E0}, {O('ev')}
-        v_and_b32 {X3}, {O('refx')}, {O('seqw')}
         v_bfe_u32 {X3}, {X3}, 8, 6
+        s_nop 0
         v_cndmask_b32 {SHRV}, {O('ev')}, {E0}, vcc
         v_cndmask_b32 {SHRRUN}, 0, {P1}, vcc
         v_cndmask_b32 {SHRST}, {O('inf')}, {SD}, vcc
@@ -212,23 +237,34 @@ def shr_pass(t, mode, mid, sfx, smr):
         v_cndmask_b32 {SHRST}, {SHRST}, {E1}, vcc
         s_branch {L('shr_done2' + sfx)}
     """)
-    t.label("shr_done" + sfx)
-    t(f"""
-        v_and_b32 {X3}, {O('refx')}, {O('seqw')}
-        v_bfe_u32 {X3}, {X3}, 8, 6
-    """)
-    t.label("shr_done2" + sfx)
+    if not mid:
+        t.label("shr_done" + sfx)
+        t(f"""
+            v_bfe_u32 {X3}, {X3}, 8, 6
+            s_branch {L('shr_done2' + sfx)}
+        """)
+    t.common()
 
 
 def len_pass(t, mid, sfx):
     """LEN candidates (cell.hpp, LEN loop; LEN_ARITH form).  On entry X3 = the six "read position i-n in an n-polymer
-    and reference position j starts one" bits.  Free: X4 X5 SD SE SF P0 P1 E0 E1."""
+    and reference position j starts one" bits.  The loop is out of line (two steps in three have no candidate).
+    Free: X4 X5 SD SE SF P0 P1 E0 E1."""
     if not mid:
         t(f"v_cndmask_b32 {X3}, 0, {X3}, {O('mhist')}")
+    t(f"""
+        v_cmp_ne_u32 vcc, 0, {X3}
+        s_cbranch_vccnz {L('len_body' + sfx)}
+    """)
+    t.label("len_done" + sfx)
+    t.rare()
     t.label("len_top" + sfx)
     t(f"""
         v_cmp_ne_u32 vcc, 0, {X3}
         s_cbranch_vccz {L('len_done' + sfx)}
+    """)
+    t.label("len_body" + sfx)
+    t(f"""
         s_mov_b64 {O('sa')}, vcc
         v_ffbh_u32 {X4}, {X3}
         v_sub_u32 {X4}, 31, {X4}
@@ -308,11 +344,11 @@ def len_pass(t, mid, sfx):
         v_cndmask_b32 {LENST}, {LENST}, {P0}, vcc
         s_branch {L('len_top' + sfx)}
     """)
-    t.label("len_done" + sfx)
+    t.common()
 
 
 def tail(t, mode, first, last, multi):
-    """MAT by two 3-way minima and equality tests (cell.hpp, Env::MIN3), stores, hand-over, loop"""
+    """MAT by two 3-way minima and equality tests (cell.hpp, Env::MIN3), stores, hand-over, next step"""
     mid = multi and not first and not last
     own_m, own_i, own_d, r1, r2 = O("matv"), O("insv"), O("delv"), O("R1"), O("R2")
     diagM = O("LMv") if mode == "I" else O("TMv")
@@ -323,13 +359,13 @@ def tail(t, mode, first, last, multi):
         v_lshl_or_b32 {SF}, {NDELR}, 3, 3
         v_min3_f32 {SD}, {SUBV}, {own_i}, {LENV}
         v_mov_b32 {diagM}, {X0}
-        v_min3_f32 {own_m}, {SD}, {own_d}, {SHRV}
+        v_min3_f32 {Q0}, {SD}, {own_d}, {SHRV}
         v_lshl_or_b32 {X3}, {LENRUN}, 3, 2
         v_lshl_or_b32 {X4}, {NINSR}, 3, 1
-        v_cmp_eq_f32 vcc, {own_d}, {own_m}
-        v_cmp_eq_f32 {O('sa')}, {LENV}, {own_m}
-        v_cmp_eq_f32 {O('sb')}, {own_i}, {own_m}
-        v_cmp_eq_f32 {O('sc')}, {SUBV}, {own_m}
+        v_cmp_eq_f32 vcc, {own_d}, {Q0}
+        v_cmp_eq_f32 {O('sa')}, {LENV}, {Q0}
+        v_cmp_eq_f32 {O('sb')}, {own_i}, {Q0}
+        v_cmp_eq_f32 {O('sc')}, {SUBV}, {Q0}
         v_cndmask_b32 {SE}, {SE}, {SF}, vcc
         v_add_u32 {SD}, 1, {DRUN}
         v_cndmask_b32 {SE}, {SE}, {X3}, {O('sa')}
@@ -337,18 +373,16 @@ def tail(t, mode, first, last, multi):
         v_cndmask_b32 {SE}, {SE}, {X4}, {O('sb')}
         v_cndmask_b32 {SD}, 0, {SD}, {O('sc')}
         v_cndmask_b32 {SE}, {SE}, {X5}, {O('sc')}
-        v_lshl_or_b32 {SF}, {SHRRUN}, 16, {LENRUN}
+        v_lshl_or_b32 {QRUNS}, {SHRRUN}, 16, {LENRUN}
+        v_add_u32 {X3}, {O('hca')}, {O('slot')}
         v_lshl_or_b32 {r1}, {NINSR}, 16, {SD}
         v_lshl_or_b32 {r2}, {NDELR}, 16, {SD}
-        v_add_u32 {X3}, {O('hca')}, {O('slot')}
+        v_mov_b32 {own_m}, {Q0}
     """)
     # history record of the band-interior columns (a middle wave holds no others)
     if not mid:
         t(f"s_mov_b64 exec, {O('mhist')}")
-    t(f"""
-        ds_write2_b32 {X3}, {own_m}, {LENST} offset1:1
-        ds_write2_b32 {X3}, {SHRST}, {SF} offset0:2 offset1:3
-    """)
+    t(f"ds_write_b128 {X3}, {QQ}")
     if not mid:
         t(f"global_store_dword {O('tboff')}, {SE}, {O('tbg')}")
         t("s_mov_b64 exec, -1")
@@ -367,27 +401,24 @@ def tail(t, mode, first, last, multi):
             v_cndmask_b32 {own_i}, {own_i}, {SD}, {O('medge')}
             v_cndmask_b32 {r1}, {r1}, 0, {O('medge')}
         """)
-    # hand-over to the neighbour waves, then the progress word (workgroup release: behind this wave's LDS writes)
+    # hand-over to the neighbour waves, then the progress word.  Release: the LDS unit serves the requests of one
+    # wave in order, so the record and the history row are in place before the progress word that follows them
+    # (OPT relaxed = False puts an explicit lgkmcnt(0) in front of it, like the C++ body's workgroup fence)
     if multi:
         t(f"v_add_u32 {O('prog')}, 1, {O('prog')}")
         if not last:
             t(f"""
                 s_mov_b64 exec, {O('ml63')}
-                ds_write_b32 {O('xown')}, {own_m} offset:{2 * XCH_WORDS * 4}
-                ds_write_b32 {O('xown')}, {own_d} offset:{2 * XCH_WORDS * 4 + 4}
-                ds_write_b32 {O('xown')}, {r2} offset:{2 * XCH_WORDS * 4 + 8}
-                ds_write_b32 {O('xown')}, {O('seqw')} offset:{2 * XCH_WORDS * 4 + 12}
+                ds_write2_b32 {O('xown')}, {own_m}, {own_d} offset0:{2 * XCH_WORDS} offset1:{2 * XCH_WORDS + 1}
+                ds_write2_b32 {O('xown')}, {r2}, {O('seqw')} offset0:{2 * XCH_WORDS + 2} offset1:{2 * XCH_WORDS + 3}
             """)
         t(f"s_mov_b64 exec, {O('ml0')}")
         if not first:
-            b = 2 * XCH_WORDS * 4 + 20
+            b = 2 * XCH_WORDS + 5
             t(f"""
-                ds_write_b32 {O('xown')}, {own_m} offset:{b}
-                ds_write_b32 {O('xown')}, {own_i} offset:{b + 4}
-                ds_write_b32 {O('xown')}, {r1} offset:{b + 8}
-                ds_write_b32 {O('xown')}, {O('refx')} offset:{b + 12}
-                ds_write_b32 {O('xown')}, {O('rc0')} offset:{b + 16}
-                ds_write_b32 {O('xown')}, {O('rc1')} offset:{b + 20}
+                ds_write2_b32 {O('xown')}, {own_m}, {own_i} offset0:{b} offset1:{b + 1}
+                ds_write2_b32 {O('xown')}, {r1}, {O('refx')} offset0:{b + 2} offset1:{b + 3}
+                ds_write2_b32 {O('xown')}, {O('rc0')}, {O('rc1')} offset0:{b + 4} offset1:{b + 5}
             """)
         if not OPT["relaxed"]:
             t("s_waitcnt lgkmcnt(0)")
@@ -403,12 +434,31 @@ def tail(t, mode, first, last, multi):
         v_add_f32 {O('ev')}, 0x42c80000, {O('ev')}
         s_add_i32 {O('bl')}, {O('bl')}, 1
         s_cmp_lt_i32 {O('bl')}, {O('b1')}
-        s_cbranch_scc1 {L('top')}
-        s_branch {L('done')}
+        s_cbranch_scc0 {L('done')}
+        s_bitcmp1_b64 {O('mask')}, {O('bl')}
     """)
+    if mode == "I":      # (the 'D' body follows)
+        t(f"s_cbranch_scc1 {L('mode_i')}")
+    else:
+        t(f"""
+            s_cbranch_scc0 {L('mode_d')}
+            s_branch {L('mode_i')}
+        """)
 
 
 def polls(t, first, last, sfx):
+    """this wave may start the anti-diagonal once its neighbour waves have finished the previous one"""
+    if not first and not last:
+        # both progress words in one round trip (the neighbours' words lie 8 bytes apart, this wave's in between)
+        t.label("pp" + sfx)
+        t(f"""
+            ds_read2_b32 {PP}, {O('pnb')} offset1:2
+            s_waitcnt lgkmcnt(0)
+            v_min_i32 {X3}, {P0}, {P1}
+            v_cmp_lt_i32 vcc, {X3}, {O('prog')}
+            s_cbranch_vccnz {L('pp' + sfx)}
+        """)
+        return
     if not last:
         t.label("pa" + sfx)
         t(f"""
@@ -447,14 +497,14 @@ def gen_role(role):
     last = role in (0, 3)
     mid = role == 2
     t = Text()
-    t.label("top")
     t(f"""
         s_bitcmp1_b64 {O('mask')}, {O('bl')}
         s_cbranch_scc0 {L('mode_d')}
     """)
     # ================= 'I' step: read words move one column up, "left" is the previous lane.  The column
-    # descriptors do not move, so everything about the SHR candidate that does not depend on the neighbour waves --
-    # the summary bits, the lane-table reads -- is done in front of the hand-shake poll.
+    # descriptors do not move and INS reads this lane's own cell, so everything that does not depend on the neighbour
+    # waves -- the descriptor's summary bits, the lane-table reads, INS -- is done in front of the hand-shake poll.
+    t.label("mode_i")
     if first:
         t(f"""
             s_cmp_ge_i32 {O('sqidx')}, 64
@@ -475,6 +525,7 @@ def gen_role(role):
         v_mov_b32 {O('TMv')}, {O('matv')}
         v_mov_b32 {O('TMr')}, {O('R1')}
     """)
+    ins_part(t, "I", X4, X5, O("sb"))
     if first:
         t(f"""
             v_readlane_b32 {O('sx')}, {O('seqq')}, {O('sqidx')}
@@ -513,12 +564,13 @@ def gen_role(role):
         """)
     sub_read(t)
     t("s_waitcnt lgkmcnt(1)")          # the candidate's source record (the substitution score may still be on its way)
-    shr_pass(t, "I", mid, "_I", SHRST)
+    shr_pass(t, mid, "_I", SHRST, lambda: del_part(t, "I", X4, X5, O("sb")), lambda: del_part(t, "I", SHRV, SHRRUN, O("sb")))
     len_pass(t, mid, "_I")
     tail(t, "I", first, last, multi)
     # ================= 'D' step: reference words (and the column descriptors) move one column down, "top" is the
-    # next lane.  Last wave of a chunk: the word entering at its last lane comes from its own queue, so the step is
-    # laid out like an 'I' step; the other waves learn it from the wave above, behind the poll.
+    # next lane.  Last wave of a chunk: the word entering at its last lane comes from its own queue and the next
+    # lane's cell is in its own registers, so all but the history reads sits in front of the poll; the other waves
+    # learn both from the wave above, behind the poll.
     t.label("mode_d")
     if last:
         t(f"""
@@ -564,6 +616,7 @@ def gen_role(role):
             v_cndmask_b32 {SHRST}, 0, {SHRST}, {O('mhist')}
         """)
         shr_tables(t)
+        ins_part(t, "D", X4, X5, O("sb"))
         if multi:
             polls(t, first, last, "_d")
         else:
@@ -605,12 +658,15 @@ def gen_role(role):
         if not mid:
             t(f"v_cndmask_b32 {SHRST}, 0, {SHRST}, {O('mhist')}")
         sub_read(t)
+        ins_part(t, "D", X4, X5, O("sb"))      # (in the shadow of the lane-table reads)
         t("s_waitcnt lgkmcnt(1)")
         shr_hist(t)
         t("s_waitcnt lgkmcnt(0)")
-    shr_pass(t, "D", mid, "_D", SHRST)
+    shr_pass(t, mid, "_D", SHRST, lambda: del_part(t, "D", X4, X5, O("sb")), lambda: del_part(t, "D", SHRV, SHRRUN, O("sb")))
     len_pass(t, mid, "_D")
     tail(t, "D", first, last, multi)
+    t.lines = t.main
+    t.main.extend(t.ool)
     # ---- refills (rare: once per 64 steps of a kind).  They wait for vmcnt(0), which also drains the traceback stores
     if first:
         # read words entering at column 0: the next 64 (SEQW_SENTINEL behind the chunk's last row)
@@ -819,7 +875,16 @@ def operands(role):
 
 
 def main():
+    import sys
     here = os.path.dirname(os.path.abspath(__file__))
+    out_path = os.path.join(here, "fill_step_asm.inc")
+    args = sys.argv[1:]
+    while args:                      # measurement variants: --relaxed, --out FILE
+        a = args.pop(0)
+        if a == "--relaxed":
+            OPT["relaxed"] = True
+        elif a == "--out":
+            out_path = args.pop(0)
     out = ["// fill_step_asm.inc -- GENERATED by gen_fill_asm.py (do not edit): the plain-step loop of fill_kernel as gfx950",
            "// assembly, one text per wave role, with the operand lists that bind it to the variables of kernels.hpp.", ""]
     for role in range(4):
@@ -838,7 +903,7 @@ def main():
         out.append(f"#define NPORE_FILL_ASM_INS_{role} " + ", ".join(f'[{n}] "{c}"({e})' for n, c, e in ins))
         out.append("")
     out.append("#define NPORE_FILL_ASM_CLOBBERS \"memory\", \"vcc\", \"scc\", " + ", ".join('"%s"' % r for r in SCRATCH))
-    with open(os.path.join(here, "fill_step_asm.inc"), "w") as fh:
+    with open(out_path, "w") as fh:
         fh.write("\n".join(out) + "\n")
     for role in range(4):
         n = gen_role(role)

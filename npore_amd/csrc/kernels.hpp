@@ -34,7 +34,10 @@
 #include <type_traits>
 
 #include "cell.hpp"
-#include "fill_step_asm.inc"
+#if !defined(NPORE_FILL_ASM_INC)
+#define NPORE_FILL_ASM_INC "fill_step_asm.inc"     // (measurement builds: another generated variant)
+#endif
+#include NPORE_FILL_ASM_INC
 #include "layout.hpp"
 
 namespace npore {
