@@ -296,6 +296,11 @@ int npore_bam_realign_file(npore_ctx *ctx, npore_bam *bam, const npore_fasta *fa
 /* Host wall time of the stages of the last npore_bam_realign_batch on `bam` (milliseconds):
  * ms[0] pack, ms[1] npore_align_batch (incl. PCIe), ms[2] standardise, ms[3] SAM formatting. */
 int npore_bam_last_timing(const npore_bam *bam, double *ms, int n);
+/* Stage clocks of the last npore_bam_realign_file on `bam` (milliseconds): [0] record fetch + pack, [1] the align calls
+ * (host wall inside npore_align_batch: upload, kernels, download), [2] standardise, [3] SAM text, [4] file write --
+ * each the SUM over the batches of the time that stage's thread spent (the stages of neighbouring batches overlap);
+ * [5] wall time of the call, [6] GPU kernel time (preparation + fill + traceback, both contexts), [7] PCIe time. */
+int npore_bam_file_timing(const npore_bam *bam, double *ms, int n);
 
 /*
  * The counting loop of calc_confusion_matrices (reference src/bam.pyx:351-499) for one range (ctg, start, end):

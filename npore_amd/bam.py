@@ -560,6 +560,14 @@ class NativeBam:
         self._lib.npore_bam_last_timing(self.handle, ms.ctypes.data, 4)
         return dict(zip(("pack_ms", "align_ms", "standardize_ms", "format_ms"), ms.tolist()))
 
+    def file_timing(self):
+        """Stage clocks (ms) of the last realign_file: per-stage sums over the batches (stages overlap), the wall time
+        of the call, the GPU's kernel and PCIe time (npore_bam_file_timing)."""
+        ms = np.zeros(8, np.float64)
+        self._lib.npore_bam_file_timing(self.handle, ms.ctypes.data, 8)
+        return dict(zip(("fetch_pack_ms", "align_call_ms", "standardize_ms", "format_ms", "write_ms", "wall_ms", "gpu_kernels_ms",
+                         "pcie_ms"), ms.tolist()))
+
     def _check(self, rc):
         if rc != 0:
             from . import _lib

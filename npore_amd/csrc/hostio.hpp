@@ -341,6 +341,7 @@ struct npore_bam {
     npore::RawBuf sam;                    // text of the last formatted batch
     npore::RawBuf w_finals;               // final CIGARs of the last batch (work buffer, reused)
     double stage_ms[4] = {0, 0, 0, 0};    // last npore_bam_realign_batch: pack, align, standardise, format
+    double file_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // last npore_bam_realign_file (npore_bam_file_timing)
 };
 
 struct npore_fasta {

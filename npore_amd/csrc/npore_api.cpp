@@ -108,6 +108,7 @@ struct HostBuf {   // pinned staging
 struct npore_batch_slot {
     RawBuf refs{true}, seqs{true}, cigs{true}, alns{true}, finals, sam;
     RecFetch rf;                 // the batch's BAM records (streamed handles: inflated for the batch)
+    double t_ms[6] = {0, 0, 0, 0, 0, 0};   // npore_bam_realign_file: fetch + pack, align call, standardise, format, write, (spare)
     std::vector<int64_t> ro, so, co, oo, fo, olen, flen;
     int64_t sam_len = 0;
     int rc = 0;
@@ -165,6 +166,7 @@ struct npore_ctx {
     std::vector<int32_t> regions;                                    // npore_np_regions: positions, then repeat counts
     DevBuf out, out_off, out_len, status;                            // outputs (host-buffer entry point)
     // host staging of the BAM -> SAM pipeline (npore_bam_realign_batch / _file): grow-only, reused across batches and files
+    double file_mark[2] = {0, 0};      // totals at the start of npore_bam_realign_file (kernels, PCIe)
     static constexpr int N_SLOTS = 6;
     npore_batch_slot *slots[N_SLOTS] = {};
     // second context of the file pipeline (its own stream and work buffers), so that the transfers, preparation and
@@ -1767,11 +1769,15 @@ try {
     for (auto &sp : ctx->slots)
         if (!sp) sp = new npore_batch_slot();
     const int64_t nb = (n + batch_reads - 1) / batch_reads;
+    const auto wall0 = std::chrono::steady_clock::now();
+    for (auto &sp : ctx->slots) std::fill(sp->t_ms, sp->t_ms + 6, 0.0);
     if (nb > 1 && !ctx->peer) {
         ctx->peer = npore_ctx_create(ctx->h_sub.data(), ctx->h_np.data(), ctx->max_n, ctx->max_l, ctx->device);
         if (!ctx->peer) { std::fclose(fh); return NPORE_E_HIP; }
     }
     npore_ctx *gctx[2] = {ctx, ctx->peer ? ctx->peer : ctx};
+    for (npore_ctx *g : {ctx, ctx->peer})
+        if (g) { g->file_mark[0] = g->totals[0] + g->totals[1] + g->totals[2]; g->file_mark[1] = g->totals[3] + g->totals[4]; }
     for (npore_ctx *g : gctx) { g->tb_budget_mb = ctx->tb_budget_mb; g->tb_kernel = ctx->tb_kernel; g->force_chunks = ctx->force_chunks; }
     constexpr int S = npore_ctx::N_SLOTS;
     auto first = [&](int64_t k) { return k * batch_reads; };
@@ -1784,7 +1790,9 @@ try {
         packed[(size_t)k] = std::async(std::launch::async, [&, k] {
             npore_batch_slot &s = *ctx->slots[(size_t)(k % S)];
             if (k >= S) posted[(size_t)(k - S)].wait();        // the slot's previous batch has been written
+            const auto t0 = std::chrono::steady_clock::now();
             s.rc = slot_pack(b, fa, fasta_of_ref, idx + first(k), count(k), threads, s);
+            s.t_ms[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (s.rc) s.err = npore_last_error();
         });
     };
@@ -1792,10 +1800,17 @@ try {
         posted[(size_t)k] = std::async(std::launch::async, [&, k] {
             npore_batch_slot &t = *ctx->slots[(size_t)(k % S)];
             if (t.rc) return;
-            t.rc = slot_post(b, idx + first(k), count(k), status + first(k), threads, t);
+            auto t0 = std::chrono::steady_clock::now();
+            double ms_std = 0.0;
+            t.rc = slot_post(b, idx + first(k), count(k), status + first(k), threads, t, &ms_std);
+            const double ms_post = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            t.t_ms[2] += ms_std;
+            t.t_ms[3] += ms_post - ms_std;
             if (t.rc) { t.err = npore_last_error(); return; }
             if (k > 0) posted[(size_t)(k - 1)].wait();         // records in input order
+            t0 = std::chrono::steady_clock::now();
             if (std::fwrite(t.sam.p, 1, (size_t)t.sam_len, fh) != (size_t)t.sam_len) { t.rc = NPORE_E_INVALID; t.err = "short write"; }
+            t.t_ms[4] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         });
     };
     int rc = NPORE_OK;
@@ -1818,7 +1833,9 @@ try {
         aligned[(size_t)k] = std::async(std::launch::async, [&, k] {
             npore_batch_slot &t = *ctx->slots[(size_t)(k % S)];
             (void)hipSetDevice(ctx->device);
+            const auto t0 = std::chrono::steady_clock::now();
             t.rc = slot_align(gctx[k & 1], count(k), indel_start, indel_extend, max_b_rows, r, status + first(k), t);
+            t.t_ms[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (t.rc) t.err = npore_last_error();
         });
         launched = k + 1;
@@ -1831,9 +1848,27 @@ try {
     for (auto &sp : ctx->slots)
         if (rc == NPORE_OK && sp->rc) { rc = sp->rc; err = sp->err; }
     if (std::fclose(fh) != 0 && rc == NPORE_OK) { rc = NPORE_E_INVALID; err = "close failed"; }
+    // stage clocks of this call: sums over the batches of the time each stage's thread spent (stages of
+    // neighbouring batches overlap, so the sums exceed the wall time), the wall time, and the GPU's share
+    std::fill(b->file_ms, b->file_ms + 8, 0.0);
+    for (auto &sp : ctx->slots)
+        for (int q = 0; q < 5; q++) b->file_ms[q] += sp->t_ms[q];
+    b->file_ms[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    for (npore_ctx *g : {ctx, ctx->peer})
+        if (g) {
+            b->file_ms[6] += g->totals[0] + g->totals[1] + g->totals[2] - g->file_mark[0];     // kernels: prep + fill + traceback
+            b->file_ms[7] += g->totals[3] + g->totals[4] - g->file_mark[1];                    // PCIe: H2D + D2H
+        }
     return rc == NPORE_OK ? NPORE_OK : fail(rc, err);
 }
 NPORE_CATCH_INT
+
+int npore_bam_file_timing(const npore_bam *b, double *ms, int n)
+{
+    if (!b || !ms) return fail(NPORE_E_INVALID, "null argument");
+    for (int k = 0; k < n; k++) ms[k] = k < 8 ? b->file_ms[k] : 0.0;
+    return NPORE_OK;
+}
 
 int npore_bam_last_timing(const npore_bam *b, double *ms, int n)
 {
