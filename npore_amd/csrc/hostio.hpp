@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -34,9 +35,37 @@
 namespace npore {
 
 // default worker count: these loops are memory-bound byte shuffles, more than 64 threads only add start-up cost
+// CPUs this process may actually use: the affinity mask, cut down by a cgroup CPU quota if there is one (a container
+// on a 256-CPU host with a 16-CPU quota sees 256 CPUs; 64 threads there only thrash and grow 64 malloc arenas)
+inline int usable_cpus()
+{
+    static const int n = [] {
+        int cpus = (int)std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = std::max(1, CPU_COUNT(&set));
+        if (FILE *fh = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {                    // cgroup v2: "<quota|max> <period>"
+            char q[32] = {0};
+            long long period = 0;
+            if (std::fscanf(fh, "%31s %lld", q, &period) == 2 && period > 0 && std::strcmp(q, "max") != 0)
+                cpus = std::min<long long>(cpus, std::max<long long>(1, (std::atoll(q) + period - 1) / period));
+            std::fclose(fh);
+        } else if (FILE *f1 = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+            long long quota = -1, period = 0;
+            if (std::fscanf(f1, "%lld", &quota) != 1) quota = -1;
+            std::fclose(f1);
+            if (FILE *f2 = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (std::fscanf(f2, "%lld", &period) != 1) period = 0;
+                std::fclose(f2);
+            }
+            if (quota > 0 && period > 0) cpus = std::min<long long>(cpus, std::max<long long>(1, (quota + period - 1) / period));
+        }
+        return cpus;
+    }();
+    return n;
+}
 inline int host_threads(int threads)
 {
-    return threads > 0 ? threads : (int)std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
+    return threads > 0 ? threads : std::min(64, usable_cpus());
 }
 
 // uninitialised byte buffer (a std::vector would zero hundreds of megabytes per batch)
