@@ -93,7 +93,11 @@ struct RawBuf {
         n += n / 4;            // head-room: batches of a run differ a little in size
         if (pinned) {
             void *q = nullptr;
-            if (hipHostMalloc(&q, n, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pinned = false; }
+            if (hipHostMalloc(&q, n, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                pinned = false;
+                if (std::getenv("NPORE_DEBUG")) std::fprintf(stderr, "npore: hipHostMalloc(%zu) failed, pageable staging buffer\n", n);
+            }
             else p = static_cast<char *>(q);
         }
         if (!pinned) p = static_cast<char *>(std::malloc(n));

@@ -83,12 +83,12 @@ def build_inputs(tmp, n, distinct, ref_len, seed):
 def run_file(ctx, bp, fa, clen, a, out, stream):
     """open -> select -> npore_bam_realign_file; returns the stage dictionary"""
     t0 = time.perf_counter()
-    nb, nf = bam.NativeBam(bp, stream=stream), bam.NativeFasta(fa)
+    nb, nf = bam.NativeBam(bp, stream=stream, threads=a.threads), bam.NativeFasta(fa)
     t1 = time.perf_counter()
     idx = nb.select([("ctg", 0, clen - 1)])
     t2 = time.perf_counter()
     bam.create_header(out, nb)
-    bam.realign_native(ctx, nb, nf, idx, out, r=a.r, batch_reads=a.batch)
+    bam.realign_native(ctx, nb, nf, idx, out, r=a.r, batch_reads=a.batch, threads=a.threads)
     t3 = time.perf_counter()
     ft = nb.file_timing()
     wall = ft["wall_ms"] * 1e-3
@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--py-reads", type=int, default=32)
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--tmp", default=None, help="directory for the generated files (default: a temporary one)")
+    ap.add_argument("--threads", type=int, default=0, help="host threads of the parallel host stages (0 = the library's default)")
     ap.add_argument("--streamed-only", action="store_true",
                     help="only the STREAMED leg, SAM text to /dev/null: the bounded-memory demonstration on a file of tens of GB")
     a = ap.parse_args()
