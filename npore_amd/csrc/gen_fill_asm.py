@@ -430,9 +430,15 @@ def tail(t, mode, first, last, multi):
         """)
     if mid:
         t(f"global_store_dword {O('tboff')}, {SE}, {O('tbg')}")
+    # next anti-diagonal; every 64th one starts a new window of input-path steps (out of line: rotate)
     t(f"""
         v_add_f32 {O('ev')}, 0x42c80000, {O('ev')}
         s_add_i32 {O('bl')}, {O('bl')}, 1
+        s_and_b32 {O('sx')}, {O('bl')}, 63
+        s_cbranch_scc0 {L('rotate' + mode)}
+    """)
+    t.label("rotated" + mode)
+    t(f"""
         s_cmp_lt_i32 {O('bl')}, {O('b1')}
         s_cbranch_scc0 {L('done')}
         s_bitcmp1_b64 {O('mask')}, {O('bl')}
@@ -444,6 +450,20 @@ def tail(t, mode, first, last, multi):
             s_cbranch_scc0 {L('mode_d')}
             s_branch {L('mode_i')}
         """)
+    # the steps that lead to anti-diagonals 64 m ... 64 m + 63 are window m (bit bl & 63); the window after the new one is
+    # fetched here, 64 steps before it is needed (the wait also drains the traceback stores, once per window)
+    t.rare()
+    t.label("rotate" + mode)
+    t(f"""
+        s_mov_b64 {O('mask')}, {O('nmask')}
+        v_add_u32 {X3}, {O('kbase')}, {O('laneid')}
+        s_add_i32 {O('kbase')}, {O('kbase')}, 64
+        global_load_ubyte {X3}, {X3}, {O('stepsg')}
+        s_waitcnt vmcnt(0)
+        v_cmp_ne_u32 {O('nmask')}, 0, {X3}
+        s_branch {L('rotated' + mode)}
+    """)
+    t.common()
 
 
 def polls(t, first, last, sfx):
@@ -841,6 +861,7 @@ def operands(role):
             ("refx", "+v", "refx"), ("rc0", "+v", "rc0"), ("rc1", "+v", "rc1"), ("tab", "+v", "env.tab_e"),
             ("slot", "+v", "slot_v"), ("tboff", "+v", "tboff_v"), ("ev", "+v", "e_v"),
             ("bl", "+s", "a_bl"), ("sdel", "+s", "a_sdel"), ("status", "=&s", "a_status"),
+            ("mask", "+s", "a_mask"), ("nmask", "+s", "a_nmask"), ("kbase", "+s", "a_kbase"),
             ("sa", "=&s", "a_sa"), ("sb", "=&s", "a_sb"), ("sc", "=&s", "a_sc")]
     if multi:
         outs += [("prog", "+v", "prog_v"), ("xown", "+v", "xown"), ("xoth", "+v", "xoth")]
@@ -849,9 +870,8 @@ def operands(role):
     if last:
         outs += [("rqidx", "+s", "a_rq"), ("rqbase", "+s", "a_rqb"), ("rqx", "+v", "ref_q.x"), ("rqz", "+v", "ref_q.z"),
                  ("rqw", "+v", "ref_q.w"), ("wfill", "+s", "a_wfill"), ("dlim", "+s", "a_dlim")]
-    if first or last:
-        outs += [("sx", "=&s", "a_sx")]
-    ins = [("mask", "s", "stepmask"), ("b1", "s", "a_b1"), ("hw16", "s", "a_hw16"), ("ringb", "s", "ring_bytes"),
+    outs += [("sx", "=&s", "a_sx")]
+    ins = [("stepsg", "s", "steps_g"), ("laneid", "v", "a_laneid"), ("b1", "s", "a_b1"), ("hw16", "s", "a_hw16"), ("ringb", "s", "ring_bytes"),
            ("tbs4", "s", "tbstride4"), ("n0", "s", "env.n0_lanes"), ("tbg", "s", "tb_g"), ("istart", "s", "a_istart"),
            ("iext", "s", "a_iext"), ("winaddr", "s", "a_winaddr"), ("wmask", "s", "a_wmask"), ("clampv", "s", "a_clampv"),
            ("clamp1", "s", "a_clamp1"), ("npdim", "s", "a_npdim"), ("gnp", "s", "env.g_np"),
@@ -869,8 +889,6 @@ def operands(role):
         ins += [("medge", "s", "a_medge"), ("dcols", "s", "a_dcols"), ("refwg", "s", "refw_g"), ("reflg", "s", "refl_g")]
     if first:
         ins += [("drows", "s", "a_drows"), ("seqwg", "s", "seqw_g")]
-    if first or last:
-        ins += [("laneid", "v", "a_laneid")]
     return outs, ins
 
 

@@ -848,10 +848,12 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
             (void)a_mhist; (void)a_ml0; (void)a_ml63; (void)a_medge; (void)a_progaddr;
             for (;;) {
                 int a_status, a_sx;
+                unsigned long long a_mask = stepmask, a_nmask = nextmask;
+                int a_kbase = 64 * ((a_bl >> 6) + 2) - 1;           // first step byte of the window after the next one, for lane 0
                 unsigned long long a_sa, a_sb, a_sc;
                 int a_wfill = uni(wfill);
                 int a_dlim = a_wfill - r - WIN_SLACK - 1;       // (the 'D' step that makes the L window refill)
-                const int bl_in = a_bl;
+                const int bl_in = a_bl, sdel_in = a_sdel;
                 int a_sq = uni(sq_idx), a_rq = uni(rq_idx), a_sqb = uni(sq_base), a_rqb = uni(rq_base);
                 (void)a_dlim; (void)a_sx; (void)a_sq; (void)a_rq; (void)a_sqb; (void)a_rqb; (void)a_wfill;
                 if constexpr (ROLE == 0)
@@ -862,13 +864,13 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
                     asm volatile(NPORE_FILL_ASM_TEXT_2 : NPORE_FILL_ASM_OUTS_2 : NPORE_FILL_ASM_INS_2 : NPORE_FILL_ASM_CLOBBERS);
                 else
                     asm volatile(NPORE_FILL_ASM_TEXT_3 : NPORE_FILL_ASM_OUTS_3 : NPORE_FILL_ASM_INS_3 : NPORE_FILL_ASM_CLOBBERS);
+                stepmask = a_mask; nextmask = a_nmask;
                 sq_idx = a_sq; sq_base = a_sqb;
                 rq_idx = a_rq; rq_base = a_rqb;
                 if constexpr (ROLE == 0 || ROLE == 3) wfill = a_wfill;
                 // the scalar bookkeeping the text does not carry: local row / column of the input path
-                const int done = a_bl - bl_in;
-                const unsigned long long took = done >= 64 ? ~0ull : (((1ull << done) - 1ull) << (bl_in & 63));
-                st.ins_l += __popcll(stepmask & took);
+                // 'I' steps = steps taken - 'D' steps taken (a 'D' step stopped behind its poll has counted itself already)
+                st.ins_l += (a_bl - bl_in) - (a_sdel - sdel_in - (a_status == 2 ? 1 : 0));
                 st.del_l = a_sdel;
                 if (!a_status) break;
                 if (a_status == 2) {       // a 'D' step, stopped behind its poll: bookkeeping and column count already advanced
@@ -878,6 +880,10 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
                 else step(std::integral_constant<int, 2>{}, role_tag, std::true_type{});
                 a_bl++;
                 a_sdel = uni(st.del_l);
+                if ((a_bl & 63) == 0) {          // the handed-over step was the last of its window
+                    stepmask = nextmask;
+                    nextmask = step_window((a_bl >> 6) + 1);
+                }
                 if (a_bl >= b1) break;
             }
         };
@@ -890,7 +896,16 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
                 // window test per step measured 1-5 % slower)
                 if (b0 >= d.plain_lo && b1 <= d.plain_hi) {      // == step_is_plain(st) for every step of the window
                     if constexpr (xp::NOASM) span(b0, b1, role_tag, std::true_type{});
-                    else plain_span(b0, b1, role_tag);
+                    else {
+                        // all the plain windows that follow in ONE go (the assembly loop rotates the step windows itself:
+                        // entering it costs the compiler's register shuffle around the statement, once per chunk then)
+                        const int pe = (d.plain_hi >> 6) << 6;            // end of the last whole window inside the plain range
+                        const int bend = pe > b1 ? pe : b1;
+                        plain_span(b0, bend, role_tag);
+                        if ((bend & 63) != 0) break;                      // (only a chunk's last window ends off a boundary)
+                        w0 = bend - 64;                                   // the step windows are rotated already
+                        continue;
+                    }
                 }
                 else span(b0, b1, role_tag, std::false_type{});
                 stepmask = nextmask;
