@@ -67,7 +67,7 @@ def L(name):
 
 # more scratch: lane-table results of the first SHR candidate, fetched before the hand-shake poll
 E0, E1 = "v89", "v90"
-OPT = {"relaxed": False}          # relaxed: no lgkmcnt wait in front of the progress store (LDS serves a wave in order)
+OPT = {"relaxed": False, "nopoll": False, "nolen": False}     # nopoll / nolen: ablations (wrong strings, timing only)          # relaxed: no lgkmcnt wait in front of the progress store (LDS serves a wave in order)
 
 
 def shr_tables(t, tmp=X3):
@@ -252,6 +252,8 @@ def len_pass(t, mid, sfx):
     Free: X4 X5 SD SE SF P0 P1 E0 E1."""
     if not mid:
         t(f"v_cndmask_b32 {X3}, 0, {X3}, {O('mhist')}")
+    if OPT["nolen"]:
+        t(f"v_mov_b32 {X3}, 0")
     t(f"""
         v_cmp_ne_u32 vcc, 0, {X3}
         s_cbranch_vccnz {L('len_body' + sfx)}
@@ -468,6 +470,8 @@ def tail(t, mode, first, last, multi):
 
 def polls(t, first, last, sfx):
     """this wave may start the anti-diagonal once its neighbour waves have finished the previous one"""
+    if OPT["nopoll"]:
+        return
     if not first and not last:
         # both progress words in one round trip (the neighbours' words lie 8 bytes apart, this wave's in between)
         t.label("pp" + sfx)
@@ -899,8 +903,8 @@ def main():
     args = sys.argv[1:]
     while args:                      # measurement variants: --relaxed, --out FILE
         a = args.pop(0)
-        if a == "--relaxed":
-            OPT["relaxed"] = True
+        if a in ("--relaxed", "--nopoll", "--nolen"):
+            OPT[a[2:]] = True
         elif a == "--out":
             out_path = args.pop(0)
     out = ["// fill_step_asm.inc -- GENERATED by gen_fill_asm.py (do not edit): the plain-step loop of fill_kernel as gfx950",
