@@ -52,6 +52,21 @@ constexpr int ANN = NPORE_X_ANN;      // annotate ablations (timing only): 1 no 
 #else
 constexpr int ANN = 0;
 #endif
+#if defined(NPORE_X_PRIO)
+constexpr int PRIO = NPORE_X_PRIO;    // issue priorities of a chunk's waves: 1 first wave highest, 2 last wave highest, 3 none, 4 middle > first > last
+#else
+constexpr int PRIO = 0;
+#endif
+#if defined(NPORE_X_NOPRETEST)
+constexpr bool NOPRETEST = true;      // annotate: no scalar pre-test of a window's masks (A/B)
+#else
+constexpr bool NOPRETEST = false;
+#endif
+#if defined(NPORE_X_ANNT)
+constexpr int ANNT = NPORE_X_ANNT;    // threads of an annotate workgroup (planes in LDS)
+#else
+constexpr int ANNT = 1024;
+#endif
 #if defined(NPORE_X_POLLSLEEP)
 constexpr int POLLSLEEP = NPORE_X_POLLSLEEP;
 #else

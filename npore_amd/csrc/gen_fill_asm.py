@@ -96,8 +96,9 @@ def sub_read(t):
     """)
 
 
-def ins_part(t, mode, A, B, msk):
-    """INS (src/aln.pyx:525-543): new value straight into the own register, run into NINSR.  A, B: free registers"""
+def ins_part(t, mode, A, B, msk, fill=()):
+    """INS (src/aln.pyx:525-543): new value straight into the own register, run into NINSR.  A, B: free registers;
+    fill: up to two independent instructions for the slots between the compare and its selects"""
     if mode == "I":
         topM, topI, topR = O("matv"), O("insv"), O("R1")
     else:
@@ -105,17 +106,19 @@ def ins_part(t, mode, A, B, msk):
     t(f"""
         v_add_f32 {A}, {O('istart')}, {topM}
         v_add_f32 {B}, {O('iext')}, {topI}
-        v_add_u32_sdwa {NINSR}, {topR}, {O('one')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD
         v_cmp_lt_f32 {msk}, {B}, {A}
-        v_mov_b32 {LENV}, {O('ev')}
-        v_mov_b32 {LENRUN}, 0
+        v_add_u32_sdwa {NINSR}, {topR}, {O('one')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD
+    """)
+    for f in fill:
+        t(f)
+    t(f"""
         v_cndmask_b32 {O('insv')}, {A}, {B}, {msk}
         v_cndmask_b32 {NINSR}, 1, {NINSR}, {msk}
     """)
 
 
 def del_part(t, mode, A, B, msk):
-    """DEL (src/aln.pyx:547-565)"""
+    """DEL (src/aln.pyx:547-565); leaves X3 = the six LEN pre-filter bits (refx & seqw flags) as its fillers"""
     if mode == "I":
         leftM, leftD, leftR = X0, X1, O("LMr")
     else:
@@ -123,10 +126,10 @@ def del_part(t, mode, A, B, msk):
     t(f"""
         v_add_f32 {A}, {O('istart')}, {leftM}
         v_add_f32 {B}, {O('iext')}, {leftD}
-        v_add_u32_sdwa {NDELR}, {leftR}, {O('one')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD
         v_cmp_lt_f32 {msk}, {B}, {A}
-        v_mov_b32 {LENST}, 0x7f800000
+        v_add_u32_sdwa {NDELR}, {leftR}, {O('one')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD
         v_and_b32 {X3}, {O('refx')}, {O('seqw')}
+        v_bfe_u32 {X3}, {X3}, 8, 6
         v_cndmask_b32 {O('delv')}, {A}, {B}, {msk}
         v_cndmask_b32 {NDELR}, 1, {NDELR}, {msk}
     """)
@@ -151,7 +154,7 @@ def shr_pass(t, mid, sfx, smr, shadow, shadow2):
             v_mov_b32 {SHRST}, 0x7f800000
         """)
         shadow()
-        t(f"s_branch {L('shr_done' + sfx)}")
+        t(f"s_branch {L('shr_done2' + sfx)}")
         t.common()
     t(f"""
         v_cmp_lt_u32 vcc, 28, {smr}
@@ -176,8 +179,6 @@ def shr_pass(t, mid, sfx, smr, shadow, shadow2):
         s_waitcnt lgkmcnt(0)
         v_add_f32 {SE}, {SD}, {SE}
         v_cmp_lt_f32 vcc, {SE}, {O('ev')}
-        v_bfe_u32 {X3}, {X3}, 8, 6
-        s_nop 0
         v_cndmask_b32 {SHRV}, {O('ev')}, {SE}, vcc
         v_cndmask_b32 {SHRRUN}, 0, {P1}, vcc
         v_cndmask_b32 {SHRST}, {O('inf')}, {SD}, vcc
@@ -223,8 +224,6 @@ def shr_pass(t, mid, sfx, smr, shadow, shadow2):
         v_add_u32 {SF}, {SF}, {SE}
         v_add_f32 {E0}, {SD}, {E0}
         v_cmp_lt_f32 vcc, {E0}, {O('ev')}
-        v_bfe_u32 {X3}, {X3}, 8, 6
-        s_nop 0
         v_cndmask_b32 {SHRV}, {O('ev')}, {E0}, vcc
         v_cndmask_b32 {SHRRUN}, 0, {P1}, vcc
         v_cndmask_b32 {SHRST}, {O('inf')}, {SD}, vcc
@@ -237,16 +236,10 @@ def shr_pass(t, mid, sfx, smr, shadow, shadow2):
         v_cndmask_b32 {SHRST}, {SHRST}, {E1}, vcc
         s_branch {L('shr_done2' + sfx)}
     """)
-    if not mid:
-        t.label("shr_done" + sfx)
-        t(f"""
-            v_bfe_u32 {X3}, {X3}, 8, 6
-            s_branch {L('shr_done2' + sfx)}
-        """)
     t.common()
 
 
-def len_pass(t, mid, sfx):
+def len_pass(t, mid, sfx, mode):
     """LEN candidates (cell.hpp, LEN loop; LEN_ARITH form).  On entry X3 = the six "read position i-n in an n-polymer
     and reference position j starts one" bits.  The loop is out of line (two steps in three have no candidate).
     Free: X4 X5 SD SE SF P0 P1 E0 E1."""
@@ -258,21 +251,25 @@ def len_pass(t, mid, sfx):
         v_cmp_ne_u32 vcc, 0, {X3}
         s_cbranch_vccnz {L('len_body' + sfx)}
     """)
-    t.label("len_done" + sfx)
     t.rare()
     t.label("len_top" + sfx)
     t(f"""
         v_cmp_ne_u32 vcc, 0, {X3}
         s_cbranch_vccz {L('len_done' + sfx)}
+        s_branch {L('len_iter' + sfx)}
     """)
     t.label("len_body" + sfx)
+    t(f"""
+        v_mov_b32 {LENV}, {O('ev')}
+        v_mov_b32 {LENRUN}, 0
+    """)
+    t.label("len_iter" + sfx)
     t(f"""
         s_mov_b64 {O('sa')}, vcc
         v_ffbh_u32 {X4}, {X3}
         v_sub_u32 {X4}, 31, {X4}
         v_bfe_u32 {X3}, {X3}, 0, {X4}
-        v_mul_u32_u24 {X5}, 3, {X4}
-        v_sub_u32 {X5}, 29, {X5}
+        v_mad_i32_i24 {X5}, {X4}, -3, 29
         v_lshrrev_b32 {SD}, 14, {O('refx')}
         v_lshrrev_b32 {SE}, {X5}, {O('seqw')}
         v_xor_b32 {SE}, {SE}, {SD}
@@ -346,48 +343,69 @@ def len_pass(t, mid, sfx):
         v_cndmask_b32 {LENST}, {LENST}, {P0}, vcc
         s_branch {L('len_top' + sfx)}
     """)
+    t.label("len_done" + sfx)
+    mat_part(t, mode, True, mid)
+    t(f"""
+        v_mov_b32 {LENST}, 0x7f800000
+        s_branch {L('post_mat' + sfx)}
+    """)
     t.common()
 
 
-def tail(t, mode, first, last, multi):
-    """MAT by two 3-way minima and equality tests (cell.hpp, Env::MIN3), stores, hand-over, next step"""
-    mid = multi and not first and not last
+def mat_part(t, mode, with_len, mid):
+    """MAT by two 3-way minima and equality tests (cell.hpp, Env::MIN3): value, traceback word, runs.  with_len = False:
+    no LEN candidate in the wave -- LEN.VAL is 100 b, its run 0, its run start +inf (LENST keeps that value from the
+    loop's entry on); True: the out-of-line variant behind the LEN loop, which reads LENV / LENRUN and restores LENST."""
     own_m, own_i, own_d, r1, r2 = O("matv"), O("insv"), O("delv"), O("R1"), O("R2")
     diagM = O("LMv") if mode == "I" else O("TMv")
+    lenv = LENV if with_len else O("ev")
     t(f"""
         s_waitcnt lgkmcnt(0)
         v_add_f32 {SUBV}, {diagM}, {SUBV}
         v_lshl_or_b32 {SE}, {SHRRUN}, 3, 4
         v_lshl_or_b32 {SF}, {NDELR}, 3, 3
-        v_min3_f32 {SD}, {SUBV}, {own_i}, {LENV}
+        v_min3_f32 {SD}, {SUBV}, {own_i}, {lenv}
         v_mov_b32 {diagM}, {X0}
         v_min3_f32 {Q0}, {SD}, {own_d}, {SHRV}
-        v_lshl_or_b32 {X3}, {LENRUN}, 3, 2
         v_lshl_or_b32 {X4}, {NINSR}, 3, 1
+    """)
+    if with_len:
+        t(f"v_lshl_or_b32 {X3}, {LENRUN}, 3, 2")
+    t(f"""
         v_cmp_eq_f32 vcc, {own_d}, {Q0}
-        v_cmp_eq_f32 {O('sa')}, {LENV}, {Q0}
+        v_cmp_eq_f32 {O('sa')}, {lenv}, {Q0}
         v_cmp_eq_f32 {O('sb')}, {own_i}, {Q0}
         v_cmp_eq_f32 {O('sc')}, {SUBV}, {Q0}
         v_cndmask_b32 {SE}, {SE}, {SF}, vcc
-        v_add_u32 {SD}, 1, {DRUN}
-        v_cndmask_b32 {SE}, {SE}, {X3}, {O('sa')}
-        v_lshl_add_u32 {X5}, {DRUN}, 3, 8
-        v_cndmask_b32 {SE}, {SE}, {X4}, {O('sb')}
-        v_cndmask_b32 {SD}, 0, {SD}, {O('sc')}
-        v_cndmask_b32 {SE}, {SE}, {X5}, {O('sc')}
-        v_lshl_or_b32 {QRUNS}, {SHRRUN}, 16, {LENRUN}
+        v_lshlrev_b32 {X5}, 3, {DRUN}
+        v_cndmask_b32 {SE}, {SE}, {X3 if with_len else 2}, {O('sa')}
         v_add_u32 {X3}, {O('hca')}, {O('slot')}
+        v_cndmask_b32 {SE}, {SE}, {X4}, {O('sb')}
+        v_cndmask_b32 {SD}, 0, {DRUN}, {O('sc')}
+        v_cndmask_b32 {SE}, {SE}, {X5}, {O('sc')}
+    """)
+    t(f"v_lshl_or_b32 {QRUNS}, {SHRRUN}, 16, {LENRUN}" if with_len else f"v_lshlrev_b32 {QRUNS}, 16, {SHRRUN}")
+    t(f"""
         v_lshl_or_b32 {r1}, {NINSR}, 16, {SD}
         v_lshl_or_b32 {r2}, {NDELR}, 16, {SD}
         v_mov_b32 {own_m}, {Q0}
     """)
-    # history record of the band-interior columns (a middle wave holds no others)
+    # history record (and, where a lane mask is needed anyway, the traceback word) of the band-interior columns; a
+    # middle wave holds no others and stores its traceback word behind the hand-over
     if not mid:
         t(f"s_mov_b64 exec, {O('mhist')}")
     t(f"ds_write_b128 {X3}, {QQ}")
     if not mid:
         t(f"global_store_dword {O('tboff')}, {SE}, {O('tbg')}")
         t("s_mov_b64 exec, -1")
+
+
+def tail(t, mode, first, last, multi):
+    """MAT, stores, hand-over, next step"""
+    mid = multi and not first and not last
+    own_m, own_i, own_d, r1, r2 = O("matv"), O("insv"), O("delv"), O("R1"), O("R2")
+    mat_part(t, mode, False, mid)
+    t.label("post_mat_" + mode)
     # band-edge cells (src/aln.pyx:502-507): the three values their one in-band neighbour reads
     if first or last:
         t(f"v_add_f32 {SD}, 0x42c80000, {O('ev')}")
@@ -522,6 +540,7 @@ def gen_role(role):
     mid = role == 2
     t = Text()
     t(f"""
+        v_mov_b32 {LENST}, 0x7f800000
         s_bitcmp1_b64 {O('mask')}, {O('bl')}
         s_cbranch_scc0 {L('mode_d')}
     """)
@@ -544,12 +563,8 @@ def gen_role(role):
     """)
     book(t, "I")
     shr_tables(t)
-    t(f"""
-        v_and_b32 {DRUN}, 0xffff, {O('LMr')}
-        v_mov_b32 {O('TMv')}, {O('matv')}
-        v_mov_b32 {O('TMr')}, {O('R1')}
-    """)
-    ins_part(t, "I", X4, X5, O("sb"))
+    t(f"v_add_u32_sdwa {DRUN}, {O('LMr')}, {O('one')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD")
+    ins_part(t, "I", X4, X5, O("sb"), (f"v_mov_b32 {O('TMv')}, {O('matv')}", f"v_mov_b32 {O('TMr')}, {O('R1')}"))
     if first:
         t(f"""
             v_readlane_b32 {O('sx')}, {O('seqq')}, {O('sqidx')}
@@ -589,7 +604,7 @@ def gen_role(role):
     sub_read(t)
     t("s_waitcnt lgkmcnt(1)")          # the candidate's source record (the substitution score may still be on its way)
     shr_pass(t, mid, "_I", SHRST, lambda: del_part(t, "I", X4, X5, O("sb")), lambda: del_part(t, "I", SHRV, SHRRUN, O("sb")))
-    len_pass(t, mid, "_I")
+    len_pass(t, mid, "_I", "I")
     tail(t, "I", first, last, multi)
     # ================= 'D' step: reference words (and the column descriptors) move one column down, "top" is the
     # next lane.  Last wave of a chunk: the word entering at its last lane comes from its own queue and the next
@@ -617,7 +632,7 @@ def gen_role(role):
     book(t, "D")
     t(f"""
         s_add_i32 {O('sdel')}, {O('sdel')}, 1
-        v_and_b32 {DRUN}, 0xffff, {O('TMr')}
+        v_add_u32_sdwa {DRUN}, {O('TMr')}, {O('one')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD
         v_mov_b32 {O('LMv')}, {O('matv')}
         v_mov_b32 {O('LMr')}, {O('R2')}
     """)
@@ -687,7 +702,7 @@ def gen_role(role):
         shr_hist(t)
         t("s_waitcnt lgkmcnt(0)")
     shr_pass(t, mid, "_D", SHRST, lambda: del_part(t, "D", X4, X5, O("sb")), lambda: del_part(t, "D", SHRV, SHRRUN, O("sb")))
-    len_pass(t, mid, "_D")
+    len_pass(t, mid, "_D", "D")
     tail(t, "D", first, last, multi)
     t.lines = t.main
     t.main.extend(t.ool)

@@ -322,7 +322,17 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
     const int cg = xp::CHUNKMAJOR ? wave / NW : wave % cpg;            // group within the workgroup
     // The middle waves of a chunk (all 64 lanes live, a neighbour wave on either side) are issued first when
     // several waves of the SIMD are ready: measured 1.5-2 % on the fill at NW = 3...7 (r = 70, 100, 140, 200)
-    if (NW > 2 && cw != 0 && cw != NW - 1) __builtin_amdgcn_s_setprio(1);
+    if constexpr (xp::PRIO == 0) {
+        if (NW > 2 && cw != 0 && cw != NW - 1) __builtin_amdgcn_s_setprio(1);
+    } else if constexpr (xp::PRIO == 1) {          // first wave highest
+        const int pr = min(3, NW - 1 - cw);
+        if (pr == 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    } else if constexpr (xp::PRIO == 2) {          // last wave highest
+        const int pr = min(3, cw);
+        if (pr == 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    } else if constexpr (xp::PRIO == 4) {          // middle 2, first 1, last 0
+        if (NW > 2 && cw != 0 && cw != NW - 1) __builtin_amdgcn_s_setprio(2); else if (cw == 0 && NW > 1) __builtin_amdgcn_s_setprio(1);
+    }
     const int hw = p.hw;
     float *chunk_lds = lds_sub + SUBT_ENTRIES + (size_t)cg * chunk_lds_floats(NW, hw, p.rwin);
     HistCell *hist = reinterpret_cast<HistCell *>(chunk_lds) + HIST_PAD;     // row 0, column 0
@@ -889,27 +899,34 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
         };
         auto run = [&](auto role_tag) __attribute__((always_inline)) {
             step(std::integral_constant<int, 0>{}, role_tag, std::false_type{});
-            for (int w0 = 0; w0 < d.nrows; w0 += 64) {
-                const int b0 = w0 ? w0 : 1, b1 = min(w0 + 64, d.nrows);
-                // (a window that is not plain from end to end runs the general cell update throughout: at most 126
-                // anti-diagonals of a chunk more than necessary; three loops -- general, plain, general -- with the
-                // window test per step measured 1-5 % slower)
-                if (b0 >= d.plain_lo && b1 <= d.plain_hi) {      // == step_is_plain(st) for every step of the window
-                    if constexpr (xp::NOASM) span(b0, b1, role_tag, std::true_type{});
-                    else {
-                        // all the plain windows that follow in ONE go (the assembly loop rotates the step windows itself:
-                        // entering it costs the compiler's register shuffle around the statement, once per chunk then)
-                        const int pe = (d.plain_hi >> 6) << 6;            // end of the last whole window inside the plain range
-                        const int bend = pe > b1 ? pe : b1;
-                        plain_span(b0, bend, role_tag);
-                        if ((bend & 63) != 0) break;                      // (only a chunk's last window ends off a boundary)
-                        w0 = bend - 64;                                   // the step windows are rotated already
-                        continue;
-                    }
-                }
-                else span(b0, b1, role_tag, std::false_type{});
+            // anti-diagonals [plain_lo, plain_hi) are plain (cell.hpp step_is_plain: both conditions are monotone along the
+            // input path): ONE run of the assembly loop; the ~2r anti-diagonals either side of it, where the band touches
+            // the chunk rectangle's border, go through the general cell update window by window
+            const int plo = xp::NOASM ? d.nrows : max(d.plain_lo, 1), phi = min(d.plain_hi, d.nrows);
+            auto rotate = [&](int w0) {
                 stepmask = nextmask;
                 nextmask = step_window((w0 >> 6) + 2);
+            };
+            int w0 = 0;
+            while (w0 < d.nrows) {
+                const int b0 = w0 ? w0 : 1, b1 = min(w0 + 64, d.nrows);
+                if (plo < phi && plo < b1 && plo >= b0) {
+                    if (b0 < plo) span(b0, plo, role_tag, std::false_type{});
+                    plain_span(plo, phi, role_tag);                 // (rotates the step windows it crosses itself)
+                    const int wend = min(((phi >> 6) << 6) + 64, d.nrows);
+                    if ((phi & 63) != 0 || phi == d.nrows) {        // the rest of the window the plain range ends in
+                        if (phi < wend) span(phi, wend, role_tag, std::false_type{});
+                        rotate(wend - 64);
+                        w0 = wend;
+                    } else {
+                        w0 = phi;                                   // ended on a window boundary: windows already rotated
+                    }
+                    continue;
+                }
+                if (xp::NOASM && b0 >= d.plain_lo && b1 <= d.plain_hi) span(b0, b1, role_tag, std::true_type{});   // (A/B: compiled plain steps)
+                else span(b0, b1, role_tag, std::false_type{});
+                rotate(w0);
+                w0 += 64;
             }
         };
         // the wave's role within its chunk decides where annotation words and boundary cells come from

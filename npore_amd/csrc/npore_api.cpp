@@ -138,17 +138,24 @@ struct WorkSet {
                        &in_refs, &in_seqs, &in_cigs, &in_off, &out, &out_len, &status};
 };
 
+// Work sets of a context: group k + 1 is prepared while group k is in the fill kernel and group k - 1 in its traceback;
+// the third set lets the host enqueue group k + 1's preparation without waiting for group k - 1's traceback to end
+// (with two, that wait sits between every pair of groups; measured equal within 1 % either way on this hardware --
+// what binds the pipelined r = 30 case is the preparation's own duration beside a running fill kernel, LABNOTES.md).
+constexpr int N_SETS = 3;
+
 struct npore_ctx {
     int device = 0;
     int n_cus = 256;
     int max_n = 6, max_l = 100;
     // three non-blocking streams: preparation (also every copy), fill kernels, traceback + gather; events order
     // the stages of a group, the streams let stages of neighbouring groups run side by side
-    hipStream_t stream = nullptr, s_fill = nullptr, s_post = nullptr;
+    hipStream_t stream = nullptr, s_fill[2] = {nullptr, nullptr}, s_post = nullptr;
+    int next_fill = 0;           // the fill stream the next group's fill kernel goes to
     hipEvent_t ev[8] = {};       // [4..7] H2D / D2H of the host-buffer entry point, [0] the caller's stream
     float *d_sub = nullptr, *d_np = nullptr;   // NULL in an annotation-only context (created without tables)
-    WorkSet ws[2];
-    int next_ws = 0;             // set the next group goes into (the older of the two)
+    WorkSet ws[N_SETS];
+    int next_ws = 0;             // set the next group goes into (the oldest of them)
     WorkSet *last_ws = nullptr;  // set of the group enqueued last (npore_debug_fetch)
     int64_t call_id = 0, timing_call = -1;
     int deferred_rc = 0;         // failure found while collecting a group of an asynchronous call
@@ -453,7 +460,7 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
         } else if (planes_in_lds) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&annotate_kernel<true, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
-            hipLaunchKernelGGL((annotate_kernel<true, true>), dim3((unsigned)(2 * max_chunks)), dim3(1024), alds, s, pp);
+            hipLaunchKernelGGL((annotate_kernel<true, true>), dim3((unsigned)(2 * max_chunks)), dim3(xp::ANNT), alds, s, pp);
         } else {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&annotate_kernel<false, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
@@ -462,8 +469,12 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(w->ev[1], s));
-    // ---- fill: behind this group's preparation, and (same stream) behind the previous group's fill
-    s = ctx->s_fill;
+    // ---- fill: behind this group's preparation.  Consecutive groups alternate between two streams: their fill
+    // kernels share nothing, so the next one's persistent workgroups move onto the CUs that this one's leave as its
+    // last chunks run out -- the tail of one launch is filled by the head of the next (C2, steps back to back:
+    // 17.1 ms per step against the 18.0 ms one fill kernel takes alone; one stream: 18.1)
+    s = ctx->s_fill[ctx->next_fill];
+    ctx->next_fill ^= 1;
     HIP_TRY(hipStreamWaitEvent(s, w->ev[1], 0));
     HIP_TRY(hipEventRecord(w->ev[2], s));
 
@@ -606,8 +617,8 @@ int quiesce(npore_ctx *ctx)
 {
     int rc = ctx->deferred_rc;
     std::string err = ctx->deferred_err;
-    for (int k = 0; k < 2; k++) {
-        WorkSet *w = &ctx->ws[(ctx->next_ws + k) & 1];
+    for (int k = 0; k < N_SETS; k++) {
+        WorkSet *w = &ctx->ws[(ctx->next_ws + k) % N_SETS];
         const int r2 = collect_group(ctx, w);
         if (r2 && !rc) { rc = r2; err = g_err; }
     }
@@ -616,7 +627,7 @@ int quiesce(npore_ctx *ctx)
     return rc ? fail(rc, err) : NPORE_OK;
 }
 
-// The batch, group by group, through the three-stage pipeline: the groups alternate between the two work sets, so
+// The batch, group by group, through the three-stage pipeline: the groups rotate through the N_SETS work sets, so
 // that group k+1 is prepared and group k-1 traced back while the fill kernel works on group k.  `user` (may be
 // NULL) is the caller's stream: the batch is ordered behind what it holds now.  sync = false returns once the
 // last group is enqueued (results complete when npore_ctx_wait returns, or for work put on `user` afterwards).
@@ -639,15 +650,16 @@ int run_core(npore_ctx *ctx, const AlignArgs &a, const OutTarget &ot, hipStream_
 
     // groups of consecutive reads whose traceback words fit the budget.  The automatic budget is this context's
     // share of the device (contexts of one device run side by side: the file pipeline's peer, bench --inflight),
-    // halved for its two work sets: 60 % of the memory divided by the live contexts, and never more than what is
+    // divided by its N_SETS work sets: 60 % of the memory divided by the live contexts, and never more than what is
     // free now plus what the context already holds.
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const int live = std::max(1, g_live_ctx[ctx->device & 15].load());
-    const size_t held = ctx->ws[0].tb.cap + ctx->ws[1].tb.cap;
+    size_t held = 0;
+    for (const auto &w0 : ctx->ws) held += w0.tb.cap;
     const int64_t budget = ctx->tb_budget_mb > 0
                                ? ctx->tb_budget_mb * (int64_t)1048576
-                               : (int64_t)(0.5 * std::min(0.6 * (double)total_b / live, 0.9 * (double)(free_b + held)));
+                               : (int64_t)(std::min(0.6 * (double)total_b / live, 0.9 * (double)(free_b + held)) / N_SETS);
     const int tbs = tb_stride(a.r);
     int64_t g0 = 0;
     int64_t max_group = a.n_reads;       // halved when a group's buffers do not fit after all
@@ -674,12 +686,13 @@ int run_core(npore_ctx *ctx, const AlignArgs &a, const OutTarget &ot, hipStream_
         }
         cells = (a.h_seq_off[g1] - a.h_seq_off[g0] + a.h_ref_off[g1] - a.h_ref_off[g0] + (g1 - g0)) * (2 * a.r + 1);
         WorkSet *w = &ctx->ws[ctx->next_ws];
-        if (int rc = collect_group(ctx, w)) {        // the set's previous group (two groups back) has to be through
+        if (int rc = collect_group(ctx, w)) {        // the set's previous group (N_SETS groups back) has to be through
             if (!ctx->deferred_rc) { ctx->deferred_rc = rc; ctx->deferred_err = g_err; }
         }
         // (the other work set still busy: its group is in the fill or traceback stage while this one is prepared,
         // and this group's gather will most likely run while the next one's fill is on the GPU)
-        const bool beside = ctx->coresident && ctx->ws[ctx->next_ws ^ 1].busy;
+        bool beside = false;
+        for (int k = 1; k < N_SETS; k++) beside |= ctx->coresident && ctx->ws[(ctx->next_ws + k) % N_SETS].busy;
         if (int rc = run_group(ctx, w, a, g0, g1, ot, shape, beside)) {
             // drain what is in flight; a failure found there (an earlier group of this call, or of a previous
             // sync = 0 call) is the older one and must not be lost: it stays deferred / is what the call returns
@@ -696,7 +709,7 @@ int run_core(npore_ctx *ctx, const AlignArgs &a, const OutTarget &ot, hipStream_
         w->cells = cells;
         w->call_id = ctx->call_id;
         ctx->last_ws = last = w;
-        ctx->next_ws ^= 1;
+        ctx->next_ws = (ctx->next_ws + 1) % N_SETS;
         g0 = g1;
     }
     if (sync) return quiesce(ctx);
@@ -758,7 +771,8 @@ try {
     ctx->max_l = max_l;
     const size_t np_elems = (size_t)max_n * (max_l + 1) * (max_l + 1);
     bool ok = hipSetDevice(device_id) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&ctx->s_fill, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&ctx->s_fill[0], hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&ctx->s_fill[1], hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->s_post, hipStreamNonBlocking) == hipSuccess;
     if (tables) {
         ctx->h_sub.assign(sub_scores, sub_scores + 25);
@@ -805,7 +819,7 @@ void npore_ctx_destroy(npore_ctx *ctx)
     if (ctx->d_np) (void)hipFree(ctx->d_np);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
-    for (hipStream_t st : {ctx->stream, ctx->s_fill, ctx->s_post})
+    for (hipStream_t st : {ctx->stream, ctx->s_fill[0], ctx->s_fill[1], ctx->s_post})
         if (st) (void)hipStreamDestroy(st);
     for (auto *sp : ctx->slots) delete sp;
     delete ctx;

@@ -388,6 +388,18 @@ __global__ __launch_bounds__(256) void sched_scatter_kernel(PrepParams p)
 // neighbouring windows is scalar work on words picked from that register; PRE = false computes every mask it looks
 // at from the bases (ballots).  All lanes of a window that reach its end are in the SAME run, so the extension is
 // wave-uniform either way.
+// does w hold K consecutive one bits?  (log-step: x bit p = "ones at p ... p + have - 1")
+template <int K>
+__host__ __device__ __forceinline__ bool has_run_of(unsigned long long w)
+{
+    unsigned long long x = w;
+    int have = 1;
+#pragma unroll
+    for (; have * 2 <= K; have *= 2) x &= x >> have;
+    if (have < K) x &= x >> (K - have);
+    return x != 0ull;
+}
+
 constexpr int MASK_BACK = 16;      // mask words held in front of the window's own (>= (max_l + 2) * 6 / 64 + 2 for max_l <= 127)
 template <int n, bool GRID = false, bool PRE = false>
 __device__ __forceinline__ void annotate_period(const uint8_t *seq, int len, int max_n, int max_l, uint8_t *planes,
@@ -421,6 +433,22 @@ __device__ __forceinline__ void annotate_period(const uint8_t *seq, int len, int
             }
         };
         const unsigned long long M0 = mask_at(0);
+        if constexpr (PRE) {
+            // Scalar pre-test: a position with three or more repeats in reach (J + q >= 2 below) lies in, or just
+            // behind, a run of at least 2 n ones of e_n, and such a run has 2 n consecutive ones within 2 n positions
+            // of the window.  Three overlapping 64-bit views cover those positions; no such run in any of them --
+            // most windows of the periods above 1 -- and the plane is zero here without any per-position work.
+            if (!Lout && !xp::NOPRETEST) {
+                constexpr int k2 = 2 * n;
+                const unsigned long long Mp = mask_at(-1), Mn = mask_at(1);       // (zero beyond the sequence's ends)
+                const unsigned long long A = (M0 << k2) | (Mp >> (64 - k2));      // positions base - 2n ... base + 63 - 2n
+                const unsigned long long C = (M0 >> k2) | (Mn << (64 - k2));      // positions base + 2n ... base + 63 + 2n
+                if (!(has_run_of<k2>(A) || has_run_of<k2>(M0) || has_run_of<k2>(C))) {
+                    if (pos < len) Ln[pos] = 0;
+                    continue;
+                }
+            }
+        }
         // forward run from pos
         int kf;
         {
