@@ -1573,7 +1573,7 @@ NPORE_CATCH_INT
 namespace {
 int pack_records(const npore_bam *b, const RecFetch &rf, const npore_fasta *fa, const int32_t *fasta_of_ref, int64_t n,
                  uint8_t *refs, const int64_t *ref_off, uint8_t *seqs, const int64_t *seq_off, char *cigs,
-                 const int64_t *cig_off, int threads);
+                 const int64_t *cig_off, int threads, bool for_upload = false);
 }
 int npore_bam_pack(const npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref, const int64_t *idx, int64_t n,
                    uint8_t *refs, const int64_t *ref_off, uint8_t *seqs, const int64_t *seq_off, char *cigs,
@@ -1591,7 +1591,7 @@ NPORE_CATCH_INT
 namespace {
 int pack_records(const npore_bam *b, const RecFetch &rf, const npore_fasta *fa, const int32_t *fasta_of_ref, int64_t n,
                  uint8_t *refs, const int64_t *ref_off, uint8_t *seqs, const int64_t *seq_off, char *cigs,
-                 const int64_t *cig_off, int threads)
+                 const int64_t *cig_off, int threads, bool for_upload)
 {
     std::atomic<int> bad{0};
     parallel_for(n, threads, [&](int64_t k) {
@@ -1623,6 +1623,11 @@ int pack_records(const npore_bam *b, const RecFetch &rf, const npore_fasta *fa, 
             if (op == 4 || op == 5) continue;
             std::memset(co, op < 10 ? CIGOPS[op] : '?', len);
             co += len;
+        }
+        if (for_upload) {       // page-locked staging about to cross PCIe: out of this core's cache first (hostio.hpp)
+            cache_writeback(ro, (size_t)rl);
+            cache_writeback(so, (size_t)sl);
+            cache_writeback(cigs + cig_off[k], (size_t)(cig_off[k + 1] - cig_off[k]));
         }
     });
     return bad ? fail(NPORE_E_INVALID, "a selected read lies on a contig that is not in the FASTA") : NPORE_OK;
@@ -1706,7 +1711,7 @@ int slot_pack(const npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of
         return fail(NPORE_E_NOMEM, "batch buffers");
     if (!fa || !fasta_of_ref) return fail(NPORE_E_INVALID, "bad argument");
     if (int rc = pack_records(b, s.rf, fa, fasta_of_ref, n, reinterpret_cast<uint8_t *>(s.refs.p), s.ro.data(),
-                              reinterpret_cast<uint8_t *>(s.seqs.p), s.so.data(), s.cigs.p, s.co.data(), threads))
+                              reinterpret_cast<uint8_t *>(s.seqs.p), s.so.data(), s.cigs.p, s.co.data(), threads, true))
         return rc;
     for (int64_t k = 0; k < n; k++) {
         const int64_t cap = (s.ro[(size_t)k + 1] - s.ro[(size_t)k]) + (s.so[(size_t)k + 1] - s.so[(size_t)k]);
