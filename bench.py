@@ -220,6 +220,9 @@ def main():
     ap.add_argument("--production-reads", type=int, default=4000, help="reads per GPU of that leg (tests use fewer)")
     ap.add_argument("--tb-kernel", type=int, default=0,
                     help="traceback kernel: 0 = chosen by batch size, 1 = windowed, 2 = row per hop (experiments)")
+    ap.add_argument("--solo-steps", type=int, default=3,
+                    help="synchronous steps after the timed region that time the fill kernel on its own (the roofline's duration); "
+                         "0 = use the timed region's events (profiler runs)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="1 (default): steps are enqueued without waiting (sync=0) -- inside the context the next batch is "
                          "prepared and the previous one traced back while the fill kernel works on the current one; the "
@@ -395,7 +398,7 @@ def main():
     # leave), so the HIP events around a launch there also span its wait for room; these launches have the GPU to
     # themselves, as under rocprofv3 (which serialises dispatches) -- the duration the roofline is priced with
     fill_solo = []
-    for _ in range(3):
+    for _ in range(args.solo_steps):
         step(0, sync=1)
         fill_solo.append(ctx.timing()["fill_ms"])
 
@@ -527,7 +530,7 @@ def main():
             a, b = int(oo[k]), int(oo[k % n_uniq])
             assert np.array_equal(out_host[a:a + int(out_len[k])], out_host[b:b + int(out_len[k])]), "copies of one read differ"
     fill_region_ms = float(np.mean(fill_ms))       # event to event in the timed region (overlapping launches)
-    fill_avg_ms = float(np.mean(fill_solo))
+    fill_avg_ms = float(np.mean(fill_solo)) if fill_solo else fill_region_ms      # (--solo-steps 0: profiler runs, which serialise anyway)
     achieved = bytes_alg / (fill_avg_ms * 1e-3) / 1e9
     shape = ctx.fill_shape(args.r)
     rows_total = sum(len(s) + len(r_) + 1 for s, r_ in zip(seqs, refs))
@@ -570,7 +573,8 @@ def main():
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "kernel": "fill_kernel", "kernel_ms": round(fill_avg_ms, 3),
-                "kernel_ms_source": "HIP events around 3 launches that had the GPU to themselves (after the timed region)",
+                "kernel_ms_source": (f"HIP events around {len(fill_solo)} launches that had the GPU to themselves (after the timed region)"
+                                     if fill_solo else "HIP events around the launches of the timed region"),
                 "kernel_ms_in_timed_region": round(fill_region_ms, 3),
                 "bytes_alg_per_launch": int(bytes_alg), "valu_issue": valu, "practical": practical, "pmc_source": pmc_src}
 

@@ -18,11 +18,13 @@ if ks:
 agg = collections.OrderedDict()
 for f in sorted(glob.glob(os.path.join(src, "pmc*", "*", "*counter_collection.csv"))):
     part = collections.defaultdict(float)
+    launches = set()
     for r in csv.DictReader(open(f)):
         if "fill_kernel" in r["Kernel_Name"]:
             part[r["Counter_Name"]] += float(r["Counter_Value"])
-    for k in sorted(part):
-        agg.setdefault(k, part[k])
+            launches.add(r["Dispatch_Id"])
+    for k in sorted(part):          # per launch: a profiled bench run holds several (the timed step + the three timed alone)
+        agg.setdefault(k, part[k] / max(1, len(launches)))
 line = None
 for l in open(os.path.join(src, "bench_trace.log")):
     if l.startswith("{"):
