@@ -560,15 +560,19 @@ def main():
             peak = N_SIMD * clock_ghz / 4.0                                       # G wave-instructions / s
             ach = insts / (fill_avg_ms * 1e-3) / 1e9
             wave_steps = float(pm.get("wave_steps") or 0)
-            # the clock the chip HELD in the profiled launch (persistent waves: a wave's lifetime = the kernel's), and
-            # the share of those cycles in which a SIMD issued a vector instruction (both counters in quad-cycles)
-            wave_quads = float(pm["SQ_WAVE_CYCLES"]) / float(pm["SQ_WAVES"])
-            held_ghz = wave_quads * 4.0 / (float(pm["kernel_ms_traced_run"]) * 1e-3) / 1e9
-            busy = float(pm["SQ_ACTIVE_INST_VALU"]) / N_SIMD / wave_quads
+            # the clock the chip HELD in the profiled launch (MI355X_MICROARCH.md: GRBM_GUI_ACTIVE / 8 XCDs / kernel
+            # time) and the share of the launch's cycles in which a SIMD issued a vector instruction
+            # (SQ_ACTIVE_INST_VALU counts quad-cycles, summed over the SIMDs)
+            held_ghz = busy = None
+            if pm.get("GRBM_GUI_ACTIVE"):
+                cyc = float(pm["GRBM_GUI_ACTIVE"]) / 8.0
+                held_ghz = cyc / (float(pm["kernel_ms_traced_run"]) * 1e-3) / 1e9
+                busy = float(pm["SQ_ACTIVE_INST_VALU"]) * 4.0 / N_SIMD / cyc
             valu = {"bound": "valu_issue", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
                     "frac": round(ach / peak, 4), "insts_valu_per_launch": int(insts),
                     "valu_per_wave_step": round(insts / wave_steps, 1) if wave_steps else None,
-                    "clock_held_ghz": round(held_ghz, 3), "valu_busy_frac_at_held_clock": round(busy, 4)}
+                    "clock_held_ghz": round(held_ghz, 3) if held_ghz else None,
+                    "valu_busy_frac_at_held_clock": round(busy, 4) if busy else None}
             pmc_src = f"profiles/r03_fill_pmc_summary.json (csrc {pm['csrc_sha']})"
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

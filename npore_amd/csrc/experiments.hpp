@@ -62,6 +62,16 @@ constexpr bool NOPRETEST = true;      // annotate: no scalar pre-test of a windo
 #else
 constexpr bool NOPRETEST = false;
 #endif
+#if defined(NPORE_X_NOASM_ROLES)
+constexpr int NOASM_ROLES = NPORE_X_NOASM_ROLES;      // bit k: the waves of role k run the compiled plain steps (race bisection)
+#else
+constexpr int NOASM_ROLES = 0;
+#endif
+#if defined(NPORE_X_ZEROLDS)
+constexpr int ZEROLDS = NPORE_X_ZEROLDS;      // 1: the chunks' LDS zeroed at kernel start, 2: filled with NaN (uninitialised-read hunt)
+#else
+constexpr int ZEROLDS = 0;
+#endif
 #if defined(NPORE_X_ANNT)
 constexpr int ANNT = NPORE_X_ANNT;    // threads of an annotate workgroup (planes in LDS)
 #else

@@ -55,6 +55,8 @@ class Text:
         for ln in s.strip("\n").split("\n"):
             ln = ln.strip()
             if ln:
+                if OPT["strictwait"] and re.fullmatch(r"s_waitcnt lgkmcnt\([1-9]\)", ln):
+                    ln = "s_waitcnt lgkmcnt(0)"
                 self.lines.append(ln)
 
     def label(self, name):
@@ -67,7 +69,7 @@ def L(name):
 
 # more scratch: lane-table results of the first SHR candidate, fetched before the hand-shake poll
 E0, E1 = "v89", "v90"
-OPT = {"relaxed": False, "nopoll": False, "nolen": False}     # nopoll / nolen: ablations (wrong strings, timing only)          # relaxed: no lgkmcnt wait in front of the progress store (LDS serves a wave in order)
+OPT = {"relaxed": False, "nopoll": False, "nolen": False, "pollfirst": False, "fence": False, "pubdelay": False, "polldelay": False, "strictwait": False}     # nopoll / nolen: ablations (wrong strings, timing only)          # relaxed: no lgkmcnt wait in front of the progress store (LDS serves a wave in order)
 
 
 def shr_tables(t, tmp=X3):
@@ -440,7 +442,13 @@ def tail(t, mode, first, last, multi):
                 ds_write2_b32 {O('xown')}, {r1}, {O('refx')} offset0:{b + 2} offset1:{b + 3}
                 ds_write2_b32 {O('xown')}, {O('rc0')}, {O('rc1')} offset0:{b + 4} offset1:{b + 5}
             """)
-        if not OPT["relaxed"]:
+        if OPT["pubdelay"]:
+            t("s_waitcnt lgkmcnt(0)")
+            t("s_nop 15")
+            t("s_nop 15")
+        elif OPT["fence"]:
+            t("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        elif not OPT["relaxed"]:
             t("s_waitcnt lgkmcnt(0)")
         t(f"""
             ds_write_b32 {O('progaddr')}, {O('prog')}
@@ -490,6 +498,9 @@ def polls(t, first, last, sfx):
     """this wave may start the anti-diagonal once its neighbour waves have finished the previous one"""
     if OPT["nopoll"]:
         return
+    if OPT["pollfirst"] and not sfx.endswith("0"):      # (diagnostic: the poll sits at the very start of the step)
+        t("s_waitcnt lgkmcnt(0)")
+        return
     if not first and not last:
         # both progress words in one round trip (the neighbours' words lie 8 bytes apart, this wave's in between)
         t.label("pp" + sfx)
@@ -500,6 +511,9 @@ def polls(t, first, last, sfx):
             v_cmp_lt_i32 vcc, {X3}, {O('prog')}
             s_cbranch_vccnz {L('pp' + sfx)}
         """)
+        if OPT["polldelay"]:
+            t("s_nop 15")
+            t("s_nop 15")
         return
     if not last:
         t.label("pa" + sfx)
@@ -509,6 +523,9 @@ def polls(t, first, last, sfx):
             v_cmp_lt_i32 vcc, {X3}, {O('prog')}
             s_cbranch_vccnz {L('pa' + sfx)}
         """)
+        if OPT["polldelay"]:
+            t("s_nop 15")
+            t("s_nop 15")
     if not first:
         t.label("pb" + sfx)
         t(f"""
@@ -517,6 +534,9 @@ def polls(t, first, last, sfx):
             v_cmp_lt_i32 vcc, {X3}, {O('prog')}
             s_cbranch_vccnz {L('pb' + sfx)}
         """)
+        if OPT["polldelay"]:
+            t("s_nop 15")
+            t("s_nop 15")
 
 
 def book(t, mode):
@@ -548,6 +568,8 @@ def gen_role(role):
     # descriptors do not move and INS reads this lane's own cell, so everything that does not depend on the neighbour
     # waves -- the descriptor's summary bits, the lane-table reads, INS -- is done in front of the hand-shake poll.
     t.label("mode_i")
+    if OPT["pollfirst"] and multi:
+        polls(t, first, last, "_i0")
     if first:
         t(f"""
             s_cmp_ge_i32 {O('sqidx')}, 64
@@ -611,6 +633,8 @@ def gen_role(role):
     # lane's cell is in its own registers, so all but the history reads sits in front of the poll; the other waves
     # learn both from the wave above, behind the poll.
     t.label("mode_d")
+    if OPT["pollfirst"] and multi:
+        polls(t, first, last, "_d0")
     if last:
         t(f"""
             s_cmp_ge_i32 {O('rqidx')}, 64
@@ -918,7 +942,7 @@ def main():
     args = sys.argv[1:]
     while args:                      # measurement variants: --relaxed, --out FILE
         a = args.pop(0)
-        if a in ("--relaxed", "--nopoll", "--nolen"):
+        if a in ("--relaxed", "--nopoll", "--nolen", "--pollfirst", "--fence", "--pubdelay", "--polldelay", "--strictwait"):
             OPT[a[2:]] = True
         elif a == "--out":
             out_path = args.pop(0)

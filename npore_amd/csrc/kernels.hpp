@@ -353,6 +353,12 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
                     : b < 0   ? INF_F
                               : (n < p.max_n && a < np_dim && b < np_dim) ? p.np_scores[((size_t)n * np_dim + a) * np_dim + b] : 0.0f;
     }
+    if constexpr (xp::ZEROLDS != 0) {      // (diagnostic: a defined value in every word of the chunks' LDS)
+        float *base = lds_sub + SUBT_ENTRIES;
+        const size_t nfl = (size_t)cpg * chunk_lds_floats(NW, hw, p.rwin);
+        for (size_t idx = threadIdx.x; idx < nfl; idx += blockDim.x) base[idx] = xp::ZEROLDS == 1 ? 0.0f : __uint_as_float(0x7fc00000u);
+        __syncthreads();
+    }
     for (int idx = threadIdx.x; idx < SUBT_ENTRIES; idx += blockDim.x) {
         const int rb = idx >> 5, sb = (idx >> 2) & 7;
         lds_sub[idx] = (rb < 5 && sb < 5) ? p.sub_scores[sb * 5 + rb] : 0.0f;
@@ -902,7 +908,8 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
             // anti-diagonals [plain_lo, plain_hi) are plain (cell.hpp step_is_plain: both conditions are monotone along the
             // input path): ONE run of the assembly loop; the ~2r anti-diagonals either side of it, where the band touches
             // the chunk rectangle's border, go through the general cell update window by window
-            const int plo = xp::NOASM ? d.nrows : max(d.plain_lo, 1), phi = min(d.plain_hi, d.nrows);
+            constexpr bool NOASM_HERE = xp::NOASM || ((xp::NOASM_ROLES >> decltype(role_tag)::value) & 1);
+            const int plo = NOASM_HERE ? d.nrows : max(d.plain_lo, 1), phi = min(d.plain_hi, d.nrows);
             auto rotate = [&](int w0) {
                 stepmask = nextmask;
                 nextmask = step_window((w0 >> 6) + 2);
@@ -923,7 +930,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
                     }
                     continue;
                 }
-                if (xp::NOASM && b0 >= d.plain_lo && b1 <= d.plain_hi) span(b0, b1, role_tag, std::true_type{});   // (A/B: compiled plain steps)
+                if (NOASM_HERE && b0 >= d.plain_lo && b1 <= d.plain_hi) span(b0, b1, role_tag, std::true_type{});   // (A/B: compiled plain steps)
                 else span(b0, b1, role_tag, std::false_type{});
                 rotate(w0);
                 w0 += 64;
