@@ -230,6 +230,7 @@ def main():
     ap.add_argument("--coresident", type=int, default=1,
                     help="1 (default): a group of reads that overlaps another one's fill kernel is prepared and gathered "
                          "by kernel shapes that fit beside the fill's workgroups; 0: always the stand-alone ones")
+    ap.add_argument("--fill-streams", type=int, default=0, help="1: consecutive fill kernels on one stream, 2: on two (the default; experiments)")
     ap.add_argument("--force-chunks", type=int, default=0, help="chunks per fill workgroup (experiments; 0 = automatic)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="batches in flight per GPU: each has its own context (stream + work buffers) and host thread, "
@@ -291,6 +292,8 @@ def main():
         if args.tb_kernel:
             c.set("traceback_kernel", args.tb_kernel)
         c.set("coresident", args.coresident)
+        if args.fill_streams:
+            c.set("fill_streams", args.fill_streams)
         if args.force_chunks:
             c.set("force_chunks", args.force_chunks)
     lib = _lib.load()

@@ -332,6 +332,11 @@ int npore_debug_divcheck(int64_t *mismatches);
  * 5 refl, 6 schedule, 7 counters); the GPU tests compare them with the host twin. */
 int npore_debug_fetch(npore_ctx *ctx, int what, void *dst, int64_t bytes);
 
+/* Debug: `bytes` of the last group's traceback words (u32 per cell: typ | run << 3,
+ * src/aln.pyx:670-742 reads the same from its state matrix) from byte `offset` on;
+ * a chunk's words start at 4 * tb_off of its descriptor. */
+int npore_debug_fetch_tb(npore_ctx *ctx, int64_t offset, void *dst, int64_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

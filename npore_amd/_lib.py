@@ -77,6 +77,7 @@ SIGNATURES = {
     "npore_debug_dpp": (C.c_int, [C.c_void_p]),
     "npore_debug_divcheck": (C.c_int, [C.c_void_p]),
     "npore_debug_fetch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+    "npore_debug_fetch_tb": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
 }
 
 

@@ -50,7 +50,11 @@ constexpr int XCH_WORDS = 12;   // per wave, per parity: boundary cells handed t
 // has read it (LDS ops of a wave are in order).  Several waves per chunk: a wave may
 // be one anti-diagonal ahead of its neighbours (it starts b+1 once they finished b),
 // so row b+1 must not land on a row (b..b-5) a neighbour may still be reading: 7 rows.
+#if defined(NPORE_X_RING)
+__host__ __device__ constexpr int ring_rows(int nw) { return nw > 1 ? NPORE_X_RING : 6; }      // (race hunt: more slack rows)
+#else
 __host__ __device__ constexpr int ring_rows(int nw) { return nw > 1 ? 7 : 6; }
+#endif
 
 struct KParams {
     const ChunkDesc *descs;

@@ -152,6 +152,7 @@ struct npore_ctx {
     // the stages of a group, the streams let stages of neighbouring groups run side by side
     hipStream_t stream = nullptr, s_fill[2] = {nullptr, nullptr}, s_post = nullptr;
     int next_fill = 0;           // the fill stream the next group's fill kernel goes to
+    int fill_streams = 2;        // 1: every fill kernel on one stream (npore_ctx_set "fill_streams")
     hipEvent_t ev[8] = {};       // [4..7] H2D / D2H of the host-buffer entry point, [0] the caller's stream
     float *d_sub = nullptr, *d_np = nullptr;   // NULL in an annotation-only context (created without tables)
     WorkSet ws[N_SETS];
@@ -474,7 +475,7 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     // last chunks run out -- the tail of one launch is filled by the head of the next (C2, steps back to back:
     // 17.1 ms per step against the 18.0 ms one fill kernel takes alone; one stream: 18.1)
     s = ctx->s_fill[ctx->next_fill];
-    ctx->next_fill ^= 1;
+    if (ctx->fill_streams == 2) ctx->next_fill ^= 1;
     HIP_TRY(hipStreamWaitEvent(s, w->ev[1], 0));
     HIP_TRY(hipEventRecord(w->ev[2], s));
 
@@ -1044,6 +1045,7 @@ try {
     if (k == "tb_budget_mb") ctx->tb_budget_mb = value;
     else if (k == "force_chunks") ctx->force_chunks = (int)value;
     else if (k == "coresident") ctx->coresident = value != 0;
+    else if (k == "fill_streams") { if (value < 1 || value > 2) return fail(NPORE_E_INVALID, "fill_streams: 1 or 2"); ctx->fill_streams = (int)value; }
     else if (k == "traceback_kernel") { if (value < 0 || value > 2) return fail(NPORE_E_INVALID, "traceback_kernel: 0, 1 or 2"); ctx->tb_kernel = (int)value; }
     else return fail(NPORE_E_INVALID, "unknown key " + k);
     return NPORE_OK;
@@ -1186,6 +1188,19 @@ int npore_debug_fetch(npore_ctx *ctx, int what, void *dst, int64_t bytes)
     if ((size_t)bytes > b[what]->cap) return fail(NPORE_E_INVALID, "more bytes than the buffer holds");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemcpy(dst, b[what]->p, bytes, hipMemcpyDeviceToHost));
+    return NPORE_OK;
+}
+
+// Debug: `bytes` of the last group's traceback words from byte `offset` on (a chunk's words start at 4 * tb_off of its
+// descriptor, one row of tb_stride(r) words per anti-diagonal)
+int npore_debug_fetch_tb(npore_ctx *ctx, int64_t offset, void *dst, int64_t bytes)
+{
+    if (!ctx || !dst || offset < 0 || bytes < 0) return fail(NPORE_E_INVALID, "bad argument");
+    if (int rc = quiesce(ctx)) return rc;
+    WorkSet *w = ctx->last_ws ? ctx->last_ws : &ctx->ws[0];
+    if ((size_t)(offset + bytes) > w->tb.cap) return fail(NPORE_E_INVALID, "beyond the traceback buffer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpy(dst, static_cast<const char *>(w->tb.p) + offset, bytes, hipMemcpyDeviceToHost));
     return NPORE_OK;
 }
 
