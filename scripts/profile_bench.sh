@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/prof_$tag
 mkdir -p $out        # (a box is fresh; locally, clear gpurun_out/prof_<tag> before a re-run: gpurun MERGES new files into it)
-B="--no-cpu --pcie-steps 0 --sustain 0 --production 0 --solo-steps 0"
+B="--no-cpu --pcie-steps 0 --sustain 0 --production 0 --solo-steps 0 --pipeline 0"    # (--pipeline 0: every step complete before the next: each kernel has the GPU to itself, as its duration is quoted)
 PMC3=${PMC3:-"WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_INSTS_VMEM"}   # (a 4 000-read launch: PMC3="WRITE_SIZE", the LDS counters take > 7 min there)
 PASSES=${PASSES:-"trace pmc1 pmc2 pmc3 pmc4"}
 ( while true; do sleep 60; date >> $out/heartbeat.log; done ) &      # the pool kills a command that writes nothing for 7 minutes

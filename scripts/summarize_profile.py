@@ -35,5 +35,13 @@ if line:
     agg.update({"reads": c["reads_per_gpu"], "ref_len": c["ref_len"], "r": c["r"], "max_b_rows": c.get("max_b_rows", 20000),
                 "base_seed": c.get("base_seed", 2), "mixed": bool(c.get("mixed", False)), "csrc_sha": bench.csrc_sha(),
                 "wave_steps": pr["waves_per_chunk"] * pr["rows_total"], "kernel_ms_traced_run": line["roofline"]["kernel_ms"]})
+# the kernel's duration in the traced run: rocprofv3's own average over the fill launches (the bench line's event times
+# there also span the profiler's serialisation of the neighbouring kernels)
+if ks:
+    for r in csv.DictReader(open(ks[0])):
+        if "fill_kernel" in r["Name"]:
+            agg["kernel_ms_traced_run"] = round(float(r["AverageNs"]) * 1e-6, 3)
+            agg["kernel_ms_traced_run_min_max"] = [round(float(r["MinNs"]) * 1e-6, 3), round(float(r["MaxNs"]) * 1e-6, 3)]
+            break
 json.dump(agg, open(os.path.join(dst, name + "_fill_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(agg, indent=1))
