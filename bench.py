@@ -121,13 +121,14 @@ def host_mem_available():
 
 
 def csrc_sha():
-    """Digest of the kernel sources the library is built from (what a committed PMC profile is valid for)."""
+    """Digest of the DEVICE sources the library's kernels are built from (what a committed PMC profile is valid for):
+    the kernel headers and the generated step assembly -- not the host side of the library (npore_api.cpp, hostio.hpp,
+    glue.hpp ...), which changes without touching a kernel."""
     h = hashlib.sha256()
     d = os.path.join(REPO, "npore_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if os.path.isfile(os.path.join(d, f)):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in ("cell.hpp", "fill_step_asm.inc", "kernels.hpp", "layout.hpp", "prep_kernels.hpp"):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 

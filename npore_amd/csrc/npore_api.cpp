@@ -72,6 +72,16 @@ struct DevBuf {
         p = nullptr;
         cap = 0;
     }
+    // best effort, no head-room: another buffer of the same role already has this capacity (presize_like)
+    void match(const DevBuf &o)
+    {
+        if (o.cap <= cap) return;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        if (hipMalloc(&p, o.cap) == hipSuccess) cap = o.cap;
+        else { p = nullptr; (void)hipGetLastError(); }
+    }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
@@ -116,8 +126,8 @@ struct npore_batch_slot {
 };
 
 // Work buffers of one group of reads on its way through the device stages (grow-only, reused).  A context has
-// two: while the fill kernel works on one group, the next group is prepared in the other set and the previous
-// group's traceback / gather drains from it (run_core).
+// N_SETS of them: while the fill kernel works on one group, the next group is prepared in another set and the previous
+// group's traceback / gather drains from a third (run_core).
 struct WorkSet {
     DevBuf rd_i32, rd_i64, steps, inss, descs, sched, hist, counters; // path + chunks
     DevBuf tiles, cwoff;                                             // CIGAR tiles; chunk positions in the output
@@ -132,6 +142,18 @@ struct WorkSet {
     bool staged = false;
     hipEvent_t ev[6] = {};       // prep start / end, fill start / end, traceback + gather start / end (= group done)
     bool busy = false;           // enqueued, not collected yet
+    // An idle set takes the capacities of one that has just been given a group: the groups of a run are alike, so its
+    // own first group then finds its buffers in place instead of allocating tens of GB in front of its kernels (with
+    // three sets that was the THIRD step of a run -- 0.4 s in a timed region that had two warm-up steps)
+    void presize_like(const WorkSet &o)
+    {
+        DevBuf WorkSet::*const all[] = {&WorkSet::rd_i32, &WorkSet::rd_i64, &WorkSet::steps, &WorkSet::inss, &WorkSet::descs, &WorkSet::sched,
+                                        &WorkSet::hist, &WorkSet::counters, &WorkSet::tiles, &WorkSet::cwoff, &WorkSet::seqw, &WorkSet::refw,
+                                        &WorkSet::refl, &WorkSet::seql, &WorkSet::tb, &WorkSet::cout_, &WorkSet::clen, &WorkSet::cstat,
+                                        &WorkSet::cnruns, &WorkSet::in_refs, &WorkSet::in_seqs, &WorkSet::in_cigs, &WorkSet::in_off,
+                                        &WorkSet::out, &WorkSet::out_len, &WorkSet::status};
+        for (auto m : all) (this->*m).match(o.*m);
+    }
     int64_t cells = 0, call_id = 0;
     DevBuf *all[26] = {&rd_i32, &rd_i64, &steps, &inss, &descs, &sched, &hist, &counters, &tiles, &cwoff,
                        &seqw, &refw, &refl, &seql, &tb, &cout_, &clen, &cstat, &cnruns,
@@ -706,6 +728,8 @@ int run_core(npore_ctx *ctx, const AlignArgs &a, const OutTarget &ot, hipStream_
             }
             return older ? older : fail(rc, this_err);
         }
+        for (auto &o : ctx->ws)
+            if (&o != w && !o.busy && o.tb.cap < w->tb.cap) o.presize_like(*w);
         w->busy = true;
         w->cells = cells;
         w->call_id = ctx->call_id;
