@@ -49,7 +49,7 @@ namespace npore {
 #include "experiments.hpp"
 #else
 #define NPORE_COUNT(k) ((void)0)
-namespace npore { namespace xp { constexpr bool NOLEN = false, NOSHR = false, NOPOLL = false, CHUNKMAJOR = false, NOASM = false, NOPRETEST = false; constexpr int POLLSLEEP = 0, ANN = 0, PRIO = 0, ANNT = 1024, NOASM_ROLES = 0, ZEROLDS = 0; } }
+namespace npore { namespace xp { constexpr bool NOLEN = false, NOSHR = false, NOPOLL = false, CHUNKMAJOR = false, NOASM = false, NOPRETEST = false, DBGMAT = false; constexpr int POLLSLEEP = 0, ANN = 0, PRIO = 0, ANNT = 1024, NOASM_ROLES = 0, ZEROLDS = 0; } }
 #endif
 namespace npore {
 

@@ -72,6 +72,11 @@ constexpr int ZEROLDS = NPORE_X_ZEROLDS;      // 1: the chunks' LDS zeroed at ke
 #else
 constexpr int ZEROLDS = 0;
 #endif
+#if defined(NPORE_X_DBGMAT)
+constexpr bool DBGMAT = true;      // every cell's MAT.VAL to a second buffer laid out like the traceback words (race hunt)
+#else
+constexpr bool DBGMAT = false;
+#endif
 #if defined(NPORE_X_ANNT)
 constexpr int ANNT = NPORE_X_ANNT;    // threads of an annotate workgroup (planes in LDS)
 #else

@@ -69,7 +69,7 @@ def L(name):
 
 # more scratch: lane-table results of the first SHR candidate, fetched before the hand-shake poll
 E0, E1 = "v89", "v90"
-OPT = {"relaxed": False, "nopoll": False, "nolen": False, "pollfirst": False, "fence": False, "pubdelay": False, "polldelay": False, "strictwait": False}     # nopoll / nolen: ablations (wrong strings, timing only)          # relaxed: no lgkmcnt wait in front of the progress store (LDS serves a wave in order)
+OPT = {"relaxed": False, "nopoll": False, "nolen": False, "pollfirst": False, "fence": False, "pubdelay": False, "polldelay": False, "strictwait": False, "dbgmat": False, "nofillwin": False, "nofillrq": False, "dbgaddr": False, "dbgshrst": False, "dbgsd": False, "dbgrec": False}     # nopoll / nolen: ablations (wrong strings, timing only)          # relaxed: no lgkmcnt wait in front of the progress store (LDS serves a wave in order)
 
 
 def shr_tables(t, tmp=X3):
@@ -85,9 +85,14 @@ def shr_tables(t, tmp=X3):
 def shr_hist(t):
     t(f"""
         v_add_u32 {E0}, {O('hca')}, {E0}
+        {"v_mov_b32 " + SD + ", 0x12345678" if OPT["dbgsd"] else ""}
         ds_read_b32 {SD}, {E0}
         ds_read_b64 {PP}, {E0} offset:8
     """)
+    if OPT["dbgaddr"]:       # (diagnostic: the address of the candidate's source record, per cell)
+        t(f"s_mov_b64 exec, {O('mhistx')}")
+        t(f"global_store_dword {O('tboff')}, {E0}, {O('dbgg')}")
+        t("s_mov_b64 exec, -1")
 
 
 def sub_read(t):
@@ -143,6 +148,10 @@ def shr_pass(t, mid, sfx, smr, shadow, shadow2):
     shadow(): work issued in the shadow of the score read (free registers X4 X5 SF); shadow2(): the same for the
     two-candidate block (free registers SHRV SHRRUN).  Leaves X3 = refx & seqw (shadow's last act) for the LEN test.
     The single-candidate case falls through; "no candidate in the wave" and "two candidates" are out of line."""
+    if OPT["dbgsd"]:
+        t(f"s_mov_b64 exec, {O('mhistx')}")
+        t(f"global_store_dword {O('tboff')}, {SD}, {O('dbgg')}")
+        t("s_mov_b64 exec, -1")
     if not mid:
         t(f"""
             v_cmp_ne_u32 vcc, 0, {smr}
@@ -347,7 +356,13 @@ def len_pass(t, mid, sfx, mode):
     """)
     t.label("len_done" + sfx)
     mat_part(t, mode, True, mid)
+    # The record's ds_write_b128 has just been issued, and LENST is one of its four data registers: an LDS write of
+    # more than 64 bits reads its data registers over several cycles, like the VMEM stores of the ISA manual's hazard
+    # table (which does not list DS) -- a VALU write right behind it can reach the register first.  Seen as records whose
+    # LEN run start was +inf in some launches and the true value in others, when this wave issued back to back (an
+    # experimental placement that leaves a wave alone on its SIMD; LABNOTES round 3).  Eight idle cycles in between.
     t(f"""
+        s_nop 7
         v_mov_b32 {LENST}, 0x7f800000
         s_branch {L('post_mat' + sfx)}
     """)
@@ -399,6 +414,11 @@ def mat_part(t, mode, with_len, mid):
     t(f"ds_write_b128 {X3}, {QQ}")
     if not mid:
         t(f"global_store_dword {O('tboff')}, {SE}, {O('tbg')}")
+        if OPT["dbgmat"] or OPT["dbgshrst"]:
+            t(f"global_store_dword {O('tboff')}, {SHRST if OPT['dbgshrst'] else Q0}, {O('dbgg')}")
+        if OPT["dbgrec"]:
+            t(f"v_lshlrev_b32 {X4}, 2, {O('tboff')}")
+            t(f"global_store_dwordx4 {X4}, {QQ}, {O('dbgg')}")
         t("s_mov_b64 exec, -1")
 
 
@@ -458,6 +478,11 @@ def tail(t, mode, first, last, multi):
         """)
     if mid:
         t(f"global_store_dword {O('tboff')}, {SE}, {O('tbg')}")
+        if OPT["dbgmat"] or OPT["dbgshrst"]:
+            t(f"global_store_dword {O('tboff')}, {SHRST if OPT['dbgshrst'] else own_m}, {O('dbgg')}")
+        if OPT["dbgrec"]:
+            t(f"v_lshlrev_b32 {X4}, 2, {O('tboff')}")
+            t(f"global_store_dwordx4 {X4}, {QQ}, {O('dbgg')}")
     # next anti-diagonal; every 64th one starts a new window of input-path steps (out of line: rotate)
     t(f"""
         v_add_f32 {O('ev')}, 0x42c80000, {O('ev')}
@@ -638,12 +663,12 @@ def gen_role(role):
     if last:
         t(f"""
             s_cmp_ge_i32 {O('rqidx')}, 64
-            s_cbranch_scc1 {L('fill_rq')}
+            s_cbranch_scc1 {L('exit') if OPT['nofillrq'] else L('fill_rq')}
         """)
         t.label("rq_ok")
         t(f"""
             s_cmp_ge_i32 {O('sdel')}, {O('dlim')}
-            s_cbranch_scc1 {L('fill_win')}
+            s_cbranch_scc1 {L('exit') if OPT['nofillwin'] else L('fill_win')}
         """)
         t.label("win_ok")
         t(f"""
@@ -915,13 +940,14 @@ def operands(role):
                  ("rqw", "+v", "ref_q.w"), ("wfill", "+s", "a_wfill"), ("dlim", "+s", "a_dlim")]
     outs += [("sx", "=&s", "a_sx")]
     ins = [("stepsg", "s", "steps_g"), ("laneid", "v", "a_laneid"), ("b1", "s", "a_b1"), ("hw16", "s", "a_hw16"), ("ringb", "s", "ring_bytes"),
-           ("tbs4", "s", "tbstride4"), ("n0", "s", "env.n0_lanes"), ("tbg", "s", "tb_g"), ("istart", "s", "a_istart"),
+           ("tbs4", "s", "tbstride4"), ("n0", "s", "env.n0_lanes"), ("tbg", "s", "tb_g"), ("dbgg", "s", "dbg_g"), ("istart", "s", "a_istart"),
            ("iext", "s", "a_iext"), ("winaddr", "s", "a_winaddr"), ("wmask", "s", "a_wmask"), ("clampv", "s", "a_clampv"),
            ("clamp1", "s", "a_clamp1"), ("npdim", "s", "a_npdim"), ("gnp", "s", "env.g_np"),
            ("hca", "v", "hist_c_addr"), ("trecip", "v", "env.t_recip"), ("one", "v", "a_one"), ("lanej", "v", "a_lanej"),
            ("inf", "v", "a_inf"), ("c100", "v", "a_c100")]
     if role != 2:
         ins += [("mhist", "s", "a_mhist")]
+    ins += [("mhistx", "s", "a_mhist")]
     if multi:
         ins += [("xsum", "s", "xsum"), ("pnb", "v", "pnb_addr"), ("progaddr", "v", "a_progaddr"), ("ml0", "s", "a_ml0")]
         if not last:
@@ -942,7 +968,7 @@ def main():
     args = sys.argv[1:]
     while args:                      # measurement variants: --relaxed, --out FILE
         a = args.pop(0)
-        if a in ("--relaxed", "--nopoll", "--nolen", "--pollfirst", "--fence", "--pubdelay", "--polldelay", "--strictwait"):
+        if a in ("--relaxed", "--nopoll", "--nolen", "--pollfirst", "--fence", "--pubdelay", "--polldelay", "--strictwait", "--dbgmat", "--nofillwin", "--nofillrq", "--dbgaddr", "--dbgshrst", "--dbgsd", "--dbgrec"):
             OPT[a[2:]] = True
         elif a == "--out":
             out_path = args.pop(0)

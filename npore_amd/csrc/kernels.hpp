@@ -67,6 +67,7 @@ struct KParams {
     const uint4 *refw;      // x, y and the two pre-decoded SHR candidates (layout.hpp)
     const uint2 *refl;      // 8 bytes per reference position
     uint32_t *tb;
+    uint32_t *dbg = nullptr;   // experiments: MAT.VAL of every cell, laid out like tb (NPORE_X_DBGMAT)
     const float *sub_scores;  // [5][5]
     const float *np_scores;   // [max_n][max_l+1][max_l+1]
     int max_n, max_l;
@@ -456,6 +457,8 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
         const uint2 *refl_g = p.refl + d.refw_off;
         const uint8_t *steps_g = p.steps + d.steps_off + d.brk;   // steps_g[k] = step from local row k to k+1
         uint32_t *tb_g = p.tb + d.tb_off;
+        uint32_t *dbg_g = p.dbg ? p.dbg + d.tb_off : p.tb + d.tb_off;      // (experiments)
+        (void)dbg_g;
         env.refw_g = refw_g;
         env.dcols = d.dcols;
 
@@ -779,6 +782,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
                     u32x4{__float_as_uint(o.matv), __float_as_uint(o.lenstart), __float_as_uint(o.shrstart),
                           (uint32_t)o.lenrun_h | ((uint32_t)o.shrrun_h << 16)};
                 asm volatile("global_store_dword %0, %1, %2" : : "v"(tboff_v), "v"(o.tb), "s"(tb_g) : "memory");
+                if constexpr (xp::DBGMAT) asm volatile("global_store_dword %0, %1, %2" : : "v"(tboff_v), "v"(__float_as_uint(o.matv)), "s"(dbg_g) : "memory");
             }
             if constexpr (NW > 1) {
                 // boundary cells for the neighbour waves: the last lane's cell for the wave above (it reads

@@ -133,6 +133,7 @@ struct WorkSet {
     DevBuf tiles, cwoff;                                             // CIGAR tiles; chunk positions in the output
     DevBuf seqw, refw, refl, seql;                                   // annotation
     DevBuf tb, cout_, clen, cstat, cnruns;                           // fill / traceback (cout_: uint32 runs)
+    DevBuf dbg;                                                      // experiments build: MAT.VAL per cell (NPORE_DBGMAT=1)
     HostBuf h_cnt;                                                   // counters read back with the group
     // host-buffer entry points: the group's slice of the caller's inputs / outputs on the device, its offset
     // arrays rebased to the slice (page-locked copy for the upload)
@@ -392,6 +393,9 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     if (int rc = w->refw.ensure((size_t)(R_tot + max_chunks + 16) * 16)) return rc;
     if (int rc = w->refl.ensure((size_t)(R_tot + max_chunks + 16) * 8)) return rc;
     if (int rc = w->tb.ensure((size_t)tb_words * 4 + 64)) return rc;
+#if defined(NPORE_EXPERIMENTS)
+    if (std::getenv("NPORE_DBGMAT")) { if (int rc = w->dbg.ensure((size_t)tb_words * 4 * (size_t)std::max(1, std::atoi(std::getenv("NPORE_DBGMAT"))) + 64)) return rc; }
+#endif
     if (int rc = w->cout_.ensure(((size_t)(S_tot + R_tot) + 64) * 4)) return rc;
     if (int rc = w->cnruns.ensure((size_t)max_chunks * 4 + 64)) return rc;
     if (int rc = w->clen.ensure((size_t)max_chunks * 4 + 64)) return rc;
@@ -512,6 +516,7 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     kp.refw = pp.refw;
     kp.refl = pp.refl;
     kp.tb = w->tb.as<uint32_t>();
+    kp.dbg = w->dbg.as<uint32_t>();
     kp.sub_scores = ctx->d_sub;
     kp.np_scores = ctx->d_np;
     kp.max_n = ctx->max_n;
@@ -1217,6 +1222,17 @@ int npore_debug_fetch(npore_ctx *ctx, int what, void *dst, int64_t bytes)
 
 // Debug: `bytes` of the last group's traceback words from byte `offset` on (a chunk's words start at 4 * tb_off of its
 // descriptor, one row of tb_stride(r) words per anti-diagonal)
+#if defined(NPORE_EXPERIMENTS)
+extern "C" int npore_debug_fetch_dbg(npore_ctx *ctx, int64_t offset, void *dst, int64_t bytes)
+{
+    if (!ctx || !dst || offset < 0 || bytes < 0) return fail(NPORE_E_INVALID, "bad argument");
+    if (int rc = quiesce(ctx)) return rc;
+    WorkSet *w = ctx->last_ws ? ctx->last_ws : &ctx->ws[0];
+    if ((size_t)(offset + bytes) > w->dbg.cap) return fail(NPORE_E_INVALID, "beyond the debug buffer");
+    HIP_TRY(hipMemcpy(dst, static_cast<const char *>(w->dbg.p) + offset, bytes, hipMemcpyDeviceToHost));
+    return NPORE_OK;
+}
+#endif
 int npore_debug_fetch_tb(npore_ctx *ctx, int64_t offset, void *dst, int64_t bytes)
 {
     if (!ctx || !dst || offset < 0 || bytes < 0) return fail(NPORE_E_INVALID, "bad argument");

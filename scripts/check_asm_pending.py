@@ -76,6 +76,42 @@ def analyse(role):
             pc += 1
     return sorted(problems)
 
+def sources_overwritten_soon(role, window=8):
+    """a VALU write to a register that a DS / VMEM instruction issued within the last `window` instructions READS
+    (address or data): such an instruction reads its registers over a few cycles after issue (measured: a
+    ds_write_b128 followed directly by a v_mov to its second data register stored the new value in some launches)"""
+    lines = [l for l in G.gen_role(role)]
+    out = []
+    recent = []      # (index, text, set of source regs)
+    for i, ln in enumerate(lines):
+        if ln.endswith(":"):
+            continue
+        p = parse(ln)
+        if not p:
+            continue
+        op, ops = p
+        if op.startswith("v_") and ops:
+            dst = vregs(ops[0])
+            for (j, t, src) in recent:
+                if i - j <= window and dst & src:
+                    out.append((j, t, i, ln, tuple(sorted(dst & src))))
+        if op.startswith(("ds_", "global_")):
+            is_load = op.startswith(("ds_read", "ds_bpermute", "global_load"))
+            src = set()
+            for o in (ops[1:] if is_load else ops):
+                src |= vregs(o)
+            if is_load:
+                src -= vregs(ops[0])      # (address == destination is the LDS unit's own business)
+            recent.append((i, ln, src))
+        recent = [r for r in recent if i - r[0] <= window]
+    return out
+
+
+for role in range(4):
+    so = sources_overwritten_soon(role)
+    print("role", role, len(so), "DS/VMEM sources overwritten within 8 instructions")
+    for j, t, i, ln, regs in so[:20]:
+        print("    %d: %s   <-  %d: %s   %s" % (j, t, i, ln, regs))
 for role in range(4):
     pr = analyse(role)
     print("role", role, len(pr), "findings")
