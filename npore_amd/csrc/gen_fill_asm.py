@@ -58,6 +58,10 @@ class Text:
                 if OPT["strictwait"] and re.fullmatch(r"s_waitcnt lgkmcnt\([1-9]\)", ln):
                     ln = "s_waitcnt lgkmcnt(0)"
                 self.lines.append(ln)
+                if OPT["waitwrites"] and ln.startswith("ds_write"):         # (diagnostic: every LDS write complete before anything else)
+                    self.lines.append("s_waitcnt lgkmcnt(0)")
+                if OPT["waitstores"] and ln.startswith("global_store"):     # (diagnostic: every store complete ...)
+                    self.lines.append("s_waitcnt vmcnt(0)")
 
     def label(self, name):
         self.lines.append(name + "_%=:")
@@ -69,7 +73,7 @@ def L(name):
 
 # more scratch: lane-table results of the first SHR candidate, fetched before the hand-shake poll
 E0, E1 = "v89", "v90"
-OPT = {"relaxed": False, "nopoll": False, "nolen": False, "pollfirst": False, "fence": False, "pubdelay": False, "polldelay": False, "strictwait": False, "dbgmat": False, "nofillwin": False, "nofillrq": False, "dbgaddr": False, "dbgshrst": False, "dbgsd": False, "dbgrec": False}     # nopoll / nolen: ablations (wrong strings, timing only)          # relaxed: no lgkmcnt wait in front of the progress store (LDS serves a wave in order)
+OPT = {"relaxed": False, "nopoll": False, "nolen": False, "pollfirst": False, "fence": False, "pubdelay": False, "polldelay": False, "strictwait": False, "dbgmat": False, "nofillwin": False, "nofillrq": False, "dbgaddr": False, "dbgshrst": False, "dbgsd": False, "dbgrec": False, "waitwrites": False, "waitstores": False}     # nopoll / nolen: ablations (wrong strings, timing only)          # relaxed: no lgkmcnt wait in front of the progress store (LDS serves a wave in order)
 
 
 def shr_tables(t, tmp=X3):
@@ -968,7 +972,7 @@ def main():
     args = sys.argv[1:]
     while args:                      # measurement variants: --relaxed, --out FILE
         a = args.pop(0)
-        if a in ("--relaxed", "--nopoll", "--nolen", "--pollfirst", "--fence", "--pubdelay", "--polldelay", "--strictwait", "--dbgmat", "--nofillwin", "--nofillrq", "--dbgaddr", "--dbgshrst", "--dbgsd", "--dbgrec"):
+        if a in ("--relaxed", "--nopoll", "--nolen", "--pollfirst", "--fence", "--pubdelay", "--polldelay", "--strictwait", "--dbgmat", "--nofillwin", "--nofillrq", "--dbgaddr", "--dbgshrst", "--dbgsd", "--dbgrec", "--waitwrites", "--waitstores"):
             OPT[a[2:]] = True
         elif a == "--out":
             out_path = args.pop(0)
