@@ -17,7 +17,7 @@ hb=$!
 [[ $PASSES == *pmc1* ]] && rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $out/pmc1 -- python3 $R/bench.py --steps 1 --warmup 0 $B "$@" > $out/bench_pmc1.log 2>&1
 [[ $PASSES == *pmc2* ]] && rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc2 -- python3 $R/bench.py --steps 1 --warmup 0 $B "$@" > $out/bench_pmc2.log 2>&1
 [[ $PASSES == *pmc3* ]] && rocprofv3 --pmc $PMC3 --output-format csv -d $out/pmc3 -- python3 $R/bench.py --steps 1 --warmup 0 $B "$@" > $out/bench_pmc3.log 2>&1
-[[ $PASSES == *pmc4* ]] && rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $out/pmc4 -- python3 $R/bench.py --steps 1 --warmup 0 $B "$@" > $out/bench_pmc4.log 2>&1    # clock held under load = GRBM_GUI_ACTIVE / 8 XCDs / kernel time
+[[ $PASSES == *pmc4* ]] && rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $out/pmc4 -- python3 $R/bench.py --steps 3 --warmup 1 $B "$@" > $out/bench_pmc4.log 2>&1    # clock held under load = GRBM_GUI_ACTIVE / 8 XCDs / kernel time
 kill $hb 2>/dev/null
 find $out -name "*.csv" | head -30
 for f in $(find $out/trace -name "*kernel_stats.csv"); do echo "== $f"; cat $f; done

@@ -18,13 +18,17 @@ if ks:
 agg = collections.OrderedDict()
 for f in sorted(glob.glob(os.path.join(src, "pmc*", "*", "*counter_collection.csv"))):
     part = collections.defaultdict(float)
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
     launches = set()
     for r in csv.DictReader(open(f)):
         if "fill_kernel" in r["Kernel_Name"]:
             part[r["Counter_Name"]] += float(r["Counter_Value"])
+            per[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
             launches.add(r["Dispatch_Id"])
-    for k in sorted(part):          # per launch: a profiled bench run holds several (the timed step + the three timed alone)
+    for k in sorted(part):          # per launch: a profiled bench run may hold several
         agg.setdefault(k, part[k] / max(1, len(launches)))
+    if "GRBM_GUI_ACTIVE" in per:    # busy cycles: the shortest launch (a first launch also spans buffer allocations beside it)
+        agg["GRBM_GUI_ACTIVE"] = min(per["GRBM_GUI_ACTIVE"].values())
 line = None
 for l in open(os.path.join(src, "bench_trace.log")):
     if l.startswith("{"):
