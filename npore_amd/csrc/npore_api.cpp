@@ -394,6 +394,7 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     if (int rc = w->refl.ensure((size_t)(R_tot + max_chunks + 16) * 8)) return rc;
     if (int rc = w->tb.ensure((size_t)tb_words * 4 + 64)) return rc;
 #if defined(NPORE_EXPERIMENTS)
+    if (std::getenv("NPORE_DBGMAT") && w->dbg.p) (void)hipMemsetAsync(w->dbg.p, 0, w->dbg.cap, ctx->stream);     // (steps of the compiled path leave zeros)
     if (std::getenv("NPORE_DBGMAT")) { if (int rc = w->dbg.ensure((size_t)tb_words * 4 * (size_t)std::max(1, std::atoi(std::getenv("NPORE_DBGMAT"))) + 64)) return rc; }
 #endif
     if (int rc = w->cout_.ensure(((size_t)(S_tot + R_tot) + 64) * 4)) return rc;
