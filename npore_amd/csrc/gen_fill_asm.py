@@ -73,7 +73,7 @@ def L(name):
 
 # more scratch: lane-table results of the first SHR candidate, fetched before the hand-shake poll
 E0, E1 = "v89", "v90"
-OPT = {"relaxed": False, "nopoll": False, "nolen": False, "pollfirst": False, "fence": False, "pubdelay": False, "polldelay": False, "strictwait": False, "dbgmat": False, "nofillwin": False, "nofillrq": False, "dbgaddr": False, "dbgshrst": False, "dbgsd": False, "dbgrec": False, "waitwrites": False, "waitstores": False, "dbgin": False}     # nopoll / nolen: ablations (wrong strings, timing only)          # relaxed: no lgkmcnt wait in front of the progress store (LDS serves a wave in order)
+OPT = {"relaxed": False, "nopoll": False, "nolen": False, "pollfirst": False, "fence": False, "pubdelay": False, "polldelay": False, "strictwait": False, "dbgmat": False, "nofillwin": False, "nofillrq": False, "dbgaddr": False, "dbgshrst": False, "dbgsd": False, "dbgrec": False, "waitwrites": False, "waitstores": False, "dbgin": False, "reread": False, "read2": False, "noentrywait": False}     # nopoll / nolen: ablations (wrong strings, timing only)          # relaxed: no lgkmcnt wait in front of the progress store (LDS serves a wave in order)
 
 
 def shr_tables(t, tmp=X3):
@@ -91,7 +91,7 @@ def shr_hist(t):
         v_add_u32 {E0}, {O('hca')}, {E0}
         {"v_mov_b32 " + SD + ", 0x12345678" if OPT["dbgsd"] else ""}
         ds_read_b32 {SD}, {E0}
-        ds_read_b64 {PP}, {E0} offset:8
+        {"ds_read2_b32 " + PP + ", " + E0 + " offset0:2 offset1:3" if OPT["read2"] else "ds_read_b64 " + PP + ", " + E0 + " offset:8"}
     """)
     if OPT["dbgaddr"]:       # (diagnostic: the address of the candidate's source record, per cell)
         t(f"s_mov_b64 exec, {O('mhistx')}")
@@ -182,6 +182,29 @@ def shr_pass(t, mid, sfx, smr, shadow, shadow2):
         s_cbranch_vccnz {L('shr_two' + sfx)}
     """)
     # ---- one candidate per column
+    if OPT["reread"]:
+        # (diagnostic: a "continue" candidate -- source runs != 0, descriptor not a start -- whose start value loaded as
+        # exactly 0: read the record's second half again, note the cell and what the second read returned)
+        t(f"""
+            v_cmp_gt_i32 vcc, 0, {O('rc0')}
+            v_cmp_eq_u32 {O('sa')}, 0, {P0}
+            v_lshrrev_b32 {X5}, 16, {P1}
+            v_cmp_ne_u32 {O('sc')}, 0, {X5}
+            s_nop 1
+            s_and_b64 {O('sa')}, {O('sa')}, {O('sc')}
+            s_andn2_b64 {O('sa')}, {O('sa')}, vcc
+            v_cmp_ne_u32 {O('sc')}, 0, {smr}
+            s_nop 1
+            s_and_b64 {O('sa')}, {O('sa')}, {O('sc')}
+            s_cbranch_scc0 {L('noreread' + sfx)}
+            ds_read_b64 {PP}, {E0} offset:8
+            s_waitcnt lgkmcnt(0)
+            v_or_b32 {X4}, 0x80000000, {P0}
+            s_mov_b64 exec, {O('sa')}
+            global_store_dword {O('tboff')}, {X4}, {O('dbgg')}
+            s_mov_b64 exec, -1
+        """)
+        t.label("noreread" + sfx)
     t(f"""
         v_cmp_gt_i32 vcc, 0, {O('rc0')}
         v_lshrrev_b32 {P1}, 16, {P1}
@@ -594,6 +617,16 @@ def gen_role(role):
     last = role in (0, 3)
     mid = role == 2
     t = Text()
+    # Nothing the compiled code around this text has in flight may still be on its way when the text starts: the
+    # scratch registers are declared clobbered, but the compiler does not wait at an inline-asm statement for loads
+    # whose DESTINATION is a clobbered register, and a global load issued by the compiled step that ran just before
+    # (the rare-path step the loop hands over) can land in one of them AFTER this text has put its own value there.
+    # Seen as a wave whose v100 read as 0 in every lane a few instructions behind the ds_read_b64 that had filled it,
+    # once in ~25 full launches with a wave placement that lets a wave issue back to back (LABNOTES round 3); the
+    # second read of the same address was right.  One wait per entry (entries = hand-overs, ~1 % of the steps): within
+    # the run-to-run spread of the fill time.
+    if not OPT["noentrywait"]:
+        t("s_waitcnt vmcnt(0) lgkmcnt(0)")
     t(f"""
         v_mov_b32 {LENST}, 0x7f800000
         s_bitcmp1_b64 {O('mask')}, {O('bl')}
@@ -978,7 +1011,7 @@ def main():
     args = sys.argv[1:]
     while args:                      # measurement variants: --relaxed, --out FILE
         a = args.pop(0)
-        if a in ("--relaxed", "--nopoll", "--nolen", "--pollfirst", "--fence", "--pubdelay", "--polldelay", "--strictwait", "--dbgmat", "--nofillwin", "--nofillrq", "--dbgaddr", "--dbgshrst", "--dbgsd", "--dbgrec", "--waitwrites", "--waitstores", "--dbgin"):
+        if a in ("--relaxed", "--nopoll", "--nolen", "--pollfirst", "--fence", "--pubdelay", "--polldelay", "--strictwait", "--dbgmat", "--nofillwin", "--nofillrq", "--dbgaddr", "--dbgshrst", "--dbgsd", "--dbgrec", "--waitwrites", "--waitstores", "--dbgin", "--reread", "--read2", "--noentrywait"):
             OPT[a[2:]] = True
         elif a == "--out":
             out_path = args.pop(0)
