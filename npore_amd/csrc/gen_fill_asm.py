@@ -28,6 +28,7 @@ P0, P1, PP = "v100", "v101", "v[100:101]"
 SUBV, DRUN, NINSR, NDELR = "v102", "v103", "v87", "v88"
 SHRV, SHRRUN, LENV, LENRUN = "v104", "v105", "v106", "v107"
 Q0, LENST, SHRST, QRUNS, QQ = "v108", "v109", "v110", "v111", "v[108:111]"      # the history record: one ds_write_b128
+HS, HP0, HP1, HQ = "v104", "v106", "v107", "v[104:107]"      # the first SHR candidate's source record (one ds_read_b128): matv, -, shrstart, runs
 SCRATCH = ["v%d" % k for k in range(87, 112)]
 
 LDS_SUB_BASE = 6 * 32 * 33 * 4      # kernels.hpp LDS_SUB_BASE
@@ -90,8 +91,7 @@ def shr_hist(t):
     t(f"""
         v_add_u32 {E0}, {O('hca')}, {E0}
         {"v_mov_b32 " + SD + ", 0x12345678" if OPT["dbgsd"] else ""}
-        ds_read_b32 {SD}, {E0}
-        {"ds_read2_b32 " + PP + ", " + E0 + " offset0:2 offset1:3" if OPT["read2"] else "ds_read_b64 " + PP + ", " + E0 + " offset:8"}
+        ds_read_b128 {HQ}, {E0}
     """)
     if OPT["dbgaddr"]:       # (diagnostic: the address of the candidate's source record, per cell)
         t(f"s_mov_b64 exec, {O('mhistx')}")
@@ -182,50 +182,27 @@ def shr_pass(t, mid, sfx, smr, shadow, shadow2):
         s_cbranch_vccnz {L('shr_two' + sfx)}
     """)
     # ---- one candidate per column
-    if OPT["reread"]:
-        # (diagnostic: a "continue" candidate -- source runs != 0, descriptor not a start -- whose start value loaded as
-        # exactly 0: read the record's second half again, note the cell and what the second read returned)
-        t(f"""
-            v_cmp_gt_i32 vcc, 0, {O('rc0')}
-            v_cmp_eq_u32 {O('sa')}, 0, {P0}
-            v_lshrrev_b32 {X5}, 16, {P1}
-            v_cmp_ne_u32 {O('sc')}, 0, {X5}
-            s_nop 1
-            s_and_b64 {O('sa')}, {O('sa')}, {O('sc')}
-            s_andn2_b64 {O('sa')}, {O('sa')}, vcc
-            v_cmp_ne_u32 {O('sc')}, 0, {smr}
-            s_nop 1
-            s_and_b64 {O('sa')}, {O('sa')}, {O('sc')}
-            s_cbranch_scc0 {L('noreread' + sfx)}
-            ds_read_b64 {PP}, {E0} offset:8
-            s_waitcnt lgkmcnt(0)
-            v_or_b32 {X4}, 0x80000000, {P0}
-            s_mov_b64 exec, {O('sa')}
-            global_store_dword {O('tboff')}, {X4}, {O('dbgg')}
-            s_mov_b64 exec, -1
-        """)
-        t.label("noreread" + sfx)
     t(f"""
         v_cmp_gt_i32 vcc, 0, {O('rc0')}
-        v_lshrrev_b32 {P1}, 16, {P1}
+        v_lshrrev_b32 {HP1}, 16, {HP1}
         v_bfe_u32 {SE}, {O('rc0')}, 15, 16
-        v_cndmask_b32 {P1}, {P1}, 0, vcc
-        v_cndmask_b32 {SD}, {P0}, {SD}, vcc
-        v_mul_u32_u24 {E1}, {P1}, {E1}
+        v_cndmask_b32 {HP1}, {HP1}, 0, vcc
+        v_cndmask_b32 {HS}, {HP0}, {HS}, vcc
+        v_mul_u32_u24 {E1}, {HP1}, {E1}
         v_bfe_u32 {E0}, {O('rc0')}, 2, 3
         v_min_u32_sdwa {E1}, {E1}, {O('rc0')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_1
-        v_add_u32 {P1}, {P1}, {E0}
+        v_add_u32 {HP1}, {HP1}, {E0}
         v_lshl_add_u32 {SE}, {E1}, 2, {SE}
         ds_read_b32 {SE}, {SE}
     """)
     shadow()
     t(f"""
         s_waitcnt lgkmcnt(0)
-        v_add_f32 {SE}, {SD}, {SE}
+        v_add_f32 {SE}, {HS}, {SE}
         v_cmp_lt_f32 vcc, {SE}, {O('ev')}
+        v_cndmask_b32 {SHRST}, {O('inf')}, {HS}, vcc
+        v_cndmask_b32 {SHRRUN}, 0, {HP1}, vcc
         v_cndmask_b32 {SHRV}, {O('ev')}, {SE}, vcc
-        v_cndmask_b32 {SHRRUN}, 0, {P1}, vcc
-        v_cndmask_b32 {SHRST}, {O('inf')}, {SD}, vcc
     """)
     t.label("shr_done2" + sfx)
     # ---- two candidates (second in rc1): its lane tables and record now, then both scores, then the compares in
@@ -238,14 +215,14 @@ def shr_pass(t, mid, sfx, smr, shadow, shadow2):
         ds_bpermute_b32 {X5}, {X3}, {O('trecip')}
         v_cmp_gt_i32 vcc, 0, {O('rc0')}
         v_cmp_gt_i32 {O('sa')}, 0, {O('rc1')}
-        v_lshrrev_b32 {P1}, 16, {P1}
+        v_lshrrev_b32 {HP1}, 16, {HP1}
         v_bfe_u32 {SE}, {O('rc0')}, 15, 16
-        v_cndmask_b32 {P1}, {P1}, 0, vcc
-        v_cndmask_b32 {SD}, {P0}, {SD}, vcc
-        v_mul_u32_u24 {E1}, {P1}, {E1}
+        v_cndmask_b32 {HP1}, {HP1}, 0, vcc
+        v_cndmask_b32 {HS}, {HP0}, {HS}, vcc
+        v_mul_u32_u24 {E1}, {HP1}, {E1}
         v_bfe_u32 {E0}, {O('rc0')}, 2, 3
         v_min_u32_sdwa {E1}, {E1}, {O('rc0')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_1
-        v_add_u32 {P1}, {P1}, {E0}
+        v_add_u32 {HP1}, {HP1}, {E0}
         v_lshl_add_u32 {E0}, {E1}, 2, {SE}
         s_waitcnt lgkmcnt(0)
         v_add_u32 {X4}, {O('hca')}, {X4}
@@ -266,11 +243,11 @@ def shr_pass(t, mid, sfx, smr, shadow, shadow2):
         v_lshl_add_u32 {X4}, {X5}, 2, {X4}
         ds_read_b32 {X4}, {X4}
         v_add_u32 {SF}, {SF}, {SE}
-        v_add_f32 {E0}, {SD}, {E0}
+        v_add_f32 {E0}, {HS}, {E0}
         v_cmp_lt_f32 vcc, {E0}, {O('ev')}
+        v_cndmask_b32 {SHRST}, {O('inf')}, {HS}, vcc
+        v_cndmask_b32 {SHRRUN}, 0, {HP1}, vcc
         v_cndmask_b32 {SHRV}, {O('ev')}, {E0}, vcc
-        v_cndmask_b32 {SHRRUN}, 0, {P1}, vcc
-        v_cndmask_b32 {SHRST}, {O('inf')}, {SD}, vcc
         s_waitcnt lgkmcnt(0)
         v_add_f32 {X4}, {E1}, {X4}
         v_cmp_lt_f32 vcc, {X4}, {SHRV}
@@ -674,7 +651,7 @@ def gen_role(role):
     shr_hist(t)
     if not first:
         t(f"""
-            s_waitcnt lgkmcnt(2)
+            s_waitcnt lgkmcnt(1)
             v_mov_b32_dpp {X3}, {O('seqw')} wave_shr:1 row_mask:0xf bank_mask:0xf
             v_mov_b32_dpp {X0}, {O('matv')} wave_shr:1 row_mask:0xf bank_mask:0xf
             v_mov_b32_dpp {X1}, {O('delv')} wave_shr:1 row_mask:0xf bank_mask:0xf
@@ -693,7 +670,7 @@ def gen_role(role):
         """)
     sub_read(t)
     t("s_waitcnt lgkmcnt(1)")          # the candidate's source record (the substitution score may still be on its way)
-    shr_pass(t, mid, "_I", SHRST, lambda: del_part(t, "I", X4, X5, O("sb")), lambda: del_part(t, "I", SHRV, SHRRUN, O("sb")))
+    shr_pass(t, mid, "_I", SHRST, lambda: del_part(t, "I", X4, X5, O("sb")), lambda: del_part(t, "I", SD, P0, O("sb")))
     len_pass(t, mid, "_I", "I")
     tail(t, "I", first, last, multi)
     # ================= 'D' step: reference words (and the column descriptors) move one column down, "top" is the
@@ -793,7 +770,7 @@ def gen_role(role):
         t("s_waitcnt lgkmcnt(1)")
         shr_hist(t)
         t("s_waitcnt lgkmcnt(0)")
-    shr_pass(t, mid, "_D", SHRST, lambda: del_part(t, "D", X4, X5, O("sb")), lambda: del_part(t, "D", SHRV, SHRRUN, O("sb")))
+    shr_pass(t, mid, "_D", SHRST, lambda: del_part(t, "D", X4, X5, O("sb")), lambda: del_part(t, "D", SD, P0, O("sb")))
     len_pass(t, mid, "_D", "D")
     tail(t, "D", first, last, multi)
     t.lines = t.main
