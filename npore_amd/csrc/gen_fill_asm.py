@@ -74,7 +74,7 @@ def L(name):
 
 # more scratch: lane-table results of the first SHR candidate, fetched before the hand-shake poll
 E0, E1 = "v89", "v90"
-OPT = {"relaxed": False, "nopoll": False, "nolen": False, "pollfirst": False, "fence": False, "pubdelay": False, "polldelay": False, "strictwait": False, "dbgmat": False, "nofillwin": False, "nofillrq": False, "dbgaddr": False, "dbgshrst": False, "dbgsd": False, "dbgrec": False, "waitwrites": False, "waitstores": False, "dbgin": False, "reread": False, "read2": False, "noentrywait": False}     # nopoll / nolen: ablations (wrong strings, timing only)          # relaxed: no lgkmcnt wait in front of the progress store (LDS serves a wave in order)
+OPT = {"relaxed": False, "nopoll": False, "nolen": False, "pollfirst": False, "fence": False, "pubdelay": False, "polldelay": False, "strictwait": False, "dbgmat": False, "nofillwin": False, "nofillrq": False, "dbgaddr": False, "dbgshrst": False, "dbgrec": False, "waitwrites": False, "waitstores": False, "noentrywait": False}     # nopoll / nolen: ablations (wrong strings, timing only)          # relaxed: no lgkmcnt wait in front of the progress store (LDS serves a wave in order)
 
 
 def shr_tables(t, tmp=X3):
@@ -90,7 +90,6 @@ def shr_tables(t, tmp=X3):
 def shr_hist(t):
     t(f"""
         v_add_u32 {E0}, {O('hca')}, {E0}
-        {"v_mov_b32 " + SD + ", 0x12345678" if OPT["dbgsd"] else ""}
         ds_read_b128 {HQ}, {E0}
     """)
     if OPT["dbgaddr"]:       # (diagnostic: the address of the candidate's source record, per cell)
@@ -152,16 +151,6 @@ def shr_pass(t, mid, sfx, smr, shadow, shadow2):
     shadow(): work issued in the shadow of the score read (free registers X4 X5 SF); shadow2(): the same for the
     two-candidate block (free registers SHRV SHRRUN).  Leaves X3 = refx & seqw (shadow's last act) for the LEN test.
     The single-candidate case falls through; "no candidate in the wave" and "two candidates" are out of line."""
-    if OPT["dbgin"]:         # (diagnostic: the candidate's loaded record words and neighbours, 8 words per cell)
-        t(f"s_mov_b64 exec, {O('mhistx')}")
-        t(f"v_lshlrev_b32 {X4}, 3, {O('tboff')}")
-        t(f"global_store_dwordx4 {X4}, v[96:99], {O('dbgg')}")
-        t(f"global_store_dwordx4 {X4}, v[100:103], {O('dbgg')} offset:16")
-        t("s_mov_b64 exec, -1")
-    if OPT["dbgsd"]:
-        t(f"s_mov_b64 exec, {O('mhistx')}")
-        t(f"global_store_dword {O('tboff')}, {SD}, {O('dbgg')}")
-        t("s_mov_b64 exec, -1")
     if not mid:
         t(f"""
             v_cmp_ne_u32 vcc, 0, {smr}
@@ -988,7 +977,7 @@ def main():
     args = sys.argv[1:]
     while args:                      # measurement variants: --relaxed, --out FILE
         a = args.pop(0)
-        if a in ("--relaxed", "--nopoll", "--nolen", "--pollfirst", "--fence", "--pubdelay", "--polldelay", "--strictwait", "--dbgmat", "--nofillwin", "--nofillrq", "--dbgaddr", "--dbgshrst", "--dbgsd", "--dbgrec", "--waitwrites", "--waitstores", "--dbgin", "--reread", "--read2", "--noentrywait"):
+        if a in ("--relaxed", "--nopoll", "--nolen", "--pollfirst", "--fence", "--pubdelay", "--polldelay", "--strictwait", "--dbgmat", "--nofillwin", "--nofillrq", "--dbgaddr", "--dbgshrst", "--dbgrec", "--waitwrites", "--waitstores", "--noentrywait"):
             OPT[a[2:]] = True
         elif a == "--out":
             out_path = args.pop(0)
