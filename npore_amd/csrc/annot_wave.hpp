@@ -1,0 +1,251 @@
+// annot_wave.hpp -- n-polymer annotation and word packing of a chunk slice by ONE wavefront, in registers.
+//
+// get_np_info (reference src/aln.pyx:179-251) on the chunk slices of src/aln.pyx:453-456, and the packed words of
+// layout.hpp, for the batch path (annotate_wave_kernel: one wave per (chunk, sequence), no LDS, no barrier, no
+// scratch memory -- it runs as well beside a fill kernel, which holds the CUs' LDS, as on an empty GPU).
+//
+// Formulation (tests/model/annot_wave_model.py is its CPU statement, checked against the oracle's literal loop):
+// with e_n[p] = (seq[p] == seq[p+n]), kf(p) = run of e_n from p on, q = kf / n, a position is an eligible start ON ITS
+// OWN when its base is not N, q >= 2 (l = q + 1 >= 3 repeats) and (q + 1) n > L_n2[p] n2 for every shorter period
+// (final values of the SAME position: periods are done in ascending order) -- one ballot per window and period.  The
+// (L, L_IDX) of period n then follow a stride-n recurrence inside a run of e_n:
+//     base != N and q + 1 > max_l            -> (max_l, 0)          (starts with more than max_l repeats overwrite
+//                                                                    each other in turn: src/aln.pyx:245-249)
+//     e_n[p-n .. p-1] set and L(p-n) != 0    -> (L(p-n), L_IDX(p-n) + 1)
+//     own(p)                                 -> (q + 1, 0)
+// which a window of 64 positions resolves in closed form: the latest start at or before the lane with more than max_l
+// repeats (an index computation), else what enters from the previous window through the (L, L_IDX) of ITS last n
+// lanes (one cross-lane read), else the earliest set bit of the window's own ballot on the lane's phase (two shifts,
+// a stride mask, count-trailing-zeros).  Look-ahead: the masks of the next window, and -- only where a run covers
+// all of it -- further windows, up to (max_l + 2) n positions (beyond that every answer is the same).
+// Windows are visited in order, the masks of window w + 1 are formed while window w is annotated.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "layout.hpp"
+#include "prep_kernels.hpp"
+
+namespace npore {
+
+__device__ __forceinline__ int ctz64_or64(unsigned long long x) { return x ? __builtin_ctzll(x) : 64; }
+__device__ __forceinline__ int clz64_or64(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
+
+// bits at multiples of n
+template <int n>
+__host__ __device__ constexpr unsigned long long stride_mask()
+{
+    unsigned long long m = 0ull;
+    for (int k = 0; k < 64; k += n) m |= 1ull << k;
+    return m;
+}
+
+// x / n for 0 <= x < 4096 (run lengths inside a window and capped look-ahead)
+template <int n>
+__device__ __forceinline__ int div_small(int x)
+{
+    if constexpr (n == 1) return x;
+    else if constexpr (n == 2) return x >> 1;
+    else if constexpr (n == 4) return x >> 2;
+    else return (int)(((uint32_t)x * (uint32_t)((65536 + n - 1) / n)) >> 16);      // exact for x < 13107 (cell.hpp recip16)
+}
+
+// one period of one window.  MC: e_n of the window's positions (bit = lane); F: ones of e_n from the next window's
+// first position on (only looked at when the window's last bit is set); B: ones of e_n at the END of the previous window
+// (<= 64); nz: the lane holds a position of the slice whose base is not N; mx: max over the shorter periods of L n2 at the
+// lane's own position; carry: the previous window's result of lane 64 - n + lane % n.  Returns L | L_IDX << 8.
+template <int n>
+__device__ __forceinline__ uint32_t annot_period(int lane, unsigned long long MC, int F, int B, bool nz, uint32_t mx, uint32_t carry,
+                                                 int max_l)
+{
+    const unsigned long long sh = MC >> lane;
+    int kf = ctz64_or64(~sh);                                   // <= 64 - lane (zeros are shifted in)
+    kf += (kf == 64 - lane) ? F : 0;
+    const int q = div_small<n>(kf);
+    const bool own = nz && q >= 2 && (uint32_t)((q + 1) * n) > mx;
+    const unsigned long long E = __builtin_amdgcn_ballot_w64(own);
+    const int kb = clz64_or64(~((MC << (63 - lane)) << 1));      // ones ending at lane - 1, <= lane
+    const int J = div_small<n>(kb);
+    const int jdiv = div_small<n>(lane), phi = lane - jdiv * n;
+    const bool entering = (kb == lane) && (B >= n - phi);
+    const int jcap = max(max(max_l - q, 2 - q), 0);
+    const uint32_t cL = carry & 0xFFu;
+    uint32_t res = 0u;
+    {
+        // earliest set bit of the window's own ballot among pos - j n, j <= J: position pos - J n to bit 0
+        const unsigned long long y = ((E << (63 - lane)) >> (63 - J * n)) & stride_mask<n>();
+        if (y) {
+            const int j = J - div_small<n>(__builtin_ctzll(y));
+            res = (uint32_t)(j + q + 1) | ((uint32_t)j << 8);
+        }
+    }
+    if (entering && cL != 0u) res = carry + ((uint32_t)(jdiv + 1) << 8);
+    if (nz && jcap <= J) res = (uint32_t)max_l | ((uint32_t)jcap << 8);
+    return res;
+}
+
+// Wave-uniform test: can any position of the window lie in an n-polymer of period n at all?  Such a position lies in
+// (or just behind) a run of at least 2 n ones of e_n: inside the window, or entering from the previous window (B ones
+// at its end + lo ones at this one's start), or leaving into the next (hi ones at this window's end + F beyond).
+template <int n>
+__device__ __forceinline__ bool annot_window_active(unsigned long long MC, int B, int lo, int hi, int F)
+{
+    return has_run_of<2 * n>(MC) || (B >= 1 && B + lo >= 2 * n) || (hi >= 1 && hi + F >= 2 * n);
+}
+
+__global__ __launch_bounds__(64) void annotate_wave_kernel(PrepParams p)
+{
+    const int k = (int)(blockIdx.x >> 1);
+    const bool is_ref = blockIdx.x & 1;
+    if (k >= p.counters[0]) return;
+    const int lane = threadIdx.x;
+    const ChunkDesc d = p.descs[k];
+    const int64_t rd = d.read_id;
+    const int64_t T = is_ref ? p.ref_off[rd + 1] - p.ref_off[rd] : p.seq_off[rd + 1] - p.seq_off[rd];
+    const int start = is_ref ? d.col0 : d.row0, span = is_ref ? d.dcols : d.drows;
+    const int len = (int)(((int64_t)start + span + 1 < T ? (int64_t)start + span + 1 : T) - start);   // src/aln.pyx:453-454
+    const uint8_t *g = (is_ref ? p.refs + p.ref_off[rd] : p.seqs + p.seq_off[rd]) + start;
+    const int max_n = p.max_n, max_l = p.max_l;
+    const int nwin = (span + 1 + 63) >> 6;                      // words i = 0 ... span are written
+    uint32_t *seqw = p.seqw + d.seqw_off;
+    uint4 *refw = p.refw + d.refw_off;
+    uint2 *refl = p.refl + d.refw_off;
+
+    // bases around every position of window v: own code c (6 past the slice), the six before it (7 in front of the
+    // slice) and the six behind it as 3-bit fields (layout.hpp), and the window's indicator masks
+    auto load_window = [&](int v, uint32_t &c, uint32_t &kp, uint32_t &kn, unsigned long long (&M)[MAX_PERIOD]) {
+        const int base = v << 6, pos = base + lane;
+        uint32_t b[13];
+        if (base >= 6 && base + 63 + 6 < len) {                 // (wave-uniform) every byte lies in the slice
+#pragma unroll
+            for (int t = 0; t < 13; t++) b[t] = g[pos - 6 + t];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 13; t++) {
+                const int idx = pos - 6 + t;
+                b[t] = idx < 0 ? 7u : idx >= len ? 6u : (uint32_t)g[idx];
+            }
+        }
+        c = b[6];
+        kp = b[0] | (b[1] << 3) | (b[2] << 6) | (b[3] << 9) | (b[4] << 12) | (b[5] << 15);
+        kn = b[6] | (b[7] << 3) | (b[8] << 6) | (b[9] << 9) | (b[10] << 12) | (b[11] << 15);
+        const bool inside = pos < len;                          // (a base past the slice equals no base: code 6 on both sides)
+#pragma unroll
+        for (int n = 1; n <= MAX_PERIOD; n++) M[n - 1] = n <= max_n ? __builtin_amdgcn_ballot_w64(inside && b[6] == b[6 + n]) : 0ull;
+    };
+    // ones of e_n from position `from` on, looked at for at most `cap` positions (rare: a run that covers a whole window)
+    auto far_ones = [&](int n, int from, int cap) {
+        int total = 0;
+        for (int base = from; base < len && total < cap; base += 64) {
+            const int pos = base + lane;
+            const bool e = pos + n < len && g[pos] == g[pos + n];
+            const int t = ctz64_or64(~__builtin_amdgcn_ballot_w64(e));
+            total += t;
+            if (t != 64) break;
+        }
+        return total;
+    };
+
+    uint32_t cC, kpC, knC, cN = 6u, kpN = 0u, knN = 0u;
+    unsigned long long MC[MAX_PERIOD], MN[MAX_PERIOD];
+    load_window(0, cC, kpC, knC, MC);
+    uint32_t Rp[MAX_PERIOD] = {0u, 0u, 0u, 0u, 0u, 0u};         // the previous window's results, per period
+    int B[MAX_PERIOD] = {0, 0, 0, 0, 0, 0};                     // ones at the end of the previous window's masks
+
+    for (int w = 0; w < nwin; w++) {
+        const int base = w << 6, pos = base + lane;
+        if (w + 1 < nwin) load_window(w + 1, cN, kpN, knN, MN);
+        else {
+#pragma unroll
+            for (int n = 0; n < MAX_PERIOD; n++) MN[n] = 0ull;
+        }
+        const bool nz = (cC - 1u) < 4u;                          // a base of the slice that is not N (codes 1 ... 4)
+        uint32_t R[MAX_PERIOD];
+        uint32_t mx = 0u;
+        auto one = [&](auto tag) __attribute__((always_inline)) {
+            constexpr int n = decltype(tag)::value;
+            R[n - 1] = 0u;
+            if (n > max_n) return;
+            const unsigned long long M = MC[n - 1];
+            const int lo = ctz64_or64(~M), hi = clz64_or64(~M);
+            int F = 0;
+            if (M >> 63) {
+                F = ctz64_or64(~MN[n - 1]);
+                if (F == 64) F += far_ones(n, base + 128, (max_l + 2) * n);
+            }
+            if (annot_window_active<n>(M, B[n - 1], lo, hi, F)) {
+                const uint32_t carry = (uint32_t)__shfl((int)Rp[n - 1], 64 - n + lane % n);
+                const uint32_t r = annot_period<n>(lane, M, F, B[n - 1], nz, mx, carry, max_l);
+                R[n - 1] = r;
+                mx = max(mx, (r & 0xFFu) * (uint32_t)n);
+            }
+            B[n - 1] = hi;
+        };
+        one(std::integral_constant<int, 1>{});
+        one(std::integral_constant<int, 2>{});
+        one(std::integral_constant<int, 3>{});
+        one(std::integral_constant<int, 4>{});
+        one(std::integral_constant<int, 5>{});
+        one(std::integral_constant<int, 6>{});
+
+        // ---- the words of positions base ... base + 63 (layout.hpp)
+        // result of period n at position pos - n: this window's lane - n, or the previous window's lane 64 - n + lane
+        uint32_t S[MAX_PERIOD];
+#pragma unroll
+        for (int n = 1; n <= MAX_PERIOD; n++)
+            S[n - 1] = (uint32_t)__shfl((int)(lane >= 64 - n ? Rp[n - 1] : R[n - 1]), (lane - n) & 63);
+        if (!is_ref) {
+            uint32_t wd = kpC << MER_SHIFT;
+#pragma unroll
+            for (int n = 1; n <= MAX_PERIOD; n++) {
+                wd |= (S[n - 1] != 0u ? 1u : 0u) << (FLAG_SHIFT + n - 1);
+                wd |= ((S[n - 1] - 1u) < 255u ? 1u : 0u) << (n - 1);          // L != 0 and L_IDX == 0
+            }
+            if (pos <= span) seqw[pos] = wd;
+        } else {
+            uint32_t x = knC << MER_SHIFT, y = 0u;
+#pragma unroll
+            for (int n = 1; n <= MAX_PERIOD; n++) {
+                x |= ((R[n - 1] - 1u) < 255u ? 1u : 0u) << (FLAG_SHIFT + n - 1);
+                y |= (S[n - 1] != 0u ? 1u : 0u) << (n - 1);
+                y |= ((S[n - 1] - 1u) < 255u ? 1u : 0u) << (6 + n - 1);
+            }
+            if (pos >= 1) x |= kpC >> 15;                        // the cell's own reference base ref[j-1]
+            const uint32_t l03 = (R[0] & 0xFFu) | ((R[1] & 0xFFu) << 8) | ((R[2] & 0xFFu) << 16) | ((R[3] & 0xFFu) << 24);
+            const uint32_t l45 = (R[4] & 0xFFu) | ((R[5] & 0xFFu) << 8);
+            uint32_t dsc0 = 0u, dsc1 = 0u;
+            if (__builtin_amdgcn_ballot_w64((y & 63u) != 0u)) {
+                // pre-decoded SHR candidates: the two highest periods flagged in y (layout.hpp)
+                const unsigned long long sl = (unsigned long long)((S[0] & 0xFFu) | ((S[1] & 0xFFu) << 8) | ((S[2] & 0xFFu) << 16) | ((S[3] & 0xFFu) << 24)) |
+                                              ((unsigned long long)((S[4] & 0xFFu) | ((S[5] & 0xFFu) << 8)) << 32);
+                uint32_t yl = y & 63u;
+                const int n1 = 32 - __builtin_clz(yl | 0x80000000u >> 31 * 0) * (yl != 0u ? 1 : 0) - (yl == 0u ? 32 : 0);
+                (void)n1;
+                int na = yl ? 32 - __builtin_clz(yl) : 0;
+                if (na) {
+                    dsc0 = make_shr_desc(na, ((y >> (6 + na - 1)) & 1u) != 0u, (uint32_t)(sl >> (8 * (na - 1))) & 0xFFu, max_l);
+                    yl &= ~(1u << (na - 1));
+                    const int nb = yl ? 32 - __builtin_clz(yl) : 0;
+                    if (nb) {
+                        dsc1 = make_shr_desc(nb, ((y >> (6 + nb - 1)) & 1u) != 0u, (uint32_t)(sl >> (8 * (nb - 1))) & 0xFFu, max_l);
+                        yl &= ~(1u << (nb - 1));
+                        if (yl) dsc1 |= DSC_MORE;
+                    }
+                }
+                if (dsc1 != 0u) dsc0 |= DSC_HAS2;
+                if (((dsc0 | dsc1) & DSC_BIGL) || (dsc1 & DSC_MORE)) dsc0 |= DSC_RARE;
+            }
+            if (pos <= span) {
+                refw[pos] = make_uint4(x, y, dsc0, dsc1);
+                refl[pos] = make_uint2(l03, l45);               // bytes 0..5 = L for n = 1..6 (0 past the slice)
+            }
+        }
+        // next window
+#pragma unroll
+        for (int n = 0; n < MAX_PERIOD; n++) { Rp[n] = R[n]; MC[n] = MN[n]; }
+        cC = cN; kpC = kpN; knC = knN;
+    }
+}
+
+}  // namespace npore

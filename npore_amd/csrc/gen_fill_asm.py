@@ -29,6 +29,8 @@ SUBV, DRUN, NINSR, NDELR = "v102", "v103", "v87", "v88"
 SHRV, SHRRUN, LENV, LENRUN = "v104", "v105", "v106", "v107"
 Q0, LENST, SHRST, QRUNS, QQ = "v108", "v109", "v110", "v111", "v[108:111]"      # the history record: one ds_write_b128
 HS, HP0, HP1, HQ = "v104", "v106", "v107", "v[104:107]"      # the first SHR candidate's source record (one ds_read_b128): matv, -, shrstart, runs
+SMR = SF      # the descriptor's summary bits (rc0 & 0xbc) from the head of a step to the SHR pass: NOT one of the record's
+              # registers v108 ... v111, which the previous step's ds_write_b128 may still be reading there
 SCRATCH = ["v%d" % k for k in range(87, 112)]
 
 LDS_SUB_BASE = 6 * 32 * 33 * 4      # kernels.hpp LDS_SUB_BASE
@@ -56,13 +58,7 @@ class Text:
         for ln in s.strip("\n").split("\n"):
             ln = ln.strip()
             if ln:
-                if OPT["strictwait"] and re.fullmatch(r"s_waitcnt lgkmcnt\([1-9]\)", ln):
-                    ln = "s_waitcnt lgkmcnt(0)"
                 self.lines.append(ln)
-                if OPT["waitwrites"] and ln.startswith("ds_write"):         # (diagnostic: every LDS write complete before anything else)
-                    self.lines.append("s_waitcnt lgkmcnt(0)")
-                if OPT["waitstores"] and ln.startswith("global_store"):     # (diagnostic: every store complete ...)
-                    self.lines.append("s_waitcnt vmcnt(0)")
 
     def label(self, name):
         self.lines.append(name + "_%=:")
@@ -74,7 +70,7 @@ def L(name):
 
 # more scratch: lane-table results of the first SHR candidate, fetched before the hand-shake poll
 E0, E1 = "v89", "v90"
-OPT = {"relaxed": False, "nopoll": False, "nolen": False, "pollfirst": False, "fence": False, "pubdelay": False, "polldelay": False, "strictwait": False, "dbgmat": False, "nofillwin": False, "nofillrq": False, "dbgaddr": False, "dbgshrst": False, "dbgrec": False, "waitwrites": False, "waitstores": False, "noentrywait": False}     # nopoll / nolen: ablations (wrong strings, timing only)          # relaxed: no lgkmcnt wait in front of the progress store (LDS serves a wave in order)
+ABLATE = {"nopoll": False, "nolen": False}      # timing-only ablations (wrong strings): --nopoll / --nolen with --out FILE
 
 
 def shr_tables(t, tmp=X3):
@@ -92,10 +88,6 @@ def shr_hist(t):
         v_add_u32 {E0}, {O('hca')}, {E0}
         ds_read_b128 {HQ}, {E0}
     """)
-    if OPT["dbgaddr"]:       # (diagnostic: the address of the candidate's source record, per cell)
-        t(f"s_mov_b64 exec, {O('mhistx')}")
-        t(f"global_store_dword {O('tboff')}, {E0}, {O('dbgg')}")
-        t("s_mov_b64 exec, -1")
 
 
 def sub_read(t):
@@ -249,13 +241,13 @@ def shr_pass(t, mid, sfx, smr, shadow, shadow2):
     t.common()
 
 
-def len_pass(t, mid, sfx, mode):
+def len_pass(t, mid, sfx, mode, first, last, multi):
     """LEN candidates (cell.hpp, LEN loop; LEN_ARITH form).  On entry X3 = the six "read position i-n in an n-polymer
     and reference position j starts one" bits.  The loop is out of line (two steps in three have no candidate).
     Free: X4 X5 SD SE SF P0 P1 E0 E1."""
     if not mid:
         t(f"v_cndmask_b32 {X3}, 0, {X3}, {O('mhist')}")
-    if OPT["nolen"]:
+    if ABLATE["nolen"]:
         t(f"v_mov_b32 {X3}, 0")
     t(f"""
         v_cmp_ne_u32 vcc, 0, {X3}
@@ -356,15 +348,22 @@ def len_pass(t, mid, sfx, mode):
     t.label("len_done" + sfx)
     mat_part(t, mode, True, mid)
     # The record's ds_write_b128 has just been issued, and LENST is one of its four data registers: an LDS write of
-    # more than 64 bits reads its data registers over several cycles, like the VMEM stores of the ISA manual's hazard
-    # table (which does not list DS) -- a VALU write right behind it can reach the register first.  Seen as records whose
-    # LEN run start was +inf in some launches and the true value in others, when this wave issued back to back (an
-    # experimental placement that leaves a wave alone on its SIMD; LABNOTES round 3).  Eight idle cycles in between.
-    t(f"""
-        s_nop 7
-        v_mov_b32 {LENST}, 0x7f800000
-        s_branch {L('post_mat' + sfx)}
-    """)
+    # more than 64 bits reads its data registers over several cycles after issue, like the VMEM stores of the ISA
+    # manual's hazard table (which does not list DS) -- a VALU write right behind it can reach the register first (seen
+    # as records whose LEN run start was +inf in some launches; LABNOTES round 3).  The architected guarantee is the
+    # counter: LENST is restored only behind an lgkmcnt wait that retires the write (the LDS unit serves a wave's
+    # requests in order).  Several waves per chunk: this variant carries its own copy of the hand-over and the
+    # progress store, and the wait in front of the progress word is that wait; a lone wave waits here (its three neighbours on the SIMD fill the gap).
+    if multi:
+        handover(t, first, last, multi)
+        publish(t, restore_lenst=True)          # (LENST is restored where all lanes are enabled again)
+        t(f"s_branch {L('published_' + mode)}")
+    else:
+        t(f"""
+            s_waitcnt lgkmcnt(0)
+            v_mov_b32 {LENST}, 0x7f800000
+            s_branch {L('post_mat_' + mode)}
+        """)
     t.common()
 
 
@@ -413,20 +412,16 @@ def mat_part(t, mode, with_len, mid):
     t(f"ds_write_b128 {X3}, {QQ}")
     if not mid:
         t(f"global_store_dword {O('tboff')}, {SE}, {O('tbg')}")
-        if OPT["dbgmat"] or OPT["dbgshrst"]:
-            t(f"global_store_dword {O('tboff')}, {SHRST if OPT['dbgshrst'] else Q0}, {O('dbgg')}")
-        if OPT["dbgrec"]:
-            t(f"v_lshlrev_b32 {X4}, 2, {O('tboff')}")
-            t(f"global_store_dwordx4 {X4}, {QQ}, {O('dbgg')}")
         t("s_mov_b64 exec, -1")
 
 
-def tail(t, mode, first, last, multi):
-    """MAT, stores, hand-over, next step"""
-    mid = multi and not first and not last
+def handover(t, first, last, multi):
+    """band-edge cells, then (several waves per chunk) the exchange records for the neighbour waves and the wait in
+    front of the progress word.  Release: the LDS unit serves the requests of one wave in order, so the record and the
+    history row are in place before the progress word that follows them; the explicit lgkmcnt(0) in front of it (like
+    the C++ body's workgroup fence) is also what retires the history record's ds_write_b128 before any of its data
+    registers is written again."""
     own_m, own_i, own_d, r1, r2 = O("matv"), O("insv"), O("delv"), O("R1"), O("R2")
-    mat_part(t, mode, False, mid)
-    t.label("post_mat_" + mode)
     # band-edge cells (src/aln.pyx:502-507): the three values their one in-band neighbour reads
     if first or last:
         t(f"v_add_f32 {SD}, 0x42c80000, {O('ev')}")
@@ -442,9 +437,6 @@ def tail(t, mode, first, last, multi):
             v_cndmask_b32 {own_i}, {own_i}, {SD}, {O('medge')}
             v_cndmask_b32 {r1}, {r1}, 0, {O('medge')}
         """)
-    # hand-over to the neighbour waves, then the progress word.  Release: the LDS unit serves the requests of one
-    # wave in order, so the record and the history row are in place before the progress word that follows them
-    # (OPT relaxed = False puts an explicit lgkmcnt(0) in front of it, like the C++ body's workgroup fence)
     if multi:
         t(f"v_add_u32 {O('prog')}, 1, {O('prog')}")
         if not last:
@@ -461,27 +453,35 @@ def tail(t, mode, first, last, multi):
                 ds_write2_b32 {O('xown')}, {r1}, {O('refx')} offset0:{b + 2} offset1:{b + 3}
                 ds_write2_b32 {O('xown')}, {O('rc0')}, {O('rc1')} offset0:{b + 4} offset1:{b + 5}
             """)
-        if OPT["pubdelay"]:
-            t("s_waitcnt lgkmcnt(0)")
-            t("s_nop 15")
-            t("s_nop 15")
-        elif OPT["fence"]:
-            t("s_waitcnt vmcnt(0) lgkmcnt(0)")
-        elif not OPT["relaxed"]:
-            t("s_waitcnt lgkmcnt(0)")
-        t(f"""
-            ds_write_b32 {O('progaddr')}, {O('prog')}
-            s_mov_b64 exec, -1
-            v_sub_u32 {O('xown')}, {O('xsum')}, {O('xown')}
-            v_sub_u32 {O('xoth')}, {O('xsum')}, {O('xoth')}
-        """)
+        t("s_waitcnt lgkmcnt(0)")
+
+
+def publish(t, restore_lenst=False):
+    """the progress word (lane 0; behind handover's wait), then the other parity's exchange records"""
+    t(f"""
+        ds_write_b32 {O('progaddr')}, {O('prog')}
+        s_mov_b64 exec, -1
+    """)
+    if restore_lenst:
+        t(f"v_mov_b32 {LENST}, 0x7f800000")
+    t(f"""
+        v_sub_u32 {O('xown')}, {O('xsum')}, {O('xown')}
+        v_sub_u32 {O('xoth')}, {O('xsum')}, {O('xoth')}
+    """)
+
+
+def tail(t, mode, first, last, multi):
+    """MAT, stores, hand-over, next step"""
+    mid = multi and not first and not last
+    own_m = O("matv")
+    mat_part(t, mode, False, mid)
+    t.label("post_mat_" + mode)
+    handover(t, first, last, multi)
+    if multi:
+        publish(t)
+        t.label("published_" + mode)
     if mid:
         t(f"global_store_dword {O('tboff')}, {SE}, {O('tbg')}")
-        if OPT["dbgmat"] or OPT["dbgshrst"]:
-            t(f"global_store_dword {O('tboff')}, {SHRST if OPT['dbgshrst'] else own_m}, {O('dbgg')}")
-        if OPT["dbgrec"]:
-            t(f"v_lshlrev_b32 {X4}, 2, {O('tboff')}")
-            t(f"global_store_dwordx4 {X4}, {QQ}, {O('dbgg')}")
     # next anti-diagonal; every 64th one starts a new window of input-path steps (out of line: rotate)
     t(f"""
         v_add_f32 {O('ev')}, 0x42c80000, {O('ev')}
@@ -520,10 +520,7 @@ def tail(t, mode, first, last, multi):
 
 def polls(t, first, last, sfx):
     """this wave may start the anti-diagonal once its neighbour waves have finished the previous one"""
-    if OPT["nopoll"]:
-        return
-    if OPT["pollfirst"] and not sfx.endswith("0"):      # (diagnostic: the poll sits at the very start of the step)
-        t("s_waitcnt lgkmcnt(0)")
+    if ABLATE["nopoll"]:
         return
     if not first and not last:
         # both progress words in one round trip (the neighbours' words lie 8 bytes apart, this wave's in between)
@@ -535,9 +532,6 @@ def polls(t, first, last, sfx):
             v_cmp_lt_i32 vcc, {X3}, {O('prog')}
             s_cbranch_vccnz {L('pp' + sfx)}
         """)
-        if OPT["polldelay"]:
-            t("s_nop 15")
-            t("s_nop 15")
         return
     if not last:
         t.label("pa" + sfx)
@@ -547,9 +541,6 @@ def polls(t, first, last, sfx):
             v_cmp_lt_i32 vcc, {X3}, {O('prog')}
             s_cbranch_vccnz {L('pa' + sfx)}
         """)
-        if OPT["polldelay"]:
-            t("s_nop 15")
-            t("s_nop 15")
     if not first:
         t.label("pb" + sfx)
         t(f"""
@@ -558,9 +549,6 @@ def polls(t, first, last, sfx):
             v_cmp_lt_i32 vcc, {X3}, {O('prog')}
             s_cbranch_vccnz {L('pb' + sfx)}
         """)
-        if OPT["polldelay"]:
-            t("s_nop 15")
-            t("s_nop 15")
 
 
 def book(t, mode):
@@ -591,8 +579,7 @@ def gen_role(role):
     # once in ~25 full launches with a wave placement that lets a wave issue back to back (LABNOTES round 3); the
     # second read of the same address was right.  One wait per entry (entries = hand-overs, ~1 % of the steps): within
     # the run-to-run spread of the fill time.
-    if not OPT["noentrywait"]:
-        t("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    t("s_waitcnt vmcnt(0) lgkmcnt(0)")
     t(f"""
         v_mov_b32 {LENST}, 0x7f800000
         s_bitcmp1_b64 {O('mask')}, {O('bl')}
@@ -602,19 +589,17 @@ def gen_role(role):
     # descriptors do not move and INS reads this lane's own cell, so everything that does not depend on the neighbour
     # waves -- the descriptor's summary bits, the lane-table reads, INS -- is done in front of the hand-shake poll.
     t.label("mode_i")
-    if OPT["pollfirst"] and multi:
-        polls(t, first, last, "_i0")
     if first:
         t(f"""
             s_cmp_ge_i32 {O('sqidx')}, 64
             s_cbranch_scc1 {L('fill_sq')}
         """)
         t.label("sq_ok")
-    t(f"v_and_b32 {SHRST}, 0xbc, {O('rc0')}")
+    t(f"v_and_b32 {SMR}, 0xbc, {O('rc0')}")
     if not mid:
-        t(f"v_cndmask_b32 {SHRST}, 0, {SHRST}, {O('mhist')}")
+        t(f"v_cndmask_b32 {SMR}, 0, {SMR}, {O('mhist')}")
     t(f"""
-        v_cmp_lt_u32 vcc, 0x7f, {SHRST}
+        v_cmp_lt_u32 vcc, 0x7f, {SMR}
         s_cbranch_vccnz {L('exit')}
     """)
     book(t, "I")
@@ -659,25 +644,23 @@ def gen_role(role):
         """)
     sub_read(t)
     t("s_waitcnt lgkmcnt(1)")          # the candidate's source record (the substitution score may still be on its way)
-    shr_pass(t, mid, "_I", SHRST, lambda: del_part(t, "I", X4, X5, O("sb")), lambda: del_part(t, "I", SD, P0, O("sb")))
-    len_pass(t, mid, "_I", "I")
+    shr_pass(t, mid, "_I", SMR, lambda: del_part(t, "I", X4, X5, O("sb")), lambda: del_part(t, "I", SD, P0, O("sb")))
+    len_pass(t, mid, "_I", "I", first, last, multi)
     tail(t, "I", first, last, multi)
     # ================= 'D' step: reference words (and the column descriptors) move one column down, "top" is the
     # next lane.  Last wave of a chunk: the word entering at its last lane comes from its own queue and the next
     # lane's cell is in its own registers, so all but the history reads sits in front of the poll; the other waves
     # learn both from the wave above, behind the poll.
     t.label("mode_d")
-    if OPT["pollfirst"] and multi:
-        polls(t, first, last, "_d0")
     if last:
         t(f"""
             s_cmp_ge_i32 {O('rqidx')}, 64
-            s_cbranch_scc1 {L('exit') if OPT['nofillrq'] else L('fill_rq')}
+            s_cbranch_scc1 {L('fill_rq')}
         """)
         t.label("rq_ok")
         t(f"""
             s_cmp_ge_i32 {O('sdel')}, {O('dlim')}
-            s_cbranch_scc1 {L('exit') if OPT['nofillwin'] else L('fill_win')}
+            s_cbranch_scc1 {L('fill_win')}
         """)
         t.label("win_ok")
         t(f"""
@@ -708,9 +691,9 @@ def gen_role(role):
             v_mov_b32_dpp {O('rc1')}, {O('rc1')} wave_shl:1 row_mask:0xf bank_mask:0xf
             v_mov_b32 {O('TMr')}, {X2}
             s_add_i32 {O('rqidx')}, {O('rqidx')}, 1
-            v_and_b32 {SHRST}, 0xbc, {O('rc0')}
+            v_and_b32 {SMR}, 0xbc, {O('rc0')}
             v_writelane_b32 {O('rc1')}, {O('sx')}, 63
-            v_cndmask_b32 {SHRST}, 0, {SHRST}, {O('mhist')}
+            v_cndmask_b32 {SMR}, 0, {SMR}, {O('mhist')}
         """)
         shr_tables(t)
         ins_part(t, "D", X4, X5, O("sb"))
@@ -739,9 +722,9 @@ def gen_role(role):
             v_mov_b32_dpp {X4}, {O('rc0')} wave_shl:1 row_mask:0xf bank_mask:0xf
             v_mov_b32 {O('rc0')}, {X4}
         """)
-        shr_tables(t, SF)          # (X3 is waiting for its exchange word)
+        shr_tables(t, SD)          # (X3 is waiting for its exchange word)
         t(f"""
-            v_and_b32 {SHRST}, 0xbc, {O('rc0')}
+            v_and_b32 {SMR}, 0xbc, {O('rc0')}
             s_waitcnt lgkmcnt(2)
             v_mov_b32_dpp {X3}, {O('refx')} wave_shl:1 row_mask:0xf bank_mask:0xf
             v_mov_b32_dpp {X5}, {O('rc1')} wave_shl:1 row_mask:0xf bank_mask:0xf
@@ -753,14 +736,14 @@ def gen_role(role):
             v_mov_b32 {O('TMr')}, {X2}
         """)
         if not mid:
-            t(f"v_cndmask_b32 {SHRST}, 0, {SHRST}, {O('mhist')}")
+            t(f"v_cndmask_b32 {SMR}, 0, {SMR}, {O('mhist')}")
         sub_read(t)
         ins_part(t, "D", X4, X5, O("sb"))      # (in the shadow of the lane-table reads)
         t("s_waitcnt lgkmcnt(1)")
         shr_hist(t)
         t("s_waitcnt lgkmcnt(0)")
-    shr_pass(t, mid, "_D", SHRST, lambda: del_part(t, "D", X4, X5, O("sb")), lambda: del_part(t, "D", SD, P0, O("sb")))
-    len_pass(t, mid, "_D", "D")
+    shr_pass(t, mid, "_D", SMR, lambda: del_part(t, "D", X4, X5, O("sb")), lambda: del_part(t, "D", SD, P0, O("sb")))
+    len_pass(t, mid, "_D", "D", first, last, multi)
     tail(t, "D", first, last, multi)
     t.lines = t.main
     t.main.extend(t.ool)
@@ -829,7 +812,6 @@ def gen_role(role):
             s_branch {L('win_ok')}
         """)
     t.label("exit2")
-    t("s_waitcnt lgkmcnt(0)")      # (exchange words still on their way into scratch registers the caller may reuse)
     t(f"s_mov_b32 {O('status')}, 2")
     t(f"s_branch {L('end')}")
     t.label("exit")
@@ -838,6 +820,10 @@ def gen_role(role):
     t.label("done")
     t(f"s_mov_b32 {O('status')}, 0")
     t.label("end")
+    # nothing of this text may be in flight when the compiled code resumes: it reuses the scratch registers at once --
+    # loads still on their way into them (exit2: the exchange words), and the history record's ds_write_b128, which
+    # reads its four data registers for a few cycles after issue
+    t("s_waitcnt lgkmcnt(0)")
     return fix_hazards(t.lines)
 
 
@@ -949,14 +935,13 @@ def operands(role):
                  ("rqw", "+v", "ref_q.w"), ("wfill", "+s", "a_wfill"), ("dlim", "+s", "a_dlim")]
     outs += [("sx", "=&s", "a_sx")]
     ins = [("stepsg", "s", "steps_g"), ("laneid", "v", "a_laneid"), ("b1", "s", "a_b1"), ("hw16", "s", "a_hw16"), ("ringb", "s", "ring_bytes"),
-           ("tbs4", "s", "tbstride4"), ("n0", "s", "env.n0_lanes"), ("tbg", "s", "tb_g"), ("dbgg", "s", "dbg_g"), ("istart", "s", "a_istart"),
+           ("tbs4", "s", "tbstride4"), ("n0", "s", "env.n0_lanes"), ("tbg", "s", "tb_g"), ("istart", "s", "a_istart"),
            ("iext", "s", "a_iext"), ("winaddr", "s", "a_winaddr"), ("wmask", "s", "a_wmask"), ("clampv", "s", "a_clampv"),
            ("clamp1", "s", "a_clamp1"), ("npdim", "s", "a_npdim"), ("gnp", "s", "env.g_np"),
            ("hca", "v", "hist_c_addr"), ("trecip", "v", "env.t_recip"), ("one", "v", "a_one"), ("lanej", "v", "a_lanej"),
            ("inf", "v", "a_inf"), ("c100", "v", "a_c100")]
     if role != 2:
         ins += [("mhist", "s", "a_mhist")]
-    ins += [("mhistx", "s", "a_mhist")]
     if multi:
         ins += [("xsum", "s", "xsum"), ("pnb", "v", "pnb_addr"), ("progaddr", "v", "a_progaddr"), ("ml0", "s", "a_ml0")]
         if not last:
@@ -975,10 +960,10 @@ def main():
     here = os.path.dirname(os.path.abspath(__file__))
     out_path = os.path.join(here, "fill_step_asm.inc")
     args = sys.argv[1:]
-    while args:                      # measurement variants: --relaxed, --out FILE
+    while args:                      # timing-only ablations: --nopoll / --nolen, with --out FILE
         a = args.pop(0)
-        if a in ("--relaxed", "--nopoll", "--nolen", "--pollfirst", "--fence", "--pubdelay", "--polldelay", "--strictwait", "--dbgmat", "--nofillwin", "--nofillrq", "--dbgaddr", "--dbgshrst", "--dbgrec", "--waitwrites", "--waitstores", "--noentrywait"):
-            OPT[a[2:]] = True
+        if a in ("--nopoll", "--nolen"):
+            ABLATE[a[2:]] = True
         elif a == "--out":
             out_path = args.pop(0)
     out = ["// fill_step_asm.inc -- GENERATED by gen_fill_asm.py (do not edit): the plain-step loop of fill_kernel as gfx950",

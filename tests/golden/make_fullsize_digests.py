@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Per-read digests of the FULL-SIZE configurations, from the pinned oracle.
+
+The oracle (oracle/npore_oracle.c) is pinned against the reference's own compiled
+Cython align() by make_golden.py; this script runs it over every read of the
+bench configurations in the build container, where CPU time
+is free, and stores (len, sha256[:16]) per read, so that the GPU tests compare
+EVERY read of every full-size configuration bit for bit at no cost on the GPU box:
+
+  c2     1 000 reads, seed 2, 10 kb, r=100                      (BASELINE configs[1])
+  r30    4 000 reads, seed 2, 10 kb, r=30                       (the tool's default band)
+  c5       256 reads, seed 5, 50 kb, r=200                      (BASELINE configs[4])
+  c3    first 10 000 reads + every 10th after, seed 3 mixed     (BASELINE configs[2])
+
+    python tests/golden/make_fullsize_digests.py [--procs 8] [--only c2,r30]
+
+Output: tests/golden/fullsize_digests.npz (<name>_idx int32, <name>_len int32,
+<name>_dig uint64 = first 16 hex digits of sha256 of the raw align() string).
+All at max_b_rows=20000, indel_start=5, indel_extend=1, max_n=6, max_l=100, tables G1.
+"""
+import argparse
+import hashlib
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+CONFIGS = {
+    # name: (base_seed, ref_len, mixed, r, indices)
+    "c2": (2, 10_000, False, 100, np.arange(1000)),
+    "r30": (2, 10_000, False, 30, np.arange(4000)),
+    "c5": (5, 50_000, False, 200, np.arange(256)),
+    "c3": (3, 10_000, True, 100, np.concatenate([np.arange(10_000), np.arange(10_000, 100_000, 10)])),
+}
+
+
+def digest(s):
+    return int(hashlib.sha256(s.encode()).hexdigest()[:16], 16)
+
+
+def _work(job):
+    import oracle
+    from npore_amd import synth
+    seed, ref_len, mixed, r, idx = job
+    z = np.load(os.path.join(HERE, "tables.npz"))
+    sub, nps = z["sub_scores"], z["np_scores"]
+    lens, digs = [], []
+    for i in idx:
+        ref, seq, cig = synth.make_pair(seed, int(i), ref_len, mixed=mixed)
+        s, st = oracle.align(ref, seq, cig, sub, nps, r=r, return_status=True)
+        assert st == 0, (seed, i, st)
+        lens.append(len(s)); digs.append(digest(s))
+    return lens, digs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--procs", type=int, default=os.cpu_count())
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    out_path = os.path.join(HERE, "fullsize_digests.npz")
+    res = dict(np.load(out_path)) if os.path.exists(out_path) else {}
+    import oracle
+    oracle.build()
+    names = [n for n in CONFIGS if not a.only or n in a.only.split(",")]
+    with mp.get_context("fork").Pool(a.procs) as pool:
+        for name in names:
+            seed, ref_len, mixed, r, idx = CONFIGS[name]
+            t0 = time.time()
+            span = 8 if ref_len > 20_000 else 50
+            jobs = [(seed, ref_len, mixed, r, idx[k:k + span]) for k in range(0, len(idx), span)]
+            parts = pool.map(_work, jobs, chunksize=1)
+            res[name + "_idx"] = idx.astype(np.int32)
+            res[name + "_len"] = np.array([x for p in parts for x in p[0]], np.int32)
+            res[name + "_dig"] = np.array([x for p in parts for x in p[1]], np.uint64)
+            np.savez_compressed(out_path, **res)
+            print(f"{name}: {len(idx)} reads in {time.time() - t0:.0f} s", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -390,6 +390,31 @@ def test_full_launch_repeated_is_identical(ctx, tables, r, n, reps):
         assert not bad, (rep, bad[:8])
 
 
+def test_chunkmajor_placement_matches_shipped(ctx, tables, tmp_path):
+    """The wave placement that EXPOSED the two inline-assembly hazards of round 3: with
+    -DNPORE_X_CHUNKMAJOR the four waves of a chunk sit on four SIMDs and each issues back to back while its neighbours
+    wait -- the only configuration in which a hazard of the step assembly (a late load into a scratch register, a VALU
+    write racing a ds_write_b128's data read) has ever shown, as one or two reads per thousand with a wrong stretch in
+    every third launch.  24 full launches of C2's 1 000 reads at r = 100 and r = 120 with that build (made by
+    __graft_entry__.build(), or here when it is missing) must give the shipped placement's strings, every launch."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    lib = os.path.join(REPO, "tests", "model", "libnpore_amd_chunkmajor.so")
+    _lib.build(defines=("NPORE_X_CHUNKMAJOR",), out=lib)
+    out = tmp_path / "cm.json"
+    subprocess.check_call([sys.executable, os.path.join(REPO, "tests", "tools", "placement_check.py"), str(out), "24", "100", "120"],
+                          env=dict(os.environ, NPORE_AMD_LIB=lib), cwd=REPO)
+    res = json.load(open(out))
+    refs, seqs, cigs = synth.make_batch(2, 1000)
+    for r in (100, 120):
+        want = ctx.align_batch(refs, seqs, cigs, r=r)
+        assert [sha(s)[:16] for s in want] == res[str(r)]["first"], r
+        bad = [(rep, d[:4]) for rep, d in enumerate(res[str(r)]["differ"]) if d]
+        assert not bad, (r, bad[:4])
+
+
 def test_fuzz_time_boxed():
     """A time-boxed leg of tests/tools/fuzz_gpu.py under the driver (fixed seeds; ~20 s over all shapes, ~25 s focused on
     what has failed before: 4-8 waves per chunk with chunk heights of 2...64 anti-diagonals, tables with max_l < 32):

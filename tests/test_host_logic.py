@@ -589,3 +589,48 @@ def test_streamed_bam_equals_resident(tmp_path, monkeypatch):
         assert not os.path.exists(shared)
         os.remove(shared.replace(".idx", ".skip"))
     a.close(); b.close(); nf.close()
+
+
+def _asm_checker():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_asm_pending", os.path.join(REPO, "scripts", "check_asm_pending.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_fill_step_asm_is_generated_and_counter_clean(tmp_path):
+    """The committed fill_step_asm.inc is what gen_fill_asm.py generates, and the generated text obeys the architected
+    ordering rules on EVERY path (scripts/check_asm_pending.py): nothing touches a register a load is still going to
+    fill, nothing writes a data register of a > 64-bit LDS write / store before a wait on its counter has retired it
+    (the ds_write_b128 hazard of round 3), the text starts with a full wait and ends with nothing on the LGKM counter."""
+    chk = _asm_checker()
+    G = chk.G
+    out = tmp_path / "gen.inc"
+    subprocess.check_call([sys.executable, os.path.join(REPO, "npore_amd", "csrc", "gen_fill_asm.py"), "--out", str(out)],
+                          stdout=subprocess.DEVNULL)
+    assert out.read_text() == open(os.path.join(REPO, "npore_amd", "csrc", "fill_step_asm.inc")).read()
+    for role in range(4):
+        assert chk.findings(role) == [], (role, chk.findings(role)[:5])
+    # the checker sees the hazards it is there for.  (1) round 3's: LENST (v109) restored right behind the record's
+    # ds_write_b128 -- eight idle cycles in between are NOT a guarantee
+    for role in range(4):
+        lines = G.gen_role(role)
+        k = max(i for i, ln in enumerate(lines) if ln.startswith("ds_write_b128"))
+        bad = lines[:k + 1] + ["s_nop 7", "v_mov_b32 v109, 0x7f800000"] + lines[k + 1:]
+        f = chk.findings(role, bad)
+        assert any(rule == "R2" and "v109" in regs for rule, _, _, regs in f), role
+    # (2) a VALU write into a register an LDS read is still going to fill
+    lines = G.gen_role(2)
+    k = next(i for i, ln in enumerate(lines) if ln.startswith("ds_read_b128"))
+    dst = re.match(r"ds_read_b128 v\[(\d+):", lines[k]).group(1)
+    f = chk.findings(2, lines[:k + 1] + [f"v_mov_b32 v{dst}, 0"] + lines[k + 1:])
+    assert any(rule == "R1" for rule, _, _, _ in f)
+    # (3) a loop-carried register written while exec is narrowed to lane 0 (the first form of this round's LEN variant)
+    lines = G.gen_role(2)
+    k = next(i for i, ln in enumerate(lines) if ln == "s_mov_b64 exec, %[ml0]")
+    f = chk.findings(2, lines[:k + 1] + ["v_mov_b32 v109, 0x7f800000"] + lines[k + 1:])
+    assert any(rule == "R4" for rule, _, _, _ in f)
+    # (4) no wait at the text's start / its end
+    assert any(rule == "R3" for rule, _, _, _ in chk.findings(0, G.gen_role(0)[1:]))
+    assert any(rule == "R3" for rule, _, _, _ in chk.findings(1, [ln for ln in G.gen_role(1)][:-1]))

@@ -151,3 +151,38 @@ def test_period_above_max_l_scores_100(tables):
             b, sb = model.align(ref, seq, cig, sub, t, max_b_rows=mbr, r=r, max_n=6, max_l=5)
             assert a == b and sa == sb, (r, mbr)
     assert oracle.align(ref, seq, cig, sub, t, r=10, max_n=6, max_l=5) == "==I=========X=X============X==="
+
+
+def _annot_cases():
+    seqs = [enc(s) for s in load_json("np_info_seqs.json")]
+    rng = np.random.default_rng(31)
+    for k in range(120):                              # low-entropy random sequences: runs of every period, incl. N
+        n = int(rng.integers(1, 400))
+        alpha = rng.integers(0, 5, size=int(rng.integers(1, 4)))
+        seqs.append(rng.choice(alpha, size=n).astype(np.uint8))
+    A, C, G, T = 1, 2, 3, 4
+    pieces = [[A] * 150, [A, C] * 70, [A, C, G] * 45, [A] * 40 + [C] * 33, [A, A, C, A, A, C] * 30, [T] * 101, [C, A, G, T] * 36,
+              [A] * 12 + [A, C] * 9 + [A, C, G] * 7, [0] * 80, [A] * 8 + [C, A, A] * 5, [A, A, A, A, G] * 4, [G] * 65, [A, C, A, C, A, G] * 13]
+    for k in range(40):                               # engineered: polymers longer than max_l / than a window, nested periods
+        s = []
+        for b in rng.permutation(len(pieces))[:5]:
+            s += [int(x) for x in rng.integers(0 if k % 4 == 0 else 1, 5, int(rng.integers(0, 20)))] + pieces[b]
+        seqs.append(np.array(s, np.uint8))
+    for k in range(30):                               # the bench generator's reads
+        seqs.append(synth.make_pair(41, k, 700, 0.15, 0.3)[0])
+    return seqs
+
+
+def test_wave_annotation_formulation_vs_oracle():
+    """The wave-local restatement of get_np_info that csrc/annot_wave.hpp evaluates (tests/model/annot_wave_model.py):
+    the stride-n recurrence and its per-window closed form, against the oracle's literal loop -- at several window
+    widths (narrow windows put every carry / look-ahead case on a window boundary) and max_l / max_n."""
+    from model import annot_wave_model as awm
+    seqs = _annot_cases()
+    for max_n, max_l in ((6, 100), (6, 7), (6, 2), (4, 3), (6, 127), (3, 1)):
+        for k, s in enumerate(seqs):
+            want = oracle.get_np_info(s, max_n=max_n, max_l=max_l)
+            assert np.array_equal(awm.recurrence(s, max_n, max_l), want), (max_n, max_l, k)
+            for W in ((64, 8) if max_l != 127 else (64,)):
+                got = awm.windows(s, max_n, max_l, W=W)
+                assert np.array_equal(got, want), (max_n, max_l, W, k, np.argwhere(got != want)[:4])
