@@ -220,9 +220,7 @@ __global__ __launch_bounds__(64) void annotate_wave_kernel(PrepParams p)
                 const unsigned long long sl = (unsigned long long)((S[0] & 0xFFu) | ((S[1] & 0xFFu) << 8) | ((S[2] & 0xFFu) << 16) | ((S[3] & 0xFFu) << 24)) |
                                               ((unsigned long long)((S[4] & 0xFFu) | ((S[5] & 0xFFu) << 8)) << 32);
                 uint32_t yl = y & 63u;
-                const int n1 = 32 - __builtin_clz(yl | 0x80000000u >> 31 * 0) * (yl != 0u ? 1 : 0) - (yl == 0u ? 32 : 0);
-                (void)n1;
-                int na = yl ? 32 - __builtin_clz(yl) : 0;
+                const int na = yl ? 32 - __builtin_clz(yl) : 0;
                 if (na) {
                     dsc0 = make_shr_desc(na, ((y >> (6 + na - 1)) & 1u) != 0u, (uint32_t)(sl >> (8 * (na - 1))) & 0xFFu, max_l);
                     yl &= ~(1u << (na - 1));

@@ -23,6 +23,7 @@
 #include "hostio.hpp"
 #include "kernels.hpp"
 #include "prep_kernels.hpp"
+#include "annot_wave.hpp"
 
 using namespace npore;
 
@@ -385,11 +386,6 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     if (int rc = w->hist.ensure((size_t)(a.max_b_rows + 2) * 4)) return rc;
     if (int rc = w->counters.ensure(64)) return rc;
     if (int rc = w->seqw.ensure((size_t)(S_tot + max_chunks + 16) * 4)) return rc;
-    {
-        const size_t need = (pstride + annotate_scratch_bytes((int)pstride) <= 160 * 1024 && !beside_fill)
-                                ? 64 : (size_t)2 * max_chunks * annotate_scratch_bytes((int)pstride);
-        if (int rc = w->seql.ensure(need)) return rc;
-    }
     if (int rc = w->refw.ensure((size_t)(R_tot + max_chunks + 16) * 16)) return rc;
     if (int rc = w->refl.ensure((size_t)(R_tot + max_chunks + 16) * 8)) return rc;
     if (int rc = w->tb.ensure((size_t)tb_words * 4 + 64)) return rc;
@@ -475,26 +471,9 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     hipLaunchKernelGGL(make_chunks_kernel, dim3(ch_blocks), dim3(256), 0, s, pp);
     hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(scan_threads), 0, s, pp);
     hipLaunchKernelGGL(sched_scatter_kernel, dim3(ch_blocks), dim3(256), 0, s, pp);
-    {
-        // slice bytes + 6 byte planes per position in LDS when that fits (it does for the default max_b_rows);
-        // sized by the longest slice of the group, so that two workgroups share a CU on 10 kb reads
-        const int planes_in_lds = pstride + annotate_scratch_bytes((int)pstride) <= 160 * 1024;
-        const size_t alds = planes_in_lds ? pstride + annotate_scratch_bytes((int)pstride) : pstride;
-        if (beside_fill) {
-            // no LDS, waves of ~30 VGPRs: fits beside the 16 waves of a fill workgroup (two such waves per SIMD).  Four
-            // waves per workgroup: 8 000 reads at r = 30 184 k reads/s, with eight 180 k, sixteen 169 k, one 187 k (but C2
-            // 50.9 instead of 51.8 k)
-            hipLaunchKernelGGL((annotate_kernel<false, false>), dim3((unsigned)(2 * max_chunks)), dim3(256), 0, s, pp);
-        } else if (planes_in_lds) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&annotate_kernel<true, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
-            hipLaunchKernelGGL((annotate_kernel<true, true>), dim3((unsigned)(2 * max_chunks)), dim3(xp::ANNT), alds, s, pp);
-        } else {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&annotate_kernel<false, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
-            hipLaunchKernelGGL((annotate_kernel<false, true>), dim3((unsigned)(2 * max_chunks)), dim3(1024), alds, s, pp);
-        }
-    }
+    // n-polymer annotation + word packing: one wave per (chunk, sequence), registers only (annot_wave.hpp) -- the same
+    // launch whether the GPU is empty or a fill kernel holds the CUs' LDS
+    hipLaunchKernelGGL(annotate_wave_kernel, dim3((unsigned)(2 * max_chunks)), dim3(64), 0, s, pp);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(w->ev[1], s));
     // ---- fill: behind this group's preparation.  Consecutive groups alternate between two streams: their fill
