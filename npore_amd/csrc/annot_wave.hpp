@@ -32,6 +32,12 @@ namespace npore {
 __device__ __forceinline__ int ctz64_or64(unsigned long long x) { return x ? __builtin_ctzll(x) : 64; }
 __device__ __forceinline__ int clz64_or64(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
 
+// value of `v` in lane `src` (mod 64): ds_bpermute takes the byte address 4 * lane and ignores the bits above
+__device__ __forceinline__ uint32_t lane_read(uint32_t v, int src)
+{
+    return (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)v);
+}
+
 // bits at multiples of n
 template <int n>
 __host__ __device__ constexpr unsigned long long stride_mask()
@@ -51,72 +57,75 @@ __device__ __forceinline__ int div_small(int x)
     else return (int)(((uint32_t)x * (uint32_t)((65536 + n - 1) / n)) >> 16);      // exact for x < 13107 (cell.hpp recip16)
 }
 
-// one period of one window.  MC: e_n of the window's positions (bit = lane); F: ones of e_n from the next window's
-// first position on (only looked at when the window's last bit is set); B: ones of e_n at the END of the previous window
-// (<= 64); nz: the lane holds a position of the slice whose base is not N; mx: max over the shorter periods of L n2 at the
-// lane's own position; carry: the previous window's result of lane 64 - n + lane % n.  Returns L | L_IDX << 8.
+// One period of one window, in two parts.
+// annot_forward: q = (run of e_n from the lane's position on) / n.  MC: e_n of the window's positions (bit = lane);
+// F: ones of e_n from the next window's first position on.
 template <int n>
-__device__ __forceinline__ uint32_t annot_period(int lane, unsigned long long MC, int F, int B, bool nz, uint32_t mx, uint32_t carry,
-                                                 int max_l)
+__device__ __forceinline__ int annot_forward(int lane, unsigned long long MC, int F)
 {
     const unsigned long long sh = MC >> lane;
     int kf = ctz64_or64(~sh);                                   // <= 64 - lane (zeros are shifted in)
     kf += (kf == 64 - lane) ? F : 0;
-    const int q = div_small<n>(kf);
-    const bool own = nz && q >= 2 && (uint32_t)((q + 1) * n) > mx;
-    const unsigned long long E = __builtin_amdgcn_ballot_w64(own);
+    return div_small<n>(kf);
+}
+// annot_resolve: B: ones of e_n at the END of the previous window (<= 64); nzmask / startable: the lanes that hold a
+// base of the slice that is not N / ... and have q >= 2 (three or more repeats from here), as lane masks; mx: max over the
+// shorter periods of L n2 at the lane's own position; carry: the previous window's result of lane 64 - n + lane % n;
+// jdiv = lane / n.  Returns L | L_IDX << 8.
+// (Only called when some lane of the window is startable or the previous window left a result: otherwise all is 0.)
+template <int n>
+__device__ __forceinline__ uint32_t annot_resolve(int lane, unsigned long long MC, int q, int B, unsigned long long nzmask,
+                                                  unsigned long long startable, uint32_t mx, uint32_t carry, int jdiv, int max_l)
+{
+    const unsigned long long E = startable & __builtin_amdgcn_ballot_w64((uint32_t)((q + 1) * n) > mx);
     const int kb = clz64_or64(~((MC << (63 - lane)) << 1));      // ones ending at lane - 1, <= lane
     const int J = div_small<n>(kb);
-    const int jdiv = div_small<n>(lane), phi = lane - jdiv * n;
-    const bool entering = (kb == lane) && (B >= n - phi);
+    const int phi = lane - jdiv * n;
     const int jcap = max(max(max_l - q, 2 - q), 0);
-    const uint32_t cL = carry & 0xFFu;
     uint32_t res = 0u;
     {
         // earliest set bit of the window's own ballot among pos - j n, j <= J: position pos - J n to bit 0
         const unsigned long long y = ((E << (63 - lane)) >> (63 - J * n)) & stride_mask<n>();
-        if (y) {
-            const int j = J - div_small<n>(__builtin_ctzll(y));
-            res = (uint32_t)(j + q + 1) | ((uint32_t)j << 8);
-        }
+        const int j = J - div_small<n>(ctz64_or64(y));
+        res = y ? (uint32_t)(j + q + 1) | ((uint32_t)j << 8) : 0u;
     }
-    if (entering && cL != 0u) res = carry + ((uint32_t)(jdiv + 1) << 8);
-    if (nz && jcap <= J) res = (uint32_t)max_l | ((uint32_t)jcap << 8);
+    const bool inherit = (kb == lane) & (B >= n - phi) & ((carry & 0xFFu) != 0u);
+    res = inherit ? carry + ((uint32_t)(jdiv + 1) << 8) : res;
+    const bool capped = ((nzmask >> lane) & 1ull) != 0ull && jcap <= J;
+    res = capped ? (uint32_t)max_l | ((uint32_t)jcap << 8) : res;
     return res;
 }
 
-// Wave-uniform test: can any position of the window lie in an n-polymer of period n at all?  Such a position lies in
-// (or just behind) a run of at least 2 n ones of e_n: inside the window, or entering from the previous window (B ones
-// at its end + lo ones at this one's start), or leaving into the next (hi ones at this window's end + F beyond).
-template <int n>
-__device__ __forceinline__ bool annot_window_active(unsigned long long MC, int B, int lo, int hi, int F)
+// ones of e_n from position `from` on, looked at for at most `cap` positions (rare: a run that covers a whole window)
+__device__ __noinline__ int annot_far_ones(const uint8_t *g, int len, int n, int from, int cap)
 {
-    return has_run_of<2 * n>(MC) || (B >= 1 && B + lo >= 2 * n) || (hi >= 1 && hi + F >= 2 * n);
+    const int lane = threadIdx.x & 63;
+    int total = 0;
+    for (int base = from; base < len && total < cap; base += 64) {
+        const int pos = base + lane;
+        const bool e = pos + n < len && g[pos] == g[pos + n];
+        const int t = ctz64_or64(~__builtin_amdgcn_ballot_w64(e));
+        total += t;
+        if (t != 64) break;
+    }
+    return total;
 }
 
-__global__ __launch_bounds__(64) void annotate_wave_kernel(PrepParams p)
+// the annotation of one slice (IS_REF: a reference slice -> refw / refl; else a read slice -> seqw)
+template <bool IS_REF, bool ALLN>
+__device__ __forceinline__ void annotate_slice(const uint8_t *g, const int len, const int span, const int max_n_, const int max_l,
+                                               uint32_t *seqw, uint4 *refw, uint2 *refl)
 {
-    const int k = (int)(blockIdx.x >> 1);
-    const bool is_ref = blockIdx.x & 1;
-    if (k >= p.counters[0]) return;
     const int lane = threadIdx.x;
-    const ChunkDesc d = p.descs[k];
-    const int64_t rd = d.read_id;
-    const int64_t T = is_ref ? p.ref_off[rd + 1] - p.ref_off[rd] : p.seq_off[rd + 1] - p.seq_off[rd];
-    const int start = is_ref ? d.col0 : d.row0, span = is_ref ? d.dcols : d.drows;
-    const int len = (int)(((int64_t)start + span + 1 < T ? (int64_t)start + span + 1 : T) - start);   // src/aln.pyx:453-454
-    const uint8_t *g = (is_ref ? p.refs + p.ref_off[rd] : p.seqs + p.seq_off[rd]) + start;
-    const int max_n = p.max_n, max_l = p.max_l;
+    const int max_n = ALLN ? MAX_PERIOD : max_n_;
     const int nwin = (span + 1 + 63) >> 6;                      // words i = 0 ... span are written
-    uint32_t *seqw = p.seqw + d.seqw_off;
-    uint4 *refw = p.refw + d.refw_off;
-    uint2 *refl = p.refl + d.refw_off;
 
     // bases around every position of window v: own code c (6 past the slice), the six before it (7 in front of the
     // slice) and the six behind it as 3-bit fields (layout.hpp), and the window's indicator masks
     auto load_window = [&](int v, uint32_t &c, uint32_t &kp, uint32_t &kn, unsigned long long (&M)[MAX_PERIOD]) {
         const int base = v << 6, pos = base + lane;
         uint32_t b[13];
+        unsigned long long inside = ~0ull;
         if (base >= 6 && base + 63 + 6 < len) {                 // (wave-uniform) every byte lies in the slice
 #pragma unroll
             for (int t = 0; t < 13; t++) b[t] = g[pos - 6 + t];
@@ -126,25 +135,13 @@ __global__ __launch_bounds__(64) void annotate_wave_kernel(PrepParams p)
                 const int idx = pos - 6 + t;
                 b[t] = idx < 0 ? 7u : idx >= len ? 6u : (uint32_t)g[idx];
             }
+            inside = __builtin_amdgcn_ballot_w64(pos < len);    // (a base past the slice equals no base: code 6 on both sides)
         }
         c = b[6];
         kp = b[0] | (b[1] << 3) | (b[2] << 6) | (b[3] << 9) | (b[4] << 12) | (b[5] << 15);
         kn = b[6] | (b[7] << 3) | (b[8] << 6) | (b[9] << 9) | (b[10] << 12) | (b[11] << 15);
-        const bool inside = pos < len;                          // (a base past the slice equals no base: code 6 on both sides)
 #pragma unroll
-        for (int n = 1; n <= MAX_PERIOD; n++) M[n - 1] = n <= max_n ? __builtin_amdgcn_ballot_w64(inside && b[6] == b[6 + n]) : 0ull;
-    };
-    // ones of e_n from position `from` on, looked at for at most `cap` positions (rare: a run that covers a whole window)
-    auto far_ones = [&](int n, int from, int cap) {
-        int total = 0;
-        for (int base = from; base < len && total < cap; base += 64) {
-            const int pos = base + lane;
-            const bool e = pos + n < len && g[pos] == g[pos + n];
-            const int t = ctz64_or64(~__builtin_amdgcn_ballot_w64(e));
-            total += t;
-            if (t != 64) break;
-        }
-        return total;
+        for (int n = 1; n <= MAX_PERIOD; n++) M[n - 1] = n <= max_n ? (__builtin_amdgcn_ballot_w64(b[6] == b[6 + n]) & inside) : 0ull;
     };
 
     uint32_t cC, kpC, knC, cN = 6u, kpN = 0u, knN = 0u;
@@ -152,35 +149,44 @@ __global__ __launch_bounds__(64) void annotate_wave_kernel(PrepParams p)
     load_window(0, cC, kpC, knC, MC);
     uint32_t Rp[MAX_PERIOD] = {0u, 0u, 0u, 0u, 0u, 0u};         // the previous window's results, per period
     int B[MAX_PERIOD] = {0, 0, 0, 0, 0, 0};                     // ones at the end of the previous window's masks
+    uint32_t left = 0u;                                         // bit n-1: the previous window's last n lanes hold a result
 
     for (int w = 0; w < nwin; w++) {
-        const int base = w << 6, pos = base + lane;
+        // (the lane number as a value the compiler cannot move out of the loop: what it derives from it per period --
+        // lane / n, lane % n, cross-lane addresses, lane masks -- would otherwise be kept in two dozen registers for
+        // the whole loop, and the kernel is held to 64)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int base = w << 6, pos = base + ln;
         if (w + 1 < nwin) load_window(w + 1, cN, kpN, knN, MN);
         else {
 #pragma unroll
             for (int n = 0; n < MAX_PERIOD; n++) MN[n] = 0ull;
         }
-        const bool nz = (cC - 1u) < 4u;                          // a base of the slice that is not N (codes 1 ... 4)
+        const unsigned long long nzmask = __builtin_amdgcn_ballot_w64((cC - 1u) < 4u);      // bases of the slice that are not N (codes 1 ... 4)
         uint32_t R[MAX_PERIOD];
         uint32_t mx = 0u;
+        uint32_t left_now = 0u;
         auto one = [&](auto tag) __attribute__((always_inline)) {
             constexpr int n = decltype(tag)::value;
             R[n - 1] = 0u;
             if (n > max_n) return;
             const unsigned long long M = MC[n - 1];
-            const int lo = ctz64_or64(~M), hi = clz64_or64(~M);
-            int F = 0;
-            if (M >> 63) {
-                F = ctz64_or64(~MN[n - 1]);
-                if (F == 64) F += far_ones(n, base + 128, (max_l + 2) * n);
-            }
-            if (annot_window_active<n>(M, B[n - 1], lo, hi, F)) {
-                const uint32_t carry = (uint32_t)__shfl((int)Rp[n - 1], 64 - n + lane % n);
-                const uint32_t r = annot_period<n>(lane, M, F, B[n - 1], nz, mx, carry, max_l);
+            int F = ctz64_or64(~MN[n - 1]);
+            if (F == 64 && (M >> 63)) F += annot_far_ones(g, len, n, base + 128, (max_l + 2) * n);      // (rare: a run over all of the next window)
+            const int q = annot_forward<n>(ln, M, F);
+            const unsigned long long startable = nzmask & __builtin_amdgcn_ballot_w64(q >= 2);
+            // a position of the window can only get a result from a startable position of the window or through what
+            // the previous window left in its last lanes
+            if (startable != 0ull || ((left >> (n - 1)) & 1u)) {
+                const int jdiv = div_small<n>(ln);
+                const uint32_t carry = lane_read(Rp[n - 1], 64 - n + ln - jdiv * n);
+                const uint32_t r = annot_resolve<n>(ln, M, q, B[n - 1], nzmask, startable, mx, carry, jdiv, max_l);
                 R[n - 1] = r;
                 mx = max(mx, (r & 0xFFu) * (uint32_t)n);
+                left_now |= ((__builtin_amdgcn_ballot_w64(r != 0u) >> (64 - n)) != 0ull ? 1u : 0u) << (n - 1);
             }
-            B[n - 1] = hi;
+            B[n - 1] = clz64_or64(~M);
         };
         one(std::integral_constant<int, 1>{});
         one(std::integral_constant<int, 2>{});
@@ -188,28 +194,29 @@ __global__ __launch_bounds__(64) void annotate_wave_kernel(PrepParams p)
         one(std::integral_constant<int, 4>{});
         one(std::integral_constant<int, 5>{});
         one(std::integral_constant<int, 6>{});
+        left = left_now;
 
-        // ---- the words of positions base ... base + 63 (layout.hpp)
-        // result of period n at position pos - n: this window's lane - n, or the previous window's lane 64 - n + lane
-        uint32_t S[MAX_PERIOD];
-#pragma unroll
-        for (int n = 1; n <= MAX_PERIOD; n++)
-            S[n - 1] = (uint32_t)__shfl((int)(lane >= 64 - n ? Rp[n - 1] : R[n - 1]), (lane - n) & 63);
-        if (!is_ref) {
+        // ---- the words of positions base ... base + 63 (layout.hpp).  Period n's result at position pos - n is this
+        // window's lane - n, or the previous window's lane 64 - n + lane
+        if constexpr (!IS_REF) {
             uint32_t wd = kpC << MER_SHIFT;
 #pragma unroll
             for (int n = 1; n <= MAX_PERIOD; n++) {
-                wd |= (S[n - 1] != 0u ? 1u : 0u) << (FLAG_SHIFT + n - 1);
-                wd |= ((S[n - 1] - 1u) < 255u ? 1u : 0u) << (n - 1);          // L != 0 and L_IDX == 0
+                const uint32_t S = lane_read(ln >= 64 - n ? Rp[n - 1] : R[n - 1], ln - n);
+                wd |= (S != 0u ? 1u : 0u) << (FLAG_SHIFT + n - 1);
+                wd |= ((S - 1u) < 255u ? 1u : 0u) << (n - 1);                  // L != 0 and L_IDX == 0
             }
             if (pos <= span) seqw[pos] = wd;
         } else {
             uint32_t x = knC << MER_SHIFT, y = 0u;
+            uint32_t sl03 = 0u, sl45 = 0u;                                     // L of period n at position pos - n, byte n - 1
 #pragma unroll
             for (int n = 1; n <= MAX_PERIOD; n++) {
+                const uint32_t S = lane_read(ln >= 64 - n ? Rp[n - 1] : R[n - 1], ln - n);
                 x |= ((R[n - 1] - 1u) < 255u ? 1u : 0u) << (FLAG_SHIFT + n - 1);
-                y |= (S[n - 1] != 0u ? 1u : 0u) << (n - 1);
-                y |= ((S[n - 1] - 1u) < 255u ? 1u : 0u) << (6 + n - 1);
+                y |= (S != 0u ? 1u : 0u) << (n - 1);
+                y |= ((S - 1u) < 255u ? 1u : 0u) << (6 + n - 1);
+                if (n <= 4) sl03 |= (S & 0xFFu) << (8 * (n - 1)); else sl45 |= (S & 0xFFu) << (8 * (n - 5));
             }
             if (pos >= 1) x |= kpC >> 15;                        // the cell's own reference base ref[j-1]
             const uint32_t l03 = (R[0] & 0xFFu) | ((R[1] & 0xFFu) << 8) | ((R[2] & 0xFFu) << 16) | ((R[3] & 0xFFu) << 24);
@@ -217,8 +224,7 @@ __global__ __launch_bounds__(64) void annotate_wave_kernel(PrepParams p)
             uint32_t dsc0 = 0u, dsc1 = 0u;
             if (__builtin_amdgcn_ballot_w64((y & 63u) != 0u)) {
                 // pre-decoded SHR candidates: the two highest periods flagged in y (layout.hpp)
-                const unsigned long long sl = (unsigned long long)((S[0] & 0xFFu) | ((S[1] & 0xFFu) << 8) | ((S[2] & 0xFFu) << 16) | ((S[3] & 0xFFu) << 24)) |
-                                              ((unsigned long long)((S[4] & 0xFFu) | ((S[5] & 0xFFu) << 8)) << 32);
+                const unsigned long long sl = (unsigned long long)sl03 | ((unsigned long long)sl45 << 32);
                 uint32_t yl = y & 63u;
                 const int na = yl ? 32 - __builtin_clz(yl) : 0;
                 if (na) {
@@ -244,6 +250,24 @@ __global__ __launch_bounds__(64) void annotate_wave_kernel(PrepParams p)
         for (int n = 0; n < MAX_PERIOD; n++) { Rp[n] = R[n]; MC[n] = MN[n]; }
         cC = cN; kpC = kpN; knC = knN;
     }
+}
+
+// One wave per (chunk, sequence).  ALLN: the context's max_n is MAX_PERIOD (the tool's default): no "n <= max_n" tests.
+// Held to 64 vector registers: a wave then fits beside the four waves a fill kernel keeps on every SIMD (kernels.hpp).
+template <bool ALLN>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void annotate_wave_kernel(PrepParams p)
+{
+    const int k = (int)(blockIdx.x >> 1);
+    const bool is_ref = blockIdx.x & 1;
+    if (k >= p.counters[0]) return;
+    const ChunkDesc d = p.descs[k];
+    const int64_t rd = d.read_id;
+    const int64_t T = is_ref ? p.ref_off[rd + 1] - p.ref_off[rd] : p.seq_off[rd + 1] - p.seq_off[rd];
+    const int start = is_ref ? d.col0 : d.row0, span = is_ref ? d.dcols : d.drows;
+    const int len = (int)(((int64_t)start + span + 1 < T ? (int64_t)start + span + 1 : T) - start);   // src/aln.pyx:453-454
+    const uint8_t *g = (is_ref ? p.refs + p.ref_off[rd] : p.seqs + p.seq_off[rd]) + start;
+    if (is_ref) annotate_slice<true, ALLN>(g, len, span, p.max_n, p.max_l, nullptr, p.refw + d.refw_off, p.refl + d.refw_off);
+    else annotate_slice<false, ALLN>(g, len, span, p.max_n, p.max_l, p.seqw + d.seqw_off, nullptr, nullptr);
 }
 
 }  // namespace npore

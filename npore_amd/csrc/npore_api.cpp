@@ -473,7 +473,8 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     hipLaunchKernelGGL(sched_scatter_kernel, dim3(ch_blocks), dim3(256), 0, s, pp);
     // n-polymer annotation + word packing: one wave per (chunk, sequence), registers only (annot_wave.hpp) -- the same
     // launch whether the GPU is empty or a fill kernel holds the CUs' LDS
-    hipLaunchKernelGGL(annotate_wave_kernel, dim3((unsigned)(2 * max_chunks)), dim3(64), 0, s, pp);
+    if (ctx->max_n == MAX_PERIOD) hipLaunchKernelGGL(annotate_wave_kernel<true>, dim3((unsigned)(2 * max_chunks)), dim3(64), 0, s, pp);
+    else hipLaunchKernelGGL(annotate_wave_kernel<false>, dim3((unsigned)(2 * max_chunks)), dim3(64), 0, s, pp);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(w->ev[1], s));
     // ---- fill: behind this group's preparation.  Consecutive groups alternate between two streams: their fill

@@ -18,6 +18,26 @@ def sha(s):
     return hashlib.sha256(s.encode()).hexdigest()
 
 
+_FULLSIZE = None
+
+
+def check_fullsize_digests(name, got, first=0):
+    """Every string of a full-size configuration against the per-read digests the pinned oracle produced in the build
+    container (tests/golden/make_fullsize_digests.py -> fullsize_digests.npz: read index, length, sha256[:16]);
+    got[k] is the string of read index first + k.  Returns the number of reads compared."""
+    global _FULLSIZE
+    if _FULLSIZE is None:
+        _FULLSIZE = np.load(os.path.join(GOLDEN, "fullsize_digests.npz"))
+    idx, ln, dig = _FULLSIZE[name + "_idx"], _FULLSIZE[name + "_len"], _FULLSIZE[name + "_dig"]
+    n = 0
+    for i, l, d in zip(idx.tolist(), ln.tolist(), dig.tolist()):
+        k = i - first
+        if 0 <= k < len(got):
+            assert len(got[k]) == l and int(sha(got[k])[:16], 16) == d, (name, i)
+            n += 1
+    return n
+
+
 @pytest.fixture(scope="module")
 def ctx(tables):
     sub, nps = tables
@@ -283,6 +303,16 @@ def test_10kb_properties(ctx, tables):
                 j += 1
     for k in (0, 17):
         assert got[k] == oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=100)
+    assert check_fullsize_digests("c2", got) == 32
+
+
+def test_c2_every_read_bit_exact(ctx):
+    """BASELINE.json configs[1] (1 000 reads of 10 kb, seed 2, r=100): EVERY read against the pinned
+    oracle's digest."""
+    refs, seqs, cigs = synth.make_batch(2, 1000)
+    got, st = ctx.align_batch(refs, seqs, cigs, r=100, return_status=True)
+    assert not st.any()
+    assert check_fullsize_digests("c2", got) == 1000
 
 
 def _check_alignment_properties(ref, seq, g):
@@ -321,6 +351,7 @@ def test_c3_all_distinct_10000_reads_one_call(ctx, tables):
     pick = list(np.argsort(dens)[[0, 1, -2, -1]])
     for k in pick:
         assert got[k] == oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=100), k
+    assert check_fullsize_digests("c3", got) == 10_000           # every read against the pinned oracle's digest
     # a batch is a function of its reads only: the same reads in a small call give the same strings
     again = ctx.align_batch(refs[4990:5010], seqs[4990:5010], cigs[4990:5010], r=100)
     assert again == got[4990:5010]
@@ -354,6 +385,8 @@ def test_c3_full_100000_reads_one_call(ctx, tables):
     dens = np.array([(np.diff(r_) == 0).mean() for r_ in refs[:400]])
     for k in list(np.argsort(dens)[[0, -1]]) + [n - 1]:
         assert got[k] == oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=100), k
+    # the first 10 000 reads and every 10th after them, bit for bit against the pinned oracle's digests
+    assert check_fullsize_digests("c3", got) == 19_000
     again = ctx.align_batch(refs[99_000:99_020], seqs[99_000:99_020], cigs[99_000:99_020], r=100)
     assert again == got[99_000:99_020]
 
@@ -369,6 +402,7 @@ def test_production_default_r30_one_full_launch(ctx, tables):
         _check_alignment_properties(ref, seq, g)
     for k in (0, 1333, 2666, 3999):
         assert got[k] == oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=30), k
+    assert check_fullsize_digests("r30", got) == 4000            # EVERY read against the pinned oracle's digest
 
 
 @pytest.mark.parametrize("r,n,reps", [(40, 1000, 16), (100, 1000, 16), (120, 1000, 16), (140, 1000, 16), (200, 1000, 16), (30, 4000, 8)])
@@ -445,6 +479,7 @@ def test_c5_256_ultralong_reads_r200(ctx, tables):
         _check_alignment_properties(ref, seq, g)
     for k in (3, 200):
         assert got[k] == oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=200), k
+    assert check_fullsize_digests("c5", got) == 256              # EVERY read against the pinned oracle's digest
 
 
 def test_realign_cli_end_to_end(tmp_path):

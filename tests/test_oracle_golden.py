@@ -87,3 +87,19 @@ def test_edge_inputs(tables):
         oracle.align(enc("ACGT"), enc("ACGT"), "===", sub, nps)      # lengths disagree
     with pytest.raises(ValueError):
         oracle.align(enc("ACGT"), enc("ACGT"), "==N=", sub, nps)     # unsupported op
+
+
+def test_fullsize_digests_are_the_oracles(tables):
+    """tests/golden/fullsize_digests.npz (per-read length + sha256[:16] of every full-size configuration, which the GPU
+    tests compare all reads against) really is what the pinned oracle gives: spot checks of each configuration."""
+    import hashlib
+    from npore_amd import synth
+    sub, nps = tables
+    z = np.load(os.path.join(GOLDEN, "fullsize_digests.npz"))
+    assert [len(z[k + "_idx"]) for k in ("c2", "r30", "c5", "c3")] == [1000, 4000, 256, 19000]
+    for name, seed, ref_len, mixed, r, i in (("c2", 2, 10_000, False, 100, 511), ("r30", 2, 10_000, False, 30, 2048),
+                                             ("c3", 3, 10_000, True, 100, 99_990), ("c3", 3, 10_000, True, 100, 4_321)):
+        ref, seq, cig = synth.make_pair(seed, i, ref_len, mixed=mixed)
+        s = oracle.align(ref, seq, cig, sub, nps, r=r)
+        k = int(np.nonzero(z[name + "_idx"] == i)[0][0])
+        assert len(s) == z[name + "_len"][k] and int(hashlib.sha256(s.encode()).hexdigest()[:16], 16) == int(z[name + "_dig"][k])
