@@ -404,48 +404,94 @@ class NativeBam:
         except OSError:
             return False
 
-    @staticmethod
-    def _shm_key(path):
+    _opens = {}          # (path, local rank) -> how many times this process has opened it for sharing (the same in every local rank)
+
+    @classmethod
+    def _shm_key(cls, path):
+        """Name of the files local rank 0 leaves for the other local ranks.  Besides the file's identity it holds what
+        makes one LAUNCH's files invisible to the next: the launcher's pid (the local ranks of one torch.distributed.run
+        are children of one agent) and MASTER_PORT, and the count of this process's opens of the path (a second
+        NativeBam of the same file in one run must not find the first one's `.skip`)."""
         import hashlib
         st = os.stat(path)
-        return hashlib.sha1(f"{os.path.abspath(path)}:{st.st_size}:{st.st_mtime_ns}:{os.environ.get('MASTER_PORT', '')}".encode()).hexdigest()[:16]
+        ap = os.path.abspath(path)
+        who = (ap, os.environ.get("LOCAL_RANK", "0"))
+        gen = cls._opens[who] = cls._opens.get(who, 0) + 1
+        ident = f"{ap}:{st.st_size}:{st.st_mtime_ns}:{os.environ.get('MASTER_PORT', '')}:{os.getppid()}:{gen}"
+        return hashlib.sha1(ident.encode()).hexdigest()[:16]
+
+    @staticmethod
+    def _announce_maker(key):
+        """local rank 0: its pid where the waiting ranks can see whether it is still alive; stale leftovers of the key removed"""
+        for ext in (".idx", ".raw", ".skip"):
+            try:
+                os.remove(f"/dev/shm/npore_bam_{key}{ext}")
+            except OSError:
+                pass
+        tmp = f"/dev/shm/npore_bam_{key}.pid.tmp"
+        with open(tmp, "w") as fh:
+            fh.write(str(os.getpid()))
+        os.replace(tmp, f"/dev/shm/npore_bam_{key}.pid")
+
+    @staticmethod
+    def _wait_for_maker(key, data, skip, timeout):
+        """other local ranks: True once `data` is there; False if the maker gave up (`skip`), died, or `timeout` passed"""
+        import time
+        pidfile = f"/dev/shm/npore_bam_{key}.pid"
+        t0 = time.time()
+        while time.time() - t0 < timeout:
+            if os.path.exists(data):
+                return True
+            if os.path.exists(skip):
+                return False
+            try:
+                pid = int(open(pidfile).read())                # (no pid file yet: the maker has not started)
+            except (OSError, ValueError):
+                pid = None
+            if pid is not None:
+                try:
+                    os.kill(pid, 0)
+                except ProcessLookupError:                     # the maker is gone: what it left is all there will be
+                    return os.path.exists(data)
+                except OSError:
+                    pass
+            time.sleep(0.05)
+        return False
 
     def _open_with_shared_index(self, path, local_rank, threads):
         """Streamed file, several local ranks: local rank 0 makes the record index (one pass over the file) and saves
         it under /dev/shm; the others wait for it and open with it.  Returns a handle or None (caller opens normally)."""
-        import time
         try:
             key = self._shm_key(path)
         except OSError:
             return None
         ix, skip = f"/dev/shm/npore_bam_{key}.idx", f"/dev/shm/npore_bam_{key}.skip"
         if local_rank == 0:
+            self._announce_maker(key)
             h = self._lib.npore_bam_open_mode(os.fsencode(path), threads, 2, None)
-            if not h or self._lib.npore_bam_save_index(h, os.fsencode(ix)) != 0:
+            if not h or self._lib.npore_bam_save_index(h, os.fsencode(ix + ".tmp")) != 0:
                 open(skip, "w").close()
+                self._shared = (ix, skip, key)
                 return h or None
-            self._shared = (ix, skip)
+            os.replace(ix + ".tmp", ix)
+            self._shared = (ix, skip, key)
             return h
-        t_end = time.time() + 3600
-        while time.time() < t_end:
-            if os.path.exists(ix):
-                return self._lib.npore_bam_open_mode(os.fsencode(path), threads, 2, os.fsencode(ix)) or None
-            if os.path.exists(skip):
-                return None
-            time.sleep(0.05)
+        if self._wait_for_maker(key, ix, skip, float(os.environ.get("NPORE_SHARE_WAIT_S", "3600"))):
+            return self._lib.npore_bam_open_mode(os.fsencode(path), threads, 2, os.fsencode(ix)) or None
         return None
 
     def _shared_copy(self, path, local_rank, threads):
         """Path to open: the inflated copy under /dev/shm (local rank 0 makes it, the others wait for it), or
         `path` itself when sharing is not possible (no room, or the maker gave up: a `.skip` marker)."""
         import shutil
-        import time
         try:
             key = self._shm_key(path)
         except OSError:
             return path
         raw, skip = f"/dev/shm/npore_bam_{key}.raw", f"/dev/shm/npore_bam_{key}.skip"
         if local_rank == 0:
+            self._announce_maker(key)
+            self._shared = (raw, skip, key)
             h = self._lib.npore_bam_open_mode(os.fsencode(path), threads, 1, None)
             if not h:
                 open(skip, "w").close()
@@ -454,22 +500,15 @@ class NativeBam:
             try:
                 size = int(self._lib.npore_bam_inflated_size(h))
                 if size * 4 <= shutil.disk_usage("/dev/shm").free:
-                    ok = self._lib.npore_bam_dump_inflated(h, os.fsencode(raw)) == 0
+                    ok = self._lib.npore_bam_dump_inflated(h, os.fsencode(raw + ".tmp")) == 0
             finally:
                 self._lib.npore_bam_close(h)
             if not ok:
                 open(skip, "w").close()
                 return path
-            self._shared = (raw, skip)
+            os.replace(raw + ".tmp", raw)
             return raw
-        t_end = time.time() + 1800
-        while time.time() < t_end:
-            if os.path.exists(raw):
-                return raw
-            if os.path.exists(skip):
-                return path
-            time.sleep(0.05)
-        return path
+        return raw if self._wait_for_maker(key, raw, skip, float(os.environ.get("NPORE_SHARE_WAIT_S", "1800"))) else path
 
     def refs_with_reads(self):
         return {i for i in range(len(self.references)) if self._lib.npore_bam_ref_has_reads(self.handle, i)}
@@ -578,13 +617,19 @@ class NativeBam:
             self._lib.npore_bam_close(self.handle)
             self.handle = None
         if self._shared:                 # the maker takes the shared copy away; a rank that comes later inflates itself
-            raw, skip = self._shared
+            raw, skip, key = self._shared
             self._shared = None
             try:
                 open(skip, "w").close()
-                os.remove(raw)
             except OSError:
                 pass
+            for f in (raw, raw + ".tmp", f"/dev/shm/npore_bam_{key}.pid"):
+                try:
+                    os.remove(f)
+                except OSError:
+                    pass
+            import atexit                # the marker for late comers goes when this process does
+            atexit.register(lambda f=skip: os.path.exists(f) and os.remove(f))
 
 
 def realign_native(ctx, bam, fasta, idx, out_sam, r=30, max_b_rows=20000, batch_reads=0, threads=0):
@@ -685,11 +730,11 @@ def get_confusion_matrices():
         print("\nERROR: --recalc_cms would overwrite the shipped guppy5_stats tables; give another --stats_dir.")
         sys.exit(1)
     from . import dist as dist_mod
-    rank, world_size, barrier = dist_mod.barrier_file_ranks()
-    total = None
-    if rank == 0:
+
+    def recount():
         print("> calculating confusion matrices")
         from .bed import get_ranges
+        total = None
         ranges = get_ranges(cfg.args.regions, cfg.args.chunk_width)
         for k, rg in enumerate(ranges):
             res = calc_confusion_matrices(rg)
@@ -704,7 +749,11 @@ def get_confusion_matrices():
             tmp = os.path.join(d, f".{k}_cm.{os.getpid()}.tmp.npy")
             np.save(tmp, m)
             os.replace(tmp, os.path.join(d, f"{k}_cm.npy"))
-    barrier()
+        return total
+
+    # several ranks: rank 0 recounts; the others learn whether it succeeded (no barrier that never comes, no 30-minute
+    # default timeout on a step that takes hours on a genome)
+    total = dist_mod.rank0_then_all(recount)
     if total is None:
         total = tuple(np.load(os.path.join(d, f"{k}_cm.npy")) for k in names)
     if getattr(cfg.args, "recalc_exit", False):

@@ -65,20 +65,66 @@ def barrier_file_ranks():
         return rank, world_size, (lambda: None)
 
     def barrier():
+        import datetime
         import torch.distributed as dist
         if not dist.is_initialized():
-            dist.init_process_group("gloo")
+            # host-only steps between barriers may take hours (a genome-scale --recalc_cms on one rank)
+            dist.init_process_group("gloo", timeout=datetime.timedelta(hours=float(os.environ.get("NPORE_HOST_STEP_TIMEOUT_H", "48"))))
         dist.barrier()
     return rank, world_size, barrier
 
 
+def rank0_then_all(work):
+    """Run `work()` on rank 0 while the other ranks wait; every rank learns whether it succeeded (rank 0 re-raises its
+    own exception, the others raise RuntimeError) -- no rank is left at a barrier that never comes.  Single process:
+    just runs it.  Returns work()'s result on rank 0, None elsewhere."""
+    rank, world_size, barrier = barrier_file_ranks()
+    if world_size == 1:
+        return work()
+    import torch
+    import torch.distributed as dist
+    barrier()                                         # (creates the gloo group with its long timeout)
+    res, err = None, None
+    if rank == 0:
+        try:
+            res = work()
+        except BaseException as e:                    # incl. SystemExit: the flag below must still go out
+            err = e
+    flag = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64)
+    dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+    if err is not None:
+        raise err
+    if flag.item() != 0.0:
+        raise RuntimeError("rank 0 failed in a host-only step (see its output)")
+    return res
+
+
+def cgroup_cpus():
+    """CPUs a cgroup quota leaves this process (None: no quota).  cgroup v2 cpu.max, v1 cfs_quota / cfs_period."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()[:2]
+            return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        return None if q <= 0 else q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+    except (OSError, ValueError):
+        return None
+
+
 def host_threads_per_rank():
     """Host threads a rank should use for the parallel host stages (BGZF inflate, packing, standardisation, SAM
-    text): the cores this process may run on, divided among the ranks of this node."""
+    text): the CPUs this process may really use -- its affinity mask cut down by a cgroup quota (a 16-CPU lease on a
+    256-CPU host reports 256 in the mask) -- divided among the ranks of this node."""
     try:
         cores = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         cores = os.cpu_count() or 1
+    quota = cgroup_cpus()
+    if quota is not None:
+        cores = min(cores, max(1, int(quota + 0.5)))
     return max(1, cores // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
 
 

@@ -202,6 +202,51 @@ def test_sharding_and_reduction_gloo_world2():
         assert sums["reads"] == 1001 and sums["cells"] == sum(range(1001)) and maxes["elapsed"] == 2.0
 
 
+def _rank0_worker(rank, world_size, port, fail, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size),
+                      LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world_size))
+    calls = []
+
+    def work():
+        calls.append(rank)
+        if fail:
+            sys.exit(3)              # the way rank 0 leaves when samtools is missing (bam.get_pileups)
+        return "done"
+    try:
+        q.put((rank, dist.rank0_then_all(work), calls, dist.host_threads_per_rank()))
+    except SystemExit as e:
+        q.put((rank, f"exit {e.code}", calls, 0))
+    except RuntimeError as e:
+        q.put((rank, f"error {e}", calls, 0))
+
+
+def test_rank0_then_all_gloo_world2():
+    """dist.rank0_then_all (the host-only steps of a multi-process run, e.g. --recalc_cms): rank 0 works, every rank
+    learns the outcome -- also when rank 0 leaves through sys.exit: the others raise instead of waiting at a barrier
+    for the process group's timeout.  host_threads_per_rank divides what the cgroup quota leaves by the local ranks."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    for fail in (False, True):
+        q = ctx.Queue()
+        port = 31500 + os.getpid() % 2000 + (7 if fail else 0)
+        procs = [ctx.Process(target=_rank0_worker, args=(r, 2, port, fail, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = dict((r[0], r[1:]) for r in (q.get(timeout=120) for _ in procs))
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+        assert res[0][1] == [0] and res[1][1] == []          # only rank 0 worked
+        if fail:
+            assert res[0][0] == "exit 3" and res[1][0].startswith("error rank 0 failed")
+        else:
+            assert res[0][0] == "done" and res[1][0] is None
+            quota = dist.cgroup_cpus()
+            cores = len(os.sched_getaffinity(0))
+            want = max(1, (min(cores, max(1, int(quota + 0.5))) if quota is not None else cores) // 2)
+            assert res[0][2] == res[1][2] == want
+
+
 def test_bench_cpu_baseline_leg(tables):
     """bench.py's CPU-baseline leg on a tiny batch (no GPU involved): one core, a pool sweep, the k-scaled
     Cython-equivalent figures, and the strings it hands back for the comparison with the GPU output."""
@@ -351,8 +396,27 @@ def test_inflated_bam_copy_shared_between_local_ranks(tmp_path, monkeypatch):
         assert user._shared is None and np.array_equal(user.select(regions), plain.select(regions))
         shared = maker._shared[0]
         user.close(); maker.close()
-        assert not os.path.exists(shared)
-        os.remove(shared.replace(".raw", ".skip"))
+        assert not os.path.exists(shared) and not os.path.exists(shared.replace(".raw", ".pid"))
+        # the next open of the same file in the same run is a new generation: the `.skip` the first maker left for late
+        # comers is not its successor's (a rank that is faster than rank 0 must WAIT for the new copy, not give up)
+        assert os.path.exists(shared.replace(".raw", ".skip"))
+        monkeypatch.setenv("LOCAL_RANK", "0")
+        maker2 = bam.NativeBam(path)
+        assert maker2._shared and maker2._shared[0] != shared and os.path.exists(maker2._shared[0])
+        monkeypatch.setenv("LOCAL_RANK", "1")
+        user2 = bam.NativeBam(path)
+        assert np.array_equal(user2.select(regions), plain.select(regions))
+        user2.close(); maker2.close()
+        # a maker that died before it left anything: the waiting rank notices and opens the file itself
+        key = "deadbeefdeadbeef"
+        import subprocess
+        pr = subprocess.Popen([sys.executable, "-c", "pass"]); pr.wait()
+        open(f"/dev/shm/npore_bam_{key}.pid", "w").write(str(pr.pid))
+        assert bam.NativeBam._wait_for_maker(key, f"/dev/shm/npore_bam_{key}.raw", f"/dev/shm/npore_bam_{key}.skip", 30.0) is False
+        os.remove(f"/dev/shm/npore_bam_{key}.pid")
+        for f in (shared.replace(".raw", ".skip"), maker2._shared and "" or ""):
+            if f and os.path.exists(f):
+                os.remove(f)
     plain.close()
     # dist._append_file: whole files, also behind existing content
     a, b = tmp_path / "a", tmp_path / "b"
