@@ -23,15 +23,16 @@ namespace npore {
 enum : uint8_t { OP_M = 0, OP_I = 1, OP_D = 2 };
 
 struct OpRun {
-    uint8_t op;
-    int64_t len;
+    int64_t len : 56;
+    uint64_t op : 8;
 };
+static_assert(sizeof(OpRun) == 8, "a run is one 8-byte word");
 
 inline void push_run(std::vector<OpRun> &runs, uint8_t op, int64_t n)
 {
     if (n <= 0) return;
     if (!runs.empty() && runs.back().op == op) runs.back().len += n;
-    else runs.push_back(OpRun{op, n});
+    else runs.push_back(OpRun{n, op});
 }
 
 // src/cig.pyx:102-159 on runs; `seq` is what push_op consumes besides the match ops (reference for D, read for I)
@@ -79,10 +80,16 @@ template <class Emit>
 inline void standardize_runs(const char *aln, int64_t aln_len, const uint8_t *ref, int64_t ref_len,
                              const uint8_t *seq, int64_t seq_len, Emit emit)
 {
-    std::vector<OpRun> a, b;
-    for (int64_t i = 0; i < aln_len; i++) {
+    static thread_local std::vector<OpRun> a, b;      // (a worker thread does thousands of reads: no allocation per read)
+    a.clear();
+    b.clear();
+    for (int64_t i = 0; i < aln_len;) {                // runs of the op string; X,=,M -> M
         const char c = aln[i];
-        push_run(a, (c == 'I') ? OP_I : (c == 'D') ? OP_D : OP_M, 1);     // X,=,M -> M
+        int64_t j = i + 1;
+        if (c == 'I' || c == 'D') { while (j < aln_len && aln[j] == c) j++; }
+        else { while (j < aln_len && aln[j] != 'I' && aln[j] != 'D') j++; }
+        a.push_back(OpRun{j - i, (uint64_t)((c == 'I') ? OP_I : (c == 'D') ? OP_D : OP_M)});
+        i = j;
     }
     push_indels_left(a, b, ref, ref_len, OP_D);
     inss_before_dels(b, a);
@@ -103,14 +110,26 @@ inline void standardize_runs(const char *aln, int64_t aln_len, const uint8_t *re
 }
 
 // ... + collapse_cigar (src/cig.pyx:13-38): run-length encoded text
+// ... written at `out` (2 bytes per op of the alignment + 16 always suffice); returns the length
+inline int64_t standardize_collapsed_into(const char *aln, int64_t aln_len, const uint8_t *ref, int64_t ref_len,
+                                          const uint8_t *seq, int64_t seq_len, char *out)
+{
+    char *o = out;
+    standardize_runs(aln, aln_len, ref, ref_len, seq, seq_len, [&](char op, int64_t n) {
+        char digits[24];
+        int nd = 0;
+        uint64_t v = (uint64_t)n;
+        do { digits[nd++] = (char)('0' + v % 10); v /= 10; } while (v);
+        while (nd) *o++ = digits[--nd];
+        *o++ = op;
+    });
+    return (int64_t)(o - out);
+}
 inline std::string standardize_collapsed(const char *aln, int64_t aln_len, const uint8_t *ref, int64_t ref_len,
                                          const uint8_t *seq, int64_t seq_len)
 {
-    std::string out;
-    standardize_runs(aln, aln_len, ref, ref_len, seq, seq_len, [&](char op, int64_t n) {
-        out += std::to_string(n);
-        out += op;
-    });
+    std::string out((size_t)(2 * aln_len + 16), '\0');
+    out.resize((size_t)standardize_collapsed_into(aln, aln_len, ref, ref_len, seq, seq_len, &out[0]));
     return out;
 }
 

@@ -559,6 +559,35 @@ inline uint8_t base_code(char c)   // src/cig.pyx:212-229: 'NACGT-' -> 0..5, any
     switch (c) { case 'A': return 1; case 'C': return 2; case 'G': return 3; case 'T': return 4; case '-': return 5; default: return 0; }
 }
 
+// base_code over a run of characters: compares and masks only, so the compiler vectorises it
+inline void base_codes(const char *src, uint8_t *dst, int64_t n)
+{
+    for (int64_t q = 0; q < n; q++) {
+        const char c = src[q];
+        dst[q] = (uint8_t)((c == 'A' ? 1 : 0) + (c == 'C' ? 2 : 0) + (c == 'G' ? 3 : 0) + (c == 'T' ? 4 : 0) + (c == '-' ? 5 : 0));
+    }
+}
+
+// base codes of n bases of a BAM record's 4-bit packed sequence from base `first` on: two per table lookup
+inline void nibble_codes(const uint8_t *packed, int64_t first, uint8_t *dst, int64_t n)
+{
+    static const struct Tab {
+        uint16_t pair[256];
+        Tab() { for (int b = 0; b < 256; b++) pair[b] = (uint16_t)(base_code(SEQ16[b >> 4]) | (base_code(SEQ16[b & 15]) << 8)); }
+    } tab;
+    int64_t q = 0, t = first;
+    if (n > 0 && (t & 1)) { dst[q++] = (uint8_t)(tab.pair[packed[t >> 1]] >> 8); t++; }
+    const uint8_t *src = packed + (t >> 1);
+    const int64_t pairs = (n - q) >> 1;
+    for (int64_t j = 0; j < pairs; j++) {
+        const uint16_t v = tab.pair[src[j]];
+        dst[q + 2 * j] = (uint8_t)v;
+        dst[q + 2 * j + 1] = (uint8_t)(v >> 8);
+    }
+    q += 2 * pairs;
+    if (q < n) dst[q] = (uint8_t)tab.pair[src[pairs]];
+}
+
 // FASTA -> contig names + upper-cased bases, on all cores: the file is cut into pieces at line starts; a first
 // pass counts the bases every piece contributes to the contig open at its start and to the contigs whose
 // headers it contains, a second pass copies the lines to their final place.  Lines are trimmed of blanks, tabs

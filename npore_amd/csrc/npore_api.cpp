@@ -8,7 +8,9 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
 #include <future>
+#include <mutex>
 #include <memory>
 #include <numeric>
 #include <string>
@@ -118,6 +120,10 @@ struct HostBuf {   // pinned staging
 // One batch on its way through the BAM -> SAM pipeline: host staging (page-locked where it crosses PCIe) and offsets.
 struct npore_batch_slot {
     RawBuf refs{true}, seqs{true}, cigs{true}, alns{true}, finals, sam;
+    RawBuf olen_pin{true}, st_pin{true};   // lengths / status bits of an ASYNCHRONOUS batch land here (page-locked: a copy into
+                                           // pageable memory would make the enqueueing call wait for the whole batch)
+    hipEvent_t done = nullptr;             // ... behind which this event is recorded (npore_bam_realign_file)
+    ~npore_batch_slot() { if (done) (void)hipEventDestroy(done); }
     RecFetch rf;                 // the batch's BAM records (streamed handles: inflated for the batch)
     double t_ms[6] = {0, 0, 0, 0, 0, 0};   // npore_bam_realign_file: fetch + pack, align call, standardise, format, write, (spare)
     std::vector<int64_t> ro, so, co, oo, fo, olen, flen;
@@ -1578,21 +1584,28 @@ int fetch_records(const npore_bam *b, const int64_t *idx, int64_t n, int threads
     if (!bam_fetch(*b, idx, n, threads, rf, err)) return fail(NPORE_E_INVALID, "BAM records: " + err);
     return NPORE_OK;
 }
-void pack_sizes_of(const RecFetch &rf, int64_t n, int64_t *ref_off, int64_t *seq_off, int64_t *cig_off)
+void pack_sizes_of(const RecFetch &rf, int64_t n, int64_t *ref_off, int64_t *seq_off, int64_t *cig_off, int threads = 0)
 {
+    // per read (a 10 kb read has thousands of CIGAR operations: all cores), then the prefix sums
     ref_off[0] = seq_off[0] = cig_off[0] = 0;
-    for (int64_t k = 0; k < n; k++) {
-        const RecView r = rec_of(rf, k);
-        int64_t lead, trail, ops = 0;
-        rec_clips(r, lead, trail);
-        for (int c = 0; c < r.n_cigar(); c++) {
-            const uint32_t w = r.cig(c), op = w & 15u;
-            if (op != 4 && op != 5) ops += w >> 4;
+    const int64_t per = 64;
+    parallel_for((n + per - 1) / per, threads, [&](int64_t t) {
+        for (int64_t k = t * per; k < std::min(n, (t + 1) * per); k++) {
+            const RecView r = rec_of(rf, k);
+            int64_t lead, trail, ops = 0, rl = 0;
+            rec_clips(r, lead, trail);
+            const int nc = r.n_cigar();
+            for (int c = 0; c < nc; c++) {
+                const uint32_t w = r.cig(c), op = w & 15u, len = w >> 4;
+                if (op != 4 && op != 5) ops += len;
+                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += len;      // (rec_ref_len: M D N = X)
+            }
+            ref_off[k + 1] = rl;
+            seq_off[k + 1] = std::max<int64_t>(0, (int64_t)r.l_seq() - lead - trail);
+            cig_off[k + 1] = ops;
         }
-        ref_off[k + 1] = ref_off[k] + rec_ref_len(r);
-        seq_off[k + 1] = seq_off[k] + std::max<int64_t>(0, (int64_t)r.l_seq() - lead - trail);
-        cig_off[k + 1] = cig_off[k] + ops;
-    }
+    });
+    for (int64_t k = 0; k < n; k++) { ref_off[k + 1] += ref_off[k]; seq_off[k + 1] += seq_off[k]; cig_off[k + 1] += cig_off[k]; }
 }
 }  // namespace
 
@@ -1601,7 +1614,7 @@ try {
     if (!pack_args_ok(b, idx, n) || !ref_off || !seq_off || !cig_off) return fail(NPORE_E_INVALID, "bad argument");
     RecFetch &rf = const_cast<npore_bam *>(b)->api_fetch;
     if (int rc = fetch_records(b, idx, n, 0, rf)) return rc;
-    pack_sizes_of(rf, n, ref_off, seq_off, cig_off);
+    pack_sizes_of(rf, n, ref_off, seq_off, cig_off, 0);
     return NPORE_OK;
 }
 NPORE_CATCH_INT
@@ -1640,24 +1653,27 @@ int pack_records(const npore_bam *b, const RecFetch &rf, const npore_fasta *fa, 
         const int64_t ctg_len = fa->len((size_t)fi);
         const int64_t rl = ref_off[k + 1] - ref_off[k], pos = r.pos();
         uint8_t *ro = refs + ref_off[k];
-        for (int64_t q = 0; q < rl; q++) ro[q] = (pos + q >= 0 && pos + q < ctg_len) ? base_code(ctg[pos + q]) : 0;
+        {
+            const int64_t q0 = std::min(rl, std::max<int64_t>(0, -pos)), q1 = std::max(q0, std::min(rl, ctg_len - pos));
+            std::memset(ro, 0, (size_t)q0);
+            base_codes(ctg + pos + q0, ro + q0, q1 - q0);
+            std::memset(ro + q1, 0, (size_t)(rl - q1));
+        }
         // query bases without the soft clips (src/bam.pyx:42)
         int64_t lead, trail;
         rec_clips(r, lead, trail);
-        const uint8_t *sq = r.seq();
         uint8_t *so = seqs + seq_off[k];
         const int64_t sl = seq_off[k + 1] - seq_off[k];
-        for (int64_t q = 0; q < sl; q++) {
-            const int64_t t = lead + q;
-            const int nib = (t & 1) ? (sq[t >> 1] & 15) : (sq[t >> 1] >> 4);
-            so[q] = base_code(SEQ16[nib]);
-        }
+        nibble_codes(r.seq(), lead, so, sl);
         // expanded CIGAR without S and H (src/bam.pyx:59)
         char *co = cigs + cig_off[k];
-        for (int c = 0; c < r.n_cigar(); c++) {
+        const int nc = r.n_cigar();
+        for (int c = 0; c < nc; c++) {
             const uint32_t w = r.cig(c), op = w & 15u, len = w >> 4;
             if (op == 4 || op == 5) continue;
-            std::memset(co, op < 10 ? CIGOPS[op] : '?', len);
+            const char ch = op < 10 ? CIGOPS[op] : '?';
+            if (len <= 8) { for (uint32_t q = 0; q < len; q++) co[q] = ch; }      // (most runs are a few ops long)
+            else std::memset(co, ch, len);
             co += len;
         }
         if (for_upload) {       // page-locked staging about to cross PCIe: out of this core's cache first (hostio.hpp)
@@ -1742,7 +1758,7 @@ int slot_pack(const npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of
     s.flen.assign((size_t)n, 0);
     if (!pack_args_ok(b, idx, n)) return fail(NPORE_E_INVALID, "bad argument");
     if (int rc = fetch_records(b, idx, n, threads, s.rf)) return rc;
-    pack_sizes_of(s.rf, n, s.ro.data(), s.so.data(), s.co.data());
+    pack_sizes_of(s.rf, n, s.ro.data(), s.so.data(), s.co.data(), threads);
     if (!s.refs.ensure((size_t)s.ro[(size_t)n] + 64) || !s.seqs.ensure((size_t)s.so[(size_t)n] + 64) || !s.cigs.ensure((size_t)s.co[(size_t)n] + 64))
         return fail(NPORE_E_NOMEM, "batch buffers");
     if (!fa || !fasta_of_ref) return fail(NPORE_E_INVALID, "bad argument");
@@ -1773,11 +1789,9 @@ int slot_post(const npore_bam *b, const int64_t *idx, int64_t n, const int32_t *
     const uint8_t *refs = reinterpret_cast<const uint8_t *>(s.refs.p), *seqs = reinterpret_cast<const uint8_t *>(s.seqs.p);
     parallel_for(n, threads, [&](int64_t k) {
         const int64_t l = s.olen[(size_t)k] > 0 ? s.olen[(size_t)k] : 0;
-        const std::string c = standardize_collapsed(s.alns.p + s.oo[(size_t)k], l, refs + s.ro[(size_t)k],
-                                                    s.ro[(size_t)k + 1] - s.ro[(size_t)k], seqs + s.so[(size_t)k],
-                                                    s.so[(size_t)k + 1] - s.so[(size_t)k]);
-        std::memcpy(s.finals.p + s.fo[(size_t)k], c.data(), c.size());     // 2 bytes per op + 16 always suffice
-        s.flen[(size_t)k] = (int64_t)c.size();
+        s.flen[(size_t)k] = standardize_collapsed_into(s.alns.p + s.oo[(size_t)k], l, refs + s.ro[(size_t)k],     // 2 bytes per op + 16 always suffice
+                                                       s.ro[(size_t)k + 1] - s.ro[(size_t)k], seqs + s.so[(size_t)k],
+                                                       s.so[(size_t)k + 1] - s.so[(size_t)k], s.finals.p + s.fo[(size_t)k]);
     });
     if (ms_std) *ms_std = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     (void)idx;
@@ -1826,27 +1840,37 @@ try {
     const int64_t nb = (n + batch_reads - 1) / batch_reads;
     const auto wall0 = std::chrono::steady_clock::now();
     for (auto &sp : ctx->slots) std::fill(sp->t_ms, sp->t_ms + 6, 0.0);
-    if (nb > 1 && !ctx->peer) {
-        ctx->peer = npore_ctx_create(ctx->h_sub.data(), ctx->h_np.data(), ctx->max_n, ctx->max_l, ctx->device);
-        if (!ctx->peer) { std::fclose(fh); return NPORE_E_HIP; }
-    }
-    npore_ctx *gctx[2] = {ctx, ctx->peer ? ctx->peer : ctx};
-    for (npore_ctx *g : {ctx, ctx->peer})
-        if (g) { g->file_mark[0] = g->totals[0] + g->totals[1] + g->totals[2]; g->file_mark[1] = g->totals[3] + g->totals[4]; }
-    for (npore_ctx *g : gctx) { g->tb_budget_mb = ctx->tb_budget_mb; g->tb_kernel = ctx->tb_kernel; g->force_chunks = ctx->force_chunks; }
+    ctx->file_mark[0] = ctx->totals[0] + ctx->totals[1] + ctx->totals[2];
+    ctx->file_mark[1] = ctx->totals[3] + ctx->totals[4];
     constexpr int S = npore_ctx::N_SLOTS;
     auto first = [&](int64_t k) { return k * batch_reads; };
     auto count = [&](int64_t k) { return std::min(batch_reads, n - k * batch_reads); };
-    // Stages: pack (helpers, two batches ahead) | align (two batches in flight, one per context, each call on its own
-    // helper thread) | standardise + format + write (helper; files are written in input order).  A slot carries a batch
-    // through all stages; six slots cover 2 packing + 2 aligning + 2 posting.
-    std::vector<std::future<void>> packed((size_t)nb), aligned((size_t)nb), posted((size_t)nb);
+    // Stages: fetch + pack (helper threads, two batches ahead) | the device path of ONE context through its
+    // asynchronous entry point -- a batch is enqueued the moment it is packed and the call returns at once, so up to
+    // N_SETS batches are on the device, the upload / preparation of one and the traceback / download of another beside
+    // the fill kernel of a third (run_core) | standardise + SAM text + ordered write (helper threads, each behind the
+    // event recorded behind its batch's download).  A slot carries a batch through all stages; six slots cover two
+    // being packed, three on the device and one being written.
+    std::vector<std::future<void>> packed((size_t)nb), posted((size_t)nb);
+    const int host_threads_half = threads > 0 ? std::max(1, threads) : 0;
+    // batches leave in input order: `written` counts the batches that are through (written, or given up on)
+    std::mutex gate_m;
+    std::condition_variable gate_cv;
+    int64_t written = 0;
+    auto wait_written = [&](int64_t upto) {                    // until `upto` batches are through
+        std::unique_lock<std::mutex> lk(gate_m);
+        gate_cv.wait(lk, [&] { return written >= upto; });
+    };
+    auto mark_written = [&] {
+        { std::lock_guard<std::mutex> lk(gate_m); written++; }
+        gate_cv.notify_all();
+    };
     auto start_pack = [&](int64_t k) {
         packed[(size_t)k] = std::async(std::launch::async, [&, k] {
             npore_batch_slot &s = *ctx->slots[(size_t)(k % S)];
-            if (k >= S) posted[(size_t)(k - S)].wait();        // the slot's previous batch has been written
+            if (k >= S) wait_written(k - S + 1);               // the slot's previous batch has been written
             const auto t0 = std::chrono::steady_clock::now();
-            s.rc = slot_pack(b, fa, fasta_of_ref, idx + first(k), count(k), threads, s);
+            s.rc = slot_pack(b, fa, fasta_of_ref, idx + first(k), count(k), host_threads_half, s);
             s.t_ms[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (s.rc) s.err = npore_last_error();
         });
@@ -1854,15 +1878,23 @@ try {
     auto start_post = [&](int64_t k) {
         posted[(size_t)k] = std::async(std::launch::async, [&, k] {
             npore_batch_slot &t = *ctx->slots[(size_t)(k % S)];
+            struct Through { decltype(wait_written) &w; decltype(mark_written) &m; int64_t k; ~Through() { w(k); m(); } } through{wait_written, mark_written, k};
             if (t.rc) return;
+            (void)hipSetDevice(ctx->device);
             auto t0 = std::chrono::steady_clock::now();
+            if (hipEventSynchronize(t.done) != hipSuccess) { t.rc = NPORE_E_HIP; t.err = "waiting for a batch failed"; return; }
+            t.t_ms[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            const int64_t m = count(k);
+            std::memcpy(t.olen.data(), t.olen_pin.p, (size_t)m * 8);
+            std::memcpy(status + first(k), t.st_pin.p, (size_t)m * 4);
+            t0 = std::chrono::steady_clock::now();
             double ms_std = 0.0;
-            t.rc = slot_post(b, idx + first(k), count(k), status + first(k), threads, t, &ms_std);
+            t.rc = slot_post(b, idx + first(k), m, status + first(k), host_threads_half, t, &ms_std);
             const double ms_post = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             t.t_ms[2] += ms_std;
             t.t_ms[3] += ms_post - ms_std;
             if (t.rc) { t.err = npore_last_error(); return; }
-            if (k > 0) posted[(size_t)(k - 1)].wait();         // records in input order
+            wait_written(k);                                   // records in input order
             t0 = std::chrono::steady_clock::now();
             if (std::fwrite(t.sam.p, 1, (size_t)t.sam_len, fh) != (size_t)t.sam_len) { t.rc = NPORE_E_INVALID; t.err = "short write"; }
             t.t_ms[4] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1870,36 +1902,29 @@ try {
     };
     int rc = NPORE_OK;
     std::string err;
-    auto retire = [&](int64_t k) {                             // batch k's align call has to be over: post it
-        aligned[(size_t)k].wait();
-        npore_batch_slot &s = *ctx->slots[(size_t)(k % S)];
-        if (s.rc && rc == NPORE_OK) { rc = s.rc; err = s.err; }
-        start_post(k);                                         // (a failed batch posts nothing, but keeps the order chain)
-    };
     for (int64_t k = 0; k < std::min<int64_t>(2, nb); k++) start_pack(k);
-    int64_t launched = 0;
     for (int64_t k = 0; k < nb && rc == NPORE_OK; k++) {
         npore_batch_slot &s = *ctx->slots[(size_t)(k % S)];
         packed[(size_t)k].wait();
         if (s.rc) { rc = s.rc; err = s.err; break; }
-        if (k >= 2) retire(k - 2);                             // frees the context batch k will use
-        if (rc != NPORE_OK) break;
         if (k + 2 < nb) start_pack(k + 2);
-        aligned[(size_t)k] = std::async(std::launch::async, [&, k] {
-            npore_batch_slot &t = *ctx->slots[(size_t)(k % S)];
-            (void)hipSetDevice(ctx->device);
-            const auto t0 = std::chrono::steady_clock::now();
-            t.rc = slot_align(gctx[k & 1], count(k), indel_start, indel_extend, max_b_rows, r, status + first(k), t);
-            t.t_ms[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            if (t.rc) t.err = npore_last_error();
-        });
-        launched = k + 1;
+        const int64_t m = count(k);
+        if (!s.olen_pin.ensure((size_t)m * 8 + 64) || !s.st_pin.ensure((size_t)m * 4 + 64)) { rc = NPORE_E_NOMEM; err = "batch buffers"; break; }
+        if (!s.done && hipEventCreateWithFlags(&s.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { rc = NPORE_E_HIP; err = "hipEventCreate"; break; }
+        // (returns once the batch's groups are enqueued; waits only when all work sets of the context are still busy)
+        s.rc = npore_align_batch_async(ctx, m, reinterpret_cast<uint8_t *>(s.refs.p), s.ro.data(), reinterpret_cast<uint8_t *>(s.seqs.p),
+                                       s.so.data(), s.cigs.p, s.co.data(), indel_start, indel_extend, max_b_rows, r, s.alns.p,
+                                       s.oo.data(), reinterpret_cast<int64_t *>(s.olen_pin.p), reinterpret_cast<int32_t *>(s.st_pin.p));
+        if (s.rc) { rc = s.rc; err = npore_last_error(); s.err = err; break; }
+        if (hipEventRecord(s.done, ctx->s_post) != hipSuccess) { rc = NPORE_E_HIP; err = "hipEventRecord"; s.rc = rc; s.err = err; break; }
+        start_post(k);
     }
-    for (int64_t k = std::max<int64_t>(0, launched - 2); k < launched; k++)
-        if (!posted[(size_t)k].valid()) retire(k);
-    for (auto &f : aligned) if (f.valid()) f.wait();
     for (auto &f : packed) if (f.valid()) f.wait();
     for (auto &f : posted) if (f.valid()) f.wait();
+    {
+        const int rcw = npore_ctx_wait(ctx);                   // stage clocks of every group; a failure found while a work set was recycled
+        if (rcw && rc == NPORE_OK) { rc = rcw; err = npore_last_error(); }
+    }
     for (auto &sp : ctx->slots)
         if (rc == NPORE_OK && sp->rc) { rc = sp->rc; err = sp->err; }
     if (std::fclose(fh) != 0 && rc == NPORE_OK) { rc = NPORE_E_INVALID; err = "close failed"; }
@@ -1909,11 +1934,8 @@ try {
     for (auto &sp : ctx->slots)
         for (int q = 0; q < 5; q++) b->file_ms[q] += sp->t_ms[q];
     b->file_ms[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-    for (npore_ctx *g : {ctx, ctx->peer})
-        if (g) {
-            b->file_ms[6] += g->totals[0] + g->totals[1] + g->totals[2] - g->file_mark[0];     // kernels: prep + fill + traceback
-            b->file_ms[7] += g->totals[3] + g->totals[4] - g->file_mark[1];                    // PCIe: H2D + D2H
-        }
+    b->file_ms[6] = ctx->totals[0] + ctx->totals[1] + ctx->totals[2] - ctx->file_mark[0];     // stage clocks of the device path (prep + fill + traceback;
+    b->file_ms[7] = ctx->totals[3] + ctx->totals[4] - ctx->file_mark[1];                     // H2D + D2H): SUMS over groups that run beside each other
     return rc == NPORE_OK ? NPORE_OK : fail(rc, err);
 }
 NPORE_CATCH_INT
