@@ -236,7 +236,9 @@ npore_bam *npore_bam_open(const char *path, int threads);
  * position, span, flag -- what npore_bam_select needs), built in one pass over windows of 256 MB, and every batch
  * (npore_bam_pack*, _format_sam, _realign_batch, _realign_file) inflates just the blocks its records lie in.
  * index_path (may be NULL): a record index written by npore_bam_save_index for this file; the handle then skips its
- * indexing pass -- with one process per GPU, one process of a node indexes and the others load. */
+ * indexing pass -- with one process per GPU, one process of a node indexes and the others load.
+ * mode 3 (ONE-PASS): only the BGZF block table and the BAM header are read; the records are visited once, in file
+ * order, by npore_bam_realign_sequential (such a handle has no record index: npore_bam_select finds nothing). */
 npore_bam *npore_bam_open_mode(const char *path, int threads, int mode, const char *index_path);
 int npore_bam_is_streamed(const npore_bam *bam);
 int npore_bam_save_index(const npore_bam *bam, const char *path);
@@ -293,6 +295,21 @@ int npore_bam_realign_batch(npore_ctx *ctx, npore_bam *bam, const npore_fasta *f
 int npore_bam_realign_file(npore_ctx *ctx, npore_bam *bam, const npore_fasta *fa, const int32_t *fasta_of_ref,
                            const int64_t *idx, int64_t n, int64_t batch_reads, float indel_start, float indel_extend,
                            int max_b_rows, int r, int threads, const char *out_path, int32_t *status);
+/* ONE-PASS ingest: the whole BAM -> realigned SAM run in one sequential pass over the file (reference src/realign.py:
+ * 100-115 with src/bam.pyx:18-47: get_read_data is a generator over bam.fetch(), read by read, feeding the pool).  The
+ * stream is inflated ONCE, window by window (64 MB), the records are filtered as they go by (at most one region per
+ * contig, in the order of the BAM header: the tool's default whole-contig regions; same overlap / flag / max_reads
+ * rules as npore_bam_select), batched, and sent through the same overlapped stages as npore_bam_realign_file -- no
+ * record index, no second inflation, memory bounded by the batches in flight.  `bam`: a handle opened in mode 3
+ * (header only) or 2.  counts[3]: reads selected, reads refused (NPORE_ST_BAD_INPUT, not written), reads with an
+ * inconsistent traceback; bad_ord / bad_status[bad_cap]: ordinal (among the selected reads) and status bits of the
+ * first such reads.  NPORE_E_UNSUPPORTED: the regions or the file's order rule the one-pass run out (the BAM is not
+ * sorted by reference, several regions per contig) -- nothing usable was written: truncate and use the indexed path. */
+int npore_bam_realign_sequential(npore_ctx *ctx, npore_bam *bam, const npore_fasta *fa, const int32_t *fasta_of_ref,
+                                 int n_regions, const int32_t *ref_id, const int64_t *start, const int64_t *stop,
+                                 int64_t max_reads, int64_t batch_reads, float indel_start, float indel_extend,
+                                 int max_b_rows, int r, int threads, const char *out_path, int64_t *counts,
+                                 int64_t *bad_ord, int32_t *bad_status, int64_t bad_cap);
 /* Host wall time of the stages of the last npore_bam_realign_batch on `bam` (milliseconds):
  * ms[0] pack, ms[1] npore_align_batch (incl. PCIe), ms[2] standardise, ms[3] SAM formatting. */
 int npore_bam_last_timing(const npore_bam *bam, double *ms, int n);

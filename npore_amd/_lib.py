@@ -72,6 +72,9 @@ SIGNATURES = {
                                           C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "npore_bam_realign_file": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                          C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_void_p]),
+    "npore_bam_realign_sequential": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_char_p,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "npore_bam_last_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "npore_bam_file_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "npore_debug_dpp": (C.c_int, [C.c_void_p]),

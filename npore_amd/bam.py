@@ -356,10 +356,14 @@ class NativeFastaSeqs:
         return list(self)
 
 
+class OnePassUnsupported(RuntimeError):
+    """NativeBam.realign_sequential cannot serve these regions / this file in one pass (take the indexed path)."""
+
+
 class NativeBam:
     """A BAM file inflated and indexed by the library (same attributes as BamFile where realign needs them)."""
 
-    def __init__(self, path, threads=0, share=None, stream=None):
+    def __init__(self, path, threads=0, share=None, stream=None, one_pass=False):
         """stream: None = the library decides (files above NPORE_BAM_STREAM_MB, default 1 GB, are STREAMED: no
         inflated copy, 22 bytes of index per record, each batch inflates the blocks its reads lie in), True / False force it.
         share: with several processes per node (one per GPU, torch.distributed.run) local rank 0 does the expensive
@@ -373,7 +377,10 @@ class NativeBam:
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if stream is None and os.environ.get("NPORE_BAM_STREAM") in ("0", "1"):
             stream = os.environ["NPORE_BAM_STREAM"] == "1"
-        mode = 0 if stream is None else (2 if stream else 1)
+        mode = 3 if one_pass else 0 if stream is None else (2 if stream else 1)
+        self.one_pass = bool(one_pass)
+        if one_pass:
+            share = False
         if share is None:
             share = local_world > 1 and os.path.isdir("/dev/shm") and os.environ.get("NPORE_SHARE_BAM", "1") != "0"
         will_stream = mode == 2 or (mode == 0 and self._auto_streams(path))
@@ -394,6 +401,14 @@ class NativeBam:
         self.references = [self._lib.npore_bam_ref_name(self.handle, i).decode() for i in range(n)]
         self.lengths = [int(self._lib.npore_bam_ref_len(self.handle, i)) for i in range(n)]
         self.n_records = int(self._lib.npore_bam_n_records(self.handle))
+
+    @staticmethod
+    def is_bgzf(path):
+        try:
+            with open(path, "rb") as fh:
+                return fh.read(2) == b"\x1f\x8b"
+        except OSError:
+            return False
 
     @staticmethod
     def _auto_streams(path):
@@ -566,6 +581,32 @@ class NativeBam:
         self._check(self._lib.npore_bam_format_sam(self.handle, idx.ctypes.data, n, buf.ctypes.data, fo.ctypes.data,
                                                    fl.ctypes.data, st.ctypes.data, threads, C.byref(sam), C.byref(sam_len)))
         return C.string_at(sam.value, sam_len.value).decode() if sam_len.value else ""
+
+    def realign_sequential(self, ctx, fasta, regions, out_path, batch_reads=4000, max_reads=0, r=30, max_b_rows=20000,
+                           indel_start=5.0, indel_extend=1.0, threads=0, bad_cap=1000):
+        """ONE PASS over the file: inflate, filter by `regions` [(contig, start, stop)] (at most one per contig, in header
+        order), batch, realign, write -- npore_bam_realign_sequential.  Returns (reads selected, [(ordinal, status)] of
+        the first bad reads, (refused, inconsistent)); raises OnePassUnsupported when the regions or the file's
+        order rule the one-pass run out (the caller truncates the output and takes the indexed path)."""
+        ids = {n: i for i, n in enumerate(self.references)}
+        rid = np.array([ids.get(c, -2) for c, _, _ in regions], np.int32)
+        beg = np.array([s for _, s, _ in regions], np.int64)
+        end = np.array([e for _, _, e in regions], np.int64)
+        if len(rid) and ((rid < 0).any() or (np.diff(rid) <= 0).any()):
+            raise OnePassUnsupported("regions are not one per contig in header order")
+        counts = np.zeros(3, np.int64)
+        bad_ord, bad_st = np.zeros(max(bad_cap, 1), np.int64), np.zeros(max(bad_cap, 1), np.int32)
+        fmap = self.fasta_map(fasta)
+        rc = self._lib.npore_bam_realign_sequential(ctx.handle, self.handle, fasta.handle, fmap.ctypes.data, len(regions), rid.ctypes.data,
+                                                    beg.ctypes.data, end.ctypes.data, int(max_reads or 0), int(batch_reads), indel_start,
+                                                    indel_extend, max_b_rows, r, threads, os.fsencode(out_path), counts.ctypes.data,
+                                                    bad_ord.ctypes.data, bad_st.ctypes.data, bad_cap)
+        if rc == -5:
+            from . import _lib
+            raise OnePassUnsupported(_lib.last_error())
+        self._check(rc)
+        nb = int(min(bad_cap, counts[1] + counts[2]))
+        return int(counts[0]), list(zip(bad_ord[:nb].tolist(), bad_st[:nb].tolist())), (int(counts[1]), int(counts[2]))
 
     def realign_batch(self, ctx, fasta, idx, r=30, max_b_rows=20000, indel_start=5.0, indel_extend=1.0, threads=0):
         """(SAM text, status[n]) of one batch: pack -> GPU align -> standardise -> format, all in the library."""

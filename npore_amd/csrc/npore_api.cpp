@@ -123,11 +123,13 @@ struct npore_batch_slot {
     RawBuf olen_pin{true}, st_pin{true};   // lengths / status bits of an ASYNCHRONOUS batch land here (page-locked: a copy into
                                            // pageable memory would make the enqueueing call wait for the whole batch)
     hipEvent_t done = nullptr;             // ... behind which this event is recorded (npore_bam_realign_file)
+    std::vector<std::shared_ptr<RawBuf>> keep;   // one-pass ingest: the inflated windows the batch's records lie in
     ~npore_batch_slot() { if (done) (void)hipEventDestroy(done); }
     RecFetch rf;                 // the batch's BAM records (streamed handles: inflated for the batch)
     double t_ms[6] = {0, 0, 0, 0, 0, 0};   // npore_bam_realign_file: fetch + pack, align call, standardise, format, write, (spare)
     std::vector<int64_t> ro, so, co, oo, fo, olen, flen;
     int64_t sam_len = 0;
+    int64_t m = 0;               // reads of the batch
     int rc = 0;
     std::string err;
 };
@@ -1409,8 +1411,37 @@ npore_bam *bam_open_streamed(const char *path, int threads, std::unique_ptr<Prea
 }
 }  // namespace
 
+// ONE-PASS open (mode 3): the BGZF block table and the BAM header, nothing else -- no record is looked at until
+// npore_bam_realign_sequential walks the stream.  Such a handle has no record index: npore_bam_select finds nothing.
+npore_bam *bam_open_header_only(const char *path, int threads, std::unique_ptr<PreadFile> file)
+{
+    std::unique_ptr<npore_bam> hold(new npore_bam());
+    npore_bam *b = hold.get();
+    b->streamed = true;
+    b->file = std::move(file);
+    uint64_t total = 0;
+    if (!bgzf_scan(*b->file, b->blocks, total)) { fail(NPORE_E_INVALID, std::string("'") + path + "' is not a BGZF file"); return nullptr; }
+    b->data_size = (size_t)total;
+    RawBuf head;
+    for (size_t b1 = std::min<size_t>(b->blocks.size(), 16);; b1 = std::min(b->blocks.size(), b1 * 4)) {
+        if (b1 == 0) { fail(NPORE_E_INVALID, std::string("'") + path + "' is not a BAM file"); return nullptr; }
+        const size_t n = (size_t)(b->blocks[b1 - 1].out_off + b->blocks[b1 - 1].out_len);
+        if (!head.ensure(n + 8) || !bgzf_inflate_range(*b->file, b->blocks, 0, b1, reinterpret_cast<uint8_t *>(head.p), threads)) {
+            fail(NPORE_E_INVALID, std::string("'") + path + "': corrupt BGZF block");
+            return nullptr;
+        }
+        size_t hdr_end = 0;
+        const int rc = bam_parse_header(b, reinterpret_cast<const uint8_t *>(head.p), n, &hdr_end);
+        if (rc == 1) break;
+        if (rc == 0 || b1 == b->blocks.size()) { fail(NPORE_E_INVALID, std::string("'") + path + "' is not a BAM file"); return nullptr; }
+    }
+    bam_finish_index(b);                                 // (empty per-reference lists)
+    b->ref_has_reads.assign(b->ref_names.size(), 1);     // unknown without a pass over the records: assume every contig has
+    return hold.release();
+}
+
 // mode 0: automatic (streamed when the file is BGZF and larger than NPORE_BAM_STREAM_MB, default 1024 MB), 1: whole file
-// resident, 2: streamed.  index_path (may be NULL): a record index saved by npore_bam_save_index for this very file --
+// resident, 2: streamed, 3: one-pass (header only; the reads through npore_bam_realign_sequential).  index_path (may be NULL): a record index saved by npore_bam_save_index for this very file --
 // a streamed handle then skips its indexing pass (one process of a node indexes, the others load).
 npore_bam *npore_bam_open_mode(const char *path, int threads, int mode, const char *index_path)
 try {
@@ -1422,6 +1453,8 @@ try {
         const bool gz = pf->size >= 28 && pf->read(0, magic, 4) && magic[0] == 31 && magic[1] == 139;
         uint64_t limit_mb = 1024;
         if (const char *e = std::getenv("NPORE_BAM_STREAM_MB")) limit_mb = (uint64_t)std::max(0ll, std::atoll(e));
+        if (gz && mode == 3) return bam_open_header_only(path, threads, std::move(pf));
+        if (mode == 3) { fail(NPORE_E_INVALID, std::string("'") + path + "' is not a BGZF file (one-pass mode)"); return nullptr; }
         if (gz && (mode == 2 || pf->size > limit_mb * 1048576ull)) return bam_open_streamed(path, threads, std::move(pf), index_path);
         if (mode == 2) { fail(NPORE_E_INVALID, std::string("'") + path + "' is not a BGZF file (streamed mode)"); return nullptr; }
     }
@@ -1750,14 +1783,12 @@ NPORE_CATCH_INT
 
 namespace {
 // pack the selected records into the slot (inputs of npore_align_batch) and size its output buffers
-int slot_pack(const npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref, const int64_t *idx, int64_t n, int threads,
-              npore_batch_slot &s)
+// (the records are in s.rf already)
+int slot_pack_records(const npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref, int64_t n, int threads, npore_batch_slot &s)
 {
     for (auto *v : {&s.ro, &s.so, &s.co, &s.oo, &s.fo}) v->assign((size_t)n + 1, 0);
     s.olen.assign((size_t)n, 0);
     s.flen.assign((size_t)n, 0);
-    if (!pack_args_ok(b, idx, n)) return fail(NPORE_E_INVALID, "bad argument");
-    if (int rc = fetch_records(b, idx, n, threads, s.rf)) return rc;
     pack_sizes_of(s.rf, n, s.ro.data(), s.so.data(), s.co.data(), threads);
     if (!s.refs.ensure((size_t)s.ro[(size_t)n] + 64) || !s.seqs.ensure((size_t)s.so[(size_t)n] + 64) || !s.cigs.ensure((size_t)s.co[(size_t)n] + 64))
         return fail(NPORE_E_NOMEM, "batch buffers");
@@ -1773,6 +1804,13 @@ int slot_pack(const npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of
     if (!s.alns.ensure((size_t)s.oo[(size_t)n] + 64) || !s.finals.ensure((size_t)s.fo[(size_t)n] + 64))
         return fail(NPORE_E_NOMEM, "batch buffers");
     return NPORE_OK;
+}
+int slot_pack(const npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref, const int64_t *idx, int64_t n, int threads,
+              npore_batch_slot &s)
+{
+    if (!pack_args_ok(b, idx, n)) return fail(NPORE_E_INVALID, "bad argument");
+    if (int rc = fetch_records(b, idx, n, threads, s.rf)) return rc;
+    return slot_pack_records(b, fa, fasta_of_ref, n, threads, s);
 }
 int slot_align(npore_ctx *ctx, int64_t n, float indel_start, float indel_extend, int max_b_rows, int r, int32_t *status,
                npore_batch_slot &s)
@@ -1827,88 +1865,102 @@ try {
 }
 NPORE_CATCH_INT
 
-int npore_bam_realign_file(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref, const int64_t *idx,
-                           int64_t n, int64_t batch_reads, float indel_start, float indel_extend, int max_b_rows, int r,
-                           int threads, const char *out_path, int32_t *status)
-try {
-    if (!ctx || !b || !fa || !out_path || (n > 0 && (!idx || !status)) || batch_reads < 1) return fail(NPORE_E_INVALID, "bad argument");
-    FILE *fh = std::fopen(out_path, "ab");
-    if (!fh) return fail(NPORE_E_INVALID, std::string("cannot open '") + out_path + "' for appending");
-    HIP_TRY(hipSetDevice(ctx->device));
+}  // extern "C"
+
+namespace {
+// The BAM -> SAM pipeline over a stream of batches.  Stages: records + pack (helper threads, two batches ahead) | the
+// device path of ONE context through its asynchronous entry point -- a batch is enqueued the moment it is packed and
+// the call returns at once, so up to N_SETS batches are on the device, the upload / preparation of one and the
+// traceback / download of another beside the fill kernel of a third (run_core) | standardise + SAM text + ordered write
+// (helper threads, each behind the event recorded behind its batch's download).  A slot carries a batch through all
+// stages; six slots cover two being packed, three on the device and one being written.
+//   acquire(k, slot) -> the records of batch k in slot.rf: their number, 0 = no further batch, < 0 = failure (fail() called);
+//     serial_acquire: called in batch order (the one-pass reader), else from the packing threads as they come;
+//   on_status(k, m, status bits): in batch order, in front of the batch's text.
+template <class Acquire, class OnStatus>
+int file_pipeline(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref, float indel_start, float indel_extend,
+                  int max_b_rows, int r, int threads, FILE *fh, bool serial_acquire, Acquire acquire, OnStatus on_status)
+{
     for (auto &sp : ctx->slots)
         if (!sp) sp = new npore_batch_slot();
-    const int64_t nb = (n + batch_reads - 1) / batch_reads;
     const auto wall0 = std::chrono::steady_clock::now();
-    for (auto &sp : ctx->slots) std::fill(sp->t_ms, sp->t_ms + 6, 0.0);
+    for (auto &sp : ctx->slots) { std::fill(sp->t_ms, sp->t_ms + 6, 0.0); sp->rc = 0; sp->m = 0; }
     ctx->file_mark[0] = ctx->totals[0] + ctx->totals[1] + ctx->totals[2];
     ctx->file_mark[1] = ctx->totals[3] + ctx->totals[4];
     constexpr int S = npore_ctx::N_SLOTS;
-    auto first = [&](int64_t k) { return k * batch_reads; };
-    auto count = [&](int64_t k) { return std::min(batch_reads, n - k * batch_reads); };
-    // Stages: fetch + pack (helper threads, two batches ahead) | the device path of ONE context through its
-    // asynchronous entry point -- a batch is enqueued the moment it is packed and the call returns at once, so up to
-    // N_SETS batches are on the device, the upload / preparation of one and the traceback / download of another beside
-    // the fill kernel of a third (run_core) | standardise + SAM text + ordered write (helper threads, each behind the
-    // event recorded behind its batch's download).  A slot carries a batch through all stages; six slots cover two
-    // being packed, three on the device and one being written.
-    std::vector<std::future<void>> packed((size_t)nb), posted((size_t)nb);
-    const int host_threads_half = threads > 0 ? std::max(1, threads) : 0;
-    // batches leave in input order: `written` counts the batches that are through (written, or given up on)
+    // Several batches are in the host stages at once (two being packed, up to two being written): each stage gets half
+    // of the CPUs, so that the process does not run five times as many busy threads as it has CPUs -- under a cgroup quota
+    // that ends in the whole process being throttled for the rest of the scheduling period
+    const int half_threads = std::max(1, host_threads(threads) / 2);
+    std::vector<std::future<void>> packed, posted;
+    // batches leave in input order: `written` counts the batches that are through (written, or given up on);
+    // `acquired` the batches whose records have been taken from a serial source
     std::mutex gate_m;
     std::condition_variable gate_cv;
-    int64_t written = 0;
-    auto wait_written = [&](int64_t upto) {                    // until `upto` batches are through
+    int64_t written = 0, acquired = 0;
+    auto wait_for = [&](int64_t &counter, int64_t upto) {
         std::unique_lock<std::mutex> lk(gate_m);
-        gate_cv.wait(lk, [&] { return written >= upto; });
+        gate_cv.wait(lk, [&] { return counter >= upto; });
     };
-    auto mark_written = [&] {
-        { std::lock_guard<std::mutex> lk(gate_m); written++; }
+    auto bump = [&](int64_t &counter) {
+        { std::lock_guard<std::mutex> lk(gate_m); counter++; }
         gate_cv.notify_all();
     };
     auto start_pack = [&](int64_t k) {
-        packed[(size_t)k] = std::async(std::launch::async, [&, k] {
+        packed.push_back(std::async(std::launch::async, [&, k] {
             npore_batch_slot &s = *ctx->slots[(size_t)(k % S)];
-            if (k >= S) wait_written(k - S + 1);               // the slot's previous batch has been written
+            if (k >= S) wait_for(written, k - S + 1);          // the slot's previous batch has been written
+            if (serial_acquire) wait_for(acquired, k);
             const auto t0 = std::chrono::steady_clock::now();
-            s.rc = slot_pack(b, fa, fasta_of_ref, idx + first(k), count(k), host_threads_half, s);
+            s.keep.clear();
+            s.rc = 0;
+            const int64_t m = acquire(k, s);
+            if (serial_acquire) bump(acquired);
+            s.m = m > 0 ? m : 0;
+            if (m < 0) s.rc = (int)m;
+            else if (m > 0) s.rc = slot_pack_records(b, fa, fasta_of_ref, m, half_threads, s);
             s.t_ms[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (s.rc) s.err = npore_last_error();
-        });
+        }));
     };
     auto start_post = [&](int64_t k) {
-        posted[(size_t)k] = std::async(std::launch::async, [&, k] {
+        posted.push_back(std::async(std::launch::async, [&, k] {
             npore_batch_slot &t = *ctx->slots[(size_t)(k % S)];
-            struct Through { decltype(wait_written) &w; decltype(mark_written) &m; int64_t k; ~Through() { w(k); m(); } } through{wait_written, mark_written, k};
+            struct Through { decltype(wait_for) &w; decltype(bump) &m; int64_t &c; int64_t k; ~Through() { w(c, k); m(c); } } through{wait_for, bump, written, k};
             if (t.rc) return;
             (void)hipSetDevice(ctx->device);
             auto t0 = std::chrono::steady_clock::now();
             if (hipEventSynchronize(t.done) != hipSuccess) { t.rc = NPORE_E_HIP; t.err = "waiting for a batch failed"; return; }
             t.t_ms[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            const int64_t m = count(k);
+            const int64_t m = t.m;
             std::memcpy(t.olen.data(), t.olen_pin.p, (size_t)m * 8);
-            std::memcpy(status + first(k), t.st_pin.p, (size_t)m * 4);
+            const int32_t *st = reinterpret_cast<const int32_t *>(t.st_pin.p);
             t0 = std::chrono::steady_clock::now();
             double ms_std = 0.0;
-            t.rc = slot_post(b, idx + first(k), m, status + first(k), host_threads_half, t, &ms_std);
+            t.rc = slot_post(b, nullptr, m, st, half_threads, t, &ms_std);
             const double ms_post = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             t.t_ms[2] += ms_std;
             t.t_ms[3] += ms_post - ms_std;
             if (t.rc) { t.err = npore_last_error(); return; }
-            wait_written(k);                                   // records in input order
+            wait_for(written, k);                              // records in input order
+            on_status(k, m, st);
             t0 = std::chrono::steady_clock::now();
             if (std::fwrite(t.sam.p, 1, (size_t)t.sam_len, fh) != (size_t)t.sam_len) { t.rc = NPORE_E_INVALID; t.err = "short write"; }
             t.t_ms[4] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        });
+            t.keep.clear();
+        }));
     };
     int rc = NPORE_OK;
     std::string err;
-    for (int64_t k = 0; k < std::min<int64_t>(2, nb); k++) start_pack(k);
-    for (int64_t k = 0; k < nb && rc == NPORE_OK; k++) {
+    start_pack(0);
+    start_pack(1);
+    for (int64_t k = 0; rc == NPORE_OK; k++) {
         npore_batch_slot &s = *ctx->slots[(size_t)(k % S)];
         packed[(size_t)k].wait();
         if (s.rc) { rc = s.rc; err = s.err; break; }
-        if (k + 2 < nb) start_pack(k + 2);
-        const int64_t m = count(k);
+        if (s.m == 0) break;                                   // the source is exhausted
+        start_pack(k + 2);
+        const int64_t m = s.m;
         if (!s.olen_pin.ensure((size_t)m * 8 + 64) || !s.st_pin.ensure((size_t)m * 4 + 64)) { rc = NPORE_E_NOMEM; err = "batch buffers"; break; }
         if (!s.done && hipEventCreateWithFlags(&s.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { rc = NPORE_E_HIP; err = "hipEventCreate"; break; }
         // (returns once the batch's groups are enqueued; waits only when all work sets of the context are still busy)
@@ -1925,9 +1977,10 @@ try {
         const int rcw = npore_ctx_wait(ctx);                   // stage clocks of every group; a failure found while a work set was recycled
         if (rcw && rc == NPORE_OK) { rc = rcw; err = npore_last_error(); }
     }
-    for (auto &sp : ctx->slots)
+    for (auto &sp : ctx->slots) {
         if (rc == NPORE_OK && sp->rc) { rc = sp->rc; err = sp->err; }
-    if (std::fclose(fh) != 0 && rc == NPORE_OK) { rc = NPORE_E_INVALID; err = "close failed"; }
+        sp->keep.clear();
+    }
     // stage clocks of this call: sums over the batches of the time each stage's thread spent (stages of
     // neighbouring batches overlap, so the sums exceed the wall time), the wall time, and the GPU's share
     std::fill(b->file_ms, b->file_ms + 8, 0.0);
@@ -1937,6 +1990,179 @@ try {
     b->file_ms[6] = ctx->totals[0] + ctx->totals[1] + ctx->totals[2] - ctx->file_mark[0];     // stage clocks of the device path (prep + fill + traceback;
     b->file_ms[7] = ctx->totals[3] + ctx->totals[4] - ctx->file_mark[1];                     // H2D + D2H): SUMS over groups that run beside each other
     return rc == NPORE_OK ? NPORE_OK : fail(rc, err);
+}
+
+// the variable-length parts the record accessors will walk lie inside the record
+bool record_is_sound(const uint8_t *q)
+{
+    const int32_t bs = rdi32(q);
+    const uint8_t *f = q + 4;
+    const int64_t l_rn = f[8], n_cig = rd16(f + 12), l_seq = rdi32(f + 16);
+    return !(l_rn < 1 || l_seq < 0 || 32 + l_rn + 4 * n_cig + (l_seq + 1) / 2 + l_seq > bs || f[32 + l_rn - 1] != 0);
+}
+}  // namespace
+
+extern "C" {
+
+int npore_bam_realign_file(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref, const int64_t *idx,
+                           int64_t n, int64_t batch_reads, float indel_start, float indel_extend, int max_b_rows, int r,
+                           int threads, const char *out_path, int32_t *status)
+try {
+    if (!ctx || !b || !fa || !fasta_of_ref || !out_path || (n > 0 && (!idx || !status)) || batch_reads < 1) return fail(NPORE_E_INVALID, "bad argument");
+    if (!pack_args_ok(b, idx, n)) return fail(NPORE_E_INVALID, "bad argument");
+    FILE *fh = std::fopen(out_path, "ab");
+    if (!fh) return fail(NPORE_E_INVALID, std::string("cannot open '") + out_path + "' for appending");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int64_t nb = (n + batch_reads - 1) / batch_reads;
+    int rc = file_pipeline(ctx, b, fa, fasta_of_ref, indel_start, indel_extend, max_b_rows, r, threads, fh, false,
+                           [&](int64_t k, npore_batch_slot &s) -> int64_t {
+                               if (k >= nb) return 0;
+                               const int64_t m = std::min(batch_reads, n - k * batch_reads);
+                               const int rcf = fetch_records(b, idx + k * batch_reads, m, threads, s.rf);
+                               return rcf ? (int64_t)rcf : m;
+                           },
+                           [&](int64_t k, int64_t m, const int32_t *st) { std::memcpy(status + k * batch_reads, st, (size_t)m * 4); });
+    if (std::fclose(fh) != 0 && rc == NPORE_OK) rc = fail(NPORE_E_INVALID, "close failed");
+    return rc;
+}
+NPORE_CATCH_INT
+
+int npore_bam_realign_sequential(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref, int n_regions,
+                                 const int32_t *ref_id, const int64_t *start, const int64_t *stop, int64_t max_reads,
+                                 int64_t batch_reads, float indel_start, float indel_extend, int max_b_rows, int r, int threads,
+                                 const char *out_path, int64_t *counts, int64_t *bad_ord, int32_t *bad_status, int64_t bad_cap)
+try {
+    if (!ctx || !b || !fa || !fasta_of_ref || !out_path || !counts || batch_reads < 1 || n_regions < 0 ||
+        (n_regions > 0 && (!ref_id || !start || !stop)) || (bad_cap > 0 && (!bad_ord || !bad_status)))
+        return fail(NPORE_E_INVALID, "bad argument");
+    if (!b->file || b->blocks.empty()) return fail(NPORE_E_INVALID, "one-pass ingest needs a handle opened on a BGZF file (modes 2 and 3)");
+    for (int g = 0; g < n_regions; g++)
+        if (ref_id[g] < 0 || ref_id[g] >= (int32_t)b->ref_names.size() || (g > 0 && ref_id[g] <= ref_id[g - 1]))
+            return fail(NPORE_E_UNSUPPORTED, "one-pass ingest takes at most one region per contig, in the order of the BAM header");
+    counts[0] = counts[1] = counts[2] = 0;
+    FILE *fh = std::fopen(out_path, "ab");
+    if (!fh) return fail(NPORE_E_INVALID, std::string("cannot open '") + out_path + "' for appending");
+    HIP_TRY(hipSetDevice(ctx->device));
+    // the reader: the stream in windows of consecutive BGZF blocks, each inflated ONCE on all cores; a record that
+    // straddles two windows is carried to the front of the next one, so every record lies in one window buffer, which
+    // lives as long as a batch points into it
+    size_t win_blocks = 1024;                // <= 64 MB of inflated stream per window
+    if (const char *e = std::getenv("NPORE_BAM_WINDOW_BLOCKS")) win_blocks = (size_t)std::max(1, std::atoi(e));
+    std::shared_ptr<RawBuf> win;
+    const uint8_t *wd = nullptr;             // the window's first byte (the carried tail sits in front of the inflated blocks)
+    size_t next_block = 0, N = 0, p = 0;
+    bool have_header = false, done = n_regions == 0;
+    int g = 0;
+    int64_t kept = 0, n_bad = 0, ordinal0 = 0;
+    int32_t last_rid = -1;
+    // the next window is inflated (on all cores) while the records of the current one are walked and packed: into its
+    // buffer behind HEAD bytes of room, where the carried tail of the current window is put once the walk has reached it
+    constexpr size_t HEAD = 4u << 20;
+    struct Pending { std::shared_ptr<RawBuf> buf; size_t bytes = 0, b1 = 0; bool ok = false; };
+    std::future<Pending> ahead;
+    auto prefetch = [&](size_t b0) {
+        ahead = std::async(std::launch::async, [&, b0] {
+            Pending pd;
+            pd.b1 = std::min(b->blocks.size(), b0 + win_blocks);
+            const uint64_t w0 = b->blocks[b0].out_off, w1 = b->blocks[pd.b1 - 1].out_off + b->blocks[pd.b1 - 1].out_len;
+            pd.bytes = (size_t)(w1 - w0);
+            pd.buf = std::make_shared<RawBuf>();
+            pd.ok = pd.buf->ensure(HEAD + pd.bytes + 8) &&
+                    bgzf_inflate_range(*b->file, b->blocks, b0, pd.b1, reinterpret_cast<uint8_t *>(pd.buf->p) + HEAD, threads);
+            return pd;
+        });
+    };
+    // -1: failure (fail() called); 0: end of the stream; 1: a new window is in place
+    auto load_window = [&]() -> int {
+        const size_t c = (win && p < N) ? N - p : 0;             // carried tail of the current window
+        if (next_block >= b->blocks.size()) {
+            if (c || !have_header) { fail(NPORE_E_INVALID, have_header ? "truncated BAM record" : "not a BAM file"); return -1; }
+            return 0;
+        }
+        if (!ahead.valid()) prefetch(next_block);
+        Pending pd = ahead.get();
+        if (!pd.ok) { fail(NPORE_E_INVALID, "corrupt BGZF block (or out of memory)"); return -1; }
+        std::shared_ptr<RawBuf> nw = pd.buf;
+        uint8_t *d0 = reinterpret_cast<uint8_t *>(nw->p) + HEAD;
+        if (c > HEAD) {                                          // a record longer than the room in front: copy once
+            auto big = std::make_shared<RawBuf>();
+            if (!big->ensure(c + pd.bytes + 8)) { fail(NPORE_E_NOMEM, "BAM window"); return -1; }
+            std::memcpy(big->p + c, d0, pd.bytes);
+            nw = big;
+            d0 = reinterpret_cast<uint8_t *>(nw->p) + c;
+        }
+        if (c) std::memcpy(d0 - c, wd + p, c);
+        win = nw;
+        wd = d0 - c;
+        N = c + pd.bytes;
+        p = 0;
+        next_block = pd.b1;
+        if (next_block < b->blocks.size()) prefetch(next_block);
+        return 1;
+    };
+    auto acquire = [&](int64_t, npore_batch_slot &s) -> int64_t {
+        s.rf.ptr.clear();
+        while ((int64_t)s.rf.ptr.size() < batch_reads && !done) {
+            const uint8_t *d = wd;
+            if (!have_header) {
+                npore_bam scratch;
+                size_t hdr_end = 0;
+                const int hrc = win ? bam_parse_header(&scratch, d, N, &hdr_end) : -1;
+                if (hrc == 0) return fail(NPORE_E_INVALID, "not a BAM file");
+                if (hrc < 0) {                                   // the header does not end in what is inflated so far
+                    p = 0;
+                    const int lw = load_window();
+                    if (lw < 0) return lw;
+                    if (lw == 0) return fail(NPORE_E_INVALID, "truncated BAM header");
+                    continue;
+                }
+                have_header = true;
+                p = hdr_end;
+                continue;
+            }
+            int32_t bs = 0;
+            if (p + 4 > N || (bs = rdi32(d + p)) < 32 || p + 4 + (size_t)bs > N) {
+                if (p + 4 <= N && bs < 32) return fail(NPORE_E_INVALID, "truncated BAM record");
+                const int lw = load_window();
+                if (lw < 0) return lw;
+                if (lw == 0) done = true;
+                continue;
+            }
+            const uint8_t *q = d + p;
+            p += 4 + (size_t)bs;
+            if (!record_is_sound(q)) return fail(NPORE_E_INVALID, "corrupt BAM record");
+            const RecView rv = rec_view(q);
+            const int32_t rid = rv.ref_id();
+            if (rid < 0) continue;                               // unplaced
+            if (rid < last_rid) return fail(NPORE_E_UNSUPPORTED, "the BAM is not sorted by reference: one-pass ingest needs a coordinate-sorted file");
+            last_rid = rid;
+            while (g < n_regions && ref_id[g] < rid) g++;
+            if (g == n_regions) { done = true; break; }
+            if (ref_id[g] != rid) continue;
+            const int64_t pos = rv.pos(), rl = rec_ref_len(rv);
+            if (!(pos < stop[g] && pos + rl > start[g])) continue;               // overlaps [start, stop)
+            if (max_reads > 0 && kept >= max_reads) { done = true; break; }      // src/bam.pyx:29-30
+            if (rv.flag() & (0x100 | 0x800 | 0x4)) continue;                     // secondary / supplementary / unmapped, :31-32
+            s.rf.ptr.push_back(q);
+            if (s.keep.empty() || s.keep.back() != win) s.keep.push_back(win);
+            kept++;
+        }
+        return (int64_t)s.rf.ptr.size();
+    };
+    auto on_status = [&](int64_t, int64_t m, const int32_t *st) {
+        for (int64_t i = 0; i < m; i++)
+            if (st[i]) {
+                counts[(st[i] & NPORE_ST_BAD_INPUT) ? 1 : 2]++;
+                if (n_bad < bad_cap) { bad_ord[n_bad] = ordinal0 + i; bad_status[n_bad] = st[i]; }
+                n_bad++;
+            }
+        ordinal0 += m;
+    };
+    int rc = file_pipeline(ctx, b, fa, fasta_of_ref, indel_start, indel_extend, max_b_rows, r, threads, fh, true, acquire, on_status);
+    if (ahead.valid()) ahead.wait();                             // (a window inflated ahead of a stream that ended early)
+    counts[0] = ordinal0;
+    if (std::fclose(fh) != 0 && rc == NPORE_OK) rc = fail(NPORE_E_INVALID, "close failed");
+    return rc;
 }
 NPORE_CATCH_INT
 

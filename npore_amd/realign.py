@@ -62,7 +62,13 @@ def main():
     print("> reading reference")
     ref_seqs = bam_mod.NativeFasta(cfg.args.ref) if native else bam_mod.read_fasta(cfg.args.ref)
     print("> selecting BAM regions")
-    bam = bam_mod.NativeBam(cfg.args.bam, threads=threads) if native else bam_mod.BamFile(cfg.args.bam)
+    # One process, the native reader, batches written by the library: ONE PASS over the BAM (bam.NativeBam.realign_sequential:
+    # no record index, every block inflated once, ingest overlapped with the GPU) -- the way the reference itself reads,
+    # a generator over bam.fetch() (src/bam.pyx:18-47).  Several ranks, or regions / a file order that rule it out: the
+    # indexed reader.
+    one_pass = (native and dist_mod.world()[1] == 1 and cfg.args.batch_reads > 0 and not getattr(cfg.args, "bed", None)
+                and os.environ.get("NPORE_BAM_ONE_PASS", "1") != "0" and bam_mod.NativeBam.is_bgzf(cfg.args.bam))
+    bam = bam_mod.NativeBam(cfg.args.bam, threads=threads, one_pass=one_pass) if native else bam_mod.BamFile(cfg.args.bam)
     bam_mod.get_bam_regions(bam, ref_seqs)
 
     if cfg.args.recalc_cms:              # src/realign.py:92-95 + src/bam.pyx:166-200
@@ -94,7 +100,27 @@ def main():
     n_dev = max(aln.device_count(), 1)
     ctx = aln.Context(cfg.args.sub_scores, cfg.args.np_scores, device=cfg.args.device % n_dev)
     n = 0
-    if native:
+    done = False
+    if native and one_pass:
+        print("> computing individual read realignments")
+        header_bytes = os.path.getsize(out_sam)
+        try:
+            n, bad, _ = bam.realign_sequential(ctx, ref_seqs, cfg.args.regions, out_sam, batch_reads=cfg.args.batch_reads,
+                                               max_reads=cfg.args.max_reads, threads=threads)
+            for k, st in bad:
+                print(f"\nERROR: read #{k} of the selected reads: " +
+                      ("CIGAR does not match sequence lengths; skipped." if st & 32 else f"inconsistent traceback (status {st})"))
+            done = True
+        except bam_mod.OnePassUnsupported as e:
+            print(f"    ({e}: taking the indexed reader)")
+            with open(out_sam, "r+b") as fh:
+                fh.truncate(header_bytes)
+            bam.close()
+            bam = bam_mod.NativeBam(cfg.args.bam, threads=threads)
+    if done:
+        bam.close()
+        ref_seqs.close()
+    elif native:
         idx = bam.select(cfg.args.regions, cfg.args.max_reads)
         # reads are independent: dealt by index, no data-path collective.  A resident BAM is dealt round-robin; a
         # STREAMED one in contiguous shares, so that a rank only ever inflates the blocks that hold its own reads

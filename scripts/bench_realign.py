@@ -104,6 +104,25 @@ def run_file(ctx, bp, fa, clen, a, out, stream):
     return res
 
 
+def run_one_pass(ctx, bp, fa, clen, a, out):
+    """header-only open -> npore_bam_realign_sequential (what `realign` does for one process and whole-contig regions)"""
+    t0 = time.perf_counter()
+    nb, nf = bam.NativeBam(bp, one_pass=True, threads=a.threads), bam.NativeFasta(fa)
+    t1 = time.perf_counter()
+    bam.create_header(out, nb)
+    n, bad, _ = nb.realign_sequential(ctx, nf, [("ctg", 0, clen - 1)], out, batch_reads=a.batch, r=a.r, threads=a.threads)
+    t2 = time.perf_counter()
+    ft = nb.file_timing()
+    res = {"one_pass": True, "reads": int(n), "open_header_s": round(t1 - t0, 3), "realign_s": round(t2 - t1, 3), "total_s": round(t2 - t0, 3),
+           "reads_per_s": round(n / (t2 - t0), 1),
+           "stage_sums_s": {k[:-3]: round(v * 1e-3, 3) for k, v in ft.items() if k not in ("wall_ms",)},
+           "stage_sums_note": "fetch_pack includes the inflation of every block (once); align_call = waiting for a batch's completion event; "
+                              "gpu_kernels / pcie are sums of stage times of groups that overlap on the device",
+           "sam_bytes": os.path.getsize(out) if out != "/dev/null" else None, "bad_reads": len(bad)}
+    nb.close(); nf.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=48000)
@@ -141,9 +160,14 @@ def main():
                               "input_generation_s": round(t_gen, 1)}))
             ctx.close()
             return
+        one_pass = run_one_pass(ctx, bp, fa, clen, a, out + ".o")
+        one_pass["peak_rss_mb"] = round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0, 1)
         resident = run_file(ctx, bp, fa, clen, a, out, False)
         resident["peak_rss_mb"] = round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0, 1)
         same = os.path.getsize(out) == os.path.getsize(out + ".s") and open(out, "rb").read(1 << 24) == open(out + ".s", "rb").read(1 << 24)
+        import hashlib
+        digest = lambda f: hashlib.sha256(open(f, "rb").read()).hexdigest()
+        same_one_pass = digest(out) == digest(out + ".o")
         # the pure-Python restatement on a few reads
         k = min(a.py_reads, a.reads)
         cfg.args.max_reads = k
@@ -159,7 +183,9 @@ def main():
                 bam.realign_reads(ctx, rds, os.path.join(tmp, "py.sam"), r=a.r)
                 t2 = time.perf_counter()
                 py = {"reads": k, "parse_whole_bam_s": round(t1 - t0, 3), "per_read_pipeline_ms": round((t2 - t1) / max(k, 1) * 1e3, 2)}
-        line = {"metric": "BAM->SAM realigned reads/sec (end to end, file to file)", "value": resident["reads_per_s"], "unit": "reads/s",
+        line = {"metric": "BAM->SAM realigned reads/sec (end to end, file to file)", "value": one_pass["reads_per_s"], "unit": "reads/s",
+                "value_is": "the one-pass reader (what `python -m npore_amd.realign` uses for one process and whole-contig regions)",
+                "one_pass": one_pass, "one_pass_output_identical": same_one_pass,
                 "reads": a.reads, "distinct_reads": min(a.distinct, a.reads), "ref_len": a.ref_len, "r": a.r, "batch": a.batch,
                 "host_cpus": len(os.sched_getaffinity(0)), "bam_bytes": os.path.getsize(bp),
                 "resident": resident, "streamed": streamed, "streamed_output_identical": same,

@@ -497,6 +497,11 @@ def test_realign_cli_end_to_end(tmp_path):
                           cwd=REPO)
     body = lambda path: [l for l in open(path) if not l.startswith("@PG")]
     assert body(prefix + ".sam") == body(prefix + "_py.sam")
+    # (the default run above read the BAM in ONE PASS; the indexed reader, which several ranks and BED regions use, writes the same)
+    subprocess.check_call([sys.executable, "-m", "npore_amd.realign", "--bam", os.path.join(GOLDEN, "data", "reads.bam"),
+                           "--ref", os.path.join(GOLDEN, "data", "ref.fasta"), "--out_prefix", prefix + "_ix"],
+                          cwd=REPO, env=dict(os.environ, NPORE_BAM_ONE_PASS="0"))
+    assert body(prefix + ".sam") == body(prefix + "_ix.sam")
 
     def records(path):
         hdr, recs = [], {}
@@ -576,6 +581,26 @@ def test_native_realign_batch_matches_python_pipeline(ctx, tmp_path):
         text4, st4 = ns.realign_batch(ctx, nf, idx[::-1], r=30)
         assert np.array_equal(st4, pst[::-1]) and sorted(bytes(text4).splitlines()) == sorted(text.splitlines())
         ns.close()
+        # ONE PASS over the file (header-only handle, no record index; every block inflated once, records filtered as they
+        # go by): the same bytes, the refused read reported by its ordinal -- also with one-block windows, so that nearly
+        # every record straddles two windows
+        for win in (None, "1"):
+            if win:
+                os.environ["NPORE_BAM_WINDOW_BLOCKS"] = win
+            try:
+                no = bam.NativeBam(str(tmp_path / "s.bam"), one_pass=True)
+                assert no.one_pass and no.references == nb.references and no.lengths == nb.lengths and len(no.select(cfg.args.regions)) == 0
+                out5 = tmp_path / f"onepass{win}.sam"
+                n5, bad5, (refused5, incons5) = no.realign_sequential(ctx, nf, cfg.args.regions, str(out5), batch_reads=5, r=30)
+                assert out5.read_bytes() == text and n5 == len(rds) and (refused5, incons5) == (1, 0) and bad5 == [(7, 32)]
+                out6 = tmp_path / f"onepass_cap{win}.sam"
+                n6, _, _ = no.realign_sequential(ctx, nf, cfg.args.regions, str(out6), batch_reads=4, max_reads=9, r=30)
+                assert n6 == 9 and out6.read_bytes() == b"".join(text.splitlines(keepends=True)[:8])      # (read 7 of the 9 is refused)
+                with pytest.raises(bam.OnePassUnsupported):
+                    no.realign_sequential(ctx, nf, cfg.args.regions * 2, str(tmp_path / "x.sam"), r=30)
+                no.close()
+            finally:
+                os.environ.pop("NPORE_BAM_WINDOW_BLOCKS", None)
     finally:
         cfg.args = old
 

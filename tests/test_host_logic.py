@@ -428,6 +428,19 @@ def test_inflated_bam_copy_shared_between_local_ranks(tmp_path, monkeypatch):
     assert dist.host_threads_per_rank() >= 1
 
 
+def test_one_pass_handle_reads_only_the_header():
+    """npore_bam_open_mode(..., 3): block table + BAM header, no record index (the reads go through
+    npore_bam_realign_sequential in one pass); a file that is not BGZF is refused."""
+    path = os.path.join(GOLDEN, "data", "reads.bam")
+    full, head = bam.NativeBam(path, share=False), bam.NativeBam(path, one_pass=True)
+    assert head.one_pass and head.streamed and head.references == full.references and head.lengths == full.lengths
+    assert head.n_records == 0 and len(head.select([("ref", 0, 1000)])) == 0 and head.refs_with_reads() == {0}
+    lib = _lib.load()
+    assert not lib.npore_bam_open_mode(os.path.join(GOLDEN, "data", "ref.fasta").encode(), 0, 3, None)
+    assert "BGZF" in _lib.last_error()
+    full.close(); head.close()
+
+
 def test_native_bam_clips_flags_tags(tmp_path):
     """A synthetic BAM with soft/hard clips, IUPAC bases, missing qualities, HP tags of several widths,
     secondary / supplementary / unmapped records, two contigs and reads hanging over a contig end."""
