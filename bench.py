@@ -251,6 +251,7 @@ def main():
     from npore_amd import synth, aln
     n = args.reads
     n_uniq = min(args.unique, n) if args.unique > 0 else n
+    t_setup0 = time.perf_counter()
     refs, seqs, cigs = make_reads(synth, args, n_uniq, rank, world)
     if n_uniq < n:
         rep = [k % n_uniq for k in range(n)]
@@ -259,6 +260,7 @@ def main():
     prod_reads = None
     if args.production > 0:
         prod_reads = make_reads(synth, args, args.production_reads, rank, world, ref_len=10_000, mixed=False, base_seed=2)
+    t_generate = time.perf_counter() - t_setup0          # host-side input generation of this rank: BEFORE the timed region
 
     # ---- 2. CPU baseline (forked pools: before the HIP runtime exists in this process)
     cpu, cpu_want = None, {}
@@ -389,8 +391,10 @@ def main():
     # the only collective of the job: sum of counters, max of the elapsed time
     from npore_amd.dist import reduce_counters
     sums, maxes = reduce_counters({"reads": n * args.steps, "bad": int(sum((o[2] != 0).sum().item() for o in outs))},
-                                  {"elapsed": elapsed}, device=dev if backend == "nccl" else None)
+                                  {"elapsed": elapsed, "generate": t_generate, "until_timed": t0 - t_setup0},
+                                  device=dev if backend == "nccl" else None)
     elapsed = maxes["elapsed"]
+    assert t_setup0 + t_generate <= t0                   # (generation is over before the first barrier of the timed region)
     n_bad = int(sums["bad"])
     total_reads = int(sums["reads"])
     assert total_reads == n * world * args.steps
@@ -640,7 +644,10 @@ def main():
                        "batches_in_flight": n_ctx, "pipelined": pipelined, "devices_visible": n_dev,
                        "value_excludes": "H2D/D2H: inputs and outputs stay in HBM across the timed region (the contract of "
                                          "`value`); the same batch through page-locked host buffers is `value_pcie_inclusive`",
-                       "reduction_backend": {"nccl": "rccl", "gloo": "gloo (ranks share a device)", None: "none"}[backend]},
+                       "reduction_backend": {"nccl": "rccl", "gloo": "gloo (ranks share a device)", None: "none"}[backend],
+                       "host_setup": {"generate_s_max_over_ranks": round(maxes["generate"], 2),
+                                      "start_to_timed_region_s_max_over_ranks": round(maxes["until_timed"], 2),
+                                      "note": "every rank generates its own reads before the first barrier: outside the timed region"}},
             "roofline": roofline, "cpu_baseline": cpu,
             "value_pcie_inclusive": pcie, "sustained": sustained, "production_default": production,
             "stage_ms": {"fill_alone": round(fill_avg_ms, 2), "fill_event_to_event_overlapped": round(fill_region_ms, 2),

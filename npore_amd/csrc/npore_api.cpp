@@ -371,7 +371,6 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     int64_t max_len = 0;
     for (int64_t i = g0; i < g1; i++)
         max_len = std::max({max_len, a.h_seq_off[i + 1] - a.h_seq_off[i], a.h_ref_off[i + 1] - a.h_ref_off[i]});
-    const size_t pstride = ((size_t)std::min<int64_t>(max_len, a.max_b_rows) + 1 + 15) & ~(size_t)15;
     int64_t max_chunks = 0;
     for (int64_t k = g0; k < g1; k++) max_chunks += chunk_bound(a.h_cig_off[k + 1] - a.h_cig_off[k], a.max_b_rows);
     if (max_chunks > (1ll << 30)) return fail(NPORE_E_UNSUPPORTED, "too many chunks in one group");
@@ -444,7 +443,6 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
         out_read_base = 0;
     }
     pp.max_b_rows = a.max_b_rows; pp.r = r; pp.tbstride = tbs; pp.max_n = ctx->max_n; pp.max_l = ctx->max_l;
-    pp.pstride = (int)pstride;
     pp.max_chunks = (int)max_chunks;
     int32_t *i32 = w->rd_i32.as<int32_t>();
     pp.rd_nsteps = i32;
@@ -464,7 +462,6 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     pp.seqw = w->seqw.as<uint32_t>();
     pp.refw = w->refw.as<uint4>();
     pp.refl = w->refl.as<uint2>();
-    pp.seql = w->seql.as<uint2>();
 
     if (int rc = w->h_cnt.ensure(64)) return rc;
     HIP_TRY(hipEventRecord(w->ev[0], s));
@@ -686,8 +683,7 @@ int run_core(npore_ctx *ctx, const AlignArgs &a, const OutTarget &ot, hipStream_
         while (g1 < a.n_reads && g1 - g0 < max_group) {
             const int64_t cl = a.h_cig_off[g1 + 1] - a.h_cig_off[g1];
             // traceback words + the per-step / per-base side arrays (steps, inss, refw, refl, seqw, runs: < 48 B per op)
-            // (+ 24 B per op: the annotation planes in global memory of a group prepared beside another one's fill)
-            const int64_t need = (2 * cl + chunk_bound(cl, a.max_b_rows)) * tbs * 4 + (ctx->coresident ? 72 : 48) * cl;
+            const int64_t need = (2 * cl + chunk_bound(cl, a.max_b_rows)) * tbs * 4 + 48 * cl;
             if (g1 > g0 && acc + need > budget) break;
             acc += need;
             g1++;

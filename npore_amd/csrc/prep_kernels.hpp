@@ -13,9 +13,8 @@
 //                   (src/aln.pyx:349-357), rectangle, sizes, size histogram
 //   chunk_scan      offsets of every chunk's arrays; schedule positions
 //   sched_scatter   chunk order for the fill kernel, largest first
-//   annotate        per chunk and sequence: n-polymer annotation
-//                   (get_np_info, src/aln.pyx:179-251, on the chunk slices of
-//                   src/aln.pyx:453-456) and word packing (layout.hpp)
+//   (annot_wave.hpp: annotate_wave_kernel -- per chunk and sequence the n-polymer annotation, get_np_info
+//                   src/aln.pyx:179-251 on the chunk slices of src/aln.pyx:453-456, and the word packing of layout.hpp)
 // All launches are sized from host-known upper bounds and read the actual counts
 // from device memory, so no host synchronisation is needed in between.
 #pragma once
@@ -35,7 +34,6 @@ struct PrepParams {
     const char *cigs;
     const int64_t *cig_off;
     int max_b_rows, r, tbstride, max_n, max_l;
-    int pstride;               // annotate: bytes per plane (>= longest chunk slice, multiple of 16)
     int max_chunks;            // capacity of the chunk arrays
     // per read
     int32_t *rd_nsteps;        // [n]
@@ -59,7 +57,6 @@ struct PrepParams {
     uint32_t *seqw;
     uint4 *refw;
     uint2 *refl;               // per reference position: bytes 0-5 L for n=1..6, byte 6 L_IDX==0 mask
-    uint2 *seql;               // same for read positions (scratch)
 };
 
 // ---------------------------------------------------------------------------
@@ -382,12 +379,10 @@ __global__ __launch_bounds__(256) void sched_scatter_kernel(PrepParams p)
 // one period (compile-time, so that the divisions by n and the shorter-period loop unroll)
 // GRID = false: the windows are dealt over the waves of this workgroup (which then owns the whole sequence);
 // GRID = true: over the waves of the whole launch (one launch per period: the next period reads this one's plane).
-// PRE = true: the indicator masks of all windows and periods were computed beforehand (indicator_masks below,
-// mrow = this period's row: one 64-bit word per window, nwin of them) -- a window then gets its own word and the
-// 16 before / 47 behind it in ONE coalesced read (lane l holds word w - 16 + l), and following a run into the
-// neighbouring windows is scalar work on words picked from that register; PRE = false computes every mask it looks
-// at from the bases (ballots).  All lanes of a window that reach its end are in the SAME run, so the extension is
-// wave-uniform either way.
+// Every mask a window looks at is computed from the bases (ballots); all lanes of a window that reach its end are in
+// the SAME run, so following a run into the neighbouring windows is wave-uniform.
+// (This per-position formulation serves the get_np_info() API and the genome-scale region kernels; the batch path's
+// chunk slices go through the wave-local formulation of annot_wave.hpp.)
 // does w hold K consecutive one bits?  (log-step: x bit p = "ones at p ... p + have - 1")
 template <int K>
 __host__ __device__ __forceinline__ bool has_run_of(unsigned long long w)
@@ -400,11 +395,9 @@ __host__ __device__ __forceinline__ bool has_run_of(unsigned long long w)
     return x != 0ull;
 }
 
-constexpr int MASK_BACK = 16;      // mask words held in front of the window's own (>= (max_l + 2) * 6 / 64 + 2 for max_l <= 127)
-template <int n, bool GRID = false, bool PRE = false>
+template <int n, bool GRID = false>
 __device__ __forceinline__ void annotate_period(const uint8_t *seq, int len, int max_n, int max_l, uint8_t *planes,
-                                                int pstride, int32_t *Lout, int32_t *Iout, int ostride = 0,
-                                                const unsigned long long *mrow = nullptr)
+                                                int pstride, int32_t *Lout, int32_t *Iout, int ostride = 0)
 {
     // (the wave index is wave-uniform: saying so keeps the window loops and their bounds in scalar registers)
     const int lane = threadIdx.x & 63;
@@ -412,43 +405,13 @@ __device__ __forceinline__ void annotate_period(const uint8_t *seq, int len, int
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (GRID ? (int)blockIdx.x * wpb : 0);
     const int64_t wstep = (int64_t)(GRID ? (int)gridDim.x * wpb : wpb) * 64;
     uint8_t *Ln = planes + (size_t)(n - 1) * pstride;
-    const int nwin = (len + 63) >> 6;
     for (int64_t base64 = (int64_t)wave * 64; base64 < len; base64 += wstep) {
         const int base = (int)base64;
         const int pos = base + lane;
         auto e_at = [&](int q) { return q >= 0 && q + n < len && seq[q] == seq[q + n]; };
-        unsigned long long mv = 0ull;      // PRE: lane l holds the mask word of window (base >> 6) - MASK_BACK + l
-        if constexpr (PRE) {
-            const int wi = (base >> 6) - MASK_BACK + lane;
-            if (wi >= 0 && wi < nwin) mv = mrow[wi];
-        }
-        // mask word of the window `k` windows after (k < 0: before) this one; k wave-uniform, -MASK_BACK <= k < 48
-        auto mask_at = [&](int k) -> unsigned long long {
-            if constexpr (PRE) {
-                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mv, MASK_BACK + k);
-                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mv >> 32), MASK_BACK + k);
-                return ((unsigned long long)hi << 32) | lo;
-            } else {
-                return __builtin_amdgcn_ballot_w64(e_at(base + 64 * k + lane));
-            }
-        };
+        // mask word of the window `k` windows after (k < 0: before) this one; k wave-uniform
+        auto mask_at = [&](int k) -> unsigned long long { return __builtin_amdgcn_ballot_w64(e_at(base + 64 * k + lane)); };
         const unsigned long long M0 = mask_at(0);
-        if constexpr (PRE) {
-            // Scalar pre-test: a position with three or more repeats in reach (J + q >= 2 below) lies in, or just
-            // behind, a run of at least 2 n ones of e_n, and such a run has 2 n consecutive ones within 2 n positions
-            // of the window.  Three overlapping 64-bit views cover those positions; no such run in any of them --
-            // most windows of the periods above 1 -- and the plane is zero here without any per-position work.
-            if (!Lout && !xp::NOPRETEST) {
-                constexpr int k2 = 2 * n;
-                const unsigned long long Mp = mask_at(-1), Mn = mask_at(1);       // (zero beyond the sequence's ends)
-                const unsigned long long A = (M0 << k2) | (Mp >> (64 - k2));      // positions base - 2n ... base + 63 - 2n
-                const unsigned long long C = (M0 >> k2) | (Mn << (64 - k2));      // positions base + 2n ... base + 63 + 2n
-                if (!(has_run_of<k2>(A) || has_run_of<k2>(M0) || has_run_of<k2>(C))) {
-                    if (pos < len) Ln[pos] = 0;
-                    continue;
-                }
-            }
-        }
         // forward run from pos
         int kf;
         {
@@ -527,157 +490,15 @@ __device__ __forceinline__ void annotate_period(const uint8_t *seq, int len, int
     }
 }
 
-// Indicator masks of a sequence owned by this workgroup: masks[(n-1) * mstride + w] bit l = e_n[64 w + l] =
-// (seq[p] == seq[p + n]) with p + n < len, for every window w and period n <= max_n.  One pass: a position reads its
-// own base and the six behind it once for all periods.
-__device__ __forceinline__ void indicator_masks(const uint8_t *seq, int len, int max_n, unsigned long long *masks, int mstride)
-{
-    const int lane = threadIdx.x & 63;
-    const int wpb = blockDim.x >> 6;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    for (int base = wave * 64; base < len; base += wpb * 64) {
-        const int pos = base + lane;
-        const int c = pos < len ? seq[pos] : -1;
-        unsigned long long mine = 0ull;
-#pragma unroll
-        for (int n = 1; n <= MAX_PERIOD; n++) {
-            const bool e = n <= max_n && pos + n < len && seq[pos + n] == c;
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(e);
-            mine = (lane == n - 1) ? m : mine;
-        }
-        if (lane < max_n) masks[(size_t)lane * mstride + (base >> 6)] = mine;
-    }
-    __threadfence_block();
-    __syncthreads();
-}
-
-// masks = nullptr: every period computes the masks it needs from the bases (callers without scratch for them)
 __device__ __forceinline__ void annotate_sequence(const uint8_t *seq, int len, int max_n, int max_l,
-                                                  uint8_t *planes, int pstride, int32_t *Lout, int32_t *Iout,
-                                                  unsigned long long *masks = nullptr, int mstride = 0)
+                                                  uint8_t *planes, int pstride, int32_t *Lout, int32_t *Iout)
 {
-    if (masks) {
-        indicator_masks(seq, len, max_n, masks, mstride);
-        if (max_n >= 1) annotate_period<1, false, true>(seq, len, max_n, max_l, planes, pstride, Lout, Iout, 0, masks);
-        if (max_n >= 2) annotate_period<2, false, true>(seq, len, max_n, max_l, planes, pstride, Lout, Iout, 0, masks + mstride);
-        if (max_n >= 3) annotate_period<3, false, true>(seq, len, max_n, max_l, planes, pstride, Lout, Iout, 0, masks + 2 * mstride);
-        if (max_n >= 4) annotate_period<4, false, true>(seq, len, max_n, max_l, planes, pstride, Lout, Iout, 0, masks + 3 * mstride);
-        if (max_n >= 5) annotate_period<5, false, true>(seq, len, max_n, max_l, planes, pstride, Lout, Iout, 0, masks + 4 * mstride);
-        if (max_n >= 6) annotate_period<6, false, true>(seq, len, max_n, max_l, planes, pstride, Lout, Iout, 0, masks + 5 * mstride);
-        return;
-    }
     if (max_n >= 1) annotate_period<1>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
     if (max_n >= 2) annotate_period<2>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
     if (max_n >= 3) annotate_period<3>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
     if (max_n >= 4) annotate_period<4>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
     if (max_n >= 5) annotate_period<5>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
     if (max_n >= 6) annotate_period<6>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
-}
-
-// scratch of one annotate workgroup: 6 byte planes of pstride (a multiple of 16) + 6 rows of indicator-mask words
-__host__ __device__ static inline int annotate_mask_words(int pstride) { return (pstride + 63) >> 6; }
-__host__ __device__ static inline size_t annotate_scratch_bytes(int pstride)
-{
-    return (size_t)6 * pstride + (size_t)MAX_PERIOD * 8 * annotate_mask_words(pstride);
-}
-
-// One workgroup per (chunk, sequence).  The slice and the L planes are staged in LDS
-// (7 bytes per position) when they fit; otherwise the planes live in global scratch.
-// SEQ_IN_LDS = false (with the planes in global scratch too): no LDS at all -- the slice is read where it lies
-// (cache hits after the first touch).  Slower on its own, but such a workgroup finds room on a CU whose LDS a
-// fill-kernel workgroup holds: the variant for preparing the next group of reads BESIDE a running fill kernel.
-template <bool PLANES_IN_LDS, bool SEQ_IN_LDS = true>
-__global__ __launch_bounds__(1024) void annotate_kernel(PrepParams p)
-{
-    static_assert(SEQ_IN_LDS || !PLANES_IN_LDS, "planes in LDS imply the slice in LDS");
-    extern __shared__ __attribute__((aligned(16))) uint8_t sbuf[];
-    const int k = blockIdx.x >> 1;
-    const bool is_ref = blockIdx.x & 1;
-    if (k >= p.counters[0]) return;
-    const ChunkDesc d = p.descs[k];
-    const int64_t rd = d.read_id;
-    const int64_t T = is_ref ? p.ref_off[rd + 1] - p.ref_off[rd] : p.seq_off[rd + 1] - p.seq_off[rd];
-    const int start = is_ref ? d.col0 : d.row0, span = is_ref ? d.dcols : d.drows;
-    const int len = (int)(((int64_t)start + span + 1 < T ? (int64_t)start + span + 1 : T) - start);   // src/aln.pyx:453-454
-    const uint8_t *g = (is_ref ? p.refs + p.ref_off[rd] : p.seqs + p.seq_off[rd]) + start;
-    const int pstride = p.pstride;
-    const uint8_t *sseq = g;
-    const int mstride = annotate_mask_words(pstride);      // indicator-mask words per period (one per 64 positions)
-    uint8_t *planes;   // a compile-time choice, so that the LDS case uses ds_* instructions rather than flat ones
-    unsigned long long *masks;
-    if constexpr (PLANES_IN_LDS) {
-        planes = sbuf + pstride;
-        masks = reinterpret_cast<unsigned long long *>(sbuf + (size_t)7 * pstride);
-    } else {
-        planes = reinterpret_cast<uint8_t *>(p.seql) + (size_t)blockIdx.x * annotate_scratch_bytes(pstride);
-        masks = reinterpret_cast<unsigned long long *>(planes + (size_t)6 * pstride);
-    }
-    if constexpr (SEQ_IN_LDS) {
-        for (int q = threadIdx.x; q < len; q += blockDim.x) sbuf[q] = g[q];
-        sseq = sbuf;
-        __syncthreads();
-    }
-    if constexpr (!(xp::ANN & 2)) annotate_sequence(sseq, len, p.max_n, p.max_l, planes, pstride, nullptr, nullptr, masks, mstride);
-    if constexpr ((xp::ANN & 1) != 0) return;
-    auto Lat = [&](int pos, int n) -> uint32_t { return planes[(size_t)(n - 1) * pstride + pos] & 127u; };
-    auto idx0 = [&](int pos, int n) -> bool { return (planes[(size_t)(n - 1) * pstride + pos] >> 7) != 0u; };
-    if (!is_ref) {
-        uint32_t *seqw = p.seqw + d.seqw_off;
-        for (int i = threadIdx.x; i <= span; i += blockDim.x) {
-            uint32_t w = 0;
-            for (int q = 0; q < 6; q++) {
-                const int pp = i - 6 + q;
-                w |= ((pp < 0) ? 7u : (uint32_t)sseq[pp]) << (MER_SHIFT + 3 * q);
-            }
-            for (int n = 1; n <= p.max_n; n++) {
-                const int pp = i - n;
-                if (pp >= 0 && pp < len && Lat(pp, n) != 0) {
-                    w |= 1u << (FLAG_SHIFT + n - 1);
-                    if (idx0(pp, n)) w |= 1u << (n - 1);
-                }
-            }
-            seqw[i] = w;
-        }
-    } else {
-        uint4 *refw = p.refw + d.refw_off;
-        uint2 *refl = p.refl + d.refw_off;
-        for (int j = threadIdx.x; j <= span; j += blockDim.x) {
-            uint32_t x = 0, y = 0, l03 = 0, l45 = 0;
-            for (int q = 0; q < 6; q++) {
-                const int pp = j + q;
-                x |= ((pp >= len) ? 6u : (uint32_t)sseq[pp]) << (MER_SHIFT + 3 * q);
-            }
-            for (int n = 1; n <= p.max_n; n++) {
-                if (j < len) {
-                    const uint32_t l = Lat(j, n);
-                    if (n <= 4) l03 |= l << (8 * (n - 1)); else l45 |= l << (8 * (n - 5));
-                    if (l != 0 && idx0(j, n)) x |= 1u << (FLAG_SHIFT + n - 1);
-                }
-                const int pp = j - n;
-                if (pp >= 0 && pp < len && Lat(pp, n) != 0) {
-                    y |= 1u << (n - 1);
-                    if (idx0(pp, n)) y |= 1u << (6 + n - 1);
-                }
-            }
-            if (j >= 1) x |= (uint32_t)sseq[j - 1];
-            // pre-decoded SHR candidates: the two highest periods flagged in y (layout.hpp)
-            uint32_t dsc0 = 0u, dsc1 = 0u;
-            int nd = 0;
-            for (int n = p.max_n; n >= 1; n--) {
-                if (!((y >> (n - 1)) & 1u)) continue;
-                const uint32_t l = Lat(j - n, n);
-                const uint32_t v = make_shr_desc(n, ((y >> (6 + n - 1)) & 1u) != 0u, l, p.max_l);
-                if (nd == 0) dsc0 = v;
-                else if (nd == 1) dsc1 = v;
-                else dsc1 |= DSC_MORE;
-                nd++;
-            }
-            if (dsc1 != 0u) dsc0 |= DSC_HAS2;
-            if (((dsc0 | dsc1) & DSC_BIGL) || (dsc1 & DSC_MORE)) dsc0 |= DSC_RARE;
-            refw[j] = make_uint4(x, y, dsc0, dsc1);
-            refl[j] = make_uint2(l03, l45);     // bytes 0..5 = L for n = 1..6 (0 past the slice)
-        }
-    }
 }
 
 // get_np_info() API: one sequence of any length, one launch per period over as many workgroups as the sequence

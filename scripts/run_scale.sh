@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 ngpu=$(python3 -c "import torch; print(torch.cuda.device_count())")
 echo "gpus visible: $ngpu"
-printf "%-6s %-14s %-12s %-10s %s\n" n_gpus reads/s ms_per_step per_gpu efficiency_vs_1
+printf "%-6s %-14s %-12s %-10s %-16s %-22s %s\n" n_gpus reads/s ms_per_step per_gpu efficiency_vs_1 host_generate_s_max backend
 base=
 for n in 1 2 4 8; do
   [ "$n" -gt "$ngpu" ] && break
@@ -22,7 +22,12 @@ for n in 1 2 4 8; do
 import json, sys
 n, line, base = int(sys.argv[1]), json.loads(sys.argv[2]), float(sys.argv[3])
 v = line["value"]
-print(f"{n:<6d} {v:<14.1f} {line['ms_per_step']:<12.2f} {v / n:<10.1f} {'' if not base else f'{v / n / base:.3f}'}")
+hs = line["config"]["host_setup"]
+eff = "" if not base else f"{v / n / base:.3f}"
+print(f"{n:<6d} {v:<14.1f} {line['ms_per_step']:<12.2f} {v / n:<10.1f} {eff:<16s} {hs['generate_s_max_over_ranks']:<22.2f} {line['config']['reduction_backend']}")
+assert line["n_gpus"] == n and line["bad_reads"] == 0
+if n > 1:
+    assert line["config"]["reduction_backend"] == "rccl", "ranks shared a device: nothing was measured"
 PY
   [ "$n" -eq 1 ] && base=$(python3 -c "import json,sys; print(json.loads(sys.argv[1])['value'])" "$line")
 done

@@ -36,6 +36,27 @@ def test_bench_two_ranks_on_one_gpu():
     assert line["config"]["reads_per_gpu"] == 96
     assert line["roofline"]["frac"] > 0 and line["cpu_baseline"] is None      # CPU baseline is an N=1 item
     assert line["value_pcie_inclusive"]["value"] > 0
+    # two ranks on ONE card: the reduction goes over gloo (RCCL needs a device per rank), host-side generation is reported
+    # and lies before the timed region
+    assert line["config"]["reduction_backend"].startswith("gloo") and line["config"]["host_setup"]["generate_s_max_over_ranks"] > 0
+
+
+def test_bench_two_ranks_production_shape_bookkeeping():
+    """`bench.py --gpus 2 --reads 4000 --band 30` with both ranks on this box's one card (the 8-GPU run's command at
+    N = 2): value = the reads of BOTH ranks / the slowest rank's time, i.e. 2 x reads_per_gpu x steps / (ms_per_step x
+    steps); every rank's strings clean."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29850 + os.getpid() % 100
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"),
+           "--gpus", "2", "--reads", "4000", "--band", "30", "--steps", "3", "--warmup", "1",
+           "--sustain", "0", "--pcie-steps", "0", "--no-cpu", "--production", "0", "--solo-steps", "1"]
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["reads_per_gpu"] == 4000 and line["bad_reads"] == 0
+    assert abs(line["value"] - 2 * 4000 / (line["ms_per_step"] * 1e-3)) < 0.01 * line["value"]
+    assert line["config"]["parallelism"] == "reads x2" and line["scaling"] == "weak"
 
 
 _NP_INFO_FIRST = r"""
