@@ -208,7 +208,7 @@ int npore_ctx_set(npore_ctx *ctx, const char *key, int64_t value);
  * the moment it has finished one, so a batch costs about ceil(full-size chunks / resident groups) chain times: at
  * r = 30, 4 000 reads of 10 kb take 21.7 ms, 4 500 take 30.6 ms (not two full rounds), and from 6 000 reads on the
  * rate stays within ~12 % of its maximum (profiles/r02_sweep_r30_queue.csv).  Batches enqueued with sync = 0 follow
- * each other without a gap.  Returns the resident groups, 0 for a band the kernels do not cover (r > 255).
+ * each other without a gap.  Returns the resident groups, 0 for a band the kernels do not cover (r > 511).
  * Replaces nothing in the reference (its pool has no such granularity, src/realign.py:110-114). */
 int64_t npore_round_chunks(npore_ctx *ctx, int r);
 /* Launch geometry of the fill kernel at band half-width r, for reports (bench.py's "practical bound"):

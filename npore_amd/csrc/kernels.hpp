@@ -43,6 +43,7 @@
 namespace npore {
 
 static_assert(NP_LT == NP_CT - NP_C0 && (NP_LT & (NP_LT - 1)) == 0, "np_full's range test");
+constexpr int MAX_WAVES_PER_CHUNK = 16;   // a workgroup of 1 024 threads: r <= 511
 constexpr int XCH_WORDS = 12;   // per wave, per parity: boundary cells handed to the neighbour waves
                                 // (words 0-3 last cell, 5-10 first cell)
 
@@ -82,7 +83,7 @@ struct KParams {
 __host__ __device__ static inline size_t chunk_lds_floats(int nw, int hw, int rwin)
 {
     // history ring + reference-L window + (several waves per chunk) exchange records, progress words, slot ring
-    return (size_t)4 * (ring_rows(nw) * hw + HIST_PAD) + 2 * (size_t)rwin + (nw > 1 ? 2 * nw * XCH_WORDS + 8 + 12 : 0);
+    return (size_t)4 * (ring_rows(nw) * hw + HIST_PAD) + 2 * (size_t)rwin + (nw > 1 ? 2 * nw * XCH_WORDS + MAX_WAVES_PER_CHUNK + 12 : 0);
 }
 static inline size_t fill_lds_floats(int nw, int chunks, int hw, int rwin)
 {
@@ -303,15 +304,20 @@ constexpr int SLOT_RING = 8;    // chunk slots published by a group's first wave
 // preparation, the previous one's traceback), so the kernel is held to 112 of the SIMD's 512 / 4 = 128 vector
 // registers -- amdgpu_num_vgpr counts in halves on this target (arch + acc registers) -- which leaves 64 for one
 // light wave per SIMD.  At 112 the spills are all in the per-chunk set-up, none in the step loop (checked in the ISA).
-template <int NW, int MAXT>
+template <int NWT, int MAXT>
 __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amdgpu_num_vgpr(56))) void fill_kernel(KParams p)
 {
-    constexpr int NSR = ring_rows(NW);
-    constexpr int WPT = NW * 64;          // physical columns per chunk
+    // NWT = 0: the number of waves per chunk comes with the launch (one chunk per workgroup: bands of more than eight
+    // waves, r = 256 ... 511 -- one instantiation for all of them; what depends on NW only as "one wave or several" stays
+    // compile-time)
+    constexpr bool MULTI = NWT != 1;
+    constexpr int NSR = ring_rows(NWT ? NWT : 2);
+    const int NW = NWT ? NWT : uni((int)(blockDim.x >> 6));
+    const int WPT = NW * 64;              // physical columns per chunk
     // reference-L window (LDS, kept by the chunk's last wave): refilled WIN_STEP positions at a time once the band
     // comes within WIN_SLACK of its end.  Several waves: a whole wave's worth, and enough slack for the waves that
     // run behind the last one.  One wave: it refills for itself, so little of both does (host: fill_geometry)
-    constexpr int WIN_STEP = NW == 1 ? 32 : 64, WIN_SLACK = NW == 1 ? 8 : 32;
+    constexpr int WIN_STEP = NWT == 1 ? 32 : 64, WIN_SLACK = NWT == 1 ? 8 : 32;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *lds_np = lds;
     float *lds_sub = lds + MAX_PERIOD * NP_LT * NP_CT;
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
         const int pr = min(3, cw);
         if (pr == 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 1) __builtin_amdgcn_s_setprio(1);
     } else if constexpr (xp::PRIO == 4) {          // middle 2, first 1, last 0
-        if (NW > 2 && cw != 0 && cw != NW - 1) __builtin_amdgcn_s_setprio(2); else if (cw == 0 && NW > 1) __builtin_amdgcn_s_setprio(1);
+        if (NW > 2 && cw != 0 && cw != NW - 1) __builtin_amdgcn_s_setprio(2); else if (cw == 0 && MULTI) __builtin_amdgcn_s_setprio(1);
     }
     const int hw = p.hw;
     float *chunk_lds = lds_sub + SUBT_ENTRIES + (size_t)cg * chunk_lds_floats(NW, hw, p.rwin);
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
     uint2 *win = reinterpret_cast<uint2 *>(chunk_lds + 4 * (NSR * hw + HIST_PAD));
     uint32_t *xchg = reinterpret_cast<uint32_t *>(chunk_lds + 4 * (NSR * hw + HIST_PAD) + 2 * p.rwin);   // [NW][2][XCH_WORDS]
     int *prog = reinterpret_cast<int *>(xchg + 2 * NW * XCH_WORDS);          // [NW] anti-diagonals completed, all chunks
-    int *slotbox = prog + 8;                                                  // [SLOT_RING] + generation word
+    int *slotbox = prog + MAX_WAVES_PER_CHUNK;                                // [SLOT_RING] + generation word
 
     // workgroup-shared tables.  A score row is stored with the call length DEcreasing, so that "q more copies
     // deleted" is q entries UP from the address a column descriptor holds, and ends in one guard entry holding
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
     // beyond the band and the pad records either side of a row are never written and stay that way for the whole
     // launch; the band-interior columns are reset by their own lanes before every chunk
     for (int k = lpos - HIST_PAD; k < NSR * hw; k += WPT) hist[k] = hist_none();
-    if constexpr (NW > 1) {
+    if constexpr (MULTI) {
         if (lane == 0) prog[cw] = 0;
         if (cw == 0 && lane <= SLOT_RING + 1) slotbox[lane] = 0;
     }
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
             // group q / grid -- so that the heavy chunks of a batch smaller than the launch are spread over all
             // CUs and SIMDs instead of filling the first workgroups; the queue hands out what lies beyond
             slot_id = cg * (int)gridDim.x + (int)blockIdx.x;
-        } else if constexpr (NW == 1) {
+        } else if constexpr (NWT == 1) {
             int v = 0;
             if (lane == 0) v = atomicAdd(p.queue, 1);
             slot_id = uni(v) + dealt;
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
         // anti-diagonals on) must be in place before any of them starts: one rendezvous per chunk.  The last wave
         // waits for everybody's progress word, refills the window and says so; the others wait for that word.
         int wfill = 0;
-        if constexpr (NW > 1) {
+        if constexpr (MULTI) {
             if (cw == NW - 1) {
                 for (;;) {
                     const int v = lane < NW - 1 ? __hip_atomic_load(&prog[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : pbase;
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
             }
             wfill += WIN_STEP;
         }
-        if constexpr (NW > 1) {
+        if constexpr (MULTI) {
             if (cw == NW - 1) {
                 NPORE_PUBLISH_FENCE();
                 if (lane == 0) __hip_atomic_store(&slotbox[SLOT_RING + 1], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -607,7 +613,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
             }
             st.init_f = e_v;
             e_v += 100.0f;
-            if constexpr (NW > 1 && MODE != 0 && !xp::NOPOLL) {
+            if constexpr (MULTI && MODE != 0 && !xp::NOPOLL) {
                 // Per-chunk hand-shake instead of a workgroup barrier: this wave may start an anti-diagonal once
                 // its two neighbour waves have finished the previous one (they own the only columns it reads),
                 // i.e. once their progress words have reached this wave's own.  The neighbour released its
@@ -784,7 +790,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
                 asm volatile("global_store_dword %0, %1, %2" : : "v"(tboff_v), "v"(o.tb), "s"(tb_g) : "memory");
                 if constexpr (xp::DBGMAT) asm volatile("global_store_dword %0, %1, %2" : : "v"(tboff_v), "v"(__float_as_uint(o.matv)), "s"(dbg_g) : "memory");
             }
-            if constexpr (NW > 1) {
+            if constexpr (MULTI) {
                 // boundary cells for the neighbour waves: the last lane's cell for the wave above (it reads
                 // it as a LEFT neighbour), the first lane's for the wave below (TOP neighbour + reference words);
                 // then the progress word, after this step's LDS writes (workgroup release: LDS only, it does not
@@ -823,7 +829,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
 
         // anti-diagonals [b0, b1) of one step window
         auto span = [&](int b0, int b1, auto role_tag, auto fast_tag) __attribute__((always_inline)) {
-            if constexpr (NW == 1) {
+            if constexpr (NWT == 1) {
                 // A match of the input path is a 'D' step followed by an 'I' step: the two as ONE straight-line body
                 // (the register shuffle where step bodies meet then comes once per two steps).  Only where a chunk
                 // is one wave: measured -2.6 % fill at r = 30, +0.5 % at r = 100, +-0 at r = 64 / 200.
@@ -945,7 +951,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
             }
         };
         // the wave's role within its chunk decides where annotation words and boundary cells come from
-        if constexpr (NW == 1) run(std::integral_constant<int, 0>{});
+        if constexpr (NWT == 1) run(std::integral_constant<int, 0>{});
         else if (cw == 0) run(std::integral_constant<int, 1>{});
         else if (cw == NW - 1) run(std::integral_constant<int, 3>{});
         else run(std::integral_constant<int, 2>{});
@@ -1152,7 +1158,9 @@ __global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
     };
     auto word = [&](int col) -> uint32_t {   // col is wave-uniform
         uint4 v = row[0];
-        if constexpr (NL > 1) { if ((col >> 8) & 1) v = row[NL - 1]; }
+#pragma unroll
+        for (int q = 1; q < NL; q++)
+            if ((col >> 8) == q) v = row[q];
         const uint32_t lo = (col & 1) ? v.y : v.x, hi = (col & 1) ? v.w : v.z;
         return (uint32_t)__builtin_amdgcn_readlane((int)((col & 2) ? hi : lo), (col & 255) >> 2);
     };

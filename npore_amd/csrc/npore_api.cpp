@@ -225,7 +225,7 @@ std::atomic<int> g_live_ctx[16];   // contexts alive per device (they share its 
 int pick_shape(int r)
 {
     const int nw = (2 * r + 1 + 63) / 64;
-    return nw <= 8 ? nw : 0;
+    return nw <= MAX_WAVES_PER_CHUNK ? nw : 0;
 }
 
 int pow2_at_least(int x)
@@ -271,12 +271,14 @@ int fill_round_workgroups(const FillGeom &g, int chunks, int n_cus)
 // gather will look for room BESIDE fill workgroups: where the fill would take (nearly) all of a CU's LDS -- r = 30:
 // 16 chunks = 159.75 KB -- a workgroup takes one chunk less (measured at r = 30, 8 000 reads per batch: 154 k
 // instead of 144 k reads/s; the scans and the gather need ~3.5 KB of LDS).
-template <int NW>
+// (NWT = 0: the instantiation that takes its wave count from the launch -- bands of 9 ... 16 waves, one chunk per workgroup)
+template <int NWT>
 hipError_t launch_fill(KParams kp, int max_chunks, int force_chunks, int n_cus, hipStream_t s, bool leave_room, bool *has_room)
 {
     constexpr int MAXT = 1024;
     FillGeom g;
-    if (!fill_geometry(kp.r, g) || g.nw != NW) return hipErrorInvalidValue;
+    if (!fill_geometry(kp.r, g) || (NWT ? g.nw != NWT : g.nw <= 8)) return hipErrorInvalidValue;
+    const int NW = g.nw;
     kp.hw = g.hw;
     kp.rwin = g.rwin;
     const int cmax = g.cmax;
@@ -296,17 +298,17 @@ hipError_t launch_fill(KParams kp, int max_chunks, int force_chunks, int n_cus, 
     // own any static LDS, so that the dynamic array starts at address 0
     static const hipError_t no_static_lds = [] {
         hipFuncAttributes at;
-        const hipError_t e0 = hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&fill_kernel<NW, MAXT>));
+        const hipError_t e0 = hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&fill_kernel<NWT, MAXT>));
         return e0 != hipSuccess ? e0 : (at.sharedSizeBytes == 0 ? hipSuccess : hipErrorInvalidDeviceFunction);
     }();
     if (no_static_lds != hipSuccess) return no_static_lds;
     // A persistent launch: as many workgroups as the GPU keeps resident (or fewer, if the batch is small); their
     // groups of NW waves pull the chunks of the schedule (largest first) from a device-side queue (kernels.hpp)
     const int resident = fill_round_workgroups(g, chunks, n_cus);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fill_kernel<NW, MAXT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fill_kernel<NWT, MAXT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((fill_kernel<NW, MAXT>), dim3(std::min((max_chunks + chunks - 1) / chunks, resident)),
+    hipLaunchKernelGGL((fill_kernel<NWT, MAXT>), dim3(std::min((max_chunks + chunks - 1) / chunks, resident)),
                        dim3(64 * NW * chunks), lds, s, kp);
     return hipGetLastError();
 }
@@ -522,6 +524,8 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
         case 6: e = launch_fill<6>(kp, mc, ctx->force_chunks, ctx->n_cus, s, overlapping, &ctx->fill_has_room); break;
         case 7: e = launch_fill<7>(kp, mc, ctx->force_chunks, ctx->n_cus, s, overlapping, &ctx->fill_has_room); break;
         case 8: e = launch_fill<8>(kp, mc, ctx->force_chunks, ctx->n_cus, s, overlapping, &ctx->fill_has_room); break;
+        case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16:
+            e = launch_fill<0>(kp, mc, ctx->force_chunks, ctx->n_cus, s, overlapping, &ctx->fill_has_room); break;
         default: return fail(NPORE_E_UNSUPPORTED, "unsupported waves-per-chunk count");
     }
     if (e != hipSuccess) return fail(NPORE_E_HIP, std::string("fill launch: ") + hipGetErrorString(e));
@@ -548,7 +552,8 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     const int tb_mode = ctx->tb_kernel ? ctx->tb_kernel : (max_chunks > 2500 ? 2 : 1);
     if (tb_mode == 1) hipLaunchKernelGGL(traceback_kernel, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
     else if (tbs <= 256) hipLaunchKernelGGL(traceback_rows_kernel<1>, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
-    else hipLaunchKernelGGL(traceback_rows_kernel<2>, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
+    else if (tbs <= 512) hipLaunchKernelGGL(traceback_rows_kernel<2>, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
+    else hipLaunchKernelGGL(traceback_rows_kernel<4>, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
     HIP_TRY(hipGetLastError());
 
     GParams gp;
@@ -654,7 +659,7 @@ int run_core(npore_ctx *ctx, const AlignArgs &a, const OutTarget &ot, hipStream_
     if (a.max_b_rows > 60000)
         return fail(NPORE_E_UNSUPPORTED, "max_b_rows > 60000: run lengths are kept in 16 bits");
     const int shape = pick_shape(a.r);
-    if (!shape) return fail(NPORE_E_UNSUPPORTED, "band half-width r > 255");
+    if (!shape) return fail(NPORE_E_UNSUPPORTED, "band half-width r > 511");
     if (a.n_reads == 0) return NPORE_OK;
     ctx->call_id++;
     if (user) {
@@ -1044,7 +1049,7 @@ int npore_fill_shape(npore_ctx *ctx, int r, int32_t *out, int n)
 {
     FillGeom g;
     if (!ctx || !out) return fail(NPORE_E_INVALID, "null argument");
-    if (!fill_geometry(r, g)) return fail(NPORE_E_UNSUPPORTED, "band half-width r > 255");
+    if (!fill_geometry(r, g)) return fail(NPORE_E_UNSUPPORTED, "band half-width r > 511");
     const size_t lds = fill_lds_floats(g.nw, g.cmax, g.hw, g.rwin) * sizeof(float);
     const int wg_per_cu = std::max(1, std::min((int)((160 * 1024) / std::max<size_t>(lds, 1)), 2048 / (64 * g.nw * g.cmax)));
     const int32_t v[5] = {g.nw, g.cmax, wg_per_cu, fill_round_workgroups(g, g.cmax, ctx->n_cus), (int32_t)lds};

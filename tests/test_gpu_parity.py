@@ -225,7 +225,7 @@ def test_large_max_b_rows(ctx, tables):
     with pytest.raises(aln.NporeError):
         ctx.align_batch(refs, seqs, cigs, r=30, max_b_rows=70000)     # refused loudly, not silently wrong
     with pytest.raises(aln.NporeError):
-        ctx.align_batch(refs, seqs, cigs, r=300)
+        ctx.align_batch(refs, seqs, cigs, r=512)
 
 
 def test_groups_under_small_traceback_budget(tables):
@@ -251,6 +251,27 @@ def test_widest_band(ctx, tables):
     assert not st.any()
     for k in range(3):
         assert got[k] == oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=255)
+
+
+@pytest.mark.parametrize("r", [256, 300, 384, 447, 511])
+def test_bands_of_nine_to_sixteen_waves(ctx, tables, r):
+    """r = 256 ... 511: 9 ... 16 waves per chunk, one chunk per workgroup, through the instantiation of the fill kernel that
+    takes its wave count from the launch (and the four-load rows of the row-per-hop traceback): strings and status
+    bits equal the oracle's, also with many short chunks and with reads whose input path is far from the best one."""
+    sub, nps = tables
+    refs, seqs, cigs = synth.make_batch(600 + r, 5, ref_len=1100, p_np=0.1)
+    ref, seq = refs[0], seqs[0]
+    m = min(len(ref), len(seq)) - 30
+    refs.append(ref); seqs.append(seq); cigs.append("I" * (len(seq) - m) + "D" * (len(ref) - m) + "=" * m)
+    c2 = aln.Context(sub, nps, max_n=6, max_l=100, device=0)
+    c2.set("traceback_kernel", 2)
+    for cx, mbrs in ((ctx, (1500, 150)), (c2, (1500,))):
+        for mbr in mbrs:
+            got, st = cx.align_batch(refs, seqs, cigs, r=r, max_b_rows=mbr, return_status=True)
+            for k in range(len(refs)):
+                want, wst = oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=r, max_b_rows=mbr, return_status=True)
+                assert got[k] == want and st[k] == wst, (r, mbr, k)
+    c2.close()
 
 
 def test_div_small_domain():
@@ -876,4 +897,5 @@ def test_round_chunks(ctx):
     """npore_round_chunks: the batch-sizing hint of the C ABI (chunks the GPU holds at a time)."""
     assert ctx.round_chunks(30) > ctx.round_chunks(100) > ctx.round_chunks(200) > 0
     assert ctx.round_chunks(100) % 4 == 0          # four chunks share a workgroup at r = 100
-    assert ctx.round_chunks(256) == 0              # band wider than the kernels cover
+    assert ctx.round_chunks(300) > 0 and ctx.round_chunks(511) > 0      # one chunk of 10 / 16 waves per workgroup
+    assert ctx.round_chunks(512) == 0              # band wider than the kernels cover
