@@ -335,6 +335,12 @@ int npore_confusion_counts(const char *lines, const int64_t *line_off, int64_t n
                            int64_t np_len, int max_n, int max_l, int64_t *subs, int64_t *nps, int64_t *inss,
                            int64_t *dels, int64_t *bad_lines, int threads);
 
+/* Debug / tests: one raw DEFLATE stream (a BGZF block's payload; the BAM reader's inner loop, pysam / htslib in the
+ * reference) of in_len bytes that must inflate to exactly out_len bytes.  force: 0 = as the readers do it (this
+ * library's decoder, csrc/inflate.hpp, and zlib for what it declines), 1 = the decoder only, 2 = zlib only.
+ * Returns 1 (inflated), 0 (refused / malformed) or a negative NPORE_E_* code.  Host code, no GPU. */
+int npore_debug_inflate(const uint8_t *in, int64_t in_len, uint8_t *out, int64_t out_len, int force);
+
 /* Debug self-test: out128[l] = value lane l receives from lane l-1 (l>0),
  * out128[64+l] = value from lane l+1 (l<63); checks the DPP wave-shift
  * directions the fill kernel relies on. */

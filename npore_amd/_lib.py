@@ -77,6 +77,7 @@ SIGNATURES = {
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "npore_bam_last_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "npore_bam_file_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "npore_debug_inflate": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int]),
     "npore_debug_dpp": (C.c_int, [C.c_void_p]),
     "npore_debug_divcheck": (C.c_int, [C.c_void_p]),
     "npore_debug_fetch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),

@@ -19,6 +19,8 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include "inflate.hpp"
+
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
@@ -222,9 +224,12 @@ inline bool bgzf_member(const uint8_t *p, size_t avail, size_t &pay_off, size_t 
     return true;
 }
 
-inline bool inflate_block(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
+inline bool inflate_block(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len, int force = 0)
 {
     if (!out_len) return true;
+    // force: 1 = this library's decoder only, 2 = zlib only (tests); 0 = the decoder, zlib for what it declines
+    if (force != 2 && inflate_raw_fast(in, in_len, out, out_len)) return true;
+    if (force == 1) return false;
     z_stream zs;
     std::memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, -15) != Z_OK) return false;

@@ -1171,6 +1171,12 @@ try {
 NPORE_CATCH_INT
 
 // debug / self-test entries (used by tests -m gpu)
+int npore_debug_inflate(const uint8_t *in, int64_t in_len, uint8_t *out, int64_t out_len, int force)
+{
+    if (!in || !out || in_len < 0 || out_len < 0) return fail(NPORE_E_INVALID, "null argument");
+    return inflate_block(in, (size_t)in_len, out, (size_t)out_len, force) ? 1 : 0;
+}
+
 int npore_debug_dpp(uint32_t *out128)
 {
     uint32_t *d = nullptr;

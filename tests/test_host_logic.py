@@ -428,6 +428,69 @@ def test_inflated_bam_copy_shared_between_local_ranks(tmp_path, monkeypatch):
     assert dist.host_threads_per_rank() >= 1
 
 
+def test_inflate_decoder_equals_zlib(tmp_path):
+    """csrc/inflate.hpp (the BGZF readers' DEFLATE decoder) against zlib: every block type (stored, fixed, dynamic), every
+    compression level and strategy, data from incompressible to one long run, the blocks of the test BAMs; streams it
+    declines (a single-symbol literal code) still inflate through the zlib fallback; corrupted and truncated streams are
+    refused or inflate to something -- never read or written out of bounds (the output buffer is guarded)."""
+    import zlib
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+
+    def inflate(raw, n, force):
+        out = np.full(n + 64, 0xA5, np.uint8)                      # 32 guard bytes either side
+        src = np.frombuffer(raw, np.uint8)
+        rc = lib.npore_debug_inflate(src.ctypes.data, len(raw), out[32:].ctypes.data, n, force)
+        assert (out[:32] == 0xA5).all() and (out[32 + n:] == 0xA5).all(), "wrote outside the block"
+        return rc, out[32:32 + n].tobytes()
+
+    def deflate(data, level, strategy=zlib.Z_DEFAULT_STRATEGY):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+        return c.compress(data) + c.flush()
+
+    datas = [b"", b"A", b"ACGT" * 5000, bytes(rng.integers(0, 256, 60000, dtype=np.uint8)), bytes(rng.integers(0, 4, 65280, dtype=np.uint8)),
+             b"\0" * 65280, bytes(rng.choice(np.frombuffer(b"ACGTN", np.uint8), 40000)) + bytes(rng.integers(33, 75, 25000, dtype=np.uint8)),
+             bytes(np.repeat(rng.integers(0, 256, 300, dtype=np.uint8), rng.integers(1, 300, 300)))[:65000]]
+    n_fast = n_all = 0
+    for data in datas:
+        for level in (0, 1, 4, 6, 9):
+            for strat in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_RLE, zlib.Z_HUFFMAN_ONLY, zlib.Z_FILTERED):
+                raw = deflate(data, level, strat)
+                rc2, got2 = inflate(raw, len(data), 2)
+                assert rc2 == 1 and got2 == data
+                rc0, got0 = inflate(raw, len(data), 0)
+                assert rc0 == 1 and got0 == data, (len(data), level, strat)
+                rc1, got1 = inflate(raw, len(data), 1)
+                assert rc1 == 0 or got1 == data, (len(data), level, strat)
+                n_fast += rc1; n_all += 1
+                if len(data) > 1:                                   # a wrong announced size is refused by both
+                    assert inflate(raw, len(data) - 1, 1)[0] == 0 and inflate(raw, len(data) + 1, 0)[0] == 0
+    assert n_fast >= 0.9 * n_all, (n_fast, n_all)                   # the decoder takes nearly everything itself
+    # the blocks of a real BAM
+    for name in ("reads.bam",):
+        raw = open(os.path.join(GOLDEN, "data", name), "rb").read()
+        p, nb = 0, 0
+        while p < len(raw):
+            xlen = int.from_bytes(raw[p + 10:p + 12], "little")
+            bsize = int.from_bytes(raw[p + 16:p + 18], "little") + 1
+            isize = int.from_bytes(raw[p + bsize - 4:p + bsize], "little")
+            pay = raw[p + 12 + xlen:p + bsize - 8]
+            rc1, got1 = inflate(pay, isize, 1)
+            assert rc1 == 1 and got1 == zlib.decompress(pay, -15)
+            p += bsize; nb += 1
+        assert nb >= 2
+    # corrupted / truncated streams: no out-of-bounds access, and whatever is accepted has the announced size
+    base = deflate(datas[6], 6)
+    for k in range(300):
+        bad = bytearray(base)
+        for _ in range(int(rng.integers(1, 4))):
+            bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        if k % 3 == 0:
+            bad = bad[:int(rng.integers(1, len(bad)))]
+        inflate(bytes(bad), len(datas[6]), 1)
+        inflate(bytes(bad), len(datas[6]), 0)
+
+
 def test_one_pass_handle_reads_only_the_header():
     """npore_bam_open_mode(..., 3): block table + BAM header, no record index (the reads go through
     npore_bam_realign_sequential in one pass); a file that is not BGZF is refused."""
