@@ -179,6 +179,16 @@ def main():
         import hashlib
         digest = lambda f: hashlib.sha256(open(f, "rb").read()).hexdigest()
         same_one_pass = digest(out) == digest(out + ".o")
+        # how busy the GPU is in the one-pass run: the indexed resident leg's batch phase runs at the device path's own rate
+        # (packed batches -> upload, kernels, download; the host stages keep up there), so that rate x the one-pass wall
+        dev_rate = resident["reads_per_s_batches_only"]
+        one_pass["gpu_busy_fraction_estimate"] = round(min(1.0, (one_pass["reads"] / dev_rate) / max(one_pass["realign_s"], 1e-9)), 3)
+        one_pass["gpu_busy_note"] = ("reads / (the device path's rate = the resident leg's batch phase) / this leg's wall; the rest of the time the "
+                                     "GPU waits for the host stages (inflate + pack in front of it, standardise + SAM text behind it)")
+        for leg in (resident, streamed):
+            leg["gpu_stage_sum_fraction_of_batches"] = leg.pop("gpu_busy_fraction_of_batches")
+            leg.pop("gpu_idle_fraction_of_batches", None)
+            leg["gpu_stage_sum_note"] = "SUM of the HIP-event stage times of groups that overlap on the device / wall: above 1 when they do"
         # the pure-Python restatement on a few reads
         k = min(a.py_reads, a.reads)
         cfg.args.max_reads = k

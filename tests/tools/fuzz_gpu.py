@@ -81,9 +81,11 @@ def fuzz(budget, seed, focus=False, log=print):
         kind = int(rng.choice([0, 0, 1, 2]))
         sub, nps = tables(rng, kind, max_n, max_l)
         ctx = aln.Context(sub, nps, max_n=max_n, max_l=max_l)
-        r = int(rng.choice([100, 127, 128, 160, 192, 200, 255] if focus else
-                           [1, 2, 3, 7, 15, 30, 31, 32, 33, 64, 65, 100, 127, 128, 160, 192, 200, 255]))
+        r = int(rng.choice([100, 127, 128, 160, 192, 200, 255, 256, 320, 511] if focus else
+                           [1, 2, 3, 7, 15, 30, 31, 32, 33, 64, 65, 100, 127, 128, 160, 192, 200, 255, 288, 448]))
         mbr = int(rng.choice([2, 3, 5, 7, 16, 64] if focus else [2, 3, 5, 16, 64, 65, 200, 1000, 20000, 60000]))
+        if r > 255:
+            mbr = min(mbr, 1000)          # (the oracle allocates and zeroes 60 B x max_b_rows x (2r+1) per read)
         ist, iex = (float(x) for x in rng.choice([[5, 1], [5, 1], [3, 0], [0, 0], [7.5, 2.25], [1, 1]]))
         n = int(rng.integers(1, 40))
         refs, seqs, cigs = [], [], []
