@@ -84,7 +84,7 @@ struct CellOut {
     int matrun;                // MAT.RUN if MAT.TYP == MAT else 0
     int insrun, delrun;
     int lenrun_h, shrrun_h;    // LEN.RUN / SHR.RUN as later "continue" moves may use them
-    uint32_t tb;               // MAT.TYP | MAT.RUN << 3
+    uint32_t tb;               // tb_word(MAT.TYP, MAT.RUN)
 };
 
 // What later LEN/SHR "start"/"continue" moves need from a finished cell.
@@ -422,33 +422,33 @@ NPORE_HD void cell_update(const Env &env, const StepInfo &st, const CellIn &in, 
     const bool diag_ok = FAST || ((i > 0) && (j > 0));
     const float vdiag = in.diagM + env.sub(in.seqw, in.refx);
     float v = diag_ok ? vdiag : delv + 100.0f;     // else-branch: "ensure val1 isn't chosen"
-    const uint32_t tr_diag = (uint32_t)T_MAT | ((uint32_t)(in.diagMrun + 1) << 3);      // typ | run<<3
-    uint32_t tr = diag_ok ? tr_diag : (uint32_t)T_MAT;
+    const uint32_t tr_diag = tb_word(T_MAT, (uint32_t)(in.diagMrun + 1));
+    uint32_t tr = diag_ok ? tr_diag : tb_word(T_MAT, 0u);
     bool t1 = false, t2 = false, t3 = false, t4 = false;
     if constexpr (FAST && Env::MIN3) {
         // The chain of strict '<' below picks the FIRST candidate, in the order MAT, INS, LEN, DEL, SHR, that attains
         // the minimum.  The same from two 3-way minima (which return one of their operands bit for bit: no NaNs
         // here, denormals are kept) and one equality test per candidate, applied last to first -- 2 selects fewer
         const float vmin = env.min3(env.min3(vdiag, insv, lenv), delv, shrv);
-        tr = (uint32_t)T_SHR | ((uint32_t)shrrun << 3);
-        tr = (delv == vmin) ? ((uint32_t)T_DEL | ((uint32_t)delrun << 3)) : tr;
-        tr = (lenv == vmin) ? ((uint32_t)T_LEN | ((uint32_t)lenrun << 3)) : tr;
-        tr = (insv == vmin) ? ((uint32_t)T_INS | ((uint32_t)insrun << 3)) : tr;
+        tr = tb_word(T_SHR, (uint32_t)shrrun);
+        tr = (delv == vmin) ? tb_word(T_DEL, (uint32_t)delrun) : tr;
+        tr = (lenv == vmin) ? tb_word(T_LEN, (uint32_t)lenrun) : tr;
+        tr = (insv == vmin) ? tb_word(T_INS, (uint32_t)insrun) : tr;
         tr = (vdiag == vmin) ? tr_diag : tr;
         v = vmin;
     } else {
         t1 = insv < v;
         v = t1 ? insv : v;
-        tr = t1 ? ((uint32_t)T_INS | ((uint32_t)insrun << 3)) : tr;
+        tr = t1 ? tb_word(T_INS, (uint32_t)insrun) : tr;
         t2 = lenv < v;
         v = t2 ? lenv : v;
-        tr = t2 ? ((uint32_t)T_LEN | ((uint32_t)lenrun << 3)) : tr;
+        tr = t2 ? tb_word(T_LEN, (uint32_t)lenrun) : tr;
         t3 = delv < v;
         v = t3 ? delv : v;
-        tr = t3 ? ((uint32_t)T_DEL | ((uint32_t)delrun << 3)) : tr;
+        tr = t3 ? tb_word(T_DEL, (uint32_t)delrun) : tr;
         t4 = shrv < v;
         v = t4 ? shrv : v;
-        tr = t4 ? ((uint32_t)T_SHR | ((uint32_t)shrrun << 3)) : tr;
+        tr = t4 ? tb_word(T_SHR, (uint32_t)shrrun) : tr;
     }
     // "no INDEL state won": every other candidate carries a non-zero TYP, so the word itself says so (one vector
     // compare; or-ing the four compare masks costs three scalar instructions, which are the dearer ones here)

@@ -22,8 +22,10 @@ import os
 import re
 
 # ---- scratch registers (clobbered) ---------------------------------------------------------------------------------
-X0, X1, X2, X3, X4, X5 = "v91", "v92", "v93", "v94", "v95", "v96"      # neighbour cell / exchange words, then scratch
-SD, SE, SF = "v97", "v98", "v99"
+# (X0 ... X3 are an aligned quad, X4 X5 an aligned pair: the exchange words of the neighbour waves arrive by ds_read_b128 / ds_read2_b32)
+X0, X1, X2, X3, X4, X5 = "v92", "v93", "v94", "v95", "v96", "v97"      # neighbour cell / exchange words, then scratch
+XQ, X01, X23, X45 = "v[92:95]", "v[92:93]", "v[94:95]", "v[96:97]"
+SD, SE, SF = "v91", "v98", "v99"
 P0, P1, PP = "v100", "v101", "v[100:101]"
 SUBV, DRUN, NINSR, NDELR = "v102", "v103", "v87", "v88"
 SHRV, SHRRUN, LENV, LENRUN = "v104", "v105", "v106", "v107"
@@ -98,6 +100,15 @@ def sub_read(t):
     """)
 
 
+def two_adds(t, A, B, m, x):
+    """A = indel_start + m, B = indel_extend + x (src/aln.pyx:530-531, 552-553).  (One v_pk_add_f32 on aligned register
+    pairs was measured: no gain -- LABNOTES round 4.)"""
+    t(f"""
+        v_add_f32 {A}, {O('istart')}, {m}
+        v_add_f32 {B}, {O('iext')}, {x}
+    """)
+
+
 def ins_part(t, mode, A, B, msk, fill=()):
     """INS (src/aln.pyx:525-543): new value straight into the own register, run into NINSR.  A, B: free registers;
     fill: up to two independent instructions for the slots between the compare and its selects"""
@@ -105,17 +116,16 @@ def ins_part(t, mode, A, B, msk, fill=()):
         topM, topI, topR = O("matv"), O("insv"), O("R1")
     else:
         topM, topI, topR = X0, X1, O("TMr")
+    two_adds(t, A, B, topM, topI)
     t(f"""
-        v_add_f32 {A}, {O('istart')}, {topM}
-        v_add_f32 {B}, {O('iext')}, {topI}
         v_cmp_lt_f32 {msk}, {B}, {A}
-        v_add_u32_sdwa {NINSR}, {topR}, {O('one')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD
+        v_add_u32_sdwa {NINSR}, {topR}, {O('oneI')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD
     """)
     for f in fill:
         t(f)
     t(f"""
         v_cndmask_b32 {O('insv')}, {A}, {B}, {msk}
-        v_cndmask_b32 {NINSR}, 1, {NINSR}, {msk}
+        v_cndmask_b32 {NINSR}, {O('oneI')}, {NINSR}, {msk}
     """)
 
 
@@ -125,25 +135,27 @@ def del_part(t, mode, A, B, msk):
         leftM, leftD, leftR = X0, X1, O("LMr")
     else:
         leftM, leftD, leftR = O("matv"), O("delv"), O("R2")
+    two_adds(t, A, B, leftM, leftD)
     t(f"""
-        v_add_f32 {A}, {O('istart')}, {leftM}
-        v_add_f32 {B}, {O('iext')}, {leftD}
         v_cmp_lt_f32 {msk}, {B}, {A}
-        v_add_u32_sdwa {NDELR}, {leftR}, {O('one')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD
+        v_add_u32_sdwa {NDELR}, {leftR}, {O('oneD')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD
         v_and_b32 {X3}, {O('refx')}, {O('seqw')}
         v_bfe_u32 {X3}, {X3}, 8, 6
         v_cndmask_b32 {O('delv')}, {A}, {B}, {msk}
-        v_cndmask_b32 {NDELR}, 1, {NDELR}, {msk}
+        v_cndmask_b32 {NDELR}, {O('oneD')}, {NDELR}, {msk}
     """)
 
 
-def shr_pass(t, mid, sfx, smr, shadow, shadow2):
+def shr_pass(t, mid, sfx, smr, shadow, shadow2, none_test=True):
     """SHR candidates of the column (cell.hpp shr_small<FAST>).  On entry: the first candidate's lane-table results in
     E0 (address of its source record) / E1 (1/n) and the record itself in SD (matv), P0 (shrstart), P1 (runs).
     shadow(): work issued in the shadow of the score read (free registers X4 X5 SF); shadow2(): the same for the
     two-candidate block (free registers SHRV SHRRUN).  Leaves X3 = refx & seqw (shadow's last act) for the LEN test.
     The single-candidate case falls through; "no candidate in the wave" and "two candidates" are out of line."""
-    if not mid:
+    # "no candidate in the wave": worth a test only where many lanes are dead -- the first and last wave of a wide band
+    # (r=100: 6 % of the wave-steps); a lone wave (r <= 31) has one in 99.8 % of its steps, and a lane without one
+    # holds the empty descriptor, whose score is +infinity
+    if not mid and none_test:
         t(f"""
             v_cmp_ne_u32 vcc, 0, {smr}
             s_cbranch_vccz {L('shr_none' + sfx)}
@@ -152,7 +164,7 @@ def shr_pass(t, mid, sfx, smr, shadow, shadow2):
         t.label("shr_none" + sfx)
         t(f"""
             v_mov_b32 {SHRV}, {O('ev')}
-            v_mov_b32 {SHRRUN}, 0
+            v_mov_b32 {SHRRUN}, {O('tagS')}
             v_mov_b32 {SHRST}, 0x7f800000
         """)
         shadow()
@@ -172,7 +184,7 @@ def shr_pass(t, mid, sfx, smr, shadow, shadow2):
         v_mul_u32_u24 {E1}, {HP1}, {E1}
         v_bfe_u32 {E0}, {O('rc0')}, 2, 3
         v_min_u32_sdwa {E1}, {E1}, {O('rc0')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_1
-        v_add_u32 {HP1}, {HP1}, {E0}
+        v_add3_u32 {HP1}, {HP1}, {E0}, {O('tagS')}
         v_lshl_add_u32 {SE}, {E1}, 2, {SE}
         ds_read_b32 {SE}, {SE}
     """)
@@ -182,7 +194,7 @@ def shr_pass(t, mid, sfx, smr, shadow, shadow2):
         v_add_f32 {SE}, {HS}, {SE}
         v_cmp_lt_f32 vcc, {SE}, {O('ev')}
         v_cndmask_b32 {SHRST}, {O('inf')}, {HS}, vcc
-        v_cndmask_b32 {SHRRUN}, 0, {HP1}, vcc
+        v_cndmask_b32 {SHRRUN}, {O('tagS')}, {HP1}, vcc
         v_cndmask_b32 {SHRV}, {O('ev')}, {SE}, vcc
     """)
     t.label("shr_done2" + sfx)
@@ -203,7 +215,7 @@ def shr_pass(t, mid, sfx, smr, shadow, shadow2):
         v_mul_u32_u24 {E1}, {HP1}, {E1}
         v_bfe_u32 {E0}, {O('rc0')}, 2, 3
         v_min_u32_sdwa {E1}, {E1}, {O('rc0')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_1
-        v_add_u32 {HP1}, {HP1}, {E0}
+        v_add3_u32 {HP1}, {HP1}, {E0}, {O('tagS')}
         v_lshl_add_u32 {E0}, {E1}, 2, {SE}
         s_waitcnt lgkmcnt(0)
         v_add_u32 {X4}, {O('hca')}, {X4}
@@ -223,11 +235,11 @@ def shr_pass(t, mid, sfx, smr, shadow, shadow2):
         v_bfe_u32 {SE}, {O('rc1')}, 2, 3
         v_lshl_add_u32 {X4}, {X5}, 2, {X4}
         ds_read_b32 {X4}, {X4}
-        v_add_u32 {SF}, {SF}, {SE}
+        v_add3_u32 {SF}, {SF}, {SE}, {O('tagS')}
         v_add_f32 {E0}, {HS}, {E0}
         v_cmp_lt_f32 vcc, {E0}, {O('ev')}
         v_cndmask_b32 {SHRST}, {O('inf')}, {HS}, vcc
-        v_cndmask_b32 {SHRRUN}, 0, {HP1}, vcc
+        v_cndmask_b32 {SHRRUN}, {O('tagS')}, {HP1}, vcc
         v_cndmask_b32 {SHRV}, {O('ev')}, {E0}, vcc
         s_waitcnt lgkmcnt(0)
         v_add_f32 {X4}, {E1}, {X4}
@@ -355,9 +367,7 @@ def len_pass(t, mid, sfx, mode, first, last, multi):
     # requests in order).  Several waves per chunk: this variant carries its own copy of the hand-over and the
     # progress store, and the wait in front of the progress word is that wait; a lone wave waits here (its three neighbours on the SIMD fill the gap).
     if multi:
-        handover(t, first, last, multi)
-        publish(t, restore_lenst=True)          # (LENST is restored where all lanes are enabled again)
-        t(f"s_branch {L('published_' + mode)}")
+        finish(t, mode, first, last, True, mid, True)      # (LENST is restored where all lanes are enabled again)
     else:
         t(f"""
             s_waitcnt lgkmcnt(0)
@@ -377,27 +387,25 @@ def mat_part(t, mode, with_len, mid):
     t(f"""
         s_waitcnt lgkmcnt(0)
         v_add_f32 {SUBV}, {diagM}, {SUBV}
-        v_lshl_or_b32 {SE}, {SHRRUN}, 3, 4
-        v_lshl_or_b32 {SF}, {NDELR}, 3, 3
         v_min3_f32 {SD}, {SUBV}, {own_i}, {lenv}
         v_mov_b32 {diagM}, {X0}
         v_min3_f32 {Q0}, {SD}, {own_d}, {SHRV}
-        v_lshl_or_b32 {X4}, {NINSR}, 3, 1
     """)
+    # (traceback words: the run registers carry their type tag -- layout.hpp tb_word -- so there is nothing to assemble;
+    # 2.0 is the inline constant whose bit pattern is T_LEN << 29)
     if with_len:
-        t(f"v_lshl_or_b32 {X3}, {LENRUN}, 3, 2")
+        t(f"v_or_b32 {X3}, 2.0, {LENRUN}")
     t(f"""
         v_cmp_eq_f32 vcc, {own_d}, {Q0}
         v_cmp_eq_f32 {O('sa')}, {lenv}, {Q0}
         v_cmp_eq_f32 {O('sb')}, {own_i}, {Q0}
         v_cmp_eq_f32 {O('sc')}, {SUBV}, {Q0}
-        v_cndmask_b32 {SE}, {SE}, {SF}, vcc
-        v_lshlrev_b32 {X5}, 3, {DRUN}
-        v_cndmask_b32 {SE}, {SE}, {X3 if with_len else 2}, {O('sa')}
+        v_cndmask_b32 {SE}, {SHRRUN}, {NDELR}, vcc
+        v_cndmask_b32 {SE}, {SE}, {X3 if with_len else '2.0'}, {O('sa')}
         v_add_u32 {X3}, {O('hca')}, {O('slot')}
-        v_cndmask_b32 {SE}, {SE}, {X4}, {O('sb')}
+        v_cndmask_b32 {SE}, {SE}, {NINSR}, {O('sb')}
         v_cndmask_b32 {SD}, 0, {DRUN}, {O('sc')}
-        v_cndmask_b32 {SE}, {SE}, {X5}, {O('sc')}
+        v_cndmask_b32 {SE}, {SE}, {DRUN}, {O('sc')}
     """)
     t(f"v_lshl_or_b32 {QRUNS}, {SHRRUN}, 16, {LENRUN}" if with_len else f"v_lshlrev_b32 {QRUNS}, 16, {SHRRUN}")
     t(f"""
@@ -415,84 +423,43 @@ def mat_part(t, mode, with_len, mid):
         t("s_mov_b64 exec, -1")
 
 
-def handover(t, first, last, multi):
-    """band-edge cells, then (several waves per chunk) the exchange records for the neighbour waves and the wait in
-    front of the progress word.  Release: the LDS unit serves the requests of one wave in order, so the record and the
-    history row are in place before the progress word that follows them; the explicit lgkmcnt(0) in front of it (like
-    the C++ body's workgroup fence) is also what retires the history record's ds_write_b128 before any of its data
-    registers is written again."""
+def edge_fix(t, first, last):
+    """band-edge cells (src/aln.pyx:502-507): the three values their one in-band neighbour reads"""
     own_m, own_i, own_d, r1, r2 = O("matv"), O("insv"), O("delv"), O("R1"), O("R2")
-    # band-edge cells (src/aln.pyx:502-507): the three values their one in-band neighbour reads
     if first or last:
         t(f"v_add_f32 {SD}, 0x42c80000, {O('ev')}")
-    if first:
+    if first and last:
+        # a lone wave holds both edges: one mask for the two lanes -- what the other edge's fix writes into an edge cell
+        # (DEL of column 2r, INS of column 0) is read by no in-band cell
+        t(f"""
+            v_cndmask_b32 {own_m}, {own_m}, {SD}, {O('me')}
+            v_cndmask_b32 {own_d}, {own_d}, {SD}, {O('me')}
+            v_cndmask_b32 {own_i}, {own_i}, {SD}, {O('me')}
+            v_cndmask_b32 {r2}, {r2}, 0, {O('me')}
+            v_cndmask_b32 {r1}, {r1}, 0, {O('me')}
+        """)
+    elif first:
         t(f"""
             v_cndmask_b32 {own_m}, {own_m}, {SD}, {O('ml0')}
             v_cndmask_b32 {own_d}, {own_d}, {SD}, {O('ml0')}
             v_cndmask_b32 {r2}, {r2}, 0, {O('ml0')}
         """)
-    if last:
+    elif last:
         t(f"""
             v_cndmask_b32 {own_m}, {own_m}, {SD}, {O('medge')}
             v_cndmask_b32 {own_i}, {own_i}, {SD}, {O('medge')}
             v_cndmask_b32 {r1}, {r1}, 0, {O('medge')}
         """)
-    if multi:
-        t(f"v_add_u32 {O('prog')}, 1, {O('prog')}")
-        if not last:
-            t(f"""
-                s_mov_b64 exec, {O('ml63')}
-                ds_write2_b32 {O('xown')}, {own_m}, {own_d} offset0:{2 * XCH_WORDS} offset1:{2 * XCH_WORDS + 1}
-                ds_write2_b32 {O('xown')}, {r2}, {O('seqw')} offset0:{2 * XCH_WORDS + 2} offset1:{2 * XCH_WORDS + 3}
-            """)
-        t(f"s_mov_b64 exec, {O('ml0')}")
-        if not first:
-            b = 2 * XCH_WORDS + 5
-            t(f"""
-                ds_write2_b32 {O('xown')}, {own_m}, {own_i} offset0:{b} offset1:{b + 1}
-                ds_write2_b32 {O('xown')}, {r1}, {O('refx')} offset0:{b + 2} offset1:{b + 3}
-                ds_write2_b32 {O('xown')}, {O('rc0')}, {O('rc1')} offset0:{b + 4} offset1:{b + 5}
-            """)
-        t("s_waitcnt lgkmcnt(0)")
 
 
-def publish(t, restore_lenst=False):
-    """the progress word (lane 0; behind handover's wait), then the other parity's exchange records"""
-    t(f"""
-        ds_write_b32 {O('progaddr')}, {O('prog')}
-        s_mov_b64 exec, -1
-    """)
-    if restore_lenst:
-        t(f"v_mov_b32 {LENST}, 0x7f800000")
-    t(f"""
-        v_sub_u32 {O('xown')}, {O('xsum')}, {O('xown')}
-        v_sub_u32 {O('xoth')}, {O('xsum')}, {O('xoth')}
-    """)
-
-
-def tail(t, mode, first, last, multi):
-    """MAT, stores, hand-over, next step"""
-    mid = multi and not first and not last
-    own_m = O("matv")
-    mat_part(t, mode, False, mid)
-    t.label("post_mat_" + mode)
-    handover(t, first, last, multi)
-    if multi:
-        publish(t)
-        t.label("published_" + mode)
-    if mid:
-        t(f"global_store_dword {O('tboff')}, {SE}, {O('tbg')}")
-    # next anti-diagonal; every 64th one starts a new window of input-path steps (out of line: rotate)
+def next_step(t, mode):
+    """loop control of a lone wave: the loop runs to `bend` = the end of the 64-step window, of the span or of what the
+    word queues hold, whichever comes first (block_end, out of line): one compare per step"""
     t(f"""
         v_add_f32 {O('ev')}, 0x42c80000, {O('ev')}
         s_add_i32 {O('bl')}, {O('bl')}, 1
-        s_and_b32 {O('sx')}, {O('bl')}, 63
-        s_cbranch_scc0 {L('rotate' + mode)}
-    """)
-    t.label("rotated" + mode)
-    t(f"""
-        s_cmp_lt_i32 {O('bl')}, {O('b1')}
-        s_cbranch_scc0 {L('done')}
+        s_cmp_lt_i32 {O('bl')}, {O('bend')}
+        s_cbranch_scc0 {L('block_end')}
         s_bitcmp1_b64 {O('mask')}, {O('bl')}
     """)
     if mode == "I":      # (the 'D' body follows)
@@ -502,53 +469,226 @@ def tail(t, mode, first, last, multi):
             s_cbranch_scc0 {L('mode_d')}
             s_branch {L('mode_i')}
         """)
-    # the steps that lead to anti-diagonals 64 m ... 64 m + 63 are window m (bit bl & 63); the window after the new one is
-    # fetched here, 64 steps before it is needed (the wait also drains the traceback stores, once per window)
-    t.rare()
-    t.label("rotate" + mode)
+
+
+def finish(t, mode, first, last, multi, mid, len_variant):
+    """behind MAT and the history record: band-edge cells, then (several waves per chunk) the hand-over and the next step.
+    The exchange record a neighbour wave will read depends on the NEXT step's kind -- an 'I' step reads the last cell
+    of the wave below as its left neighbour, a 'D' step the first cell of the wave above (and the reference words that
+    move down with it) as its top neighbour -- and that kind is known here (the loop's own dispatch, done first): only
+    that record is written.  At the end of a block of steps (the kind is in another mask word) both are.
+    Release: the LDS unit serves the requests of one wave in order, so the record and the history row are in place
+    before the progress word that follows them; the explicit lgkmcnt(0) in front of it (like the C++ body's workgroup
+    fence) is also what retires the history record's ds_write_b128 before any of its data registers is written again
+    (LENST: restored behind it in the variant that follows a LEN candidate)."""
+    own_m, own_i, own_d, r1, r2 = O("matv"), O("insv"), O("delv"), O("R1"), O("R2")
+    edge_fix(t, first, last)
+    if not multi:
+        next_step(t, mode)
+        return
+    tag = mode + ("L" if len_variant else "")
+
+    def rec63():      # last lane's cell, for the wave above
+        t(f"""
+            s_mov_b64 exec, {O('ml63')}
+            ds_write2_b32 {O('xown')}, {own_m}, {own_d} offset0:{2 * XCH_WORDS} offset1:{2 * XCH_WORDS + 1}
+            ds_write2_b32 {O('xown')}, {r2}, {O('seqw')} offset0:{2 * XCH_WORDS + 2} offset1:{2 * XCH_WORDS + 3}
+        """)
+
+    def rec0():       # first lane's cell and its reference words, for the wave below (exec = lane 0)
+        b = 2 * XCH_WORDS + 5
+        t(f"""
+            ds_write2_b32 {O('xown')}, {own_m}, {own_i} offset0:{b} offset1:{b + 1}
+            ds_write2_b32 {O('xown')}, {r1}, {O('refx')} offset0:{b + 2} offset1:{b + 3}
+            ds_write2_b32 {O('xown')}, {O('rc0')}, {O('rc1')} offset0:{b + 4} offset1:{b + 5}
+        """)
+
+    def publish():    # (exec = lane 0) the progress word, then the other parity's exchange records
+        t(f"""
+            s_waitcnt lgkmcnt(0)
+            ds_write_b32 {O('progaddr')}, {O('prog')}
+            s_mov_b64 exec, -1
+        """)
+        if len_variant:
+            t(f"v_mov_b32 {LENST}, 0x7f800000")
+        t(f"""
+            v_sub_u32 {O('xown')}, {O('xsum')}, {O('xown')}
+            v_sub_u32 {O('xoth')}, {O('xsum')}, {O('xoth')}
+        """)
+        if mid:
+            t(f"global_store_dword {O('tboff')}, {SE}, {O('tbg')}")
+        t(f"v_add_f32 {O('ev')}, 0x42c80000, {O('ev')}")
+
     t(f"""
+        v_add_u32 {O('prog')}, 1, {O('prog')}
+        s_add_i32 {O('bl')}, {O('bl')}, 1
+        s_cmp_lt_i32 {O('bl')}, {O('bend')}
+        s_cbranch_scc0 {L('ho_both_' + tag)}
+        s_bitcmp1_b64 {O('mask')}, {O('bl')}
+        s_cbranch_scc0 {L('ho_d_' + tag)}
+    """)
+    # the next step is an 'I' step
+    if not last:
+        rec63()
+    t(f"s_mov_b64 exec, {O('ml0')}")
+    publish()
+    t(f"s_branch {L('mode_i')}")
+    # the next step is a 'D' step (behind the 'I' body's main path it falls through into the 'D' body)
+    t.label("ho_d_" + tag)
+    t(f"s_mov_b64 exec, {O('ml0')}")
+    if not first:
+        rec0()
+    publish()
+    if not (mode == "I" and not len_variant):
+        t(f"s_branch {L('mode_d')}")
+    # the end of a block of steps
+    was_rare = t.lines is t.ool
+    t.rare()
+    t.label("ho_both_" + tag)
+    if not last:
+        rec63()
+    t(f"s_mov_b64 exec, {O('ml0')}")
+    if not first:
+        rec0()
+    publish()
+    t(f"s_branch {L('block_end')}")
+    if not was_rare:
+        t.common()
+
+
+def tail(t, mode, first, last, multi):
+    """MAT, stores, hand-over, next step"""
+    mid = multi and not first and not last
+    mat_part(t, mode, False, mid)
+    t.label("post_mat_" + mode)
+    finish(t, mode, first, last, multi, mid, False)
+
+
+def block_end(t, first, last):
+    """bl has reached bend, the end of a block of steps that needs no test but its own count: the 64-step window, the
+    span, and what the word queues (read words entering at column 0: first wave; reference words entering at the last
+    column: last wave) and the reference-L window (last wave) hold -- a block is at most as many steps, of either kind, as
+    the emptiest of them has entries, so the steps themselves carry no queue tests; near a refill the blocks get short
+    (halving), a dozen scalar instructions per block.
+    At a window boundary the step window after the new one is fetched, 64 steps before it is needed (the wait also
+    drains the traceback stores, once per window) -- also when the span ends there (the caller counts on it).
+    blk_setup is also where the text is entered."""
+    t.label("block_end")
+    t(f"""
+        s_and_b32 {O('sx')}, {O('bl')}, 63
+        s_cbranch_scc1 {L('rotated')}
         s_mov_b64 {O('mask')}, {O('nmask')}
         v_add_u32 {X3}, {O('kbase')}, {O('laneid')}
         s_add_i32 {O('kbase')}, {O('kbase')}, 64
         global_load_ubyte {X3}, {X3}, {O('stepsg')}
         s_waitcnt vmcnt(0)
         v_cmp_ne_u32 {O('nmask')}, 0, {X3}
-        s_branch {L('rotated' + mode)}
     """)
-    t.common()
+    t.label("rotated")
+    t(f"""
+        s_cmp_lt_i32 {O('bl')}, {O('b1')}
+        s_cbranch_scc0 {L('done')}
+    """)
+    t.label("blk_setup")
+    t(f"""
+        s_or_b32 {O('bend')}, {O('bl')}, 63
+        s_add_i32 {O('bend')}, {O('bend')}, 1
+        s_min_i32 {O('bend')}, {O('bend')}, {O('b1')}
+    """)
+    if first:
+        t(f"""
+            s_cmp_ge_i32 {O('sqidx')}, 64
+            s_cbranch_scc1 {L('fill_sq')}
+        """)
+        t.label("sq_ok")
+        t(f"""
+            s_sub_i32 {O('sx')}, {O('bl')}, {O('sqidx')}
+            s_add_i32 {O('sx')}, {O('sx')}, 64
+            s_min_i32 {O('bend')}, {O('bend')}, {O('sx')}
+        """)
+    if last:
+        t(f"""
+            s_cmp_ge_i32 {O('rqidx')}, 64
+            s_cbranch_scc1 {L('fill_rq')}
+        """)
+        t.label("rq_ok")
+        t(f"""
+            s_sub_i32 {O('sx')}, {O('bl')}, {O('rqidx')}
+            s_add_i32 {O('sx')}, {O('sx')}, 64
+            s_min_i32 {O('bend')}, {O('bend')}, {O('sx')}
+            s_cmp_ge_i32 {O('sdel')}, {O('dlim')}
+            s_cbranch_scc1 {L('fill_win')}
+        """)
+        t.label("win_ok")
+        t(f"""
+            s_sub_i32 {O('sx')}, {O('dlim')}, {O('sdel')}
+            s_add_i32 {O('sx')}, {O('sx')}, {O('bl')}
+            s_min_i32 {O('bend')}, {O('bend')}, {O('sx')}
+        """)
+    t(f"""
+        s_bitcmp1_b64 {O('mask')}, {O('bl')}
+        s_cbranch_scc0 {L('mode_d')}
+        s_branch {L('mode_i')}
+    """)
 
 
-def polls(t, first, last, sfx):
+def xch_reads(t, mode, first, last):
+    """the neighbour wave's boundary cell of the previous anti-diagonal (its exchange record of the other parity): an 'I'
+    step reads the last cell of the wave below (words 0-3: MAT, DEL, runs, read word), a 'D' step the first cell of the
+    wave above (words 5-10: MAT, INS, runs, reference word, the two column descriptors; the descriptors first)"""
+    if mode == "I" and not first:
+        t(f"ds_read_b128 {XQ}, {O('xoth')}")
+    if mode == "D" and not last:
+        b = (4 * XCH_WORDS + 5)
+        t(f"""
+            ds_read2_b32 {X45}, {O('xoth')} offset0:{b + 4} offset1:{b + 5}
+            ds_read2_b32 {X01}, {O('xoth')} offset0:{b} offset1:{b + 1}
+            ds_read2_b32 {X23}, {O('xoth')} offset0:{b + 2} offset1:{b + 3}
+        """)
+
+
+def poll_issue(t, mode, first, last):
+    """the FIRST look at the neighbours' progress words and, right behind it, the read of the neighbour's boundary cell,
+    both issued at the head of the step: by the time the work in front of the hand-shake is done they are here.  A
+    neighbour that had finished when the look was served has finished now (the words only grow), and the LDS unit
+    serves a wave's requests in order, so the cell read behind a look that succeeded is the finished one: the usual
+    step then waits for no LDS round trip at the hand-shake.  A look that fails goes on polling out of line and reads
+    the cell again."""
+    if not ABLATE["nopoll"]:
+        if not first and not last:
+            t(f"ds_read2_b32 {PP}, {O('pnb')} offset1:2")       # (the neighbours' words lie 8 bytes apart, this wave's in between)
+        elif not last:
+            t(f"ds_read_b32 {P0}, {O('pnb')} offset:8")
+        elif not first:
+            t(f"ds_read_b32 {P0}, {O('pnb')}")
+    xch_reads(t, mode, first, last)
+
+
+def polls(t, mode, first, last, sfx):
     """this wave may start the anti-diagonal once its neighbour waves have finished the previous one"""
+    if first and last:
+        return
+    t("s_waitcnt lgkmcnt(0)")
     if ABLATE["nopoll"]:
         return
-    if not first and not last:
-        # both progress words in one round trip (the neighbours' words lie 8 bytes apart, this wave's in between)
-        t.label("pp" + sfx)
-        t(f"""
-            ds_read2_b32 {PP}, {O('pnb')} offset1:2
-            s_waitcnt lgkmcnt(0)
-            v_min_i32 {X3}, {P0}, {P1}
-            v_cmp_lt_i32 vcc, {X3}, {O('prog')}
-            s_cbranch_vccnz {L('pp' + sfx)}
-        """)
-        return
-    if not last:
-        t.label("pa" + sfx)
-        t(f"""
-            ds_read_b32 {X3}, {O('pnb')} offset:8
-            s_waitcnt lgkmcnt(0)
-            v_cmp_lt_i32 vcc, {X3}, {O('prog')}
-            s_cbranch_vccnz {L('pa' + sfx)}
-        """)
-    if not first:
-        t.label("pb" + sfx)
-        t(f"""
-            ds_read_b32 {X3}, {O('pnb')}
-            s_waitcnt lgkmcnt(0)
-            v_cmp_lt_i32 vcc, {X3}, {O('prog')}
-            s_cbranch_vccnz {L('pb' + sfx)}
-        """)
+    both = not first and not last
+    again = f"ds_read2_b32 {PP}, {O('pnb')} offset1:2" if both else f"ds_read_b32 {P0}, {O('pnb')}" + (" offset:8" if not last else "")
+    test = (f"v_min_i32 {SD}, {P0}, {P1}\nv_cmp_lt_i32 vcc, {SD}, {O('prog')}" if both else f"v_cmp_lt_i32 vcc, {P0}, {O('prog')}")
+    t(test)
+    t(f"s_cbranch_vccnz {L('pp' + sfx)}")
+    t.label("pp_ok" + sfx)
+    t.rare()
+    t.label("pp" + sfx)
+    t(again)
+    t("s_waitcnt lgkmcnt(0)")
+    t(test)
+    t(f"s_cbranch_vccnz {L('pp' + sfx)}")
+    xch_reads(t, mode, first, last)
+    t(f"""
+        s_waitcnt lgkmcnt(0)
+        s_branch {L('pp_ok' + sfx)}
+    """)
+    t.common()
 
 
 def book(t, mode):
@@ -580,30 +720,32 @@ def gen_role(role):
     # second read of the same address was right.  One wait per entry (entries = hand-overs, ~1 % of the steps): within
     # the run-to-run spread of the fill time.
     t("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    # The rare-path test of the column descriptors (DSC_RARE), once per entry, over every lane whose descriptor is in
+    # the band or on its way there (the lanes beyond the band's last column hold the descriptors that will move into
+    # it): an 'I' step does not move the descriptors and a 'D' step tests the one that enters at its last lane before
+    # it moves them, so inside the loop no lane ever holds a rare one and a step carries no test of its own
     t(f"""
         v_mov_b32 {LENST}, 0x7f800000
-        s_bitcmp1_b64 {O('mask')}, {O('bl')}
-        s_cbranch_scc0 {L('mode_d')}
+        v_and_b32 {SMR}, 0x80, {O('rc0')}
+    """)
+    if first and multi:
+        t(f"v_cndmask_b32 {SMR}, 0, {SMR}, {O('mhist')}")      # (column 0, an edge: its descriptor moves out)
+    t(f"""
+        v_cmp_ne_u32 vcc, 0, {SMR}
+        s_cbranch_vccnz {L('exit')}
+        s_branch {L('blk_setup')}
     """)
     # ================= 'I' step: read words move one column up, "left" is the previous lane.  The column
     # descriptors do not move and INS reads this lane's own cell, so everything that does not depend on the neighbour
     # waves -- the descriptor's summary bits, the lane-table reads, INS -- is done in front of the hand-shake poll.
     t.label("mode_i")
-    if first:
-        t(f"""
-            s_cmp_ge_i32 {O('sqidx')}, 64
-            s_cbranch_scc1 {L('fill_sq')}
-        """)
-        t.label("sq_ok")
     t(f"v_and_b32 {SMR}, 0xbc, {O('rc0')}")
     if not mid:
         t(f"v_cndmask_b32 {SMR}, 0, {SMR}, {O('mhist')}")
-    t(f"""
-        v_cmp_lt_u32 vcc, 0x7f, {SMR}
-        s_cbranch_vccnz {L('exit')}
-    """)
+    if multi:
+        poll_issue(t, "I", first, last)
     book(t, "I")
-    shr_tables(t)
+    shr_tables(t, X3 if first else SD)          # (X3 is waiting for its exchange word)
     t(f"v_add_u32_sdwa {DRUN}, {O('LMr')}, {O('one')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD")
     ins_part(t, "I", X4, X5, O("sb"), (f"v_mov_b32 {O('TMv')}, {O('matv')}", f"v_mov_b32 {O('TMr')}, {O('R1')}"))
     if first:
@@ -612,20 +754,12 @@ def gen_role(role):
             s_add_i32 {O('sqidx')}, {O('sqidx')}, 1
         """)
     if multi:
-        polls(t, first, last, "_i")
-    if not first:
-        t(f"""
-            ds_read_b32 {X0}, {O('xoth')}
-            ds_read_b32 {X1}, {O('xoth')} offset:4
-            ds_read_b32 {X2}, {O('xoth')} offset:8
-            ds_read_b32 {X3}, {O('xoth')} offset:12
-        """)
+        polls(t, "I", first, last, "_i")
     else:
         t("s_waitcnt lgkmcnt(0)")
     shr_hist(t)
     if not first:
         t(f"""
-            s_waitcnt lgkmcnt(1)
             v_mov_b32_dpp {X3}, {O('seqw')} wave_shr:1 row_mask:0xf bank_mask:0xf
             v_mov_b32_dpp {X0}, {O('matv')} wave_shr:1 row_mask:0xf bank_mask:0xf
             v_mov_b32_dpp {X1}, {O('delv')} wave_shr:1 row_mask:0xf bank_mask:0xf
@@ -644,7 +778,7 @@ def gen_role(role):
         """)
     sub_read(t)
     t("s_waitcnt lgkmcnt(1)")          # the candidate's source record (the substitution score may still be on its way)
-    shr_pass(t, mid, "_I", SMR, lambda: del_part(t, "I", X4, X5, O("sb")), lambda: del_part(t, "I", SD, P0, O("sb")))
+    shr_pass(t, mid, "_I", SMR, lambda: del_part(t, "I", X4, X5, O("sb")), lambda: del_part(t, "I", SD, P0, O("sb")), multi)
     len_pass(t, mid, "_I", "I", first, last, multi)
     tail(t, "I", first, last, multi)
     # ================= 'D' step: reference words (and the column descriptors) move one column down, "top" is the
@@ -654,22 +788,12 @@ def gen_role(role):
     t.label("mode_d")
     if last:
         t(f"""
-            s_cmp_ge_i32 {O('rqidx')}, 64
-            s_cbranch_scc1 {L('fill_rq')}
-        """)
-        t.label("rq_ok")
-        t(f"""
-            s_cmp_ge_i32 {O('sdel')}, {O('dlim')}
-            s_cbranch_scc1 {L('fill_win')}
-        """)
-        t.label("win_ok")
-        t(f"""
             v_readlane_b32 {O('sx')}, {O('rqz')}, {O('rqidx')}
-            v_or_b32 {SD}, {O('sx')}, {O('rc0')}
-            v_and_b32 {SD}, 0x80, {SD}
-            v_cmp_ne_u32 vcc, 0, {SD}
-            s_cbranch_vccnz {L('exit')}
+            s_bitcmp1_b32 {O('sx')}, 7
+            s_cbranch_scc1 {L('exit')}
         """)
+    if multi:
+        poll_issue(t, "D", first, last)
     book(t, "D")
     t(f"""
         s_add_i32 {O('sdel')}, {O('sdel')}, 1
@@ -698,34 +822,24 @@ def gen_role(role):
         shr_tables(t)
         ins_part(t, "D", X4, X5, O("sb"))
         if multi:
-            polls(t, first, last, "_d")
+            polls(t, "D", first, last, "_d")
         else:
             t("s_waitcnt lgkmcnt(0)")
         shr_hist(t)
         sub_read(t)
         t("s_waitcnt lgkmcnt(1)")
     else:
-        polls(t, first, last, "_d")
-        b = (4 * XCH_WORDS + 5) * 4
+        polls(t, "D", first, last, "_d")
         t(f"""
-            ds_read_b32 {X4}, {O('xoth')} offset:{b + 16}
-            ds_read_b32 {X0}, {O('xoth')} offset:{b}
-            ds_read_b32 {X1}, {O('xoth')} offset:{b + 4}
-            ds_read_b32 {X2}, {O('xoth')} offset:{b + 8}
-            ds_read_b32 {X3}, {O('xoth')} offset:{b + 12}
-            ds_read_b32 {X5}, {O('xoth')} offset:{b + 20}
-            s_waitcnt lgkmcnt(5)
-            v_or_b32 {SD}, {O('rc0')}, {X4}
-            v_and_b32 {SD}, 0x80, {SD}
+            v_and_b32 {SD}, 0x80, {X4}
             v_cmp_ne_u32 vcc, 0, {SD}
             s_cbranch_vccnz {L('exit2')}
             v_mov_b32_dpp {X4}, {O('rc0')} wave_shl:1 row_mask:0xf bank_mask:0xf
             v_mov_b32 {O('rc0')}, {X4}
         """)
-        shr_tables(t, SD)          # (X3 is waiting for its exchange word)
+        shr_tables(t, SD)          # (X3 holds its exchange word)
         t(f"""
             v_and_b32 {SMR}, 0xbc, {O('rc0')}
-            s_waitcnt lgkmcnt(2)
             v_mov_b32_dpp {X3}, {O('refx')} wave_shl:1 row_mask:0xf bank_mask:0xf
             v_mov_b32_dpp {X5}, {O('rc1')} wave_shl:1 row_mask:0xf bank_mask:0xf
             v_mov_b32_dpp {X0}, {O('matv')} wave_shl:1 row_mask:0xf bank_mask:0xf
@@ -742,7 +856,7 @@ def gen_role(role):
         t("s_waitcnt lgkmcnt(1)")
         shr_hist(t)
         t("s_waitcnt lgkmcnt(0)")
-    shr_pass(t, mid, "_D", SMR, lambda: del_part(t, "D", X4, X5, O("sb")), lambda: del_part(t, "D", SD, P0, O("sb")))
+    shr_pass(t, mid, "_D", SMR, lambda: del_part(t, "D", X4, X5, O("sb")), lambda: del_part(t, "D", SD, P0, O("sb")), multi)
     len_pass(t, mid, "_D", "D", first, last, multi)
     tail(t, "D", first, last, multi)
     t.lines = t.main
@@ -811,6 +925,7 @@ def gen_role(role):
             s_add_i32 {O('dlim')}, {O('dlim')}, {ws}
             s_branch {L('win_ok')}
         """)
+    block_end(t, first, last)
     t.label("exit2")
     t(f"s_mov_b32 {O('status')}, 2")
     t(f"s_branch {L('end')}")
@@ -925,7 +1040,7 @@ def operands(role):
             ("slot", "+v", "slot_v"), ("tboff", "+v", "tboff_v"), ("ev", "+v", "e_v"),
             ("bl", "+s", "a_bl"), ("sdel", "+s", "a_sdel"), ("status", "=&s", "a_status"),
             ("mask", "+s", "a_mask"), ("nmask", "+s", "a_nmask"), ("kbase", "+s", "a_kbase"),
-            ("sa", "=&s", "a_sa"), ("sb", "=&s", "a_sb"), ("sc", "=&s", "a_sc")]
+            ("sa", "=&s", "a_sa"), ("sb", "=&s", "a_sb"), ("sc", "=&s", "a_sc"), ("bend", "=&s", "a_bend")]
     if multi:
         outs += [("prog", "+v", "prog_v"), ("xown", "+v", "xown"), ("xoth", "+v", "xoth")]
     if first:
@@ -939,7 +1054,8 @@ def operands(role):
            ("iext", "s", "a_iext"), ("winaddr", "s", "a_winaddr"), ("wmask", "s", "a_wmask"), ("clampv", "s", "a_clampv"),
            ("clamp1", "s", "a_clamp1"), ("npdim", "s", "a_npdim"), ("gnp", "s", "env.g_np"),
            ("hca", "v", "hist_c_addr"), ("trecip", "v", "env.t_recip"), ("one", "v", "a_one"), ("lanej", "v", "a_lanej"),
-           ("inf", "v", "a_inf"), ("c100", "v", "a_c100")]
+           ("inf", "v", "a_inf"), ("c100", "v", "a_c100"),
+           ("oneI", "v", "a_oneI"), ("oneD", "v", "a_oneD"), ("tagS", "v", "a_tagS")]
     if role != 2:
         ins += [("mhist", "s", "a_mhist")]
     if multi:
@@ -947,7 +1063,7 @@ def operands(role):
         if not last:
             ins += [("ml63", "s", "a_ml63")]
     elif first:
-        ins += [("ml0", "s", "a_ml0")]
+        ins += [("ml0", "s", "a_ml0"), ("me", "s", "a_me")]
     if last:
         ins += [("medge", "s", "a_medge"), ("dcols", "s", "a_dcols"), ("refwg", "s", "refw_g"), ("reflg", "s", "refl_g")]
     if first:

@@ -871,17 +871,19 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
             const float a_istart = st.indel_start, a_iext = st.indel_extend;
             const uint32_t a_winaddr = (uint32_t)(reinterpret_cast<const char *>(win) - reinterpret_cast<const char *>(lds));
             const unsigned long long a_mhist = __builtin_amdgcn_ballot_w64(hist_lane), a_ml0 = 1ull, a_ml63 = 1ull << 63,
-                                     a_medge = __builtin_amdgcn_ballot_w64(tcol == 2 * r);
+                                     a_medge = __builtin_amdgcn_ballot_w64(tcol == 2 * r), a_me = a_ml0 | a_medge;
             uint32_t a_one = 1u, a_lanej = (uint32_t)(tcol - r);
             uint32_t a_progaddr = (uint32_t)(reinterpret_cast<const char *>(prog + cw) - reinterpret_cast<const char *>(lds));
             float a_inf = huge_f(), a_c100 = INF_F;          // (a literal and VCC do not fit one v_cndmask: constants in registers)
+            // run registers carry the type tag of their traceback word (layout.hpp tb_word): "run + 1" / "run 1" of INS and DEL, "run 0" of SHR
+            uint32_t a_oneI = tb_word(T_INS, 1u), a_oneD = tb_word(T_DEL, 1u), a_tagS = tb_word(T_SHR, 0u);
             uint32_t a_laneid = (uint32_t)lane;
             const int a_drows = d.drows, a_dcols = d.dcols;
-            asm volatile("" : "+v"(a_one), "+v"(a_lanej), "+v"(a_progaddr), "+v"(a_inf), "+v"(a_c100), "+v"(a_laneid));
+            asm volatile("" : "+v"(a_one), "+v"(a_lanej), "+v"(a_progaddr), "+v"(a_inf), "+v"(a_c100), "+v"(a_laneid), "+v"(a_oneI), "+v"(a_oneD), "+v"(a_tagS));
             (void)a_laneid; (void)a_drows; (void)a_dcols;
-            (void)a_mhist; (void)a_ml0; (void)a_ml63; (void)a_medge; (void)a_progaddr;
+            (void)a_mhist; (void)a_ml0; (void)a_ml63; (void)a_medge; (void)a_me; (void)a_progaddr;
             for (;;) {
-                int a_status, a_sx;
+                int a_status, a_sx, a_bend;
                 unsigned long long a_mask = stepmask, a_nmask = nextmask;
                 int a_kbase = 64 * ((a_bl >> 6) + 2) - 1;           // first step byte of the window after the next one, for lane 0
                 unsigned long long a_sa, a_sb, a_sc;
@@ -889,7 +891,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
                 int a_dlim = a_wfill - r - WIN_SLACK - 1;       // (the 'D' step that makes the L window refill)
                 const int bl_in = a_bl, sdel_in = a_sdel;
                 int a_sq = uni(sq_idx), a_rq = uni(rq_idx), a_sqb = uni(sq_base), a_rqb = uni(rq_base);
-                (void)a_dlim; (void)a_sx; (void)a_sq; (void)a_rq; (void)a_sqb; (void)a_rqb; (void)a_wfill;
+                (void)a_dlim; (void)a_sx; (void)a_bend; (void)a_sq; (void)a_rq; (void)a_sqb; (void)a_rqb; (void)a_wfill;
                 if constexpr (ROLE == 0)
                     asm volatile(NPORE_FILL_ASM_TEXT_0 : NPORE_FILL_ASM_OUTS_0 : NPORE_FILL_ASM_INS_0 : NPORE_FILL_ASM_CLOBBERS);
                 else if constexpr (ROLE == 1)
@@ -1089,7 +1091,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(TParams p)
                 break;
             }
             const uint32_t w = word(cur, bl, bc);
-            const int typ = (int)(w & 7u), run = (int)(w >> 3);     // src/aln.pyx:684-685
+            const int typ = tb_typ(w), run = tb_run(w);     // src/aln.pyx:684-685
             if ((run < 1) | (run > pos) | (typ > T_SHR)) {
                 status |= (run < 1) ? 4 : (run > pos) ? 16 : 8;
                 why = 3;
@@ -1189,7 +1191,7 @@ __global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
             break;
         }
         const uint32_t x = word(bc);
-        const int typ = (int)(x & 7u), run = (int)(x >> 3);     // src/aln.pyx:684-685
+        const int typ = tb_typ(x), run = tb_run(x);     // src/aln.pyx:684-685
         if ((run < 1) | (run > pos) | (typ > T_SHR)) {
             status |= (run < 1) ? 4 : (run > pos) ? 16 : 8;
             break;

@@ -42,8 +42,10 @@
 // chunk's own slices (src/aln.pyx:453-456); flags are stored from the point of
 // view of the cell that RECEIVES a lengthen/shorten move (see kernels.hpp).
 //
-// Traceback word per cell (the only per-cell HBM traffic): typ | run<<3, the
-// MAT.TYP / MAT.RUN pair the reference's traceback reads (src/aln.pyx:684-685).
+// Traceback word per cell (the only per-cell HBM traffic): run | typ << 29 (tb_word), the
+// MAT.TYP / MAT.RUN pair the reference's traceback reads (src/aln.pyx:684-685).  The type sits in the TOP bits so
+// that a run register can carry its type tag through the recurrence -- run + 1 of a tagged run is the tagged run + 1,
+// the tag falls out of a 16-bit shift -- and the fill kernel never has to assemble the word.
 #pragma once
 #include <stdint.h>
 
@@ -56,6 +58,12 @@
 namespace npore {
 
 enum : int { T_MAT = 0, T_INS = 1, T_LEN = 2, T_DEL = 3, T_SHR = 4 };
+
+constexpr int TB_TYP_SHIFT = 29;
+constexpr uint32_t TB_RUN_MASK = (1u << TB_TYP_SHIFT) - 1u;
+NPORE_HD uint32_t tb_word(int typ, uint32_t run) { return ((uint32_t)typ << TB_TYP_SHIFT) | run; }
+NPORE_HD int tb_typ(uint32_t w) { return (int)(w >> TB_TYP_SHIFT); }
+NPORE_HD int tb_run(uint32_t w) { return (int)(w & TB_RUN_MASK); }
 
 constexpr int MER_SHIFT = 14, FLAG_SHIFT = 8;  // positions of the 18-bit base field and of the 6 "in an n-polymer" flags
 constexpr uint32_t SEQW_SENTINEL = 0x3FFFFu << MER_SHIFT;  // six code-7 bases, no flags

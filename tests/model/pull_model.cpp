@@ -184,7 +184,7 @@ extern "C" int64_t pull_model_align(const uint8_t *full_ref, int64_t ref_len, co
             const int64_t bc = (int64_t)path.inss[a_row + a_col] - a_row + r;
             if (bc < 0 || bc >= W) { *status |= 16; break; }
             const uint32_t w = tb[(size_t)bl * W + bc];
-            const int typ = w & 7, run = (int)(w >> 3);
+            const int typ = npore::tb_typ(w), run = npore::tb_run(w);
             if (run < 1) { *status |= 4; break; }
             if (typ == T_LEN || typ == T_INS) { aln.append(run, 'I'); a_row -= run; }
             else if (typ == T_SHR || typ == T_DEL) { aln.append(run, 'D'); a_col -= run; }
