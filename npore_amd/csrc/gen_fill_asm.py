@@ -675,14 +675,19 @@ def polls(t, mode, first, last, sfx):
     again = f"ds_read2_b32 {PP}, {O('pnb')} offset1:2" if both else f"ds_read_b32 {P0}, {O('pnb')}" + (" offset:8" if not last else "")
     test = (f"v_min_i32 {SD}, {P0}, {P1}\nv_cmp_lt_i32 vcc, {SD}, {O('prog')}" if both else f"v_cmp_lt_i32 vcc, {P0}, {O('prog')}")
     t(test)
-    t(f"s_cbranch_vccnz {L('pp' + sfx)}")
+    t(f"s_cbranch_vccnz {L('pp_first' + sfx)}")
     t.label("pp_ok" + sfx)
+    # a wave that has to wait looks again at the LOWEST issue priority: its looks then take no issue slot that a wave of
+    # the SIMD with work to do could use (the waves of a chunk share one SIMD, and the one being waited for is among them)
     t.rare()
+    t.label("pp_first" + sfx)
+    t("s_setprio 0")
     t.label("pp" + sfx)
     t(again)
     t("s_waitcnt lgkmcnt(0)")
     t(test)
     t(f"s_cbranch_vccnz {L('pp' + sfx)}")
+    t(f"s_setprio {2 if both else 1}")
     xch_reads(t, mode, first, last)
     t(f"""
         s_waitcnt lgkmcnt(0)

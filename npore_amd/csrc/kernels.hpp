@@ -338,7 +338,11 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
     // The middle waves of a chunk (all 64 lanes live, a neighbour wave on either side) are issued first when
     // several waves of the SIMD are ready: measured 1.5-2 % on the fill at NW = 3...7 (r = 70, 100, 140, 200)
     if constexpr (xp::PRIO == 0) {
-        if (NW > 2 && cw != 0 && cw != NW - 1) __builtin_amdgcn_s_setprio(1);
+        // (the step assembly drops a wave to priority 0 while it waits for a neighbour: gen_fill_asm.py polls)
+        if constexpr (MULTI) {
+            if (NW > 2 && cw != 0 && cw != NW - 1) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(1);
+        }
     } else if constexpr (xp::PRIO == 1) {          // first wave highest
         const int pr = min(3, NW - 1 - cw);
         if (pr == 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 1) __builtin_amdgcn_s_setprio(1);

@@ -12,8 +12,9 @@ for _name in list(_lib.SIGNATURES):
 from npore_amd import aln, synth
 sub, nps, _, _ = aln.load_default_tables()
 ctx = aln.Context(sub, nps)
-refs, seqs, cigs = synth.make_batch(2, 1000, ref_len=10000)
+_r, _n = (int(x) for x in os.environ.get('PMC_CASE', '100:1000').split(':'))
+refs, seqs, cigs = synth.make_batch(2, _n, ref_len=10000)
 for rep in range(2):
-    out, st = ctx.align_batch(refs, seqs, cigs, r=100, return_status=True)
+    out, st = ctx.align_batch(refs, seqs, cigs, r=_r, return_status=True)
 t = ctx.timing()
 print('fill', round(t['fill_ms'], 2), 'prep', round(t['dev_prep_ms'], 2), 'tb', round(t['traceback_ms'], 2))
