@@ -114,6 +114,23 @@ int npore_align_batch_async(npore_ctx *ctx, int64_t n_reads,
                             int64_t *out_len, int32_t *status);
 
 /*
+ * align() AND realign_read's glue for a batch (reference src/bam.pyx:59-78: align(), then X,= -> M, one pass of
+ * push-D-left / I-through-D / push-I-left / I-through-D (src/cig.pyx:102-192), 'ID' -> 'M', collapse_cigar
+ * src/cig.pyx:13-38), all on the device: out receives the collapsed, standardised CIGAR TEXT of read i in
+ * out[out_off[i] .. out_off[i] + out_len[i]) instead of the op string; slots of 2 * (ref + read bases) + 16 bytes always
+ * suffice (NPORE_ST_OUT_CAP otherwise).  A read align() refuses gets an empty text.  Same bytes as
+ * npore_align_batch followed by npore_standardize_batch; the op strings never leave the GPU.  Synchronous.
+ */
+int npore_align_batch_cigars(npore_ctx *ctx, int64_t n_reads,
+                            const uint8_t *refs, const int64_t *ref_off,
+                            const uint8_t *seqs, const int64_t *seq_off,
+                            const char *cigars, const int64_t *cig_off,
+                            float indel_start, float indel_extend,
+                            int max_b_rows, int r,
+                            char *out, const int64_t *out_off,
+                            int64_t *out_len, int32_t *status);
+
+/*
  * Device-resident variant used by bench.py and by pipelines that already hold
  * the reads in HBM: same arguments, but every pointer except ctx is a DEVICE
  * pointer (hipMalloc'ed by the caller, e.g. a torch.cuda tensor's data_ptr()).

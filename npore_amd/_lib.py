@@ -28,6 +28,8 @@ SIGNATURES = {
                           [C.c_float, C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 4),
     "npore_align_batch_async": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 6 +
                                 [C.c_float, C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 4),
+    "npore_align_batch_cigars": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 6 +
+                                 [C.c_float, C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 4),
     "npore_align_batch_device": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 6 +
                                  [C.c_float, C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 4 +
                                  [C.c_void_p, C.c_int]),

@@ -122,9 +122,10 @@ class Context:
         _check(self.lib.npore_ctx_wait(self.handle))
 
     def align_batch(self, refs, seqs, cigars, indel_start=5, indel_extend=1, max_b_rows=20000, r=30,
-                    return_status=False):
+                    return_status=False, final_cigars=False):
         """refs/seqs: sequences of uint8 code arrays; cigars: expanded op strings/bytes.
-        Returns list[str] (and int32 status array)."""
+        Returns list[str] (and int32 status array).  final_cigars=True: what realign_read makes of the strings
+        (reference src/bam.pyx:59-78: standardised, collapsed CIGAR text), done on the device (npore_align_batch_cigars)."""
         n = len(refs)
         if n == 0:
             return ([], np.zeros(0, np.int32)) if return_status else []
@@ -134,14 +135,15 @@ class Context:
         ro = np.zeros(n + 1, np.int64); np.cumsum([len(x) for x in refs], out=ro[1:])
         so = np.zeros(n + 1, np.int64); np.cumsum([len(x) for x in seqs], out=so[1:])
         co = np.zeros(n + 1, np.int64); np.cumsum([len(x) for x in cigs], out=co[1:])
-        oo = np.zeros(n + 1, np.int64); np.cumsum([len(a) + len(b) for a, b in zip(refs, seqs)], out=oo[1:])
+        oo = np.zeros(n + 1, np.int64)
+        np.cumsum([(2 * (len(a) + len(b)) + 16) if final_cigars else (len(a) + len(b)) for a, b in zip(refs, seqs)], out=oo[1:])
         rb = np.concatenate(refs + [np.zeros(1, np.uint8)])
         sb = np.concatenate(seqs + [np.zeros(1, np.uint8)])
         cb = np.frombuffer(b"".join(cigs) + b"\0", dtype=np.uint8)
         out = np.zeros(int(oo[-1]) + 1, np.uint8)
         olen = np.zeros(n, np.int64)
         st = np.zeros(n, np.int32)
-        _check(self.lib.npore_align_batch(
+        _check((self.lib.npore_align_batch_cigars if final_cigars else self.lib.npore_align_batch)(
             self.handle, n, rb.ctypes.data, ro.ctypes.data, sb.ctypes.data, so.ctypes.data,
             cb.ctypes.data, co.ctypes.data, indel_start, indel_extend, max_b_rows, r,
             out.ctypes.data, oo.ctypes.data, olen.ctypes.data, st.ctypes.data))

@@ -39,6 +39,7 @@
 #endif
 #include NPORE_FILL_ASM_INC
 #include "layout.hpp"
+#include "std_stream.hpp"
 
 namespace npore {
 
@@ -1378,6 +1379,94 @@ __global__ __launch_bounds__(256) void gather_kernel(GParams p)
             for (int k = t; k < U1 - U0; k += T) dst[len - 1 - U0 - k] = l_ops[k];
             __syncthreads();
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// realign_read's glue on the device (reference src/bam.pyx:59-78 with src/cig.pyx:13-38, 102-192): ONE LANE PER READ runs
+// the streaming standardisation of std_stream.hpp over the read's traceback runs (chunk after chunk, each chunk's runs
+// last-recorded first: that is read order) and writes the collapsed CIGAR text -- digits and 'M' / 'I' / 'D' -- into the
+// read's output slot, where gather_kernel would have put the op string.  The stages are sequential by nature (every
+// indel run sees the list as the ones before left it); a batch has thousands of reads, and this kernel runs beside the
+// next batch's fill kernel (no LDS, one wave per 64 reads), so the serial chain costs the pipeline nothing while the
+// host is spared its dearest stage after inflation (70 us per 10 kb read and core) and the op strings never cross PCIe.
+// A read align() refused (out_len < 0 from gather_scan_kernel) gets an empty text, like the host path's empty string.
+struct StdKParams {
+    const ChunkDesc *descs;
+    const int32_t *read_first_chunk;   // [n_reads+1]
+    const uint32_t *chunk_runs;
+    const int32_t *chunk_nruns;
+    const uint8_t *refs, *seqs;        // the batch's bases, only compared for equality
+    const int64_t *ref_off, *seq_off;  // [n_reads+1], this group's
+    uint8_t *out;
+    const int64_t *out_off;            // [n_reads+1] in the caller's buffer: 2 bytes per op + 16 always suffice
+    int64_t *out_len;                  // in: ops of the alignment (or < 0); out: bytes of text
+    int32_t *status;
+    int64_t read_base, n_reads;
+};
+
+struct CigarTextSink {
+    uint8_t *o, *end;
+    bool overflow;
+    __device__ __forceinline__ void operator()(uint32_t op, int32_t n)
+    {
+        uint32_t v = (uint32_t)n;
+        int nd = 1;
+        for (uint32_t t = v; t >= 10u; t /= 10u) nd++;
+        if (o + nd + 1 > end) { overflow = true; return; }
+        for (int k = nd - 1; k >= 0; k--) { o[k] = (uint8_t)('0' + v % 10u); v /= 10u; }
+        o[nd] = (uint8_t)(op == SOP_M ? 'M' : op == SOP_I ? 'I' : 'D');
+        o += nd + 1;
+    }
+};
+
+// Held to 64 vector registers: what the fill kernel's four waves leave on a SIMD (fill_kernel) -- with more it would wait
+// for a fill workgroup to leave its CU, i.e. for the end of the launch it is meant to run beside.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(32))) void standardize_kernel(StdKParams p)
+{
+    // a chain of dependent loads per lane, a few dozen waves per batch: at the highest issue priority it keeps its own
+    // pace beside a fill kernel's waves and takes a fraction of a percent of their issue slots
+    __builtin_amdgcn_s_setprio(3);
+    const int64_t rd = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (rd >= p.n_reads) return;
+    const int64_t grd = p.read_base + rd;
+    if (p.out_len[grd] < 0) { p.out_len[grd] = 0; return; }
+    uint8_t *start = p.out + p.out_off[grd];
+    CigarTextSink sink{start, p.out + p.out_off[grd + 1], false};
+    // (32-bit lengths and positions: a read has fewer than 2^31 ops -- run_core refuses longer ones)
+    StdStream<CigarTextSink, int32_t> st(sink, p.refs + p.ref_off[rd], (int32_t)(p.ref_off[rd + 1] - p.ref_off[rd]), p.seqs + p.seq_off[rd],
+                                         (int32_t)(p.seq_off[rd + 1] - p.seq_off[rd]));
+    const int c0 = p.read_first_chunk[rd], c1 = p.read_first_chunk[rd + 1];
+    // (one call site of the stages -- their code is large -- with the next run's load issued before the current run is
+    // processed: the loads of a lane are what its chain waits for)
+    int c = c0;
+    const uint32_t *runs = nullptr;
+    int e = -1;
+    auto next_run = [&](uint32_t &x) -> bool {          // the read's runs in read order
+        while (e < 0) {
+            if (c >= c1) return false;
+            runs = p.chunk_runs + p.descs[c].out_off;
+            e = p.chunk_nruns[c] - 1;
+            c++;
+        }
+        x = runs[e--];
+        return true;
+    };
+    uint32_t x = 0u, xn = 0u;
+    bool have = next_run(x);
+    while (have) {
+        const bool have_next = next_run(xn);
+        const int typ = (int)(x & 7u);
+        st.feed(typ == T_MAT ? SOP_M : (typ == T_INS || typ == T_LEN) ? SOP_I : SOP_D, (int32_t)(x >> 3));
+        x = xn;
+        have = have_next;
+    }
+    st.finish();
+    if (sink.overflow) {
+        p.out_len[grd] = -1;
+        p.status[grd] |= 64;          // NPORE_ST_OUT_CAP
+    } else {
+        p.out_len[grd] = (int64_t)(sink.o - start);
     }
 }
 

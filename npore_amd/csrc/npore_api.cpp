@@ -198,6 +198,7 @@ struct npore_ctx {
     int64_t tb_budget_mb = 0;   // 0 = auto
     int tb_kernel = 0;          // 0 = by batch size, 1 = windowed traceback, 2 = row per hop
     int force_chunks = 0;
+    int device_glue = 1;        // BAM -> SAM pipeline: realign_read's glue on the device (0: on the host, from the op strings)
     int coresident = 1;         // kernel shapes that fit beside a fill kernel for a group that overlaps another one's
     bool fill_has_room = false; // the last fill launch left LDS for such kernels on its CUs
     HostBuf h_offs;             // offset arrays of a device-resident batch (npore_align_batch_device)
@@ -340,6 +341,9 @@ struct AlignArgs {
     const int64_t *h_out_off = nullptr;
     int64_t *h_out_len = nullptr;
     int32_t *h_status = nullptr;
+    // the output is the collapsed, standardised CIGAR text (realign_read's glue on the device, kernels.hpp
+    // standardize_kernel) instead of the op string; out_len = bytes of text
+    bool final_text = false;
     bool staged() const { return h_out != nullptr; }
 };
 
@@ -575,6 +579,22 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     gp.n_reads = nr;
     gp.chunk_woff = w->cwoff.as<int64_t>();
     hipLaunchKernelGGL(gather_scan_kernel, dim3(rd_blocks), dim3(256), 0, s, gp);
+    if (a.final_text) {
+        StdKParams sp;
+        sp.descs = pp.descs;
+        sp.read_first_chunk = pp.rd_chunk_first;
+        sp.chunk_runs = tp.chunk_runs;
+        sp.chunk_nruns = tp.chunk_nruns;
+        sp.refs = pp.refs; sp.ref_off = pp.ref_off;
+        sp.seqs = pp.seqs; sp.seq_off = pp.seq_off;
+        sp.out = got.d_out;
+        sp.out_off = got.d_out_off;
+        sp.out_len = got.d_out_len;
+        sp.status = got.d_status;
+        sp.read_base = out_read_base;
+        sp.n_reads = nr;
+        hipLaunchKernelGGL(standardize_kernel, dim3((unsigned)((nr + 63) / 64)), dim3(64), 0, s, sp);
+    } else
     // LDS of gather_kernel: one tile of ops + (when a chunk's two base slices fit beside it) the slices
     {
         const int64_t rows_max = std::min<int64_t>(max_len, a.max_b_rows) + 1;    // longest slice of any chunk
@@ -787,6 +807,7 @@ try {
     g_live_ctx[device_id & 15]++;
     ctx->device = device_id;
     ctx->n_cus = pr.multiProcessorCount;
+    if (const char *e = std::getenv("NPORE_DEVICE_GLUE")) ctx->device_glue = std::atoi(e) != 0;      // (A/B of the BAM -> SAM pipeline: scripts/bench_realign.py)
     ctx->max_n = max_n;
     ctx->max_l = max_l;
     const size_t np_elems = (size_t)max_n * (max_l + 1) * (max_l + 1);
@@ -848,7 +869,7 @@ void npore_ctx_destroy(npore_ctx *ctx)
 static int align_batch_host(npore_ctx *ctx, int64_t n_reads, const uint8_t *refs, const int64_t *ref_off,
                             const uint8_t *seqs, const int64_t *seq_off, const char *cigars, const int64_t *cig_off,
                             float indel_start, float indel_extend, int max_b_rows, int r, char *out,
-                            const int64_t *out_off, int64_t *out_len, int32_t *status, bool sync)
+                            const int64_t *out_off, int64_t *out_len, int32_t *status, bool sync, bool final_text = false)
 {
     if (!ctx) return fail(NPORE_E_INVALID, "null context");
     if (n_reads < 0) return fail(NPORE_E_INVALID, "n_reads < 0");
@@ -864,6 +885,7 @@ static int align_batch_host(npore_ctx *ctx, int64_t n_reads, const uint8_t *refs
                 indel_start, indel_extend, max_b_rows, r};
     a.h_refs = refs; a.h_seqs = seqs; a.h_cigs = cigars;
     a.h_out = out; a.h_out_off = out_off; a.h_out_len = out_len; a.h_status = status;
+    a.final_text = final_text;
     return run_core(ctx, a, OutTarget{nullptr, nullptr, nullptr, nullptr}, nullptr, sync);
 }
 
@@ -884,6 +906,16 @@ int npore_align_batch_async(npore_ctx *ctx, int64_t n_reads, const uint8_t *refs
 try {
     return align_batch_host(ctx, n_reads, refs, ref_off, seqs, seq_off, cigars, cig_off, indel_start, indel_extend,
                             max_b_rows, r, out, out_off, out_len, status, false);
+}
+NPORE_CATCH_INT
+
+int npore_align_batch_cigars(npore_ctx *ctx, int64_t n_reads, const uint8_t *refs, const int64_t *ref_off,
+                             const uint8_t *seqs, const int64_t *seq_off, const char *cigars, const int64_t *cig_off,
+                             float indel_start, float indel_extend, int max_b_rows, int r, char *out,
+                             const int64_t *out_off, int64_t *out_len, int32_t *status)
+try {
+    return align_batch_host(ctx, n_reads, refs, ref_off, seqs, seq_off, cigars, cig_off, indel_start, indel_extend,
+                            max_b_rows, r, out, out_off, out_len, status, true, true);
 }
 NPORE_CATCH_INT
 
@@ -1064,6 +1096,7 @@ try {
     if (k == "tb_budget_mb") ctx->tb_budget_mb = value;
     else if (k == "force_chunks") ctx->force_chunks = (int)value;
     else if (k == "coresident") ctx->coresident = value != 0;
+    else if (k == "device_glue") ctx->device_glue = value != 0;
     else if (k == "fill_streams") { if (value < 1 || value > 2) return fail(NPORE_E_INVALID, "fill_streams: 1 or 2"); ctx->fill_streams = (int)value; }
     else if (k == "traceback_kernel") { if (value < 0 || value > 2) return fail(NPORE_E_INVALID, "traceback_kernel: 0, 1 or 2"); ctx->tb_kernel = (int)value; }
     else return fail(NPORE_E_INVALID, "unknown key " + k);
@@ -1791,7 +1824,8 @@ NPORE_CATCH_INT
 namespace {
 // pack the selected records into the slot (inputs of npore_align_batch) and size its output buffers
 // (the records are in s.rf already)
-int slot_pack_records(const npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref, int64_t n, int threads, npore_batch_slot &s)
+int slot_pack_records(const npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref, int64_t n, int threads, npore_batch_slot &s,
+                      bool device_glue = false)
 {
     for (auto *v : {&s.ro, &s.so, &s.co, &s.oo, &s.fo}) v->assign((size_t)n + 1, 0);
     s.olen.assign((size_t)n, 0);
@@ -1805,10 +1839,11 @@ int slot_pack_records(const npore_bam *b, const npore_fasta *fa, const int32_t *
         return rc;
     for (int64_t k = 0; k < n; k++) {
         const int64_t cap = (s.ro[(size_t)k + 1] - s.ro[(size_t)k]) + (s.so[(size_t)k + 1] - s.so[(size_t)k]);
-        s.oo[(size_t)k + 1] = s.oo[(size_t)k] + cap;
+        // (device glue: the slot receives the collapsed CIGAR text instead of the op string -- 2 bytes per op + 16 always suffice)
+        s.oo[(size_t)k + 1] = s.oo[(size_t)k] + (device_glue ? 2 * cap + 16 : cap);
         s.fo[(size_t)k + 1] = s.fo[(size_t)k] + 2 * cap + 16;
     }
-    if (!s.alns.ensure((size_t)s.oo[(size_t)n] + 64) || !s.finals.ensure((size_t)s.fo[(size_t)n] + 64))
+    if (!s.alns.ensure((size_t)s.oo[(size_t)n] + 64) || (!device_glue && !s.finals.ensure((size_t)s.fo[(size_t)n] + 64)))
         return fail(NPORE_E_NOMEM, "batch buffers");
     return NPORE_OK;
 }
@@ -1828,8 +1863,13 @@ int slot_align(npore_ctx *ctx, int64_t n, float indel_start, float indel_extend,
 }
 // realign_read's glue (src/bam.pyx:65-78) and the SAM lines; reads refused by align() have no string and get an empty CIGAR
 int slot_post(const npore_bam *b, const int64_t *idx, int64_t n, const int32_t *status, int threads, npore_batch_slot &s,
-              double *ms_std = nullptr)
+              double *ms_std = nullptr, bool device_glue = false)
 {
+    if (device_glue) {          // the slots hold the final CIGAR text already (standardize_kernel)
+        if (ms_std) *ms_std = 0.0;
+        for (int64_t k = 0; k < n; k++) s.flen[(size_t)k] = s.olen[(size_t)k] > 0 ? s.olen[(size_t)k] : 0;
+        return format_sam_into(b, s.rf, n, s.alns.p, s.oo.data(), s.flen.data(), status, threads, s.sam, &s.sam_len);
+    }
     const auto t0 = std::chrono::steady_clock::now();
     const uint8_t *refs = reinterpret_cast<const uint8_t *>(s.refs.p), *seqs = reinterpret_cast<const uint8_t *>(s.seqs.p);
     parallel_for(n, threads, [&](int64_t k) {
@@ -1899,6 +1939,10 @@ int file_pipeline(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int
     // of the CPUs, so that the process does not run five times as many busy threads as it has CPUs -- under a cgroup quota
     // that ends in the whole process being throttled for the rest of the scheduling period
     const int half_threads = std::max(1, host_threads(threads) / 2);
+    // (experiments: NPORE_PACK_THREADS / NPORE_POST_THREADS override the split)
+    const int pack_threads = std::getenv("NPORE_PACK_THREADS") ? std::max(1, std::atoi(std::getenv("NPORE_PACK_THREADS"))) : half_threads;
+    const int post_threads = std::getenv("NPORE_POST_THREADS") ? std::max(1, std::atoi(std::getenv("NPORE_POST_THREADS"))) : half_threads;
+    const bool glue = ctx->device_glue != 0;      // realign_read's glue on the device: the slots receive the final CIGAR text
     std::vector<std::future<void>> packed, posted;
     // batches leave in input order: `written` counts the batches that are through (written, or given up on);
     // `acquired` the batches whose records have been taken from a serial source
@@ -1925,7 +1969,7 @@ int file_pipeline(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int
             if (serial_acquire) bump(acquired);
             s.m = m > 0 ? m : 0;
             if (m < 0) s.rc = (int)m;
-            else if (m > 0) s.rc = slot_pack_records(b, fa, fasta_of_ref, m, half_threads, s);
+            else if (m > 0) s.rc = slot_pack_records(b, fa, fasta_of_ref, m, pack_threads, s, glue);
             s.t_ms[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (s.rc) s.err = npore_last_error();
         }));
@@ -1944,7 +1988,7 @@ int file_pipeline(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int
             const int32_t *st = reinterpret_cast<const int32_t *>(t.st_pin.p);
             t0 = std::chrono::steady_clock::now();
             double ms_std = 0.0;
-            t.rc = slot_post(b, nullptr, m, st, half_threads, t, &ms_std);
+            t.rc = slot_post(b, nullptr, m, st, post_threads, t, &ms_std, glue);
             const double ms_post = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             t.t_ms[2] += ms_std;
             t.t_ms[3] += ms_post - ms_std;
@@ -1971,9 +2015,9 @@ int file_pipeline(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int
         if (!s.olen_pin.ensure((size_t)m * 8 + 64) || !s.st_pin.ensure((size_t)m * 4 + 64)) { rc = NPORE_E_NOMEM; err = "batch buffers"; break; }
         if (!s.done && hipEventCreateWithFlags(&s.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { rc = NPORE_E_HIP; err = "hipEventCreate"; break; }
         // (returns once the batch's groups are enqueued; waits only when all work sets of the context are still busy)
-        s.rc = npore_align_batch_async(ctx, m, reinterpret_cast<uint8_t *>(s.refs.p), s.ro.data(), reinterpret_cast<uint8_t *>(s.seqs.p),
-                                       s.so.data(), s.cigs.p, s.co.data(), indel_start, indel_extend, max_b_rows, r, s.alns.p,
-                                       s.oo.data(), reinterpret_cast<int64_t *>(s.olen_pin.p), reinterpret_cast<int32_t *>(s.st_pin.p));
+        s.rc = align_batch_host(ctx, m, reinterpret_cast<uint8_t *>(s.refs.p), s.ro.data(), reinterpret_cast<uint8_t *>(s.seqs.p),
+                                s.so.data(), s.cigs.p, s.co.data(), indel_start, indel_extend, max_b_rows, r, s.alns.p,
+                                s.oo.data(), reinterpret_cast<int64_t *>(s.olen_pin.p), reinterpret_cast<int32_t *>(s.st_pin.p), false, glue);
         if (s.rc) { rc = s.rc; err = npore_last_error(); s.err = err; break; }
         if (hipEventRecord(s.done, ctx->s_post) != hipSuccess) { rc = NPORE_E_HIP; err = "hipEventRecord"; s.rc = rc; s.err = err; break; }
         start_post(k);

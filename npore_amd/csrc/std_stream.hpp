@@ -29,22 +29,23 @@ namespace npore {
 
 enum : uint32_t { SOP_M = 0, SOP_I = 1, SOP_D = 2, SOP_NONE = 3 };
 
-// Sink: void operator()(uint32_t op, int64_t len) -- called once per run of the result, never twice in a row with the
-// same op.  `ref` / `seq`: the bases the alignment pairs (any encoding: only compared for equality).
-template <class Sink>
+// Sink: void operator()(uint32_t op, Int len) -- called once per run of the result, never twice in a row with the
+// same op.  `ref` / `seq`: the bases the alignment pairs (any encoding: only compared for equality).  Int: the type of
+// lengths and positions (the device kernel uses 32 bits -- a read has fewer than 2^31 ops -- to halve its registers).
+template <class Sink, class Int = int64_t>
 struct StdStream {
     Sink &sink;
     const uint8_t *ref, *seq;
-    int64_t ref_len, seq_len;
+    Int ref_len, seq_len;
 
-    NPORE_STD_HD StdStream(Sink &s, const uint8_t *r, int64_t rl, const uint8_t *q, int64_t ql)
+    NPORE_STD_HD StdStream(Sink &s, const uint8_t *r, Int rl, const uint8_t *q, Int ql)
         : sink(s), ref(r), seq(q), ref_len(rl), seq_len(ql) {}
 
     // ---- stage E: 'ID' -> 'M', then the sink (a held run so that equal neighbours merge)
     uint32_t e_op = SOP_NONE;
-    int64_t e_len = 0;
-    int64_t e_pend_i = 0;                                  // an insertion run waiting to see whether a deletion run follows
-    NPORE_STD_HD void e_push(uint32_t op, int64_t len)
+    Int e_len = 0;
+    Int e_pend_i = 0;                                  // an insertion run waiting to see whether a deletion run follows
+    NPORE_STD_HD void e_push(uint32_t op, Int len)
     {
         if (len <= 0) return;
         if (e_op == op) { e_len += len; return; }
@@ -52,10 +53,10 @@ struct StdStream {
         e_op = op;
         e_len = len;
     }
-    NPORE_STD_HD void e_feed(uint32_t op, int64_t len)
+    NPORE_STD_HD void e_feed(uint32_t op, Int len)
     {
         if (e_pend_i) {
-            const int64_t a = e_pend_i;
+            const Int a = e_pend_i;
             e_pend_i = 0;
             if (op == SOP_D) {                             // 'I..I D..D' -> 'I..(a-1) M D..(b-1)'
                 e_push(SOP_I, a - 1);
@@ -77,18 +78,18 @@ struct StdStream {
 
     // ---- stages B / D: insertions before deletions within a block
     struct Block {
-        int64_t ni = 0, nd = 0;
+        Int ni = 0, nd = 0;
     };
     Block blk_b, blk_d;
     template <int WHICH>
-    NPORE_STD_HD void blk_out(uint32_t op, int64_t len)
+    NPORE_STD_HD void blk_out(uint32_t op, Int len)
     {
         if (len <= 0) return;
         if (WHICH == 0) c_feed(op, len);
         else e_feed(op, len);
     }
     template <int WHICH>
-    NPORE_STD_HD void blk_feed(uint32_t op, int64_t len)
+    NPORE_STD_HD void blk_feed(uint32_t op, Int len)
     {
         Block &k = WHICH == 0 ? blk_b : blk_d;
         if (op == SOP_M) {
@@ -114,18 +115,18 @@ struct StdStream {
     // ---- stages A / C: push the runs of one indel kind left
     struct Push {
         uint32_t op0 = SOP_NONE, op1 = SOP_NONE;          // the two runs held back (op1 the later one)
-        int64_t len0 = 0, len1 = 0;
-        int64_t p = 0;                                     // position in the consumed sequence of the next op
+        Int len0 = 0, len1 = 0;
+        Int p = 0;                                     // position in the consumed sequence of the next op
     };
     Push push_a, push_c;
     template <int WHICH>
-    NPORE_STD_HD void push_out(uint32_t op, int64_t len)
+    NPORE_STD_HD void push_out(uint32_t op, Int len)
     {
         if (WHICH == 0) blk_feed<0>(op, len);
         else blk_feed<1>(op, len);
     }
     template <int WHICH>
-    NPORE_STD_HD void push_run(uint32_t op, int64_t len)  // append to the stage's output, merging with its last run
+    NPORE_STD_HD void push_run(uint32_t op, Int len)  // append to the stage's output, merging with its last run
     {
         Push &w = WHICH == 0 ? push_a : push_c;
         if (len <= 0) return;
@@ -142,12 +143,12 @@ struct StdStream {
         }
     }
     template <int WHICH>
-    NPORE_STD_HD void push_feed(uint32_t op, int64_t len)
+    NPORE_STD_HD void push_feed(uint32_t op, Int len)
     {
         Push &w = WHICH == 0 ? push_a : push_c;
         const uint32_t push_op = WHICH == 0 ? SOP_D : SOP_I;
         const uint8_t *s_ = WHICH == 0 ? ref : seq;
-        const int64_t s_len = WHICH == 0 ? ref_len : seq_len;
+        const Int s_len = WHICH == 0 ? ref_len : seq_len;
         if (op != push_op) {
             push_run<WHICH>(op, len);
             if (op == SOP_M) w.p += len;
@@ -156,9 +157,9 @@ struct StdStream {
         // the last run of the output, if it is a match run: where it lies in the window
         const bool last1 = w.op1 != SOP_NONE;
         const uint32_t lop = last1 ? w.op1 : w.op0;
-        const int64_t k = len, m = (lop == SOP_M) ? (last1 ? w.len1 : w.len0) : 0;
-        int64_t s = 0;
-        const int64_t p = w.p;
+        const Int k = len, m = (lop == SOP_M) ? (last1 ? w.len1 : w.len0) : 0;
+        Int s = 0;
+        const Int p = w.p;
         while (s < m && p - s - 1 + k < s_len && s_[p - s - 1] == s_[p - s - 1 + k]) s++;      // (the reference indexes unchecked)
         if (s) {
             if (last1) { w.len1 -= s; if (w.len1 == 0) w.op1 = SOP_NONE; }
@@ -176,12 +177,12 @@ struct StdStream {
         if (w.op1 != SOP_NONE) push_out<WHICH>(w.op1, w.len1);
         w.op0 = w.op1 = SOP_NONE;
     }
-    NPORE_STD_HD void c_feed(uint32_t op, int64_t len) { push_feed<1>(op, len); }
+    NPORE_STD_HD void c_feed(uint32_t op, Int len) { push_feed<1>(op, len); }
 
     // ---- the source side: runs of the alignment in read order ('=', 'X', 'M' all SOP_M); equal neighbours are merged here
     uint32_t in_op = SOP_NONE;
-    int64_t in_len = 0;
-    NPORE_STD_HD void feed(uint32_t op, int64_t len)
+    Int in_len = 0;
+    NPORE_STD_HD void feed(uint32_t op, Int len)
     {
         if (len <= 0) return;
         if (op == in_op) { in_len += len; return; }

@@ -760,6 +760,48 @@ def test_both_traceback_kernels(tables, mode):
     c.close()
 
 
+def test_device_glue_equals_host_glue(ctx, tables):
+    """npore_align_batch_cigars (realign_read's glue on the device: one lane per read runs csrc/std_stream.hpp over the
+    traceback runs) == npore_align_batch followed by the host glue (npore_standardize_batch, the same header on the op
+    string) and == the Python restatement on the oracle's strings: long reads, many chunks per read (tiny max_b_rows),
+    low-complexity reads whose indel runs travel far and meet, a refused read (empty text, same status bits), reads whose
+    input path is far from the best one (status bits, truncated strings)."""
+    from npore_amd import cig
+    sub, nps = tables
+    refs, seqs, cigs = synth.make_batch(909, 24, ref_len=3000, p_np=0.2)
+    r2, s2, c2 = synth.make_batch(910, 40, ref_len=400, p_np=0.6)
+    refs += r2; seqs += s2; cigs += c2
+    rng = np.random.default_rng(5)
+    for k in range(12):                                      # two-letter reads: everything is a repeat
+        n = int(rng.integers(50, 400))
+        ref = rng.integers(1, 3, size=n).astype(np.uint8)
+        ops, seq, j = [], [], 0
+        while j < n:
+            e = rng.random()
+            if e < 0.12:
+                ops.append("D"); j += 1
+            elif e < 0.24:
+                ops.append("I"); seq.append(int(rng.integers(1, 3)))
+            else:
+                ops.append("="); seq.append(int(ref[j])); j += 1
+        refs.append(ref); seqs.append(np.array(seq, np.uint8)); cigs.append("".join(ops))
+    for k in range(3):                                       # a bad input path
+        ref, seq = refs[k], seqs[k]
+        m = min(len(ref), len(seq)) - 40
+        refs.append(ref); seqs.append(seq)
+        cigs.append("I" * (len(seq) - m) + "D" * (len(ref) - m) + "=" * m)
+    refs.append(refs[0]); seqs.append(seqs[0]); cigs.append(cigs[0][:-3])      # lengths disagree: refused
+    for r, mbr in ((30, 20000), (100, 700), (10, 37)):
+        raw, st = ctx.align_batch(refs, seqs, cigs, r=r, max_b_rows=mbr, return_status=True)
+        fin, st2 = ctx.align_batch(refs, seqs, cigs, r=r, max_b_rows=mbr, return_status=True, final_cigars=True)
+        assert (st == st2).all(), (r, mbr)
+        assert st[-1] & 32 and fin[-1] == ""
+        assert fin == cig.standardize_batch(raw, refs, seqs), (r, mbr)
+        for k in (0, 30, 70, len(refs) - 3):
+            want = oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=r, max_b_rows=mbr)
+            assert fin[k] == cig.collapse_cigar(cig.standardize(want, refs[k], seqs[k])), (r, mbr, k)
+
+
 @pytest.mark.parametrize("max_n,max_l", [(6, 20), (4, 20), (1, 5), (6, 31), (6, 32), (3, 127), (6, 5), (6, 3), (4, 2)])
 def test_other_table_shapes(tables, max_n, max_l):
     """Contexts with other max_n / max_l (the CLI's --max_n / --max_l): row clamp at max_l - 1 also where the
