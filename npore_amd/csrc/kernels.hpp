@@ -888,7 +888,12 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
             (void)a_laneid; (void)a_drows; (void)a_dcols;
             (void)a_mhist; (void)a_ml0; (void)a_ml63; (void)a_medge; (void)a_me; (void)a_progaddr;
             for (;;) {
-                int a_status, a_sx, a_bend;
+                int a_status = 1, a_sx, a_bend;
+                // A column descriptor that needs the rare path (DSC_RARE) stays in the wave's lanes for up to 64 'D' steps, and
+                // every step of that stretch is a compiled one: the text is not visited only to leave it again at its
+                // entry test (its wait for everything in flight, the operands' way into and out of the statement)
+                const bool rare_here = __builtin_amdgcn_ballot_w64((rc0 & DSC_RARE) != 0u && (ROLE != 1 || hist_lane)) != 0ull;
+                if (!rare_here) {
                 unsigned long long a_mask = stepmask, a_nmask = nextmask;
                 int a_kbase = 64 * ((a_bl >> 6) + 2) - 1;           // first step byte of the window after the next one, for lane 0
                 unsigned long long a_sa, a_sb, a_sc;
@@ -913,6 +918,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
                 // 'I' steps = steps taken - 'D' steps taken (a 'D' step stopped behind its poll has counted itself already)
                 st.ins_l += (a_bl - bl_in) - (a_sdel - sdel_in - (a_status == 2 ? 1 : 0));
                 st.del_l = a_sdel;
+                }
                 if (!a_status) break;
                 if (a_status == 2) {       // a 'D' step, stopped behind its poll: bookkeeping and column count already advanced
                     st.del_l = a_sdel - 1;
