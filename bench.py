@@ -127,7 +127,7 @@ def csrc_sha():
     glue.hpp ...), which changes without touching a kernel."""
     h = hashlib.sha256()
     d = os.path.join(REPO, "npore_amd", "csrc")
-    for f in ("annot_wave.hpp", "cell.hpp", "fill_step_asm.inc", "kernels.hpp", "layout.hpp", "prep_kernels.hpp"):
+    for f in ("annot_wave.hpp", "cell.hpp", "fill_step_asm.inc", "kernels.hpp", "layout.hpp", "prep_kernels.hpp", "std_stream.hpp"):
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
