@@ -1140,17 +1140,12 @@ __global__ __launch_bounds__(64) void traceback_kernel(TParams p)
     if (lane < (nruns & 63)) runs[(nruns & ~63) + lane] = rbuf;
 }
 
-// The same traceback with coalesced loads of whole anti-diagonals (16 bytes per lane) plus inss[b], requested as soon as
-// the next cell is known: a third of the instructions per hop of the windowed kernel.  With thousands of chunks in flight
-// the round trips of different chunks overlap; with one wave per SIMD (a batch of 1 000 reads) the windows win.
-// A chunk's traceback is a chain of dependent round trips, and what a launch of thousands of chunks takes is that chain
-// at the occupancy the registers allow (eight waves per SIMD hold a whole batch of 8 000 chunks at once).  KR = 3 (bands of
-// one load per lane, r <= 127): a request fetches THREE consecutive anti-diagonals -- the one the path lands on and the two
-// below it; a diagonal run (whose length decides where the path lands) is usually followed by a short indel hop, one or
-// two anti-diagonals down, which then costs no round trip of its own.  Held to 64 registers: with more, half as many
-// waves are resident and the launch takes twice as long (measured: LABNOTES round 4).
-// NL: uint4 loads per lane covering a row (tbstride <= 256 * NL).
-template <int NL, int KR>
+// The same traceback with ONE coalesced load of the whole anti-diagonal (16 bytes per lane) plus inss[b] per
+// hop, requested as soon as the next cell is known: a third of the instructions per hop of the windowed
+// kernel, one memory round trip per hop instead of one per ~4 hops.  With thousands of chunks in flight the
+// round trips of different chunks overlap and the instruction count decides; with one wave per SIMD (a
+// batch of 1 000 reads) the windows win.  NL: uint4 loads per lane covering a row (tbstride <= 256 * NL).
+template <int NL>
 __global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
 {
     const int k = blockIdx.x;
@@ -1167,41 +1162,22 @@ __global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
     uint32_t rbuf = 0u;    // lane l: run number (nruns & ~63) + l
 
     const int32_t *inss = p.inss + d.inss_off + d.brk;
-    // (explicit registers, not arrays: an array indexed by the held row's number ends up in scratch memory -- measured:
-    // the launch then takes twice as long)
-    static_assert(KR == 1 || (KR == 3 && NL == 1), "three held rows: bands of one load per lane");
-    uint4 row[NL];         // KR = 1: the anti-diagonal `base`
-    uint4 rw0 = make_uint4(0u, 0u, 0u, 0u), rw1 = rw0, rw2 = rw0;   // KR = 3: anti-diagonals base, base - 1, base - 2
-    int ri0 = 0, ri1 = 0, ri2 = 0;
-    int base = -(1 << 30);
-    auto load_one = [&](int rb, uint4 &w, int &wi) {
-        wi = rb >= 0 ? inss[rb] : 0;
-        w = (rb >= 0 && lane * 4 < stride) ? *reinterpret_cast<const uint4 *>(tb + (size_t)rb * stride + lane * 4) : make_uint4(0u, 0u, 0u, 0u);
-    };
-    auto load_rows = [&](int bl) {
-        base = bl;
-        if constexpr (KR == 3) {
-            load_one(bl, rw0, ri0); load_one(bl - 1, rw1, ri1); load_one(bl - 2, rw2, ri2);
-        } else {
-            ri0 = inss[bl];
+    uint4 row[NL];
+    int row_ins = 0;
+    auto load_row = [&](int bl) {
+        row_ins = inss[bl];
 #pragma unroll
-            for (int q = 0; q < NL; q++) {
-                const int idx = (q * 64 + lane) * 4;
-                row[q] = (idx < stride) ? *reinterpret_cast<const uint4 *>(tb + (size_t)bl * stride + idx) : make_uint4(0u, 0u, 0u, 0u);
-            }
+        for (int q = 0; q < NL; q++) {
+            const int idx = (q * 64 + lane) * 4;
+            row[q] = (idx < stride) ? *reinterpret_cast<const uint4 *>(tb + (size_t)bl * stride + idx)
+                                    : make_uint4(0u, 0u, 0u, 0u);
         }
     };
-    // (kr and col are wave-uniform: selects on uniform conditions)
-    auto word = [&](int kr, int col) -> uint32_t {
-        uint4 v;
-        if constexpr (KR == 3) {
-            v = kr == 0 ? rw0 : kr == 1 ? rw1 : rw2;
-        } else {
-            v = row[0];
+    auto word = [&](int col) -> uint32_t {   // col is wave-uniform
+        uint4 v = row[0];
 #pragma unroll
-            for (int q = 1; q < NL; q++)
-                if ((col >> 8) == q) v = row[q];
-        }
+        for (int q = 1; q < NL; q++)
+            if ((col >> 8) == q) v = row[q];
         const uint32_t lo = (col & 1) ? v.y : v.x, hi = (col & 1) ? v.w : v.z;
         return (uint32_t)__builtin_amdgcn_readlane((int)((col & 2) ? hi : lo), (col & 255) >> 2);
     };
@@ -1210,24 +1186,22 @@ __global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
         return ar >= d.row0 && ac >= d.col0 && bl >= 0 && bl < d.nrows;
     };
 
-    if ((a_row > d.row0 || a_col > d.col0) && in_chunk(a_row, a_col)) load_rows(a_row + a_col - d.brk);
+    if ((a_row > d.row0 || a_col > d.col0) && in_chunk(a_row, a_col)) load_row(a_row + a_col - d.brk);
     // two combined tests per ordinary hop; what stopped the loop is sorted out in the reference's order
     // (src/aln.pyx:680-716) where it stops, so the status bits are those of one test per condition
     for (;;) {
-        a_row = uni(a_row); a_col = uni(a_col); pos = uni(pos); nruns = uni(nruns); base = uni(base);
+        a_row = uni(a_row); a_col = uni(a_col); pos = uni(pos); nruns = uni(nruns);
         const bool live = (a_row > d.row0) | (a_col > d.col0);
         if (!(live & in_chunk(a_row, a_col))) {
             if (live) status |= 16;
             break;
         }
-        const int kr = base - (a_row + a_col - d.brk);      // 0 ... KR - 1: a cell outside the held rows was requested below
-        const int ins_b = (KR == 3) ? (kr == 0 ? ri0 : kr == 1 ? ri1 : ri2) : ri0;
-        const int bc = uni(ins_b) - a_row + p.r;     // inss[b] - a_row + r, src/aln.pyx:322-326
+        const int bc = uni(row_ins) - a_row + p.r;     // inss[b] - a_row + r, src/aln.pyx:322-326
         if ((bc <= 0) | (bc >= W - 1)) {
             status |= (bc < 0 || bc >= W) ? 16 : 4;    // band edge: TYP = MAT, RUN = 0 (src/aln.pyx:502-507) -> "run < 1"
             break;
         }
-        const uint32_t x = word(kr, bc);
+        const uint32_t x = word(bc);
         const int typ = tb_typ(x), run = tb_run(x);     // src/aln.pyx:684-685
         if ((run < 1) | (run > pos) | (typ > T_SHR)) {
             status |= (run < 1) ? 4 : (run > pos) ? 16 : 8;
@@ -1240,13 +1214,10 @@ __global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
             emit = run < lim ? run : lim;                          // diagonal steps that stay in the chunk
         }
         const int n_row = a_row - (del ? 0 : emit), n_col = a_col - (ins ? 0 : emit);
-        // request the next rows now, unless they are held already
-        if (emit == run && (n_row > d.row0 || n_col > d.col0) && in_chunk(n_row, n_col)) {
-            const int n_bl = n_row + n_col - d.brk;
-            if ((unsigned)(base - n_bl) >= (unsigned)KR) load_rows(n_bl);
-        }
+        // request the next row now
+        if (emit == run && (n_row > d.row0 || n_col > d.col0) && in_chunk(n_row, n_col)) load_row(n_row + n_col - d.brk);
         if (emit > 0) {
-            rbuf = (lane == (nruns & 63)) ? ((uint32_t)typ | ((uint32_t)emit << 3)) : rbuf;      // (run records: typ | length << 3, TParams)
+            rbuf = (lane == (nruns & 63)) ? ((uint32_t)typ | ((uint32_t)emit << 3)) : rbuf;
             nruns++;
             if ((nruns & 63) == 0) runs[nruns - 64 + lane] = rbuf;
         }

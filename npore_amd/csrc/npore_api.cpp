@@ -555,10 +555,9 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     // r=30 and favour the windows by 15 % at r=100; 3 000-4 000 slots favour the rows by 12-30 %)
     const int tb_mode = ctx->tb_kernel ? ctx->tb_kernel : (max_chunks > 2500 ? 2 : 1);
     if (tb_mode == 1) hipLaunchKernelGGL(traceback_kernel, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
-    else if (tbs <= 256 && !std::getenv("NPORE_TB_KR1")) hipLaunchKernelGGL((traceback_rows_kernel<1, 3>), dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
-    else if (tbs <= 256) hipLaunchKernelGGL((traceback_rows_kernel<1, 1>), dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
-    else if (tbs <= 512) hipLaunchKernelGGL((traceback_rows_kernel<2, 1>), dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
-    else hipLaunchKernelGGL((traceback_rows_kernel<4, 1>), dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
+    else if (tbs <= 256) hipLaunchKernelGGL(traceback_rows_kernel<1>, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
+    else if (tbs <= 512) hipLaunchKernelGGL(traceback_rows_kernel<2>, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
+    else hipLaunchKernelGGL(traceback_rows_kernel<4>, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
     HIP_TRY(hipGetLastError());
 
     GParams gp;
