@@ -407,7 +407,7 @@ struct npore_bam {
     std::vector<std::vector<int64_t>> by_ref;   // record indices per reference id, file order
     std::vector<uint8_t> ref_sorted;      // ... which is ascending in position (regions then need no full scan)
     std::vector<int64_t> ref_max_len;     // longest reference span of a record on that reference
-    npore::RecFetch api_fetch;            // records of the last npore_bam_pack_sizes / _pack / _format_sam call
+    npore::RecFetch api_fetch;            // records of the last npore_bam_format_sam call (the const entry points keep theirs local)
     npore::RawBuf sam;                    // text of the last formatted batch
     npore::RawBuf w_finals;               // final CIGARs of the last batch (work buffer, reused)
     double stage_ms[4] = {0, 0, 0, 0};    // last npore_bam_realign_batch: pack, align, standardise, format

@@ -1685,7 +1685,7 @@ void pack_sizes_of(const RecFetch &rf, int64_t n, int64_t *ref_off, int64_t *seq
 int npore_bam_pack_sizes(const npore_bam *b, const int64_t *idx, int64_t n, int64_t *ref_off, int64_t *seq_off, int64_t *cig_off)
 try {
     if (!pack_args_ok(b, idx, n) || !ref_off || !seq_off || !cig_off) return fail(NPORE_E_INVALID, "bad argument");
-    RecFetch &rf = const_cast<npore_bam *>(b)->api_fetch;
+    RecFetch rf;          // (local to the call: the handle is const here, and two threads may size / pack from one handle)
     if (int rc = fetch_records(b, idx, n, 0, rf)) return rc;
     pack_sizes_of(rf, n, ref_off, seq_off, cig_off, 0);
     return NPORE_OK;
@@ -1704,7 +1704,7 @@ try {
     if (!pack_args_ok(b, idx, n) || !fa || !fasta_of_ref || !ref_off || !seq_off || !cig_off ||
         (n > 0 && (!refs || !seqs || !cigs)))
         return fail(NPORE_E_INVALID, "bad argument");
-    RecFetch &rf = const_cast<npore_bam *>(b)->api_fetch;
+    RecFetch rf;
     if (int rc = fetch_records(b, idx, n, threads, rf)) return rc;
     return pack_records(b, rf, fa, fasta_of_ref, n, refs, ref_off, seqs, seq_off, cigs, cig_off, threads);
 }
