@@ -8,9 +8,14 @@ formulation removed them.  Here every loop-carried value has ONE register for th
 step kinds update it in place, and the temporaries are fixed scratch registers (v91 ... v111, declared clobbered).
 
 What the text does is exactly the `step` lambda of kernels.hpp for FASTSEL = true (cell.hpp cell_update<FAST>), for as
-many steps of one 64-step window as it can take: it returns with status 1 in front of a step that needs one of the
-rare paths (a column descriptor with DSC_RARE, a word queue or the L window about to run out) -- nothing of that step
-is done yet -- and the caller runs that one step through the C++ body and comes back.
+many steps of a span as it can take, in BLOCKS (to the end of the 64-step window, of the span, or of what the word queues
+and the L window hold: `block_end`): it returns with status 1 in front of a step that needs the rare path (a column
+descriptor with DSC_RARE: tested once per entry and, in a 'D' step, on the descriptor that enters) -- nothing of that step
+is done yet -- or with status 2 behind the poll of a 'D' step whose entering descriptor (learnt from the wave above) is
+rare, and the caller runs that one step through the C++ body and comes back.
+Several waves per chunk: the hand-over writes only the exchange record the NEXT step reads (`finish`), the first look at
+the neighbours' progress words and the read of the neighbour's boundary cell are issued at the head of the step
+(`poll_issue`), a wave that has to wait polls at issue priority 0 (`polls`).
 
     python npore_amd/csrc/gen_fill_asm.py        # rewrites fill_step_asm.inc next to this file
 
