@@ -35,6 +35,10 @@ P0, P1, PP = "v100", "v101", "v[100:101]"
 SUBV, DRUN, NINSR, NDELR = "v102", "v103", "v87", "v88"
 SHRV, SHRRUN, LENV, LENRUN = "v104", "v105", "v106", "v107"
 Q0, LENST, SHRST, QRUNS, QQ = "v108", "v109", "v110", "v111", "v[108:111]"      # the history record: one ds_write_b128
+# MAT.VAL of the lane's cell LIVES in the record's first register for the whole loop (copied in from / out to the operand
+# `matv` where the text is entered / left): the step's last 3-way minimum writes it there and the record is stored from
+# there -- no copy per step.  Like LENST it is a data register of the ds_write_b128: written again only behind a wait.
+MATV = Q0
 HS, HP0, HP1, HQ = "v104", "v106", "v107", "v[104:107]"      # the first SHR candidate's source record (one ds_read_b128): matv, -, shrstart, runs
 SMR = SF      # the descriptor's summary bits (rc0 & 0xbc) from the head of a step to the SHR pass: NOT one of the record's
               # registers v108 ... v111, which the previous step's ds_write_b128 may still be reading there
@@ -118,7 +122,7 @@ def ins_part(t, mode, A, B, msk, fill=()):
     """INS (src/aln.pyx:525-543): new value straight into the own register, run into NINSR.  A, B: free registers;
     fill: up to two independent instructions for the slots between the compare and its selects"""
     if mode == "I":
-        topM, topI, topR = O("matv"), O("insv"), O("R1")
+        topM, topI, topR = MATV, O("insv"), O("R1")
     else:
         topM, topI, topR = X0, X1, O("TMr")
     two_adds(t, A, B, topM, topI)
@@ -139,7 +143,7 @@ def del_part(t, mode, A, B, msk):
     if mode == "I":
         leftM, leftD, leftR = X0, X1, O("LMr")
     else:
-        leftM, leftD, leftR = O("matv"), O("delv"), O("R2")
+        leftM, leftD, leftR = MATV, O("delv"), O("R2")
     two_adds(t, A, B, leftM, leftD)
     t(f"""
         v_cmp_lt_f32 {msk}, {B}, {A}
@@ -261,7 +265,8 @@ def shr_pass(t, mid, sfx, smr, shadow, shadow2, none_test=True):
 def len_pass(t, mid, sfx, mode, first, last, multi):
     """LEN candidates (cell.hpp, LEN loop; LEN_ARITH form).  On entry X3 = the six "read position i-n in an n-polymer
     and reference position j starts one" bits.  The loop is out of line (two steps in three have no candidate).
-    Free: X4 X5 SD SE SF P0 P1 E0 E1."""
+    Free: X4 X5 SD SE SF P0 P1 E0 E1.  (Lengths of 32 and more -- `big` -- are read from the full table in global memory; the
+    LDS read of that lane then lands somewhere in the LDS and is not used: its index is formed without range masks.)"""
     if not mid:
         t(f"v_cndmask_b32 {X3}, 0, {X3}, {O('mhist')}")
     if ABLATE["nolen"]:
@@ -327,11 +332,9 @@ def len_pass(t, mid, sfx, mode, first, last, multi):
         v_min_u32 {P1}, {O('clampv')}, {P1}
         v_or_b32 {SE}, {SD}, {P1}
         v_cmp_lt_u32 vcc, 31, {SE}
-        v_and_b32 {SE}, 31, {SD}
-        v_lshl_or_b32 {SE}, {X4}, 5, {SE}
+        v_lshl_or_b32 {SE}, {X4}, 5, {SD}
         v_mul_u32_u24 {SE}, 33, {SE}
-        v_and_b32 {X5}, 31, {P1}
-        v_sub_u32 {SE}, {SE}, {X5}
+        v_sub_u32 {SE}, {SE}, {P1}
         v_add_u32 {SE}, 31, {SE}
         v_lshlrev_b32 {SE}, 2, {SE}
         ds_read_b32 {SE}, {SE}
@@ -363,7 +366,7 @@ def len_pass(t, mid, sfx, mode, first, last, multi):
         s_branch {L('len_top' + sfx)}
     """)
     t.label("len_done" + sfx)
-    mat_part(t, mode, True, mid)
+    mat_part(t, mode, True, mid, first, last)
     # The record's ds_write_b128 has just been issued, and LENST is one of its four data registers: an LDS write of
     # more than 64 bits reads its data registers over several cycles after issue, like the VMEM stores of the ISA
     # manual's hazard table (which does not list DS) -- a VALU write right behind it can reach the register first (seen
@@ -382,11 +385,11 @@ def len_pass(t, mid, sfx, mode, first, last, multi):
     t.common()
 
 
-def mat_part(t, mode, with_len, mid):
+def mat_part(t, mode, with_len, mid, first=False, last=False):
     """MAT by two 3-way minima and equality tests (cell.hpp, Env::MIN3): value, traceback word, runs.  with_len = False:
     no LEN candidate in the wave -- LEN.VAL is 100 b, its run 0, its run start +inf (LENST keeps that value from the
     loop's entry on); True: the out-of-line variant behind the LEN loop, which reads LENV / LENRUN and restores LENST."""
-    own_m, own_i, own_d, r1, r2 = O("matv"), O("insv"), O("delv"), O("R1"), O("R2")
+    own_m, own_i, own_d, r1, r2 = MATV, O("insv"), O("delv"), O("R1"), O("R2")
     diagM = O("LMv") if mode == "I" else O("TMv")
     lenv = LENV if with_len else O("ev")
     t(f"""
@@ -396,6 +399,14 @@ def mat_part(t, mode, with_len, mid):
         v_mov_b32 {diagM}, {X0}
         v_min3_f32 {Q0}, {SD}, {own_d}, {SHRV}
     """)
+    # band-edge cells: MAT.VAL = 100 (b + 1) (src/aln.pyx:502-507) goes in HERE, in front of the record's store (Q0 is one
+    # of its data registers); the edge lanes' own compares below then see it -- their traceback word and history record
+    # are not stored, their runs are zeroed by edge_fix.  X5 keeps 100 (b + 1) for edge_fix.
+    if first or last:
+        t(f"""
+            v_add_f32 {X5}, 0x42c80000, {O('ev')}
+            v_cndmask_b32 {Q0}, {Q0}, {X5}, {O('me') if first and last else O('ml0') if first else O('medge')}
+        """)
     # (traceback words: the run registers carry their type tag -- layout.hpp tb_word -- so there is nothing to assemble;
     # 2.0 is the inline constant whose bit pattern is T_LEN << 29)
     if with_len:
@@ -416,7 +427,6 @@ def mat_part(t, mode, with_len, mid):
     t(f"""
         v_lshl_or_b32 {r1}, {NINSR}, 16, {SD}
         v_lshl_or_b32 {r2}, {NDELR}, 16, {SD}
-        v_mov_b32 {own_m}, {Q0}
     """)
     # history record (and, where a lane mask is needed anyway, the traceback word) of the band-interior columns; a
     # middle wave holds no others and stores its traceback word behind the hand-over
@@ -429,30 +439,26 @@ def mat_part(t, mode, with_len, mid):
 
 
 def edge_fix(t, first, last):
-    """band-edge cells (src/aln.pyx:502-507): the three values their one in-band neighbour reads"""
-    own_m, own_i, own_d, r1, r2 = O("matv"), O("insv"), O("delv"), O("R1"), O("R2")
-    if first or last:
-        t(f"v_add_f32 {SD}, 0x42c80000, {O('ev')}")
+    """band-edge cells (src/aln.pyx:502-507): the values their one in-band neighbour reads, MAT.VAL aside (mat_part, which
+    also left 100 (b + 1) in X5)"""
+    own_i, own_d, r1, r2 = O("insv"), O("delv"), O("R1"), O("R2")
     if first and last:
         # a lone wave holds both edges: one mask for the two lanes -- what the other edge's fix writes into an edge cell
         # (DEL of column 2r, INS of column 0) is read by no in-band cell
         t(f"""
-            v_cndmask_b32 {own_m}, {own_m}, {SD}, {O('me')}
-            v_cndmask_b32 {own_d}, {own_d}, {SD}, {O('me')}
-            v_cndmask_b32 {own_i}, {own_i}, {SD}, {O('me')}
+            v_cndmask_b32 {own_d}, {own_d}, {X5}, {O('me')}
+            v_cndmask_b32 {own_i}, {own_i}, {X5}, {O('me')}
             v_cndmask_b32 {r2}, {r2}, 0, {O('me')}
             v_cndmask_b32 {r1}, {r1}, 0, {O('me')}
         """)
     elif first:
         t(f"""
-            v_cndmask_b32 {own_m}, {own_m}, {SD}, {O('ml0')}
-            v_cndmask_b32 {own_d}, {own_d}, {SD}, {O('ml0')}
+            v_cndmask_b32 {own_d}, {own_d}, {X5}, {O('ml0')}
             v_cndmask_b32 {r2}, {r2}, 0, {O('ml0')}
         """)
     elif last:
         t(f"""
-            v_cndmask_b32 {own_m}, {own_m}, {SD}, {O('medge')}
-            v_cndmask_b32 {own_i}, {own_i}, {SD}, {O('medge')}
+            v_cndmask_b32 {own_i}, {own_i}, {X5}, {O('medge')}
             v_cndmask_b32 {r1}, {r1}, 0, {O('medge')}
         """)
 
@@ -486,7 +492,7 @@ def finish(t, mode, first, last, multi, mid, len_variant):
     before the progress word that follows them; the explicit lgkmcnt(0) in front of it (like the C++ body's workgroup
     fence) is also what retires the history record's ds_write_b128 before any of its data registers is written again
     (LENST: restored behind it in the variant that follows a LEN candidate)."""
-    own_m, own_i, own_d, r1, r2 = O("matv"), O("insv"), O("delv"), O("R1"), O("R2")
+    own_m, own_i, own_d, r1, r2 = MATV, O("insv"), O("delv"), O("R1"), O("R2")
     edge_fix(t, first, last)
     if not multi:
         next_step(t, mode)
@@ -564,7 +570,7 @@ def finish(t, mode, first, last, multi, mid, len_variant):
 def tail(t, mode, first, last, multi):
     """MAT, stores, hand-over, next step"""
     mid = multi and not first and not last
-    mat_part(t, mode, False, mid)
+    mat_part(t, mode, False, mid, first, last)
     t.label("post_mat_" + mode)
     finish(t, mode, first, last, multi, mid, False)
 
@@ -730,6 +736,7 @@ def gen_role(role):
     # second read of the same address was right.  One wait per entry (entries = hand-overs, ~1 % of the steps): within
     # the run-to-run spread of the fill time.
     t("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    t(f"v_mov_b32 {MATV}, {O('matv')}")
     # The rare-path test of the column descriptors (DSC_RARE), once per entry, over every lane whose descriptor is in
     # the band or on its way there (the lanes beyond the band's last column hold the descriptors that will move into
     # it): an 'I' step does not move the descriptors and a 'D' step tests the one that enters at its last lane before
@@ -749,15 +756,15 @@ def gen_role(role):
     # descriptors do not move and INS reads this lane's own cell, so everything that does not depend on the neighbour
     # waves -- the descriptor's summary bits, the lane-table reads, INS -- is done in front of the hand-shake poll.
     t.label("mode_i")
-    t(f"v_and_b32 {SMR}, 0xbc, {O('rc0')}")
-    if not mid:
-        t(f"v_cndmask_b32 {SMR}, 0, {SMR}, {O('mhist')}")
+    # (summary bits of the band-interior columns only: the mask 0xbc comes per lane, zero in the lanes of the band's edge
+    # columns and beyond -- one instruction where a mask and a select used to be; a middle wave holds no such lanes)
+    t(f"v_and_b32 {SMR}, {'0xbc' if mid else O('livebc')}, {O('rc0')}")
     if multi:
         poll_issue(t, "I", first, last)
     book(t, "I")
     shr_tables(t, X3 if first else SD)          # (X3 is waiting for its exchange word)
     t(f"v_add_u32_sdwa {DRUN}, {O('LMr')}, {O('one')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD")
-    ins_part(t, "I", X4, X5, O("sb"), (f"v_mov_b32 {O('TMv')}, {O('matv')}", f"v_mov_b32 {O('TMr')}, {O('R1')}"))
+    ins_part(t, "I", X4, X5, O("sb"), (f"v_mov_b32 {O('TMv')}, {MATV}", f"v_mov_b32 {O('TMr')}, {O('R1')}"))
     if first:
         t(f"""
             v_readlane_b32 {O('sx')}, {O('seqq')}, {O('sqidx')}
@@ -771,7 +778,7 @@ def gen_role(role):
     if not first:
         t(f"""
             v_mov_b32_dpp {X3}, {O('seqw')} wave_shr:1 row_mask:0xf bank_mask:0xf
-            v_mov_b32_dpp {X0}, {O('matv')} wave_shr:1 row_mask:0xf bank_mask:0xf
+            v_mov_b32_dpp {X0}, {MATV} wave_shr:1 row_mask:0xf bank_mask:0xf
             v_mov_b32_dpp {X1}, {O('delv')} wave_shr:1 row_mask:0xf bank_mask:0xf
             v_mov_b32_dpp {X2}, {O('R2')} wave_shr:1 row_mask:0xf bank_mask:0xf
             v_mov_b32 {O('seqw')}, {X3}
@@ -780,7 +787,7 @@ def gen_role(role):
     else:
         t(f"""
             v_mov_b32_dpp {O('seqw')}, {O('seqw')} wave_shr:1 row_mask:0xf bank_mask:0xf
-            v_mov_b32_dpp {X0}, {O('matv')} wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+            v_mov_b32_dpp {X0}, {MATV} wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
             v_mov_b32_dpp {X1}, {O('delv')} wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
             v_mov_b32_dpp {X2}, {O('R2')} wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
             v_writelane_b32 {O('seqw')}, {O('sx')}, 0
@@ -808,13 +815,13 @@ def gen_role(role):
     t(f"""
         s_add_i32 {O('sdel')}, {O('sdel')}, 1
         v_add_u32_sdwa {DRUN}, {O('TMr')}, {O('one')} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD
-        v_mov_b32 {O('LMv')}, {O('matv')}
+        v_mov_b32 {O('LMv')}, {MATV}
         v_mov_b32 {O('LMr')}, {O('R2')}
     """)
     if last:
         t(f"""
             v_mov_b32_dpp {O('rc0')}, {O('rc0')} wave_shl:1 row_mask:0xf bank_mask:0xf
-            v_mov_b32_dpp {X0}, {O('matv')} wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+            v_mov_b32_dpp {X0}, {MATV} wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
             v_writelane_b32 {O('rc0')}, {O('sx')}, 63
             v_readlane_b32 {O('sx')}, {O('rqx')}, {O('rqidx')}
             v_mov_b32_dpp {O('refx')}, {O('refx')} wave_shl:1 row_mask:0xf bank_mask:0xf
@@ -825,9 +832,8 @@ def gen_role(role):
             v_mov_b32_dpp {O('rc1')}, {O('rc1')} wave_shl:1 row_mask:0xf bank_mask:0xf
             v_mov_b32 {O('TMr')}, {X2}
             s_add_i32 {O('rqidx')}, {O('rqidx')}, 1
-            v_and_b32 {SMR}, 0xbc, {O('rc0')}
+            v_and_b32 {SMR}, {O('livebc')}, {O('rc0')}
             v_writelane_b32 {O('rc1')}, {O('sx')}, 63
-            v_cndmask_b32 {SMR}, 0, {SMR}, {O('mhist')}
         """)
         shr_tables(t)
         ins_part(t, "D", X4, X5, O("sb"))
@@ -849,18 +855,16 @@ def gen_role(role):
         """)
         shr_tables(t, SD)          # (X3 holds its exchange word)
         t(f"""
-            v_and_b32 {SMR}, 0xbc, {O('rc0')}
+            v_and_b32 {SMR}, {'0xbc' if mid else O('livebc')}, {O('rc0')}
             v_mov_b32_dpp {X3}, {O('refx')} wave_shl:1 row_mask:0xf bank_mask:0xf
             v_mov_b32_dpp {X5}, {O('rc1')} wave_shl:1 row_mask:0xf bank_mask:0xf
-            v_mov_b32_dpp {X0}, {O('matv')} wave_shl:1 row_mask:0xf bank_mask:0xf
+            v_mov_b32_dpp {X0}, {MATV} wave_shl:1 row_mask:0xf bank_mask:0xf
             v_mov_b32_dpp {X1}, {O('insv')} wave_shl:1 row_mask:0xf bank_mask:0xf
             v_mov_b32_dpp {X2}, {O('R1')} wave_shl:1 row_mask:0xf bank_mask:0xf
             v_mov_b32 {O('refx')}, {X3}
             v_mov_b32 {O('rc1')}, {X5}
             v_mov_b32 {O('TMr')}, {X2}
         """)
-        if not mid:
-            t(f"v_cndmask_b32 {SMR}, 0, {SMR}, {O('mhist')}")
         sub_read(t)
         ins_part(t, "D", X4, X5, O("sb"))      # (in the shadow of the lane-table reads)
         t("s_waitcnt lgkmcnt(1)")
@@ -945,6 +949,7 @@ def gen_role(role):
     t.label("done")
     t(f"s_mov_b32 {O('status')}, 0")
     t.label("end")
+    t(f"v_mov_b32 {O('matv')}, {MATV}")
     # nothing of this text may be in flight when the compiled code resumes: it reuses the scratch registers at once --
     # loads still on their way into them (exit2: the exchange words), and the history record's ds_write_b128, which
     # reads its four data registers for a few cycles after issue
@@ -1065,7 +1070,7 @@ def operands(role):
            ("clamp1", "s", "a_clamp1"), ("npdim", "s", "a_npdim"), ("gnp", "s", "env.g_np"),
            ("hca", "v", "hist_c_addr"), ("trecip", "v", "env.t_recip"), ("one", "v", "a_one"), ("lanej", "v", "a_lanej"),
            ("inf", "v", "a_inf"), ("c100", "v", "a_c100"),
-           ("oneI", "v", "a_oneI"), ("oneD", "v", "a_oneD"), ("tagS", "v", "a_tagS")]
+           ("oneI", "v", "a_oneI"), ("oneD", "v", "a_oneD"), ("tagS", "v", "a_tagS"), ("livebc", "v", "a_livebc")]
     if role != 2:
         ins += [("mhist", "s", "a_mhist")]
     if multi:

@@ -882,9 +882,11 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(4, 4), amd
             float a_inf = huge_f(), a_c100 = INF_F;          // (a literal and VCC do not fit one v_cndmask: constants in registers)
             // run registers carry the type tag of their traceback word (layout.hpp tb_word): "run + 1" / "run 1" of INS and DEL, "run 0" of SHR
             uint32_t a_oneI = tb_word(T_INS, 1u), a_oneD = tb_word(T_DEL, 1u), a_tagS = tb_word(T_SHR, 0u);
+            uint32_t a_livebc = hist_lane ? (DSC_N4 | DSC_HAS2 | DSC_RARE) : 0u;      // the descriptor's summary bits, band-interior columns only
             uint32_t a_laneid = (uint32_t)lane;
             const int a_drows = d.drows, a_dcols = d.dcols;
-            asm volatile("" : "+v"(a_one), "+v"(a_lanej), "+v"(a_progaddr), "+v"(a_inf), "+v"(a_c100), "+v"(a_laneid), "+v"(a_oneI), "+v"(a_oneD), "+v"(a_tagS));
+            asm volatile("" : "+v"(a_one), "+v"(a_lanej), "+v"(a_progaddr), "+v"(a_inf), "+v"(a_c100), "+v"(a_laneid), "+v"(a_oneI), "+v"(a_oneD), "+v"(a_tagS), "+v"(a_livebc));
+            (void)a_livebc;
             (void)a_laneid; (void)a_drows; (void)a_dcols;
             (void)a_mhist; (void)a_ml0; (void)a_ml63; (void)a_medge; (void)a_me; (void)a_progaddr;
             for (;;) {

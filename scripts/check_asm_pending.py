@@ -14,7 +14,7 @@ counter).  The rules are the architected ones -- counters, not instruction dista
       no wide store on the VM counter (the compiled code reuses the scratch registers at once); plain 32-bit traceback
       stores may stay in flight;
   R4  no VALU writes a LOOP-CARRIED register (an in/out operand of the statement, or LENST, the one scratch register
-      whose value lives from step to step) while exec is narrowed to some lanes (the hand-over's lane 0 / lane 63
+      whose value lives from step to step -- and MATV, the record's first register, where MAT.VAL lives) while exec is narrowed to some lanes (the hand-over's lane 0 / lane 63
       regions, the masked stores): the other lanes would keep a stale value.  The word queues (rqx / rqz / rqw), which
       are refilled under the mask of their valid lanes on purpose, are exempt.
 
@@ -66,7 +66,7 @@ def findings(role, lines=None):
     if not ins or ins[0] != "s_waitcnt vmcnt(0) lgkmcnt(0)":
         out.add(("R3", 0, ins[0] if ins else "", ("the text must begin with s_waitcnt vmcnt(0) lgkmcnt(0)",)))
     seen = set()
-    carried = {"%" + n for n, c, _ in G.operands(role)[0] if c.startswith("+")} - {"%rqx", "%rqz", "%rqw"} | {G.LENST}
+    carried = {"%" + n for n, c, _ in G.operands(role)[0] if c.startswith("+")} - {"%rqx", "%rqz", "%rqw"} | {G.LENST, G.MATV}
     # an operation in flight: (registers a load will fill, data registers of a wide write)
     stack = [(0, (), (), True)]
     while stack:
