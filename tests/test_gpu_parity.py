@@ -241,6 +241,11 @@ def test_groups_under_small_traceback_budget(tables):
     assert c.timing()["launches"] >= 4
     for k in (0, 39):
         assert got[k] == oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=30)
+    # the same through the device glue: every group standardises its own reads
+    from npore_amd import cig
+    fin, st = c.align_batch(refs, seqs, cigs, r=30, return_status=True, final_cigars=True)
+    assert not st.any() and fin == cig.standardize_batch(want, refs, seqs)
+    assert c.timing()["launches"] >= 4
     c.close()
 
 
