@@ -304,8 +304,8 @@ constexpr int SLOT_RING = 8;    // chunk slots published by a group's first wave
 // Registers: four of these waves share a SIMD with whatever the NEXT batch runs beside them (npore_api.cpp: its
 // preparation, the previous one's traceback), so the kernel is held to 112 of the SIMD's 512 / 4 = 128 vector
 // registers -- amdgpu_num_vgpr counts in halves on this target (arch + acc registers) -- which leaves 64 for one
-// light wave per SIMD (this round's annotate_wave_kernel is held to those 64).  The cap costs spills (NW >= 2: 46 vector
-// registers, 164 bytes of scratch per lane; NW = 1: 13 / 56 -- hipcc -Rpass-analysis=kernel-resource-usage): none inside the
+// light wave per SIMD (this round's annotate_wave_kernel is held to those 64).  The cap costs spills (NW >= 2: 59 vector
+// registers, 168 bytes of scratch per lane; NW = 1: 16 / 68 -- hipcc -Rpass-analysis=kernel-resource-usage): none inside the
 // assembly text, four stores + reloads around every ENTRY of the assembly (v97 - v100 are live across the statement
 // that clobbers them; an entry is a hand-over, ~1 % of the steps) and two 8-byte reloads in the compiled rare step's
 // per-period candidate loop -- under half a percent of the step time, and the price of the co-residency.
