@@ -12,7 +12,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import oracle
-from npore_amd import aln, synth
+from npore_amd import aln, synth, cig as cig_mod
 
 _tables0 = None
 
@@ -116,6 +116,16 @@ def fuzz(budget, seed, focus=False, log=print):
                 cig = bytes(cg[:at]) + b"=" * len(rep) + bytes(cg[at:])
             refs.append(ref); seqs.append(seq); cigs.append(cig)
         got, st = ctx.align_batch(refs, seqs, cigs, indel_start=ist, indel_extend=iex, r=r, max_b_rows=mbr, return_status=True)
+        # every fourth round also through the device glue (standardize_kernel): its text must be what the host glue makes
+        # of the op strings just returned (the strings themselves are compared with the oracle below)
+        if rounds % 4 == 0:
+            fin, st2 = ctx.align_batch(refs, seqs, cigs, indel_start=ist, indel_extend=iex, r=r, max_b_rows=mbr, return_status=True,
+                                       final_cigars=True)
+            host = cig_mod.standardize_batch(got, refs, seqs)
+            for k in range(n):
+                if fin[k] != host[k] or st2[k] != st[k]:
+                    bad += 1
+                    log(f"GLUE MISMATCH seed={seed} round={rounds} read={k} r={r} mbr={mbr} len={len(refs[k])}/{len(seqs[k])} status={st[k]}/{st2[k]}")
         ctx.close()
         for k in range(n):
             try:
