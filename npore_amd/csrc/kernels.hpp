@@ -1142,19 +1142,29 @@ __global__ __launch_bounds__(64) void traceback_kernel(TParams p)
     if (lane < (nruns & 63)) runs[(nruns & ~63) + lane] = rbuf;
 }
 
-// The same traceback with ONE coalesced load of the whole anti-diagonal (16 bytes per lane) plus inss[b] per
-// hop, requested as soon as the next cell is known: a third of the instructions per hop of the windowed
-// kernel, one memory round trip per hop instead of one per ~4 hops.  With thousands of chunks in flight the
-// round trips of different chunks overlap and the instruction count decides; with one wave per SIMD (a
-// batch of 1 000 reads) the windows win.  NL: uint4 loads per lane covering a row (tbstride <= 256 * NL).
-template <int NL>
+// The same traceback with ONE coalesced load of the whole anti-diagonal plus inss[b] per hop, requested as soon
+// as the next cell is known: one memory round trip per hop instead of one per ~4 hops, a fraction of the windowed
+// kernel's instructions.  With thousands of chunks in flight the round trips of different chunks overlap and the
+// SCALAR instruction count per hop decides (everything here is wave-uniform: a SIMD issues one scalar instruction
+// per four cycles whatever the number of waves it holds); with one wave per SIMD (a batch of 1 000 reads) the
+// windows win.
+// Of a row the wave holds ONE group of 64 columns, one word per lane (lane l = column 64 g + l), so the cell's word is
+// one v_readlane.  The group requested with a row is the one the path is in now: its band column changes only where
+// the new alignment leaves the input one, so the next cell is nearly always in the same group; where it is not, the row
+// is requested again with the right group (one more round trip, once per crossing of a multiple of 64).  The bytes per
+// hop are those of r <= 31 whatever the band.
+// Hops run through a FAST loop while nothing special happens -- the word is a valid run that fits the slot, the cell is
+// inside the band, and the next cell lies strictly inside the chunk rectangle (row0 + col0 == brk, so it is then inside
+// the chunk's anti-diagonals too: they only decrease) -- 34 scalar instructions; the first hop that fails one of
+// those tests is handed, untouched, to the general loop below, which decides in the reference's order
+// (src/aln.pyx:680-716) what it was.  Every such hop is one of the chunk's last few.
 __global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
 {
     const int k = blockIdx.x;
     if (k >= *p.n_chunks) return;
     const int lane = threadIdx.x;
     const ChunkDesc d = p.descs[k];
-    const uint32_t *tb = p.tb + d.tb_off;
+    const char *tb = reinterpret_cast<const char *>(p.tb + d.tb_off);
     uint32_t *runs = p.chunk_runs + d.out_off;
     const int W = 2 * p.r + 1, stride = p.tbstride;
     int a_row = d.row0 + d.drows, a_col = d.col0 + d.dcols;
@@ -1163,32 +1173,112 @@ __global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
     int nruns = 0;
     uint32_t rbuf = 0u;    // lane l: run number (nruns & ~63) + l
 
-    const int32_t *inss = p.inss + d.inss_off + d.brk;
-    uint4 row[NL];
+    const char *inss = reinterpret_cast<const char *>(p.inss + d.inss_off + d.brk);
+    const uint32_t stride4 = (uint32_t)stride * 4u;
+    uint32_t row = 0u;
     int row_ins = 0;
-    auto load_row = [&](int bl) {
-        row_ins = inss[bl];
-#pragma unroll
-        for (int q = 0; q < NL; q++) {
-            const int idx = (q * 64 + lane) * 4;
-            row[q] = (idx < stride) ? *reinterpret_cast<const uint4 *>(tb + (size_t)bl * stride + idx)
-                                    : make_uint4(0u, 0u, 0u, 0u);
-        }
+    int grp = p.r >> 6;    // the group held (the input path runs along band column r)
+    auto load_row = [&](int bl, int g) {            // a chunk's block is < 2^32 bytes (60 000 rows x 1 024 words)
+        row_ins = *reinterpret_cast<const int32_t *>(inss + (uint32_t)bl * 4u);
+        const uint32_t o = (uint32_t)bl * stride4;
+        row = *reinterpret_cast<const uint32_t *>(tb + (o + min((uint32_t)(g * 256 + lane * 4), stride4 - 4u)));   // kept inside the row
     };
-    auto word = [&](int col) -> uint32_t {   // col is wave-uniform
-        uint4 v = row[0];
-#pragma unroll
-        for (int q = 1; q < NL; q++)
-            if ((col >> 8) == q) v = row[q];
-        const uint32_t lo = (col & 1) ? v.y : v.x, hi = (col & 1) ? v.w : v.z;
-        return (uint32_t)__builtin_amdgcn_readlane((int)((col & 2) ? hi : lo), (col & 255) >> 2);
-    };
+    auto word = [&](int col) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)row, col & 63); };      // col is wave-uniform
     auto in_chunk = [&](int ar, int ac) {
         const int bl = ar + ac - d.brk;
         return ar >= d.row0 && ac >= d.col0 && bl >= 0 && bl < d.nrows;
     };
 
-    if ((a_row > d.row0 || a_col > d.col0) && in_chunk(a_row, a_col)) load_row(a_row + a_col - d.brk);
+    if ((a_row > d.row0 || a_col > d.col0) && in_chunk(a_row, a_col)) {
+        load_row(a_row + a_col - d.brk, grp);
+        // ---- fast hops: the row of (a_row, a_col) is loaded and the cell is inside the chunk.  Written out (34 scalar
+        // instructions per hop; the compiler's form of the same loop has 55, a third of them moves and masks of its
+        // control flow): every exit leaves a_row / a_col / pos / nruns / grp / row / row_ins / rbuf as they were
+        // before the hop that could not be taken, with no load in flight.
+        // gfx950 wait states kept by the order of the text: the compare that writes vcc and the select that reads it
+        // are three scalar instructions apart (two needed); x (written by v_readlane) is read by a vector instruction
+        // ~25 instructions later; lane selects are written by scalar instructions (no wait needed).
+        {
+            a_row = uni(a_row); a_col = uni(a_col); pos = uni(pos); nruns = uni(nruns); grp = uni(grp);
+            uint32_t vg = min((uint32_t)(grp * 256 + lane * 4), stride4 - 4u);       // this lane's byte in a row
+            const int lane4 = lane * 4;
+            int t0, t1, bc, run, x;
+            uint32_t va, vt;
+            asm volatile(
+                "hop_%=:\n\t"
+                "s_waitcnt vmcnt(0)\n\t"
+                "v_readfirstlane_b32 %[t0], %[ins]\n\t"
+                "s_sub_i32 %[bc], %[t0], %[A]\n\t"
+                "s_add_i32 %[bc], %[bc], %[R]\n\t"                 // inss[b] - a_row + r
+                "s_add_i32 %[t0], %[bc], -1\n\t"
+                "s_cmp_ge_u32 %[t0], %[WM2]\n\t"
+                "s_cbranch_scc1 out_%=\n\t"                         // band edge or outside the band
+                "s_lshr_b32 %[t0], %[bc], 6\n\t"
+                "s_cmp_lg_u32 %[t0], %[G]\n\t"
+                "s_cbranch_scc1 regroup_%=\n\t"
+                "v_readlane_b32 %[x], %[row], %[bc]\n\t"
+                "s_and_b32 %[run], %[x], 0x1fffffff\n\t"
+                "s_add_i32 %[t0], %[run], -1\n\t"
+                "s_cmp_ge_u32 %[t0], %[P]\n\t"
+                "s_cbranch_scc1 out_%=\n\t"                         // run < 1 or run > pos
+                "s_cmp_ge_u32 %[x], 0xa0000000\n\t"
+                "s_cbranch_scc1 out_%=\n\t"                         // no such state
+                "s_cmp_lt_u32 %[x], 0x60000000\n\t"                // MAT, INS, LEN: the read position moves
+                "s_cselect_b32 %[t0], %[run], 0\n\t"
+                "s_add_i32 %[t1], %[x], 0xe0000000\n\t"
+                "s_cmp_ge_u32 %[t1], 0x40000000\n\t"               // not INS / LEN: the reference position moves
+                "s_cselect_b32 %[t1], %[run], 0\n\t"
+                "s_sub_i32 %[A], %[A], %[t0]\n\t"
+                "s_sub_i32 %[C], %[C], %[t1]\n\t"
+                "s_cmp_le_i32 %[A], %[ROW0]\n\t"
+                "s_cbranch_scc1 undo_%=\n\t"                        // the chunk's first row / column: the general loop
+                "s_cmp_le_i32 %[C], %[COL0]\n\t"
+                "s_cbranch_scc1 undo_%=\n\t"
+                "s_add_i32 %[t0], %[A], %[C]\n\t"
+                "s_sub_i32 %[t0], %[t0], %[BRK]\n\t"
+                "s_lshl_b32 %[t1], %[t0], 2\n\t"
+                "s_mul_i32 %[t0], %[t0], %[S4]\n\t"
+                "v_mov_b32 %[va], %[t1]\n\t"
+                "global_load_dword %[ins], %[va], %[IB]\n\t"
+                "v_add_u32 %[va], %[t0], %[vg]\n\t"
+                "global_load_dword %[row], %[va], %[TB]\n\t"
+                "v_alignbit_b32 %[vt], %[x], %[x], 29\n\t"         // typ | run << 3
+                "s_and_b32 %[t0], %[N], 63\n\t"
+                "v_cmp_eq_u32 vcc, %[t0], %[lane]\n\t"
+                "s_add_i32 %[N], %[N], 1\n\t"
+                "s_sub_i32 %[P], %[P], %[run]\n\t"
+                "s_and_b32 %[t0], %[N], 63\n\t"
+                "v_cndmask_b32 %[rbuf], %[rbuf], %[vt], vcc\n\t"
+                "s_cbranch_scc1 hop_%=\n\t"
+                "s_lshl_b32 %[t0], %[N], 2\n\t"                    // 64 runs recorded: store them
+                "s_add_i32 %[t0], %[t0], 0xffffff00\n\t"
+                "v_add_u32 %[va], %[t0], %[lane4]\n\t"
+                "global_store_dword %[va], %[rbuf], %[RB]\n\t"
+                "s_branch hop_%=\n\t"
+                "regroup_%=:\n\t"                                    // the path has crossed into another group: same row again
+                "s_mov_b32 %[G], %[t0]\n\t"
+                "s_lshl_b32 %[t0], %[t0], 8\n\t"
+                "v_add_u32 %[vg], %[t0], %[lane4]\n\t"
+                "v_min_u32 %[vg], %[S4M4], %[vg]\n\t"
+                "s_add_i32 %[t0], %[A], %[C]\n\t"
+                "s_sub_i32 %[t0], %[t0], %[BRK]\n\t"
+                "s_mul_i32 %[t0], %[t0], %[S4]\n\t"
+                "s_nop 0\n\t"
+                "v_add_u32 %[va], %[t0], %[vg]\n\t"
+                "global_load_dword %[row], %[va], %[TB]\n\t"
+                "s_branch hop_%=\n\t"
+                "undo_%=:\n\t"
+                "s_add_i32 %[A], %[A], %[t0]\n\t"
+                "s_add_i32 %[C], %[C], %[t1]\n\t"
+                "out_%=:\n\t"
+                : [A] "+s"(a_row), [C] "+s"(a_col), [P] "+s"(pos), [N] "+s"(nruns), [G] "+s"(grp), [row] "+v"(row),
+                  [ins] "+v"(row_ins), [rbuf] "+v"(rbuf), [vg] "+v"(vg), [t0] "=&s"(t0), [t1] "=&s"(t1), [bc] "=&s"(bc),
+                  [run] "=&s"(run), [x] "=&s"(x), [va] "=&v"(va), [vt] "=&v"(vt)
+                : [R] "s"(p.r), [WM2] "s"(W - 2), [ROW0] "s"(d.row0), [COL0] "s"(d.col0), [BRK] "s"(d.brk), [S4] "s"(stride4),
+                  [S4M4] "s"(stride4 - 4u), [TB] "s"(tb), [IB] "s"(inss), [RB] "s"(runs), [lane] "v"(lane), [lane4] "v"(lane4)
+                : "vcc", "scc", "memory");
+        }
+    }
     // two combined tests per ordinary hop; what stopped the loop is sorted out in the reference's order
     // (src/aln.pyx:680-716) where it stops, so the status bits are those of one test per condition
     for (;;) {
@@ -1202,6 +1292,11 @@ __global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
         if ((bc <= 0) | (bc >= W - 1)) {
             status |= (bc < 0 || bc >= W) ? 16 : 4;    // band edge: TYP = MAT, RUN = 0 (src/aln.pyx:502-507) -> "run < 1"
             break;
+        }
+        if ((bc >> 6) != uni(grp)) {
+            grp = bc >> 6;
+            load_row(a_row + a_col - d.brk, grp);
+            continue;
         }
         const uint32_t x = word(bc);
         const int typ = tb_typ(x), run = tb_run(x);     // src/aln.pyx:684-685
@@ -1217,7 +1312,7 @@ __global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
         }
         const int n_row = a_row - (del ? 0 : emit), n_col = a_col - (ins ? 0 : emit);
         // request the next row now
-        if (emit == run && (n_row > d.row0 || n_col > d.col0) && in_chunk(n_row, n_col)) load_row(n_row + n_col - d.brk);
+        if (emit == run && (n_row > d.row0 || n_col > d.col0) && in_chunk(n_row, n_col)) load_row(n_row + n_col - d.brk, grp);
         if (emit > 0) {
             rbuf = (lane == (nruns & 63)) ? ((uint32_t)typ | ((uint32_t)emit << 3)) : rbuf;
             nruns++;

@@ -550,14 +550,12 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     tp.chunk_status = w->cstat.as<int32_t>();
     tp.r = r;
     tp.tbstride = tbs;
-    // windowed traceback for small batches (about one wave per SIMD), row-per-hop for large ones (kernels.hpp)
-    // windowed traceback up to ~one wave per SIMD, row per hop beyond (measured crossover: 2 000 chunk slots tie at
-    // r=30 and favour the windows by 15 % at r=100; 3 000-4 000 slots favour the rows by 12-30 %)
-    const int tb_mode = ctx->tb_kernel ? ctx->tb_kernel : (max_chunks > 2500 ? 2 : 1);
+    // windowed traceback up to ~one wave per SIMD, row per hop beyond (kernels.hpp).  Measured: the windows take 0.58 ms
+    // up to 1 024 chunk slots and grow in proportion beyond; the rows take 0.70 ms + 0.04 ms per 1 000 slots at any band
+    // width (10 kb reads): they cross at ~1 300 slots
+    const int tb_mode = ctx->tb_kernel ? ctx->tb_kernel : (max_chunks > 1300 ? 2 : 1);
     if (tb_mode == 1) hipLaunchKernelGGL(traceback_kernel, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
-    else if (tbs <= 256) hipLaunchKernelGGL(traceback_rows_kernel<1>, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
-    else if (tbs <= 512) hipLaunchKernelGGL(traceback_rows_kernel<2>, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
-    else hipLaunchKernelGGL(traceback_rows_kernel<4>, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
+    else hipLaunchKernelGGL(traceback_rows_kernel, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
     HIP_TRY(hipGetLastError());
 
     GParams gp;

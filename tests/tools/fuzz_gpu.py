@@ -4,7 +4,8 @@ driver-run GPU suite, half of it FOCUSED on the two regions that have failed bef
 chunk; max_l < 32).
 Every round draws a band half-width, chunk height, gap penalties, a score-table variant (the shipped tables, tables
 with random entries incl. ties/negatives, other max_n / max_l) and a batch of short-to-medium reads (random n-polymer
-density, N bases, input paths that hug the band edge) and compares every string and status with the oracle's."""
+density, N bases, input paths that hug the band edge) and one of the two traceback kernels, and compares every string
+and status with the oracle's."""
 import os
 import sys
 import time
@@ -81,6 +82,8 @@ def fuzz(budget, seed, focus=False, log=print):
         kind = int(rng.choice([0, 0, 1, 2]))
         sub, nps = tables(rng, kind, max_n, max_l)
         ctx = aln.Context(sub, nps, max_n=max_n, max_l=max_l)
+        tbk = int(rng.choice([0, 1, 2, 2]))     # the traceback kernel: by batch size (these batches: the windows), windows, rows
+        ctx.set("traceback_kernel", tbk)
         r = int(rng.choice([100, 127, 128, 160, 192, 200, 255, 256, 320, 511] if focus else
                            [1, 2, 3, 7, 15, 30, 31, 32, 33, 64, 65, 100, 127, 128, 160, 192, 200, 255, 288, 448]))
         mbr = int(rng.choice([2, 3, 5, 7, 16, 64] if focus else [2, 3, 5, 16, 64, 65, 200, 1000, 20000, 60000]))
@@ -140,7 +143,7 @@ def fuzz(budget, seed, focus=False, log=print):
             if not ok:
                 bad += 1
                 log(f"MISMATCH seed={seed} round={rounds} read={k} r={r} mbr={mbr} gaps=({ist},{iex}) tables={kind} max_n={max_n} "
-                      f"max_l={max_l} len={len(refs[k])}/{len(seqs[k])} status={st[k]} want_status={wst}")
+                      f"max_l={max_l} len={len(refs[k])}/{len(seqs[k])} status={st[k]} want_status={wst} traceback_kernel={tbk}")
         rounds += 1
         reads += n
     return rounds, reads, bad
