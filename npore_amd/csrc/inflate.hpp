@@ -180,7 +180,10 @@ class FastInflate {
     {
         // The fast loop: while 16 input bytes and 320 output bytes of the block's own room remain, nothing in it needs a
         // bounds check -- one refill feeds up to three literals or a whole length + distance pair (at most 48 bits), a
-        // match is copied in words of eight bytes (at most 258 + 7 bytes written).  A symbol it cannot finish
+        // match is copied in words of eight bytes (at most 258 + 7 bytes written).  The table entry of the NEXT symbol is
+        // looked up as soon as the bits of this one are consumed -- for a match: before its bytes are copied -- so the
+        // lookup's latency lies beside the copy (the bench BAM's blocks are 5.2 M matches of 8.4 bytes on average and
+        // 3.7 M literals per 48 MB: 394 -> 478 MB/s on the build container's core).  A symbol it cannot finish
         // unchecked (a match reaching in front of the output, a bad code) leaves the bit buffer untouched and falls
         // to the careful loop below, which decides.
         {
@@ -193,61 +196,75 @@ class FastInflate {
             uint64_t bb = bb_;
             int bc = bc_;
             const uint32_t *const lit = lit_, *const dst = dist_;
-            while (in <= in_stop && o <= out_stop) {
-                {
-                    uint64_t w;
-                    std::memcpy(&w, in, 8);
-                    bb |= w << bc;
-                    in += (63 - bc) >> 3;
-                    bc |= 56;
-                }
-                uint32_t e = lit[bb & ((1u << LB) - 1)];
-                if (__builtin_expect((e & 0xFF00u) == 0, 1)) {          // K_LIT
+#define NPORE_INFL_REFILL() do { uint64_t w_; std::memcpy(&w_, in, 8); bb |= w_ << bc; in += (63 - bc) >> 3; bc |= 56; } while (0)
+            if (in <= in_stop && o <= out_stop) {
+                NPORE_INFL_REFILL();
+                uint32_t e = lit[bb & ((1u << LB) - 1)];       // the next symbol's entry is always looked up ahead
+                for (;;) {
+                    if ((e & 0xFF00u) == 0) {                   // K_LIT: up to three from the bits at hand (<= 33 of >= 56)
+                        bb >>= (e & 0xFF); bc -= (int)(e & 0xFF);
+                        *o++ = (uint8_t)(e >> 16);
+                        e = lit[bb & ((1u << LB) - 1)];
+                        if ((e & 0xFF00u) == 0) {
+                            bb >>= (e & 0xFF); bc -= (int)(e & 0xFF);
+                            *o++ = (uint8_t)(e >> 16);
+                            e = lit[bb & ((1u << LB) - 1)];
+                            if ((e & 0xFF00u) == 0) {
+                                bb >>= (e & 0xFF); bc -= (int)(e & 0xFF);
+                                *o++ = (uint8_t)(e >> 16);
+                                e = lit[bb & ((1u << LB) - 1)];
+                            }
+                        }
+                        if (!(in <= in_stop && o <= out_stop)) break;
+                        NPORE_INFL_REFILL();                    // (the low bits e was looked up with stay where they are)
+                        continue;
+                    }
+                    const uint64_t bb0 = bb;
+                    const int bc0 = bc;
+                    if ((e >> 8 & 0xFF) == K_SUB) e = lit[(e >> 16) + ((bb >> LB) & ((1u << (e & 0xFF)) - 1))];
+                    const uint32_t kind = e >> 8 & 0xFF;
                     bb >>= (e & 0xFF); bc -= (int)(e & 0xFF);
-                    *o++ = (uint8_t)(e >> 16);
+                    if (kind == K_LIT) {
+                        *o++ = (uint8_t)(e >> 16);
+                        if (!(in <= in_stop && o <= out_stop)) break;
+                        NPORE_INFL_REFILL();
+                        e = lit[bb & ((1u << LB) - 1)];
+                        continue;
+                    }
+                    if (kind != K_LEN) { bb = bb0; bc = bc0; break; }       // end of block, or a bad code: the careful loop
+                    const uint32_t v = e >> 16, xl = v >> 12;
+                    const int len = (int)(v & 0xFFF) + (int)(bb & ((1u << xl) - 1));
+                    bb >>= xl; bc -= (int)xl;
+                    uint32_t d = dst[bb & ((1u << DB) - 1)];
+                    if ((d >> 8 & 0xF) == K_SUB) d = dst[(d >> 16) + ((bb >> DB) & ((1u << (d & 0xFF)) - 1))];
+                    if ((d >> 8 & 0xF) != K_DIST) { bb = bb0; bc = bc0; break; }
+                    bb >>= (d & 0xFF); bc -= (int)(d & 0xFF);
+                    const uint32_t xd = d >> 12 & 0xF;
+                    const size_t dist = (size_t)(d >> 16) + (size_t)(bb & ((1u << xd) - 1));
+                    bb >>= xd; bc -= (int)xd;
+                    if (dist > (size_t)(o - out0)) { bb = bb0; bc = bc0; break; }
+                    // the next symbol's entry before the copy (16 input bytes are there: the loop's condition held)
+                    NPORE_INFL_REFILL();
                     e = lit[bb & ((1u << LB) - 1)];
-                    if ((e & 0xFF00u) != 0) continue;
-                    bb >>= (e & 0xFF); bc -= (int)(e & 0xFF);
-                    *o++ = (uint8_t)(e >> 16);
-                    e = lit[bb & ((1u << LB) - 1)];
-                    if ((e & 0xFF00u) != 0) continue;
-                    bb >>= (e & 0xFF); bc -= (int)(e & 0xFF);
-                    *o++ = (uint8_t)(e >> 16);
-                    continue;
+                    const uint8_t *src = o - dist;
+                    if (dist >= 8) {                             // words of eight, one after the other: each reads bytes already written
+                        uint64_t w;
+                        std::memcpy(&w, src, 8); std::memcpy(o, &w, 8);
+                        if (len > 8) {
+                            std::memcpy(&w, src + 8, 8); std::memcpy(o + 8, &w, 8);
+                            for (int k = 16; k < len; k += 8) { std::memcpy(&w, src + k, 8); std::memcpy(o + k, &w, 8); }
+                        }
+                    } else if (dist == 1) {
+                        const uint64_t w = 0x0101010101010101ull * (uint64_t)*src;
+                        for (int k = 0; k < len; k += 8) std::memcpy(o + k, &w, 8);
+                    } else {
+                        for (int k = 0; k < len; k++) o[k] = src[k];
+                    }
+                    o += len;
+                    if (!(in <= in_stop && o <= out_stop)) break;
                 }
-                const uint64_t bb0 = bb;
-                const int bc0 = bc;
-                if ((e >> 8 & 0xFF) == K_SUB) e = lit[(e >> 16) + ((bb >> LB) & ((1u << (e & 0xFF)) - 1))];
-                const uint32_t kind = e >> 8 & 0xFF;
-                bb >>= (e & 0xFF); bc -= (int)(e & 0xFF);
-                if (kind == K_LIT) { *o++ = (uint8_t)(e >> 16); continue; }
-                if (kind != K_LEN) { bb = bb0; bc = bc0; break; }       // end of block, or a bad code: the careful loop
-                const uint32_t v = e >> 16, xl = v >> 12;
-                const int len = (int)(v & 0xFFF) + (int)(bb & ((1u << xl) - 1));
-                bb >>= xl; bc -= (int)xl;
-                uint32_t d = dst[bb & ((1u << DB) - 1)];
-                if ((d >> 8 & 0xF) == K_SUB) d = dst[(d >> 16) + ((bb >> DB) & ((1u << (d & 0xFF)) - 1))];
-                if ((d >> 8 & 0xF) != K_DIST) { bb = bb0; bc = bc0; break; }
-                bb >>= (d & 0xFF); bc -= (int)(d & 0xFF);
-                const uint32_t xd = d >> 12 & 0xF;
-                const size_t dist = (size_t)(d >> 16) + (size_t)(bb & ((1u << xd) - 1));
-                bb >>= xd; bc -= (int)xd;
-                if (dist > (size_t)(o - out0)) { bb = bb0; bc = bc0; break; }
-                const uint8_t *src = o - dist;
-                if (dist >= 16) {
-                    for (int k = 0; k < len; k += 16) { uint64_t w0, w1; std::memcpy(&w0, src + k, 8); std::memcpy(&w1, src + k + 8, 8); std::memcpy(o + k, &w0, 8); std::memcpy(o + k + 8, &w1, 8); }
-                } else if (dist >= 8) {
-                    // the first 16 bytes in words of eight; from there on the bytes also repeat at twice the distance (>= 16)
-                    { uint64_t w; std::memcpy(&w, src, 8); std::memcpy(o, &w, 8); std::memcpy(&w, src + 8, 8); std::memcpy(o + 8, &w, 8); }
-                    const uint8_t *src2 = o - 2 * dist;
-                    for (int k = 16; k < len; k += 16) { uint64_t w0, w1; std::memcpy(&w0, src2 + k, 8); std::memcpy(&w1, src2 + k + 8, 8); std::memcpy(o + k, &w0, 8); std::memcpy(o + k + 8, &w1, 8); }
-                } else if (dist == 1) {
-                    std::memset(o, *src, (size_t)len);
-                } else {
-                    for (int k = 0; k < len; k++) o[k] = src[k];
-                }
-                o += len;
             }
+#undef NPORE_INFL_REFILL
             out = o; in_ = in; bb_ = bb; bc_ = bc;
         }
         for (;;) {

@@ -1763,6 +1763,23 @@ int format_sam_into(const npore_bam *b, const RecFetch &rf, int64_t n, const cha
         return fail(NPORE_E_INVALID, "bad argument");
     // pass 1: line sizes; pass 2: fill (both parallel over reads)
     std::vector<int64_t> off((size_t)n + 1, 0);
+    // decimal text of v at dst (dst == nullptr: only the length), no terminator
+    auto put_int = [](char *dst, long long v) -> int {
+        char tmp[24];
+        int nd = 0;
+        unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+        do { tmp[nd++] = (char)('0' + u % 10); u /= 10; } while (u);
+        const int neg = v < 0;
+        if (dst) {
+            if (neg) *dst++ = '-';
+            for (int q = 0; q < nd; q++) dst[q] = tmp[nd - 1 - q];
+        }
+        return nd + neg;
+    };
+    static const struct PairTab {      // two bases of the 4-bit packed sequence per lookup
+        uint16_t pair[256];
+        PairTab() { for (int v = 0; v < 256; v++) pair[v] = (uint16_t)((uint8_t)SEQ16[v >> 4] | ((uint8_t)SEQ16[v & 15] << 8)); }
+    } seqtab;
     auto line = [&](int64_t k, char *dst) -> int64_t {    // returns the length; writes when dst != nullptr
         if (status[k] & NPORE_ST_BAD_INPUT) return 0;    // refused reads are not written
         const RecView r = rec_of(rf, k);
@@ -1772,31 +1789,43 @@ int format_sam_into(const npore_bam *b, const RecFetch &rf, int64_t n, const cha
         const int32_t rid = r.ref_id();
         const std::string &rn = (rid >= 0 && rid < (int32_t)b->ref_names.size()) ? b->ref_names[(size_t)rid] : std::string("*");
         const bool noq = r.l_seq() == 0 || r.qual()[0] == 0xFF;
-        char head[96], mid[64], tail[48];
-        const int hl = std::snprintf(head, sizeof head, "\t%d\t", r.flag());
-        const int ml = std::snprintf(mid, sizeof mid, "\t%lld\t%d\t", (long long)r.pos() + 1, r.mapq());
-        const int tl = std::snprintf(tail, sizeof tail, "\tHP:i:%lld\n", (long long)rec_hp(r));
-        char rlen[32];
-        const int rll = std::snprintf(rlen, sizeof rlen, "\t*\t0\t%lld\t", (long long)rec_ref_len(r));
         const size_t nl = std::strlen(r.name());
-        const int64_t total = (int64_t)nl + hl + (int64_t)rn.size() + ml + final_len[k] + rll + sl + 1 + (noq ? 1 : sl) + tl;
-        if (!dst) return total;
+        const long long flag = r.flag(), pos1 = (long long)r.pos() + 1, mapq = r.mapq(), hp = (long long)rec_hp(r),
+                        reflen = (long long)rec_ref_len(r);
+        if (!dst)       // name \t flag \t rname \t pos \t mapq \t cigar \t * \t 0 \t tlen \t seq \t qual \t HP:i:n \n
+            return (int64_t)nl + 1 + put_int(nullptr, flag) + 1 + (int64_t)rn.size() + 1 + put_int(nullptr, pos1) + 1 +
+                   put_int(nullptr, mapq) + 1 + final_len[k] + 5 + put_int(nullptr, reflen) + 1 + sl + 1 + (noq ? 1 : sl) + 6 +
+                   put_int(nullptr, hp) + 1;
         char *o = dst;
         std::memcpy(o, r.name(), nl); o += nl;
-        std::memcpy(o, head, hl); o += hl;
+        *o++ = '\t'; o += put_int(o, flag); *o++ = '\t';
         std::memcpy(o, rn.data(), rn.size()); o += rn.size();
-        std::memcpy(o, mid, ml); o += ml;
+        *o++ = '\t'; o += put_int(o, pos1); *o++ = '\t'; o += put_int(o, mapq); *o++ = '\t';
         std::memcpy(o, finals + final_off[k], (size_t)final_len[k]); o += final_len[k];
-        std::memcpy(o, rlen, rll); o += rll;
-        const uint8_t *sq = r.seq();
-        for (int64_t q = 0; q < sl; q++) {
-            const int64_t t = lead + q;
-            *o++ = SEQ16[(t & 1) ? (sq[t >> 1] & 15) : (sq[t >> 1] >> 4)];
+        std::memcpy(o, "\t*\t0\t", 5); o += 5;
+        o += put_int(o, reflen); *o++ = '\t';
+        {
+            const uint8_t *sq = r.seq();
+            int64_t q = 0, t = lead;
+            if (q < sl && (t & 1)) { o[q++] = SEQ16[sq[t >> 1] & 15]; t++; }
+            const uint8_t *src = sq + (t >> 1);
+            const int64_t pairs = (sl - q) >> 1;
+            char *po = o + q;
+            for (int64_t j = 0; j < pairs; j++) { const uint16_t v = seqtab.pair[src[j]]; std::memcpy(po + 2 * j, &v, 2); }
+            q += 2 * pairs;
+            if (q < sl) { o[q] = SEQ16[src[pairs] >> 4]; q++; }
+            o += sl;
         }
         *o++ = '\t';
         if (noq) *o++ = '*';
-        else { const uint8_t *ql = r.qual() + lead; for (int64_t q = 0; q < sl; q++) *o++ = (char)(33 + ql[q]); }
-        std::memcpy(o, tail, tl); o += tl;
+        else {
+            const uint8_t *__restrict ql = r.qual() + lead;
+            char *__restrict qo = o;
+            for (int64_t q = 0; q < sl; q++) qo[q] = (char)(33 + ql[q]);
+            o += sl;
+        }
+        std::memcpy(o, "\tHP:i:", 6); o += 6;
+        o += put_int(o, hp); *o++ = '\n';
         return (int64_t)(o - dst);
     };
     parallel_for(n, threads, [&](int64_t k) { off[(size_t)k + 1] = line(k, nullptr); });
