@@ -757,9 +757,13 @@ def test_both_traceback_kernels(tables, mode):
         m = min(len(ref), len(seq)) - 40
         refs.append(ref); seqs.append(seq)
         cigs.append("I" * (len(seq) - m) + "D" * (len(ref) - m) + "=" * m)
-    for r, mbr in ((30, 20000), (100, 20000), (140, 300), (10, 37)):
+    # (the row kernel holds one 64-column group of an anti-diagonal: the drifting paths cross groups at r >= 64 -- at
+    # r = 255 / 400 through several of them -- and leave the band at r = 10)
+    for r, mbr in ((30, 20000), (100, 20000), (140, 300), (10, 37), (255, 500), (400, 150)):
         got, st = c.align_batch(refs, seqs, cigs, r=r, max_b_rows=mbr, return_status=True)
         for k in range(len(refs)):
+            if r > 255 and k % 3:
+                continue                            # (the oracle's state matrix at r = 400 is slow to set up: a third of the reads)
             want, wst = oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=r, max_b_rows=mbr, return_status=True)
             assert got[k] == want and st[k] == wst, (mode, r, mbr, k)
     c.close()
