@@ -1155,7 +1155,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(TParams p)
 // hop are those of r <= 31 whatever the band.
 // Hops run through a FAST loop while nothing special happens -- the word is a valid run that fits the slot, the cell is
 // inside the band, and the next cell lies strictly inside the chunk rectangle (row0 + col0 == brk, so it is then inside
-// the chunk's anti-diagonals too: they only decrease) -- 34 scalar instructions; the first hop that fails one of
+// the chunk's anti-diagonals too: they only decrease) -- 27 scalar instructions; the first hop that fails one of
 // those tests is handed, untouched, to the general loop below, which decides in the reference's order
 // (src/aln.pyx:680-716) what it was.  Every such hop is one of the chunk's last few.
 __global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
@@ -1191,17 +1191,23 @@ __global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
 
     if ((a_row > d.row0 || a_col > d.col0) && in_chunk(a_row, a_col)) {
         load_row(a_row + a_col - d.brk, grp);
-        // ---- fast hops: the row of (a_row, a_col) is loaded and the cell is inside the chunk.  Written out (34 scalar
+        // ---- fast hops: the row of (a_row, a_col) is loaded and the cell is inside the chunk.  Written out (27 scalar
         // instructions per hop; the compiler's form of the same loop has 55, a third of them moves and masks of its
         // control flow): every exit leaves a_row / a_col / pos / nruns / grp / row / row_ins / rbuf as they were
-        // before the hop that could not be taken, with no load in flight.
+        // before the hop that could not be taken, with no load in flight.  Inside, the read position is kept relative to
+        // the chunk's first anti-diagonal (arel = a_row - brk: the next anti-diagonal is arel + a_col), the run count as
+        // n64 + nl (nl = the lane of rbuf the next run goes to), and the columns of the band the held group covers as
+        // [lo, lo + span): one unsigned compare tells "inside the band and inside the group" from everything else.
         // gfx950 wait states kept by the order of the text: the compare that writes vcc and the select that reads it
         // are three scalar instructions apart (two needed); x (written by v_readlane) is read by a vector instruction
-        // ~25 instructions later; lane selects are written by scalar instructions (no wait needed).
+        // ~20 instructions later; lane selects are written by scalar instructions (no wait needed).
         {
-            a_row = uni(a_row); a_col = uni(a_col); pos = uni(pos); nruns = uni(nruns); grp = uni(grp);
+            a_col = uni(a_col); pos = uni(pos); grp = uni(grp);
+            int arel = uni(a_row) - d.brk, nl = uni(nruns) & 63, n64 = uni(nruns) & ~63;
+            int lo = max(1, grp * 64), span = min(W - 1, grp * 64 + 64) - lo;
             uint32_t vg = min((uint32_t)(grp * 256 + lane * 4), stride4 - 4u);       // this lane's byte in a row
             const int lane4 = lane * 4;
+            const uint32_t vs4 = stride4;
             int t0, t1, bc, run, x;
             uint32_t va, vt;
             asm volatile(
@@ -1210,12 +1216,9 @@ __global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
                 "v_readfirstlane_b32 %[t0], %[ins]\n\t"
                 "s_sub_i32 %[bc], %[t0], %[A]\n\t"
                 "s_add_i32 %[bc], %[bc], %[R]\n\t"                 // inss[b] - a_row + r
-                "s_add_i32 %[t0], %[bc], -1\n\t"
-                "s_cmp_ge_u32 %[t0], %[WM2]\n\t"
-                "s_cbranch_scc1 out_%=\n\t"                         // band edge or outside the band
-                "s_lshr_b32 %[t0], %[bc], 6\n\t"
-                "s_cmp_lg_u32 %[t0], %[G]\n\t"
-                "s_cbranch_scc1 regroup_%=\n\t"
+                "s_sub_i32 %[t0], %[bc], %[LO]\n\t"
+                "s_cmp_ge_u32 %[t0], %[SPAN]\n\t"
+                "s_cbranch_scc1 other_%=\n\t"                       // not a band column of the held group
                 "v_readlane_b32 %[x], %[row], %[bc]\n\t"
                 "s_and_b32 %[run], %[x], 0x1fffffff\n\t"
                 "s_add_i32 %[t0], %[run], -1\n\t"
@@ -1234,49 +1237,54 @@ __global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
                 "s_cbranch_scc1 undo_%=\n\t"                        // the chunk's first row / column: the general loop
                 "s_cmp_le_i32 %[C], %[COL0]\n\t"
                 "s_cbranch_scc1 undo_%=\n\t"
-                "s_add_i32 %[t0], %[A], %[C]\n\t"
-                "s_sub_i32 %[t0], %[t0], %[BRK]\n\t"
-                "s_lshl_b32 %[t1], %[t0], 2\n\t"
-                "s_mul_i32 %[t0], %[t0], %[S4]\n\t"
-                "v_mov_b32 %[va], %[t1]\n\t"
+                "s_add_i32 %[t0], %[A], %[C]\n\t"                  // the anti-diagonal landed on
+                "v_lshlrev_b32 %[va], 2, %[t0]\n\t"
                 "global_load_dword %[ins], %[va], %[IB]\n\t"
-                "v_add_u32 %[va], %[t0], %[vg]\n\t"
+                "v_mad_u32_u24 %[va], %[t0], %[vs4], %[vg]\n\t"
                 "global_load_dword %[row], %[va], %[TB]\n\t"
                 "v_alignbit_b32 %[vt], %[x], %[x], 29\n\t"         // typ | run << 3
-                "s_and_b32 %[t0], %[N], 63\n\t"
-                "v_cmp_eq_u32 vcc, %[t0], %[lane]\n\t"
-                "s_add_i32 %[N], %[N], 1\n\t"
+                "v_cmp_eq_u32 vcc, %[NL], %[lane]\n\t"
                 "s_sub_i32 %[P], %[P], %[run]\n\t"
-                "s_and_b32 %[t0], %[N], 63\n\t"
+                "s_add_i32 %[NL], %[NL], 1\n\t"
+                "s_and_b32 %[NL], %[NL], 63\n\t"
                 "v_cndmask_b32 %[rbuf], %[rbuf], %[vt], vcc\n\t"
                 "s_cbranch_scc1 hop_%=\n\t"
-                "s_lshl_b32 %[t0], %[N], 2\n\t"                    // 64 runs recorded: store them
-                "s_add_i32 %[t0], %[t0], 0xffffff00\n\t"
+                "s_lshl_b32 %[t0], %[N64], 2\n\t"                  // 64 runs recorded: store them
+                "s_add_i32 %[N64], %[N64], 64\n\t"
                 "v_add_u32 %[va], %[t0], %[lane4]\n\t"
                 "global_store_dword %[va], %[rbuf], %[RB]\n\t"
                 "s_branch hop_%=\n\t"
-                "regroup_%=:\n\t"                                    // the path has crossed into another group: same row again
-                "s_mov_b32 %[G], %[t0]\n\t"
-                "s_lshl_b32 %[t0], %[t0], 8\n\t"
+                "other_%=:\n\t"
+                "s_add_i32 %[t0], %[bc], -1\n\t"
+                "s_cmp_ge_u32 %[t0], %[WM2]\n\t"
+                "s_cbranch_scc1 out_%=\n\t"                         // band edge or outside the band
+                "s_lshr_b32 %[G], %[bc], 6\n\t"                    // the path has crossed into another group: same row again
+                "s_lshl_b32 %[t0], %[G], 6\n\t"
+                "s_max_i32 %[LO], %[t0], 1\n\t"
+                "s_add_i32 %[t0], %[t0], 64\n\t"
+                "s_add_i32 %[t1], %[WM2], 1\n\t"
+                "s_min_i32 %[t0], %[t0], %[t1]\n\t"
+                "s_sub_i32 %[SPAN], %[t0], %[LO]\n\t"
+                "s_lshl_b32 %[t0], %[G], 8\n\t"
                 "v_add_u32 %[vg], %[t0], %[lane4]\n\t"
                 "v_min_u32 %[vg], %[S4M4], %[vg]\n\t"
                 "s_add_i32 %[t0], %[A], %[C]\n\t"
-                "s_sub_i32 %[t0], %[t0], %[BRK]\n\t"
-                "s_mul_i32 %[t0], %[t0], %[S4]\n\t"
                 "s_nop 0\n\t"
-                "v_add_u32 %[va], %[t0], %[vg]\n\t"
+                "v_mad_u32_u24 %[va], %[t0], %[vs4], %[vg]\n\t"
                 "global_load_dword %[row], %[va], %[TB]\n\t"
                 "s_branch hop_%=\n\t"
                 "undo_%=:\n\t"
                 "s_add_i32 %[A], %[A], %[t0]\n\t"
                 "s_add_i32 %[C], %[C], %[t1]\n\t"
                 "out_%=:\n\t"
-                : [A] "+s"(a_row), [C] "+s"(a_col), [P] "+s"(pos), [N] "+s"(nruns), [G] "+s"(grp), [row] "+v"(row),
-                  [ins] "+v"(row_ins), [rbuf] "+v"(rbuf), [vg] "+v"(vg), [t0] "=&s"(t0), [t1] "=&s"(t1), [bc] "=&s"(bc),
-                  [run] "=&s"(run), [x] "=&s"(x), [va] "=&v"(va), [vt] "=&v"(vt)
-                : [R] "s"(p.r), [WM2] "s"(W - 2), [ROW0] "s"(d.row0), [COL0] "s"(d.col0), [BRK] "s"(d.brk), [S4] "s"(stride4),
-                  [S4M4] "s"(stride4 - 4u), [TB] "s"(tb), [IB] "s"(inss), [RB] "s"(runs), [lane] "v"(lane), [lane4] "v"(lane4)
+                : [A] "+s"(arel), [C] "+s"(a_col), [P] "+s"(pos), [NL] "+s"(nl), [N64] "+s"(n64), [G] "+s"(grp), [LO] "+s"(lo),
+                  [SPAN] "+s"(span), [row] "+v"(row), [ins] "+v"(row_ins), [rbuf] "+v"(rbuf), [vg] "+v"(vg), [t0] "=&s"(t0),
+                  [t1] "=&s"(t1), [bc] "=&s"(bc), [run] "=&s"(run), [x] "=&s"(x), [va] "=&v"(va), [vt] "=&v"(vt)
+                : [R] "s"(p.r - d.brk), [WM2] "s"(W - 2), [ROW0] "s"(d.row0 - d.brk), [COL0] "s"(d.col0), [S4M4] "s"(stride4 - 4u),
+                  [TB] "s"(tb), [IB] "s"(inss), [RB] "s"(runs), [lane] "v"(lane), [lane4] "v"(lane4), [vs4] "v"(vs4)
                 : "vcc", "scc", "memory");
+            a_row = arel + d.brk;
+            nruns = n64 + nl;
         }
     }
     // two combined tests per ordinary hop; what stopped the loop is sorted out in the reference's order
