@@ -26,6 +26,7 @@
 #include "kernels.hpp"
 #include "prep_kernels.hpp"
 #include "annot_wave.hpp"
+#include "unpack_kernels.hpp"
 
 using namespace npore;
 
@@ -120,6 +121,8 @@ struct HostBuf {   // pinned staging
 // One batch on its way through the BAM -> SAM pipeline: host staging (page-locked where it crosses PCIe) and offsets.
 struct npore_batch_slot {
     RawBuf refs{true}, seqs{true}, cigs{true}, alns{true}, finals, sam;
+    RawBuf raw{true};            // device pack: the heads of the batch's records (fixed fields ... 4-bit bases), one after the other
+    std::vector<int64_t> rawo;   // ... and where each starts
     RawBuf olen_pin{true}, st_pin{true};   // lengths / status bits of an ASYNCHRONOUS batch land here (page-locked: a copy into
                                            // pageable memory would make the enqueueing call wait for the whole batch)
     hipEvent_t done = nullptr;             // ... behind which this event is recorded (npore_bam_realign_file)
@@ -147,6 +150,7 @@ struct WorkSet {
     // host-buffer entry points: the group's slice of the caller's inputs / outputs on the device, its offset
     // arrays rebased to the slice (page-locked copy for the upload)
     DevBuf in_refs, in_seqs, in_cigs, in_off, out, out_len, status;
+    DevBuf in_raw;               // device pack (unpack_kernels.hpp): the group's record heads
     HostBuf h_off;
     hipEvent_t evc[4] = {};      // H2D start / end, D2H start / end of a staged group
     bool staged = false;
@@ -161,13 +165,13 @@ struct WorkSet {
                                         &WorkSet::hist, &WorkSet::counters, &WorkSet::tiles, &WorkSet::cwoff, &WorkSet::seqw, &WorkSet::refw,
                                         &WorkSet::refl, &WorkSet::seql, &WorkSet::tb, &WorkSet::cout_, &WorkSet::clen, &WorkSet::cstat,
                                         &WorkSet::cnruns, &WorkSet::in_refs, &WorkSet::in_seqs, &WorkSet::in_cigs, &WorkSet::in_off,
-                                        &WorkSet::out, &WorkSet::out_len, &WorkSet::status};
+                                        &WorkSet::out, &WorkSet::out_len, &WorkSet::status, &WorkSet::in_raw};
         for (auto m : all) (this->*m).match(o.*m);
     }
     int64_t cells = 0, call_id = 0;
-    DevBuf *all[26] = {&rd_i32, &rd_i64, &steps, &inss, &descs, &sched, &hist, &counters, &tiles, &cwoff,
+    DevBuf *all[27] = {&rd_i32, &rd_i64, &steps, &inss, &descs, &sched, &hist, &counters, &tiles, &cwoff,
                        &seqw, &refw, &refl, &seql, &tb, &cout_, &clen, &cstat, &cnruns,
-                       &in_refs, &in_seqs, &in_cigs, &in_off, &out, &out_len, &status};
+                       &in_refs, &in_seqs, &in_cigs, &in_off, &out, &out_len, &status, &in_raw};
 };
 
 // Work sets of a context: group k + 1 is prepared while group k is in the fill kernel and group k - 1 in its traceback;
@@ -200,6 +204,12 @@ struct npore_ctx {
     int force_chunks = 0;
     int device_glue = 1;        // BAM -> SAM pipeline: realign_read's glue on the device (0: on the host, from the op strings)
     int coresident = 1;         // kernel shapes that fit beside a fill kernel for a group that overlaps another one's
+    int device_pack = 1;        // BAM -> SAM pipeline with the glue on the device: align()'s inputs unpacked from the records on the device
+    // device pack: the FASTA of the current run on the device (uploaded once per FASTA), the contig of every BAM reference
+    DevBuf d_fasta, d_ctg;
+    const npore_fasta *d_fasta_of = nullptr;
+    size_t d_fasta_bytes = 0;
+    int n_ctg = 0;
     bool fill_has_room = false; // the last fill launch left LDS for such kernels on its CUs
     HostBuf h_offs;             // offset arrays of a device-resident batch (npore_align_batch_device)
     // device buffers (grow-only, reused across calls)
@@ -344,6 +354,12 @@ struct AlignArgs {
     // the output is the collapsed, standardised CIGAR text (realign_read's glue on the device, kernels.hpp
     // standardize_kernel) instead of the op string; out_len = bytes of text
     bool final_text = false;
+    // device pack: instead of h_refs / h_seqs / h_cigs the heads of the BAM records; every group uploads its slice and
+    // unpacks it on the device (unpack_kernels.hpp)
+    const uint8_t *h_raw = nullptr;
+    const int64_t *h_raw_off = nullptr;
+    const CtgEntry *d_ctg = nullptr;
+    int n_ctg = 0;
     bool staged() const { return h_out != nullptr; }
 };
 
@@ -422,11 +438,11 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     if (a.staged()) {
         // upload the group's slice: bases + CIGAR ops as they lie, the four offset arrays rebased to the slice
         const int64_t out_bytes = a.h_out_off[g1] - a.h_out_off[g0];
-        if (int rc = w->h_off.ensure((size_t)4 * (nr + 1) * 8)) return rc;
+        if (int rc = w->h_off.ensure((size_t)5 * (nr + 1) * 8)) return rc;
         if (int rc = w->in_refs.ensure((size_t)R_tot + 64)) return rc;
         if (int rc = w->in_seqs.ensure((size_t)S_tot + 64)) return rc;
         if (int rc = w->in_cigs.ensure((size_t)cig_bytes + 64)) return rc;
-        if (int rc = w->in_off.ensure((size_t)4 * (nr + 1) * 8)) return rc;
+        if (int rc = w->in_off.ensure((size_t)5 * (nr + 1) * 8)) return rc;
         if (int rc = w->out.ensure((size_t)out_bytes + 64)) return rc;
         if (int rc = w->out_len.ensure((size_t)nr * 8)) return rc;
         if (int rc = w->status.ensure((size_t)nr * 4)) return rc;
@@ -435,13 +451,34 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
             hro[i] = a.h_ref_off[g0 + i] - a.h_ref_off[g0]; hso[i] = a.h_seq_off[g0 + i] - a.h_seq_off[g0];
             hco[i] = a.h_cig_off[g0 + i] - a.h_cig_off[g0]; hoo[i] = a.h_out_off[g0 + i] - a.h_out_off[g0];
         }
+        const int64_t raw_bytes = a.h_raw ? a.h_raw_off[g1] - a.h_raw_off[g0] : 0;
+        if (a.h_raw) {
+            int64_t *hwo = ho + 4 * (nr + 1);
+            for (int64_t i = 0; i <= nr; i++) hwo[i] = a.h_raw_off[g0 + i] - a.h_raw_off[g0];
+            if (int rc = w->in_raw.ensure((size_t)raw_bytes + 64)) return rc;
+        }
         HIP_TRY(hipEventRecord(w->evc[0], s));
-        HIP_TRY(hipMemcpyAsync(w->in_refs.p, a.h_refs + a.h_ref_off[g0], (size_t)R_tot, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(w->in_seqs.p, a.h_seqs + a.h_seq_off[g0], (size_t)S_tot, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(w->in_cigs.p, a.h_cigs + a.h_cig_off[g0], (size_t)cig_bytes, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(w->in_off.p, ho, (size_t)4 * (nr + 1) * 8, hipMemcpyHostToDevice, s));
+        if (a.h_raw) {
+            HIP_TRY(hipMemcpyAsync(w->in_raw.p, a.h_raw + a.h_raw_off[g0], (size_t)raw_bytes, hipMemcpyHostToDevice, s));
+        } else {
+            HIP_TRY(hipMemcpyAsync(w->in_refs.p, a.h_refs + a.h_ref_off[g0], (size_t)R_tot, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(w->in_seqs.p, a.h_seqs + a.h_seq_off[g0], (size_t)S_tot, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(w->in_cigs.p, a.h_cigs + a.h_cig_off[g0], (size_t)cig_bytes, hipMemcpyHostToDevice, s));
+        }
+        HIP_TRY(hipMemcpyAsync(w->in_off.p, ho, (size_t)5 * (nr + 1) * 8, hipMemcpyHostToDevice, s));
         HIP_TRY(hipEventRecord(w->evc[1], s));
         const int64_t *d_off = w->in_off.as<int64_t>();
+        if (a.h_raw) {          // align()'s three inputs from the record heads (unpack_kernels.hpp), where the copies above would have put them
+            UnpackParams up;
+            up.raw = w->in_raw.as<uint8_t>(); up.raw_off = d_off + 4 * (nr + 1);
+            up.ctg = a.d_ctg; up.n_ctg = a.n_ctg;
+            up.refs = w->in_refs.as<uint8_t>(); up.ref_off = d_off;
+            up.seqs = w->in_seqs.as<uint8_t>(); up.seq_off = d_off + (nr + 1);
+            up.cigs = w->in_cigs.as<char>(); up.cig_off = d_off + 2 * (nr + 1);
+            up.n_reads = nr;
+            hipLaunchKernelGGL(unpack_records_kernel, dim3((unsigned)nr), dim3(256), 0, s, up);
+            HIP_TRY(hipGetLastError());
+        }
         pp.refs = w->in_refs.as<uint8_t>(); pp.ref_off = d_off;
         pp.seqs = w->in_seqs.as<uint8_t>(); pp.seq_off = d_off + (nr + 1);
         pp.cigs = w->in_cigs.as<char>(); pp.cig_off = d_off + 2 * (nr + 1);
@@ -842,7 +879,8 @@ void npore_ctx_destroy(npore_ctx *ctx)
     npore_ctx_destroy(ctx->peer);
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();       // nothing of this context may still be running
-    for (DevBuf *b : {&ctx->in_refs, &ctx->in_seqs, &ctx->in_cigs, &ctx->in_off, &ctx->out, &ctx->out_off, &ctx->out_len, &ctx->status})
+    for (DevBuf *b : {&ctx->in_refs, &ctx->in_seqs, &ctx->in_cigs, &ctx->in_off, &ctx->out, &ctx->out_off, &ctx->out_len, &ctx->status,
+                      &ctx->d_fasta, &ctx->d_ctg})
         b->release();
     for (auto &w : ctx->ws) {
         for (DevBuf *b : w.all) b->release();
@@ -885,6 +923,53 @@ static int align_batch_host(npore_ctx *ctx, int64_t n_reads, const uint8_t *refs
     a.h_out = out; a.h_out_off = out_off; a.h_out_len = out_len; a.h_status = status;
     a.final_text = final_text;
     return run_core(ctx, a, OutTarget{nullptr, nullptr, nullptr, nullptr}, nullptr, sync);
+}
+
+// The same with align()'s inputs still inside BAM records: `raw` holds the heads of the records (fixed fields ... 4-bit
+// bases) one after the other, raw_off[n + 1] where each starts; the three offset arrays are the sizes pack_sizes_of
+// found.  Every group uploads its slice of `raw` and unpacks it on the device (unpack_kernels.hpp); the contigs are the
+// context's device copy of the FASTA (device_fasta).  Asynchronous, final CIGAR text out: the file pipeline's call.
+static int align_batch_raw(npore_ctx *ctx, int64_t n_reads, const uint8_t *raw, const int64_t *raw_off, const int64_t *ref_off,
+                           const int64_t *seq_off, const int64_t *cig_off, float indel_start, float indel_extend, int max_b_rows,
+                           int r, char *out, const int64_t *out_off, int64_t *out_len, int32_t *status)
+{
+    if (!ctx) return fail(NPORE_E_INVALID, "null context");
+    if (n_reads <= 0) return n_reads < 0 ? fail(NPORE_E_INVALID, "n_reads < 0") : NPORE_OK;
+    if (!raw || !raw_off || !out || !ref_off || !seq_off || !cig_off || !out_off || !out_len || !status || !ctx->d_ctg.p)
+        return fail(NPORE_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->deferred_rc) return quiesce(ctx);
+    AlignArgs a{n_reads, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ref_off, seq_off, cig_off,
+                indel_start, indel_extend, max_b_rows, r};
+    a.h_raw = raw; a.h_raw_off = raw_off;
+    a.d_ctg = ctx->d_ctg.as<CtgEntry>(); a.n_ctg = ctx->n_ctg;
+    a.h_out = out; a.h_out_off = out_off; a.h_out_len = out_len; a.h_status = status;
+    a.final_text = true;
+    return run_core(ctx, a, OutTarget{nullptr, nullptr, nullptr, nullptr}, nullptr, false);
+}
+
+// The FASTA on the device (once per FASTA and context) and, per BAM reference, where its contig lies there.
+static int device_fasta(npore_ctx *ctx, const npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref)
+{
+    const size_t bytes = fa->off.empty() ? 0 : (size_t)fa->off.back();
+    if (ctx->d_fasta_of != fa || ctx->d_fasta_bytes != bytes) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (int rc = ctx->d_fasta.ensure(bytes + 64)) return rc;
+        HIP_TRY(hipMemcpy(ctx->d_fasta.p, fa->bases.p, bytes, hipMemcpyHostToDevice));
+        ctx->d_fasta_of = fa;
+        ctx->d_fasta_bytes = bytes;
+    }
+    const size_t nref = b->ref_names.size();
+    std::vector<CtgEntry> tab(std::max<size_t>(1, nref), CtgEntry{nullptr, 0});
+    for (size_t k = 0; k < nref; k++) {
+        const int fi = fasta_of_ref[k];
+        if (fi >= 0 && fi < (int)fa->names.size()) tab[k] = CtgEntry{ctx->d_fasta.as<char>() + fa->off[(size_t)fi], fa->len((size_t)fi)};
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));       // (no group of an earlier run still reads the table)
+    if (int rc = ctx->d_ctg.ensure(tab.size() * sizeof(CtgEntry))) return rc;
+    HIP_TRY(hipMemcpy(ctx->d_ctg.p, tab.data(), tab.size() * sizeof(CtgEntry), hipMemcpyHostToDevice));
+    ctx->n_ctg = (int)nref;
+    return NPORE_OK;
 }
 
 int npore_align_batch(npore_ctx *ctx, int64_t n_reads, const uint8_t *refs, const int64_t *ref_off,
@@ -1095,6 +1180,7 @@ try {
     else if (k == "force_chunks") ctx->force_chunks = (int)value;
     else if (k == "coresident") ctx->coresident = value != 0;
     else if (k == "device_glue") ctx->device_glue = value != 0;
+    else if (k == "device_pack") ctx->device_pack = value != 0;
     else if (k == "fill_streams") { if (value < 1 || value > 2) return fail(NPORE_E_INVALID, "fill_streams: 1 or 2"); ctx->fill_streams = (int)value; }
     else if (k == "traceback_kernel") { if (value < 0 || value > 2) return fail(NPORE_E_INVALID, "traceback_kernel: 0, 1 or 2"); ctx->tb_kernel = (int)value; }
     else return fail(NPORE_E_INVALID, "unknown key " + k);
@@ -1874,6 +1960,38 @@ int slot_pack_records(const npore_bam *b, const npore_fasta *fa, const int32_t *
         return fail(NPORE_E_NOMEM, "batch buffers");
     return NPORE_OK;
 }
+// device pack: the sizes as above, and instead of the three arrays the HEADS of the records (block_size word, fixed fields,
+// name, CIGAR words, 4-bit bases -- about half of a record; qualities and tags are not needed on the device) copied one
+// after the other into the slot's page-locked buffer; unpack_kernels.hpp does the rest per group.  Device glue only
+// (the host glue reads the base arrays).
+int slot_pack_raw(const npore_bam *b, const int32_t *fasta_of_ref, int n_fasta, int64_t n, int threads, npore_batch_slot &s)
+{
+    for (auto *v : {&s.ro, &s.so, &s.co, &s.oo, &s.fo}) v->assign((size_t)n + 1, 0);
+    s.rawo.assign((size_t)n + 1, 0);
+    s.olen.assign((size_t)n, 0);
+    s.flen.assign((size_t)n, 0);
+    pack_sizes_of(s.rf, n, s.ro.data(), s.so.data(), s.co.data(), threads);
+    for (int64_t k = 0; k < n; k++) {
+        const RecView r = rec_of(s.rf, k);
+        const int32_t rid = r.ref_id();
+        const int fi = (rid >= 0 && rid < (int32_t)b->ref_names.size()) ? fasta_of_ref[rid] : -1;
+        if (fi < 0 || fi >= n_fasta) return fail(NPORE_E_INVALID, "a selected read lies on a contig that is not in the FASTA");
+        s.rawo[(size_t)k + 1] = s.rawo[(size_t)k] + (int64_t)(r.qual() - r.p) + 4;
+        const int64_t cap = (s.ro[(size_t)k + 1] - s.ro[(size_t)k]) + (s.so[(size_t)k + 1] - s.so[(size_t)k]);
+        s.oo[(size_t)k + 1] = s.oo[(size_t)k] + 2 * cap + 16;
+    }
+    if (!s.raw.ensure((size_t)s.rawo[(size_t)n] + 64) || !s.alns.ensure((size_t)s.oo[(size_t)n] + 64)) return fail(NPORE_E_NOMEM, "batch buffers");
+    const int64_t per = 16;
+    parallel_for((n + per - 1) / per, threads, [&](int64_t t) {
+        for (int64_t k = t * per; k < std::min(n, (t + 1) * per); k++) {
+            char *dst = s.raw.p + s.rawo[(size_t)k];
+            const size_t len = (size_t)(s.rawo[(size_t)k + 1] - s.rawo[(size_t)k]);
+            std::memcpy(dst, s.rf.ptr[(size_t)k], len);
+            cache_writeback(dst, len);         // page-locked staging about to cross PCIe: out of this core's cache first (hostio.hpp)
+        }
+    });
+    return NPORE_OK;
+}
 int slot_pack(const npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref, const int64_t *idx, int64_t n, int threads,
               npore_batch_slot &s)
 {
@@ -1970,6 +2088,20 @@ int file_pipeline(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int
     const int pack_threads = std::getenv("NPORE_PACK_THREADS") ? std::max(1, std::atoi(std::getenv("NPORE_PACK_THREADS"))) : half_threads;
     const int post_threads = std::getenv("NPORE_POST_THREADS") ? std::max(1, std::atoi(std::getenv("NPORE_POST_THREADS"))) : half_threads;
     const bool glue = ctx->device_glue != 0;      // realign_read's glue on the device: the slots receive the final CIGAR text
+    // ... and align()'s inputs unpacked from the records on the device (the host glue needs the base arrays on the host)
+    const bool dpack = glue && ctx->device_pack != 0 && !(std::getenv("NPORE_DEVICE_PACK") && std::atoi(std::getenv("NPORE_DEVICE_PACK")) == 0);
+    if (dpack)
+        if (int rc = device_fasta(ctx, b, fa, fasta_of_ref)) return rc;
+    const int n_fasta = (int)fa->names.size();
+    // NPORE_PIPE_TRACE=1: one line per batch and stage boundary on stderr (ms since the call began)
+    const bool trace = std::getenv("NPORE_PIPE_TRACE") != nullptr;
+    std::mutex trace_m;
+    auto mark = [&](const char *what, int64_t k) {
+        if (!trace) return;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        std::lock_guard<std::mutex> lk(trace_m);
+        std::fprintf(stderr, "pipe %8.2f ms  batch %3lld  %s\n", ms, (long long)k, what);
+    };
     std::vector<std::future<void>> packed, posted;
     // batches leave in input order: `written` counts the batches that are through (written, or given up on);
     // `acquired` the batches whose records have been taken from a serial source
@@ -1990,14 +2122,18 @@ int file_pipeline(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int
             if (k >= S) wait_for(written, k - S + 1);          // the slot's previous batch has been written
             if (serial_acquire) wait_for(acquired, k);
             const auto t0 = std::chrono::steady_clock::now();
+            mark("acquire begins", k);
             s.keep.clear();
             s.rc = 0;
             const int64_t m = acquire(k, s);
+            mark("acquired", k);
             if (serial_acquire) bump(acquired);
             s.m = m > 0 ? m : 0;
             if (m < 0) s.rc = (int)m;
-            else if (m > 0) s.rc = slot_pack_records(b, fa, fasta_of_ref, m, pack_threads, s, glue);
+            else if (m > 0) s.rc = dpack ? slot_pack_raw(b, fasta_of_ref, n_fasta, m, pack_threads, s)
+                                         : slot_pack_records(b, fa, fasta_of_ref, m, pack_threads, s, glue);
             s.t_ms[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            mark("packed", k);
             if (s.rc) s.err = npore_last_error();
         }));
     };
@@ -2009,6 +2145,7 @@ int file_pipeline(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int
             (void)hipSetDevice(ctx->device);
             auto t0 = std::chrono::steady_clock::now();
             if (hipEventSynchronize(t.done) != hipSuccess) { t.rc = NPORE_E_HIP; t.err = "waiting for a batch failed"; return; }
+            mark("device done", k);
             t.t_ms[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             const int64_t m = t.m;
             std::memcpy(t.olen.data(), t.olen_pin.p, (size_t)m * 8);
@@ -2020,11 +2157,13 @@ int file_pipeline(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int
             t.t_ms[2] += ms_std;
             t.t_ms[3] += ms_post - ms_std;
             if (t.rc) { t.err = npore_last_error(); return; }
+            mark("text made", k);
             wait_for(written, k);                              // records in input order
             on_status(k, m, st);
             t0 = std::chrono::steady_clock::now();
             if (std::fwrite(t.sam.p, 1, (size_t)t.sam_len, fh) != (size_t)t.sam_len) { t.rc = NPORE_E_INVALID; t.err = "short write"; }
             t.t_ms[4] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            mark("written", k);
             t.keep.clear();
         }));
     };
@@ -2042,11 +2181,18 @@ int file_pipeline(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int
         if (!s.olen_pin.ensure((size_t)m * 8 + 64) || !s.st_pin.ensure((size_t)m * 4 + 64)) { rc = NPORE_E_NOMEM; err = "batch buffers"; break; }
         if (!s.done && hipEventCreateWithFlags(&s.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { rc = NPORE_E_HIP; err = "hipEventCreate"; break; }
         // (returns once the batch's groups are enqueued; waits only when all work sets of the context are still busy)
-        s.rc = align_batch_host(ctx, m, reinterpret_cast<uint8_t *>(s.refs.p), s.ro.data(), reinterpret_cast<uint8_t *>(s.seqs.p),
-                                s.so.data(), s.cigs.p, s.co.data(), indel_start, indel_extend, max_b_rows, r, s.alns.p,
-                                s.oo.data(), reinterpret_cast<int64_t *>(s.olen_pin.p), reinterpret_cast<int32_t *>(s.st_pin.p), false, glue);
+        mark("enqueue begins", k);
+        if (dpack)
+            s.rc = align_batch_raw(ctx, m, reinterpret_cast<uint8_t *>(s.raw.p), s.rawo.data(), s.ro.data(), s.so.data(), s.co.data(),
+                                   indel_start, indel_extend, max_b_rows, r, s.alns.p, s.oo.data(),
+                                   reinterpret_cast<int64_t *>(s.olen_pin.p), reinterpret_cast<int32_t *>(s.st_pin.p));
+        else
+            s.rc = align_batch_host(ctx, m, reinterpret_cast<uint8_t *>(s.refs.p), s.ro.data(), reinterpret_cast<uint8_t *>(s.seqs.p),
+                                    s.so.data(), s.cigs.p, s.co.data(), indel_start, indel_extend, max_b_rows, r, s.alns.p,
+                                    s.oo.data(), reinterpret_cast<int64_t *>(s.olen_pin.p), reinterpret_cast<int32_t *>(s.st_pin.p), false, glue);
         if (s.rc) { rc = s.rc; err = npore_last_error(); s.err = err; break; }
         if (hipEventRecord(s.done, ctx->s_post) != hipSuccess) { rc = NPORE_E_HIP; err = "hipEventRecord"; s.rc = rc; s.err = err; break; }
+        mark("enqueued", k);
         start_post(k);
     }
     for (auto &f : packed) if (f.valid()) f.wait();

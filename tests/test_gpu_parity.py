@@ -549,8 +549,8 @@ def test_realign_cli_end_to_end(tmp_path):
 
 def test_native_realign_batch_matches_python_pipeline(ctx, tmp_path):
     """BAM records -> SAM text through npore_bam_realign_batch == the Python pipeline (get_read_data ->
-    align_batch -> standardize_batch -> sam_line) on a synthetic BAM with clips, both strands, HP tags and
-    a read whose CIGAR disagrees with its sequence (refused, not written)."""
+    align_batch -> standardize_batch -> sam_line) on a synthetic BAM with soft and hard clips, N / ambiguity codes, both
+    strands, HP tags and a read whose CIGAR disagrees with its sequence (refused, not written)."""
     import argparse
     from npore_amd import bam, cfg
     from npore_amd.cig import bases_to_int, expand_cigar, standardize_batch
@@ -571,8 +571,15 @@ def test_native_realign_batch_matches_python_pipeline(ctx, tmp_path):
         runs.append(("MIDNSHP=XB".index(last), cnt))
         lead, trail = (3 if k % 2 else 0), (2 if k % 3 == 0 else 0)
         cig = ([(4, lead)] if lead else []) + runs + ([(4, trail)] if trail else [])
+        if k % 6 == 2:
+            cig = [(5, 4)] + cig                    # hard clips outside the soft ones (or alone)
+        if k % 4 == 3:
+            cig = cig + [(5, 7)]
+        body = dec(sq)
+        if k % 7 == 3:                              # N in the read, an ambiguity code (both are base code 0)
+            body = body[:11] + "N" + body[12:40] + "R" + body[41:]
         recs.append(dict(name=f"r{k}", flag=16 if k % 4 == 1 else 0, ref_id=0, pos=pos0[-1], cigar=cig,
-                         seq="A" * lead + dec(sq) + "C" * trail, qual=None if k % 5 == 0 else bytes([30]) * (lead + len(sq) + trail),
+                         seq="A" * lead + body + "C" * trail, qual=None if k % 5 == 0 else bytes([30]) * (lead + len(sq) + trail),
                          hp=k % 3))
     recs[7]["cigar"] = recs[7]["cigar"][:-1] + [(0, 5)] if recs[7]["cigar"][-1][0] != 4 else recs[7]["cigar"] + [(0, 5)]   # lengths now disagree
     contig = "".join(contig) + "ACGT" * 10
@@ -598,6 +605,15 @@ def test_native_realign_batch_matches_python_pipeline(ctx, tmp_path):
         out = tmp_path / "pipe.sam"
         st2 = nb.realign_file(ctx, nf, idx, str(out), batch_reads=5, r=30)
         assert np.array_equal(st2, pst) and out.read_bytes() == text
+        # (that loop hands the device the HEADS of the records and unpacks align()'s inputs there, unpack_kernels.hpp;
+        # with the pack on the host, and with the glue on the host as well, the file is the same)
+        for key in ("device_pack", "device_glue"):
+            ctx.set(key, 0)
+            outh = tmp_path / f"pipe_no_{key}.sam"
+            sth = nb.realign_file(ctx, nf, idx, str(outh), batch_reads=5, r=30)
+            assert np.array_equal(sth, pst) and outh.read_bytes() == text, key
+        ctx.set("device_pack", 1)
+        ctx.set("device_glue", 1)
         # a STREAMED handle (bounded-memory ingest: every batch inflates the BGZF blocks its records lie in) writes the same
         ns = bam.NativeBam(str(tmp_path / "s.bam"), stream=True)
         assert ns.streamed and np.array_equal(ns.select(cfg.args.regions), idx)
