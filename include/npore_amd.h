@@ -215,7 +215,12 @@ int npore_total_timing(npore_ctx *ctx, double *ms, int n);
 /* Tunables: key in {"tb_budget_mb","force_chunks","traceback_kernel","coresident"} (traceback budget in MiB per
  * work set, chunks per fill workgroup, 1 = windowed / 2 = row-per-hop traceback; 0 = automatic.  "coresident"
  * (default 1): a group of reads that overlaps another one on the device is prepared and gathered by kernel shapes
- * that run beside the fill kernel's workgroups, and the fill leaves them room; 0 = always the stand-alone shapes). */
+ * that run beside the fill kernel's workgroups, and the fill leaves them room; 0 = always the stand-alone shapes).
+ * "fill_streams" (1 | 2, default 2): fill kernels of consecutive groups on one stream or alternating between two.
+ * The BAM -> SAM pipeline (npore_bam_realign_file / _sequential): "device_glue" (default 1): realign_read's glue
+ * (src/bam.pyx:65-78) on the device, 0 = on the host from the op strings; "device_pack" (default 1, with the device
+ * glue): align()'s inputs (src/bam.pyx:42, 45, 59-61) unpacked from the BAM records on the device, 0 = packed on the
+ * host and uploaded. */
 int npore_ctx_set(npore_ctx *ctx, const char *key, int64_t value);
 
 /* Batch sizing.  The DP of a chunk (at most max_b_rows anti-diagonals of a read; reference src/aln.pyx:344-358,
