@@ -418,6 +418,7 @@ struct npore_fasta {
     std::vector<std::string> names;
     npore::RawBuf bases;                  // all contigs back to back, upper-cased
     std::vector<int64_t> off;             // [n + 1] contig k = bases[off[k] .. off[k+1])
+    uint64_t serial = 0;                  // unique per opened FASTA of the process (a context's device copy is keyed by it, not by the address)
     int64_t len(size_t k) const { return off[k + 1] - off[k]; }
     const char *seq(size_t k) const { return bases.p + off[k]; }
 };

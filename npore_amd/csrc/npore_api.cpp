@@ -207,7 +207,7 @@ struct npore_ctx {
     int device_pack = 1;        // BAM -> SAM pipeline with the glue on the device: align()'s inputs unpacked from the records on the device
     // device pack: the FASTA of the current run on the device (uploaded once per FASTA), the contig of every BAM reference
     DevBuf d_fasta, d_ctg;
-    const npore_fasta *d_fasta_of = nullptr;
+    uint64_t d_fasta_serial = 0;
     size_t d_fasta_bytes = 0;
     int n_ctg = 0;
     bool fill_has_room = false; // the last fill launch left LDS for such kernels on its CUs
@@ -952,11 +952,11 @@ static int align_batch_raw(npore_ctx *ctx, int64_t n_reads, const uint8_t *raw, 
 static int device_fasta(npore_ctx *ctx, const npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref)
 {
     const size_t bytes = fa->off.empty() ? 0 : (size_t)fa->off.back();
-    if (ctx->d_fasta_of != fa || ctx->d_fasta_bytes != bytes) {
+    if (ctx->d_fasta_serial != fa->serial || ctx->d_fasta_bytes != bytes) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (int rc = ctx->d_fasta.ensure(bytes + 64)) return rc;
         HIP_TRY(hipMemcpy(ctx->d_fasta.p, fa->bases.p, bytes, hipMemcpyHostToDevice));
-        ctx->d_fasta_of = fa;
+        ctx->d_fasta_serial = fa->serial;
         ctx->d_fasta_bytes = bytes;
     }
     const size_t nref = b->ref_names.size();
@@ -1713,6 +1713,8 @@ try {
     MappedFile mf;
     if (!mf.open(path)) { fail(NPORE_E_INVALID, std::string("could not open FASTA '") + path + "'"); return nullptr; }
     std::unique_ptr<npore_fasta> hold(new npore_fasta());
+    static std::atomic<uint64_t> next_serial{1};
+    hold->serial = next_serial.fetch_add(1);
     npore_fasta *f = hold.get();
     if (!fasta_parse(ByteSpan{mf.p, mf.n}, 0, *f)) { fail(NPORE_E_NOMEM, "FASTA: out of memory"); return nullptr; }
     return hold.release();

@@ -614,6 +614,17 @@ def test_native_realign_batch_matches_python_pipeline(ctx, tmp_path):
             assert np.array_equal(sth, pst) and outh.read_bytes() == text, key
         ctx.set("device_pack", 1)
         ctx.set("device_glue", 1)
+        # another FASTA of the same size through the same context: the device copy follows the FASTA, not its size or address
+        (tmp_path / "c2.fa").write_text(">ctg\n" + contig[::-1] + "\n")
+        nf2 = bam.NativeFasta(str(tmp_path / "c2.fa"))
+        out_d, out_h = tmp_path / "other_fa_dev.sam", tmp_path / "other_fa_host.sam"
+        st_d = nb.realign_file(ctx, nf2, idx, str(out_d), batch_reads=5, r=30)
+        ctx.set("device_pack", 0)
+        st_h = nb.realign_file(ctx, nf2, idx, str(out_h), batch_reads=5, r=30)
+        ctx.set("device_pack", 1)
+        assert np.array_equal(st_d, st_h) and out_d.read_bytes() == out_h.read_bytes() and out_d.read_bytes() != text
+        st_b = nb.realign_file(ctx, nf, idx, str(tmp_path / "back.sam"), batch_reads=5, r=30)
+        assert np.array_equal(st_b, pst) and (tmp_path / "back.sam").read_bytes() == text
         # a STREAMED handle (bounded-memory ingest: every batch inflates the BGZF blocks its records lie in) writes the same
         ns = bam.NativeBam(str(tmp_path / "s.bam"), stream=True)
         assert ns.streamed and np.array_equal(ns.select(cfg.args.regions), idx)
