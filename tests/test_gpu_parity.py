@@ -625,6 +625,13 @@ def test_native_realign_batch_matches_python_pipeline(ctx, tmp_path):
         assert np.array_equal(st_d, st_h) and out_d.read_bytes() == out_h.read_bytes() and out_d.read_bytes() != text
         st_b = nb.realign_file(ctx, nf, idx, str(tmp_path / "back.sam"), batch_reads=5, r=30)
         assert np.array_equal(st_b, pst) and (tmp_path / "back.sam").read_bytes() == text
+        # a traceback budget that cuts every batch into several groups of reads: each group uploads and unpacks its own slice
+        ctx.set("tb_budget_mb", 2)
+        try:
+            st_g = nb.realign_file(ctx, nf, idx, str(tmp_path / "groups.sam"), batch_reads=12, r=30)
+            assert np.array_equal(st_g, pst) and (tmp_path / "groups.sam").read_bytes() == text
+        finally:
+            ctx.set("tb_budget_mb", 0)
         # a STREAMED handle (bounded-memory ingest: every batch inflates the BGZF blocks its records lie in) writes the same
         ns = bam.NativeBam(str(tmp_path / "s.bam"), stream=True)
         assert ns.streamed and np.array_equal(ns.select(cfg.args.regions), idx)
