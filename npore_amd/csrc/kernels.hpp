@@ -1146,8 +1146,8 @@ __global__ __launch_bounds__(64) void traceback_kernel(TParams p)
 // as the next cell is known: one memory round trip per hop instead of one per ~4 hops, a fraction of the windowed
 // kernel's instructions.  With thousands of chunks in flight the round trips of different chunks overlap and the
 // SCALAR instruction count per hop decides (everything here is wave-uniform: a SIMD issues one scalar instruction
-// per four cycles whatever the number of waves it holds); with one wave per SIMD (a batch of 1 000 reads) the
-// windows win.
+// per four cycles whatever the number of waves it holds); below that the chunk's chain of round trips does, which
+// the row requested BELOW every row shortens by the hops that land there (an indel of one base behind a diagonal run).
 // Of a row the wave holds ONE group of 64 columns, one word per lane (lane l = column 64 g + l), so the cell's word is
 // one v_readlane.  The group requested with a row is the one the path is in now: its band column changes only where
 // the new alignment leaves the input one, so the next cell is nearly always in the same group; where it is not, the row
@@ -1155,7 +1155,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(TParams p)
 // hop are those of r <= 31 whatever the band.
 // Hops run through a FAST loop while nothing special happens -- the word is a valid run that fits the slot, the cell is
 // inside the band, and the next cell lies strictly inside the chunk rectangle (row0 + col0 == brk, so it is then inside
-// the chunk's anti-diagonals too: they only decrease) -- 27 scalar instructions; the first hop that fails one of
+// the chunk's anti-diagonals too: they only decrease) -- ~30 scalar instructions; the first hop that fails one of
 // those tests is handed, untouched, to the general loop below, which decides in the reference's order
 // (src/aln.pyx:680-716) what it was.  Every such hop is one of the chunk's last few.
 __global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
@@ -1191,8 +1191,8 @@ __global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
 
     if ((a_row > d.row0 || a_col > d.col0) && in_chunk(a_row, a_col)) {
         load_row(a_row + a_col - d.brk, grp);
-        // ---- fast hops: the row of (a_row, a_col) is loaded and the cell is inside the chunk.  Written out (27 scalar
-        // instructions per hop; the compiler's form of the same loop has 55, a third of them moves and masks of its
+        // ---- fast hops: the row of (a_row, a_col) is loaded and the cell is inside the chunk.  Written out (31 scalar
+        // instructions per hop that requests rows, 29 per hop into the row already held; the compiler's form of the same loop has 55, a third of them moves and masks of its
         // control flow): every exit leaves a_row / a_col / pos / nruns / grp / row / row_ins / rbuf as they were
         // before the hop that could not be taken, with no load in flight.  Inside, the read position is kept relative to
         // the chunk's first anti-diagonal (arel = a_row - brk: the next anti-diagonal is arel + a_col), the run count as
@@ -1210,9 +1210,14 @@ __global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
             const uint32_t vs4 = stride4;
             int t0, t1, bc, run, x;
             uint32_t va, vt;
+            // With every row the one BELOW it (one anti-diagonal earlier) is requested as well: a diagonal run is mostly
+            // followed by an indel of one base, whose cell lies there -- that hop then needs no round trip (`below`).
+            uint32_t row2 = 0u;
+            int ins2 = 0, v2 = 0;       // v2 = 1: row2 / ins2 hold the group's words / inss of the anti-diagonal below the current one
             asm volatile(
                 "hop_%=:\n\t"
                 "s_waitcnt vmcnt(0)\n\t"
+                "hop_nw_%=:\n\t"
                 "v_readfirstlane_b32 %[t0], %[ins]\n\t"
                 "s_sub_i32 %[bc], %[t0], %[A]\n\t"
                 "s_add_i32 %[bc], %[bc], %[R]\n\t"                 // inss[b] - a_row + r
@@ -1237,23 +1242,38 @@ __global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
                 "s_cbranch_scc1 undo_%=\n\t"                        // the chunk's first row / column: the general loop
                 "s_cmp_le_i32 %[C], %[COL0]\n\t"
                 "s_cbranch_scc1 undo_%=\n\t"
-                "s_add_i32 %[t0], %[A], %[C]\n\t"                  // the anti-diagonal landed on
-                "v_lshlrev_b32 %[va], 2, %[t0]\n\t"
-                "global_load_dword %[ins], %[va], %[IB]\n\t"
-                "v_mad_u32_u24 %[va], %[t0], %[vs4], %[vg]\n\t"
-                "global_load_dword %[row], %[va], %[TB]\n\t"
+                "s_add_i32 %[t1], %[t0], %[t1]\n\t"                // anti-diagonals moved (>= 1)
                 "v_alignbit_b32 %[vt], %[x], %[x], 29\n\t"         // typ | run << 3
                 "v_cmp_eq_u32 vcc, %[NL], %[lane]\n\t"
                 "s_sub_i32 %[P], %[P], %[run]\n\t"
                 "s_add_i32 %[NL], %[NL], 1\n\t"
                 "s_and_b32 %[NL], %[NL], 63\n\t"
                 "v_cndmask_b32 %[rbuf], %[rbuf], %[vt], vcc\n\t"
-                "s_cbranch_scc1 hop_%=\n\t"
+                "s_cbranch_scc0 flush_%=\n\t"
+                "recorded_%=:\n\t"
+                "s_cmp_eq_u32 %[t1], %[V2]\n\t"
+                "s_cbranch_scc1 below_%=\n\t"
+                "s_add_i32 %[t0], %[A], %[C]\n\t"                  // the anti-diagonal landed on (>= 2: the one below exists)
+                "v_lshlrev_b32 %[va], 2, %[t0]\n\t"
+                "global_load_dword %[ins], %[va], %[IB]\n\t"
+                "global_load_dword %[ins2], %[va], %[IB] offset:-4\n\t"
+                "v_mad_u32_u24 %[va], %[t0], %[vs4], %[vg]\n\t"
+                "global_load_dword %[row], %[va], %[TB]\n\t"
+                "v_sub_u32 %[va], %[va], %[vs4]\n\t"
+                "global_load_dword %[row2], %[va], %[TB]\n\t"
+                "s_mov_b32 %[V2], 1\n\t"
+                "s_branch hop_%=\n\t"
+                "below_%=:\n\t"                                      // one anti-diagonal down, held: no request
+                "v_mov_b32 %[row], %[row2]\n\t"
+                "v_mov_b32 %[ins], %[ins2]\n\t"
+                "s_mov_b32 %[V2], 0\n\t"
+                "s_branch hop_nw_%=\n\t"
+                "flush_%=:\n\t"
                 "s_lshl_b32 %[t0], %[N64], 2\n\t"                  // 64 runs recorded: store them
                 "s_add_i32 %[N64], %[N64], 64\n\t"
                 "v_add_u32 %[va], %[t0], %[lane4]\n\t"
                 "global_store_dword %[va], %[rbuf], %[RB]\n\t"
-                "s_branch hop_%=\n\t"
+                "s_branch recorded_%=\n\t"
                 "other_%=:\n\t"
                 "s_add_i32 %[t0], %[bc], -1\n\t"
                 "s_cmp_ge_u32 %[t0], %[WM2]\n\t"
@@ -1269,7 +1289,7 @@ __global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
                 "v_add_u32 %[vg], %[t0], %[lane4]\n\t"
                 "v_min_u32 %[vg], %[S4M4], %[vg]\n\t"
                 "s_add_i32 %[t0], %[A], %[C]\n\t"
-                "s_nop 0\n\t"
+                "s_mov_b32 %[V2], 0\n\t"
                 "v_mad_u32_u24 %[va], %[t0], %[vs4], %[vg]\n\t"
                 "global_load_dword %[row], %[va], %[TB]\n\t"
                 "s_branch hop_%=\n\t"
@@ -1278,8 +1298,9 @@ __global__ __launch_bounds__(64) void traceback_rows_kernel(TParams p)
                 "s_add_i32 %[C], %[C], %[t1]\n\t"
                 "out_%=:\n\t"
                 : [A] "+s"(arel), [C] "+s"(a_col), [P] "+s"(pos), [NL] "+s"(nl), [N64] "+s"(n64), [G] "+s"(grp), [LO] "+s"(lo),
-                  [SPAN] "+s"(span), [row] "+v"(row), [ins] "+v"(row_ins), [rbuf] "+v"(rbuf), [vg] "+v"(vg), [t0] "=&s"(t0),
-                  [t1] "=&s"(t1), [bc] "=&s"(bc), [run] "=&s"(run), [x] "=&s"(x), [va] "=&v"(va), [vt] "=&v"(vt)
+                  [SPAN] "+s"(span), [V2] "+s"(v2), [row] "+v"(row), [ins] "+v"(row_ins), [row2] "+v"(row2), [ins2] "+v"(ins2),
+                  [rbuf] "+v"(rbuf), [vg] "+v"(vg), [t0] "=&s"(t0), [t1] "=&s"(t1), [bc] "=&s"(bc), [run] "=&s"(run), [x] "=&s"(x),
+                  [va] "=&v"(va), [vt] "=&v"(vt)
                 : [R] "s"(p.r - d.brk), [WM2] "s"(W - 2), [ROW0] "s"(d.row0 - d.brk), [COL0] "s"(d.col0), [S4M4] "s"(stride4 - 4u),
                   [TB] "s"(tb), [IB] "s"(inss), [RB] "s"(runs), [lane] "v"(lane), [lane4] "v"(lane4), [vs4] "v"(vs4)
                 : "vcc", "scc", "memory");

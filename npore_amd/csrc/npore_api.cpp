@@ -590,10 +590,11 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     tp.chunk_status = w->cstat.as<int32_t>();
     tp.r = r;
     tp.tbstride = tbs;
-    // windowed traceback up to ~one wave per SIMD, row per hop beyond (kernels.hpp).  Measured: the windows take 0.58 ms
-    // up to 1 024 chunk slots and grow in proportion beyond; the rows take 0.70 ms + 0.04 ms per 1 000 slots at any band
-    // width (10 kb reads): they cross at ~1 300 slots
-    const int tb_mode = ctx->tb_kernel ? ctx->tb_kernel : (max_chunks > 1300 ? 2 : 1);
+    // the row kernel (kernels.hpp) unless the windowed one is asked for: since it requests the anti-diagonal below with every
+    // row it is the faster one at every batch size measured (10 kb reads: 0.53 ms at 500 chunk slots, 0.83 ms at 8 000; the
+    // windows: 0.58 ms up to 1 024 slots, in proportion beyond).  The windowed kernel stays as the second implementation the
+    // tests and the fuzz tool run against it.
+    const int tb_mode = ctx->tb_kernel ? ctx->tb_kernel : 2;
     if (tb_mode == 1) hipLaunchKernelGGL(traceback_kernel, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
     else hipLaunchKernelGGL(traceback_rows_kernel, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
     HIP_TRY(hipGetLastError());
