@@ -213,7 +213,7 @@ int npore_last_timing(npore_ctx *ctx, double *ms, int n);
 int npore_total_timing(npore_ctx *ctx, double *ms, int n);
 
 /* Tunables: key in {"tb_budget_mb","force_chunks","traceback_kernel","coresident"} (traceback budget in MiB per
- * work set, chunks per fill workgroup, 1 = windowed / 2 = row-per-hop traceback; 0 = automatic.  "coresident"
+ * work set, chunks per fill workgroup, 1 = windowed / 2 = row-per-hop traceback; 0 = automatic (the row kernel).  "coresident"
  * (default 1): a group of reads that overlaps another one on the device is prepared and gathered by kernel shapes
  * that run beside the fill kernel's workgroups, and the fill leaves them room; 0 = always the stand-alone shapes).
  * "fill_streams" (1 | 2, default 2): fill kernels of consecutive groups on one stream or alternating between two.
