@@ -20,10 +20,12 @@
 //                     100*b, progress count, record addresses) is kept in VECTOR registers:
 //                     scalar instructions cost a wave about twice as much here, and the
 //                     kernel runs at the vector issue rate (DESIGN.md sections 4.1, 6).
-//   traceback_kernel  one wavefront per chunk: follows MAT.TYP/MAT.RUN words
-//                     (reference src/aln.pyx:670-742) through register windows of
-//                     the band strip around the path and records the path as
-//                     (type, length) runs.
+//   traceback_rows_kernel   one wavefront per chunk: follows MAT.TYP/MAT.RUN words
+//                     (reference src/aln.pyx:670-742) and records the path as (type, length)
+//                     runs; per hop one 64-column group of the anti-diagonal landed on and
+//                     of the one below it, the hop loop written out in scalar instructions.
+//   traceback_kernel  the same through register windows of the band strip around the
+//                     path (the second implementation: run on request, tests, fuzz).
 //   gather_scan /     per read: length and status of the output, where every chunk's ops go;
 //   gather_kernel     one workgroup per chunk: expands the chunk's runs into the op
 //                     string in the caller's output buffer (src/aln.pyx:719-742);
