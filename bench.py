@@ -133,6 +133,44 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
+DIGESTS = os.path.join(REPO, "tests", "golden", "fullsize_digests.npz")
+# (base_seed, mixed, ref_len, r, max_b_rows) -> name in the digest file (tests/golden/make_fullsize_digests.py)
+DIGEST_CONFIGS = {(2, False, 10_000, 100, 20000): "c2", (2, False, 10_000, 30, 20000): "r30", (3, True, 10_000, 100, 20000): "c3",
+                  (4, True, 10_000, 100, 20000): "c4", (5, False, 50_000, 200, 20000): "c5"}
+_DIGESTS = None
+
+
+def digest_parity(key, read_index, out_host, oo, out_len):
+    """Every output string of this rank whose read has a COMMITTED digest of the pinned oracle (tests/golden/
+    fullsize_digests.npz: per read index the length and sha256[:16] of the oracle's align() string, made in the build
+    container by tests/golden/make_fullsize_digests.py) against that digest -- data, not the oracle: this works on any
+    rank of any world size, costs a hash per string and needs nothing of oracle/.  read_index[k] = generator index of
+    local read k.  Returns (compared, bad)."""
+    global _DIGESTS
+    name = DIGEST_CONFIGS.get(key)
+    if name is None or not os.path.exists(DIGESTS):
+        return 0, 0
+    if _DIGESTS is None:
+        _DIGESTS = np.load(DIGESTS)
+    if name + "_idx" not in _DIGESTS:
+        return 0, 0
+    idx = _DIGESTS[name + "_idx"].astype(np.int64)
+    order = np.argsort(idx)
+    idx_s = idx[order]
+    ln, dg = _DIGESTS[name + "_len"][order], _DIGESTS[name + "_dig"][order]
+    read_index = np.asarray(read_index, np.int64)
+    pos = np.searchsorted(idx_s, read_index)
+    pos[pos >= len(idx_s)] = 0
+    hit = idx_s[pos] == read_index
+    compared = bad = 0
+    for k in np.nonzero(hit)[0]:
+        a, l = int(oo[k]), int(out_len[k])
+        ok = l == int(ln[pos[k]]) and int(hashlib.sha256(out_host[a:a + l].tobytes()).hexdigest()[:16], 16) == int(dg[pos[k]])
+        compared += 1
+        bad += 0 if ok else 1
+    return compared, bad
+
+
 def cpu_baseline(args, refs, seqs, cigs, sub, nps):
     """The oracle (plain-C port of the reference's align(), proven equal to the Cython build in the build
     container) on the GPU box's host cores: one core on a sample, then a process pool over reads -- the
@@ -162,6 +200,11 @@ def cpu_baseline(args, refs, seqs, cigs, sub, nps):
         cpu["k_cython_over_port"] = {"k": kval, "measured_at_r": int(rk), "source": "tests/golden/k_cython_over_port.json "
                                      "(tests/golden/measure_k.py, build container: reference Cython vs this port, same reads)"}
         cpu["cython_equivalent"] = {"value": round(k / dt1 * kval, 3), "unit": "reads/s", "cores": 1}
+    share = (hc["cgroup_cpus"] or hc["usable"])
+    cpu["host_note"] = (f"this process may use {share:g} of the host's {hc['cpu_count']} logical CPUs (cgroup quota of a 1-GPU lease); "
+                        f"`all_reads` is the best pool inside that share, NOT a whole host: scaled linearly to all {hc['cpu_count']} CPUs "
+                        f"(optimistic for the CPU: the port is memory-bound at many workers) it would be x{hc['cpu_count'] / share:.1f}, "
+                        "see `all_reads.whole_host_linear_estimate` and `gpu_speedup.vs_cython_equivalent_whole_host_linear_estimate`")
     if args.cpu_threads != 1:
         state_bytes = 60 * (args.max_b_rows + 1) * (2 * args.r + 1)     # the reference's / the port's state matrix per worker
         avail = host_mem_available()
@@ -188,8 +231,11 @@ def cpu_baseline(args, refs, seqs, cigs, sub, nps):
                                       f"(the reference's own parallelism; each worker holds a {state_bytes >> 20} MB state matrix); "
                                       f"best of the pool sizes in `sweep`, every string compared with the GPU output",
                             "sweep": sweep}
+        scale = hc["cpu_count"] / share
+        cpu["all_reads"]["whole_host_linear_estimate"] = round(best["value"] * scale, 1)
         if kval is not None:
             cpu["all_reads"]["cython_equivalent"] = round(best["value"] * kval, 2)
+            cpu["all_reads"]["cython_equivalent_whole_host_linear_estimate"] = round(best["value"] * kval * scale, 1)
     return cpu, want
 
 
@@ -220,8 +266,6 @@ def main():
                     help="seconds of the `production_default` leg: the tool's default band (r=30, max_b_rows=20000, reference "
                          "src/realign.py:46-51) on one full launch of the fill kernel (4 000 reads of 10 kb), pipelined; 0 = skip")
     ap.add_argument("--production-reads", type=int, default=4000, help="reads per GPU of that leg (tests use fewer)")
-    ap.add_argument("--tb-kernel", type=int, default=0,
-                    help="traceback kernel: 0 = chosen by batch size, 1 = windowed, 2 = row per hop (experiments)")
     ap.add_argument("--solo-steps", type=int, default=3,
                     help="synchronous steps after the timed region that time the fill kernel on its own (the roofline's duration); "
                          "0 = use the timed region's events (profiler runs)")
@@ -293,8 +337,6 @@ def main():
     ctxs = [aln.Context(sub, nps, max_n=6, max_l=100, device=dev_index) for _ in range(n_ctx)]
     ctx = ctxs[0]
     for c in ctxs:
-        if args.tb_kernel:
-            c.set("traceback_kernel", args.tb_kernel)
         c.set("coresident", args.coresident)
         if args.fill_streams:
             c.set("fill_streams", args.fill_streams)
@@ -401,6 +443,11 @@ def main():
     value = total_reads / elapsed
     out_len = d_len.cpu().numpy()
     out_host = d_out.cpu().numpy()
+    # ---- 3a. EVERY rank proves its strings: each output whose (seed, index, r, max_b_rows) has a committed digest of
+    # the pinned oracle is compared with it (any world size; the per-rank counts are summed below)
+    par_n, par_bad = digest_parity((args.base_seed, bool(args.mixed), args.ref_len, args.r, args.max_b_rows),
+                                   [rank + (k % n_uniq) * world for k in range(n)], out_host, oo, out_len)
+    parity = {"main": {"strings_compared": par_n, "strings_bad": par_bad}}
 
     # ---- 3b. the dominant kernel on its own: three more steps, each complete before the next is enqueued.  In the
     # timed region consecutive fill launches OVERLAP (the next one's workgroups move onto the CUs the previous one's
@@ -543,6 +590,9 @@ def main():
         p_fill_alone = float(np.mean([x["fill_ms"] for x in p_solo]))
         p_bytes = sum(4 * (len(s_) + len(r_) + 1) * 61 + 2 * (len(s_) + len(r_)) for s_, r_ in zip(p_seqs, p_refs)) + int(p_len.sum().item())
         assert int((p_st != 0).sum().item()) == 0
+        pp_n, pp_bad = digest_parity((2, False, 10_000, 30, 20000), [rank + k * world for k in range(pn)],
+                                     p_out.cpu().numpy(), poo, p_len.cpu().numpy())
+        parity["production_default"] = {"strings_compared": pp_n, "strings_bad": pp_bad}
         production = {"workload": f"{pn} synthetic 10 kb reads per GPU (base_seed=2), r=30, max_b_rows=20000: the tool's defaults "
                                   "(reference src/realign.py:46-51) at one full launch of the fill kernel; device-resident, pipelined",
                       "value": round(pn * world * done / mx["e"], 1), "unit": "reads/s", "steps": done,
@@ -599,7 +649,11 @@ def main():
         if same_cmd and pm.get("csrc_sha") == csrc_sha():
             traffic = int((2 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024)      # gfx950: FETCH_SIZE counts 64 B as 32
             insts = float(pm["SQ_INSTS_VALU"])
-            peak = N_SIMD * clock_ghz / 4.0                                       # G wave-instructions / s
+            # a SIMD-32 of gfx950 issues one wave64 VOP2 instruction per 2 cycles once two or more of its waves are ready
+            # (MI355X_MICROARCH.md "Wave scheduling"; scripts/microbench/valu_issue.cpp on this pool: 2.15 cycles per
+            # v_add with 2 ... 8 waves per SIMD, 4.3 for back-to-back VOP3 / DPP / SDWA / VOPC, 4.3 - 5 for ONE wave alone);
+            # rounds 1 - 4 priced this with 4 cycles per instruction, which is what one wave alone gets
+            peak = N_SIMD * clock_ghz / 2.0                                       # G wave-instructions / s
             ach = insts / (fill_avg_ms * 1e-3) / 1e9
             wave_steps = float(pm.get("wave_steps") or 0)
             # the clock the chip HELD in the profiled launch (MI355X_MICROARCH.md: GRBM_GUI_ACTIVE / 8 XCDs / kernel
@@ -613,8 +667,13 @@ def main():
             valu = {"bound": "valu_issue", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
                     "frac": round(ach / peak, 4), "insts_valu_per_launch": int(insts),
                     "valu_per_wave_step": round(insts / wave_steps, 1) if wave_steps else None,
+                    "peak_note": "1 024 SIMD-32 x clock / 2 cycles per wave64 VOP2 instruction (needs >= 2 ready waves per SIMD; "
+                                 "VOP3 / DPP / SDWA / compares back to back run at half of it: scripts/microbench/valu_issue.cpp)",
                     "clock_held_ghz": round(held_ghz, 3) if held_ghz else None,
-                    "valu_busy_frac_at_held_clock": round(busy, 4) if busy else None}
+                    "valu_busy_frac_at_held_clock": round(busy, 4) if busy else None,
+                    "valu_busy_note": "SQ_ACTIVE_INST_VALU x 4 cycles / SIMD / cycles of the launch: the counter advances once per "
+                                      "vector instruction (it equals SQ_INSTS_VALU within 0.5 %), so this prices every instruction "
+                                      "at 4 cycles -- an upper bound of the issue pipe's occupancy, not a measurement of it"}
             pmc_src = f"profiles/{PMC_SUMMARY} (csrc {pm['csrc_sha']}): quoted from that committed rocprofv3 --pmc run of this same command, not measured by this process"
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -628,6 +687,16 @@ def main():
                                      if fill_solo else "HIP events around the launches of the timed region"),
                 "kernel_ms_in_timed_region": round(fill_region_ms, 3),
                 "bytes_alg_per_launch": int(bytes_alg), "valu_issue": valu, "practical": practical, "pmc_source": pmc_src}
+
+    # ---- 5c. the ranks' parity counts, summed (a second tiny reduction, outside every timed region)
+    flat = {f"{leg}.{q}": v for leg, d_ in parity.items() for q, v in d_.items()}
+    flat, _ = reduce_counters(flat, {}, device=dev if backend == "nccl" else None)
+    parity = {leg: {q: int(flat[f"{leg}.{q}"]) for q in d_} for leg, d_ in parity.items()}
+    parity["strings_compared"] = sum(d_["strings_compared"] for d_ in parity.values() if isinstance(d_, dict))
+    parity["strings_bad"] = sum(d_["strings_bad"] for d_ in parity.values() if isinstance(d_, dict))
+    parity["source"] = ("tests/golden/fullsize_digests.npz: per-read (length, sha256[:16]) of the pinned oracle's align() string, "
+                        "made in the build container (tests/golden/make_fullsize_digests.py); every rank compares every "
+                        "output whose (base_seed, read index, r, max_b_rows) is in the file, counts summed over ranks")
 
     # ---- 6. every CPU string against the GPU's
     if cpu is not None:
@@ -644,6 +713,10 @@ def main():
             sp["vs_cython_equivalent_1core"] = round(value / cpu["cython_equivalent"]["value"], 1)
             if "all_reads" in cpu:
                 sp["vs_cython_equivalent_all_cores"] = round(value / cpu["all_reads"]["cython_equivalent"], 1)
+                sp["vs_cython_equivalent_whole_host_linear_estimate"] = round(
+                    value / cpu["all_reads"]["cython_equivalent_whole_host_linear_estimate"], 1)
+                sp["note"] = ("`all_cores` = the cores of this lease's cgroup share (cpu_baseline.host_note), not of the host; the "
+                              "whole-host figure is a linear extrapolation")
         cpu["gpu_speedup"] = sp
 
     if rank == 0:
@@ -659,8 +732,10 @@ def main():
                        "reads_per_gpu": n, "ref_len": args.ref_len, "r": args.r, "max_b_rows": args.max_b_rows,
                        "base_seed": args.base_seed, "mixed": bool(args.mixed), "parallelism": f"reads x{world}",
                        "batches_in_flight": n_ctx, "pipelined": pipelined, "devices_visible": n_dev,
-                       "value_excludes": "H2D/D2H: inputs and outputs stay in HBM across the timed region (the contract of "
+                       "value_excludes": "H2D/D2H: inputs and outputs stay in HBM across the timed region (the bench contract of "
                                          "`value`); the same batch through page-locked host buffers is `value_pcie_inclusive`",
+                       "survey_8d_metric": "SURVEY.md 8(d) words the metric with H2D/D2H INCLUDED: that figure is "
+                                           "`value_pcie_inclusive.value` (host buffers in, strings out), reported beside `value`",
                        "reduction_backend": {"nccl": "rccl", "gloo": "gloo (ranks share a device)", None: "none"}[backend],
                        "host_setup": {"generate_s_max_over_ranks": round(maxes["generate"], 2),
                                       "start_to_timed_region_s_max_over_ranks": round(maxes["until_timed"], 2),
@@ -671,13 +746,17 @@ def main():
                          "traceback_gather": round(float(np.mean(tb_ms)), 2), "prep": round(float(np.mean(prep_ms)), 2),
                          "note": "fill_alone: the kernel with the GPU to itself (what the roofline is priced with); the other "
                                  "three are HIP-event times inside the timed region, where consecutive steps' stages overlap"},
-            "bad_reads": n_bad,
+            "bad_reads": n_bad, "parity": parity,
         }
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()
     for c in ctxs:
         c.close()
+    if parity["strings_bad"]:
+        print(f"bench.py: {parity['strings_bad']} of {parity['strings_compared']} strings differ from the pinned oracle's digests",
+              file=sys.stderr)
+        sys.exit(1)
 
 
 if __name__ == "__main__":

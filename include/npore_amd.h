@@ -212,8 +212,8 @@ int npore_last_timing(npore_ctx *ctx, double *ms, int n);
  * that keeps batches in flight: differences over a timed region). */
 int npore_total_timing(npore_ctx *ctx, double *ms, int n);
 
-/* Tunables: key in {"tb_budget_mb","force_chunks","traceback_kernel","coresident"} (traceback budget in MiB per
- * work set, chunks per fill workgroup, 1 = windowed / 2 = row-per-hop traceback; 0 = automatic (the row kernel).  "coresident"
+/* Tunables: key in {"tb_budget_mb","force_chunks","coresident"} (traceback budget in MiB per
+ * work set, chunks per fill workgroup).  "coresident"
  * (default 1): a group of reads that overlaps another one on the device is prepared and gathered by kernel shapes
  * that run beside the fill kernel's workgroups, and the fill leaves them room; 0 = always the stand-alone shapes).
  * "fill_streams" (1 | 2, default 2): fill kernels of consecutive groups on one stream or alternating between two.
@@ -362,6 +362,11 @@ int npore_confusion_counts(const char *lines, const int64_t *line_off, int64_t n
  * library's decoder, csrc/inflate.hpp, and zlib for what it declines), 1 = the decoder only, 2 = zlib only.
  * Returns 1 (inflated), 0 (refused / malformed) or a negative NPORE_E_* code.  Host code, no GPU. */
 int npore_debug_inflate(const uint8_t *in, int64_t in_len, uint8_t *out, int64_t out_len, int force);
+/* The same for TWO independent streams decoded side by side by one thread, as the BGZF readers take a file's blocks
+ * (csrc/inflate.hpp: two dependent chains in one loop).  Returns bit 0 = stream a inflated, bit 1 = stream b inflated,
+ * or a negative NPORE_E_* code. */
+int npore_debug_inflate_pair(const uint8_t *in_a, int64_t in_len_a, uint8_t *out_a, int64_t out_len_a, const uint8_t *in_b,
+                             int64_t in_len_b, uint8_t *out_b, int64_t out_len_b, int force);
 
 /* Debug self-test: out128[l] = value lane l receives from lane l-1 (l>0),
  * out128[64+l] = value from lane l+1 (l<63); checks the DPP wave-shift

@@ -80,6 +80,7 @@ SIGNATURES = {
     "npore_bam_last_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "npore_bam_file_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "npore_debug_inflate": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int]),
+    "npore_debug_inflate_pair": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int]),
     "npore_debug_dpp": (C.c_int, [C.c_void_p]),
     "npore_debug_divcheck": (C.c_int, [C.c_void_p]),
     "npore_debug_fetch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),

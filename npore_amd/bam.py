@@ -423,16 +423,22 @@ class NativeBam:
 
     @classmethod
     def _shm_key(cls, path):
-        """Name of the files local rank 0 leaves for the other local ranks.  Besides the file's identity it holds what
-        makes one LAUNCH's files invisible to the next: the launcher's pid (the local ranks of one torch.distributed.run
-        are children of one agent) and MASTER_PORT, and the count of this process's opens of the path (a second
-        NativeBam of the same file in one run must not find the first one's `.skip`)."""
+        """Name of the files local rank 0 leaves for the other local ranks.  Besides the file's identity it holds only
+        what the LAUNCHER hands to every local rank alike -- the rendezvous (MASTER_ADDR : MASTER_PORT), torchrun's run
+        id, a batch system's job id -- and the count of this process's opens of the path (SPMD code opens the same
+        files in the same order on every rank; a second NativeBam of the same file in one run then does not find the
+        first one's `.skip`).  Nothing per-process goes in (rounds 3 - 4 hashed the parent's pid: local ranks started
+        by per-rank wrapper scripts have different parents and never met).  Two launches that share all of this share
+        the key; local rank 0 removes what an earlier one left (`_announce_maker`), and a rank whose key does diverge
+        for a reason not foreseen here gives up after a grace period (`_wait_for_maker`)."""
         import hashlib
         st = os.stat(path)
         ap = os.path.abspath(path)
         who = (ap, os.environ.get("LOCAL_RANK", "0"))
         gen = cls._opens[who] = cls._opens.get(who, 0) + 1
-        ident = f"{ap}:{st.st_size}:{st.st_mtime_ns}:{os.environ.get('MASTER_PORT', '')}:{os.getppid()}:{gen}"
+        job = ":".join(os.environ.get(k, "") for k in ("MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "SLURM_JOB_ID",
+                                                         "SLURM_STEP_ID", "PBS_JOBID", "LSB_JOBID", "NPORE_JOB_ID"))
+        ident = f"{ap}:{st.st_size}:{st.st_mtime_ns}:{job}:{gen}"
         return hashlib.sha1(ident.encode()).hexdigest()[:16]
 
     @staticmethod
@@ -450,10 +456,14 @@ class NativeBam:
 
     @staticmethod
     def _wait_for_maker(key, data, skip, timeout):
-        """other local ranks: True once `data` is there; False if the maker gave up (`skip`), died, or `timeout` passed"""
+        """other local ranks: True once `data` is there; False if the maker gave up (`skip`), died, never showed up
+        (no pid file within NPORE_SHARE_GRACE_S, 30 s: the ranks' keys differ, or local rank 0 is not running this
+        code -- the caller then opens the file itself), or `timeout` passed"""
         import time
         pidfile = f"/dev/shm/npore_bam_{key}.pid"
+        grace = float(os.environ.get("NPORE_SHARE_GRACE_S", "30"))
         t0 = time.time()
+        seen_maker = False
         while time.time() - t0 < timeout:
             if os.path.exists(data):
                 return True
@@ -461,8 +471,11 @@ class NativeBam:
                 return False
             try:
                 pid = int(open(pidfile).read())                # (no pid file yet: the maker has not started)
+                seen_maker = True
             except (OSError, ValueError):
                 pid = None
+            if not seen_maker and time.time() - t0 > grace:
+                return False
             if pid is not None:
                 try:
                     os.kill(pid, 0)

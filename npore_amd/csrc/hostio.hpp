@@ -243,6 +243,25 @@ inline bool inflate_block(const uint8_t *in, size_t in_len, uint8_t *out, size_t
     return ok;
 }
 
+// several blocks by one thread, side by side (inflate.hpp: as many dependent chains in one loop); zlib for what the decoder
+// declines.  Returns the number of blocks that did not inflate.
+inline int inflate_blocks(const FastInflate::Job *jobs, int n, int force = 0)
+{
+    int bad = 0;
+    if (force == 2) {
+        for (int k = 0; k < n; k++) bad += !inflate_block(jobs[k].in, jobs[k].in_len, jobs[k].out, jobs[k].out_len, 2);
+        return bad;
+    }
+    bool ok_small[64];
+    std::vector<char> ok_big;
+    bool *ok = ok_small;
+    if (n > 64) { ok_big.resize((size_t)n); ok = reinterpret_cast<bool *>(ok_big.data()); }
+    inflate_raw_fast_many(jobs, n, ok);
+    for (int k = 0; k < n; k++)
+        if (!ok[k] && (force == 1 || !inflate_block(jobs[k].in, jobs[k].in_len, jobs[k].out, jobs[k].out_len, 2))) bad++;
+    return bad;
+}
+
 inline bool bgzf_inflate(const ByteSpan &raw, int threads, RawBuf &out, size_t &out_size, std::string &err)
 {
     typedef BgzfBlock Blk;
@@ -260,9 +279,14 @@ inline bool bgzf_inflate(const ByteSpan &raw, int threads, RawBuf &out, size_t &
         if (!out.ensure(total + 1)) { err = "out of memory"; return false; }
         out_size = total;
         std::atomic<int> bad{0};
-        parallel_for((int64_t)blocks.size(), threads, [&](int64_t i) {
-            const Blk &b = blocks[(size_t)i];
-            if (!inflate_block(raw.data() + b.in_off, b.in_len, reinterpret_cast<uint8_t *>(out.p) + b.out_off, b.out_len)) bad++;
+        const int64_t per = 8;                                  // blocks per task
+        parallel_for(((int64_t)blocks.size() + per - 1) / per, threads, [&](int64_t t) {
+            FastInflate::Job jobs[8];
+            int n = 0;
+            uint8_t *const o = reinterpret_cast<uint8_t *>(out.p);
+            for (size_t i = (size_t)(t * per); i < std::min(blocks.size(), (size_t)((t + 1) * per)); i++)
+                jobs[n++] = {raw.data() + blocks[i].in_off, blocks[i].in_len, o + blocks[i].out_off, blocks[i].out_len};
+            bad += inflate_blocks(jobs, n);
         });
         if (bad) { err = "corrupt BGZF block"; return false; }
         return true;
@@ -366,10 +390,12 @@ inline bool bgzf_inflate_range(const PreadFile &f, const std::vector<BgzfBlock> 
     const uint64_t o0 = blocks[b0].out_off;
     const int64_t per = 8;                                      // blocks per task
     parallel_for(((int64_t)(b1 - b0) + per - 1) / per, threads, [&](int64_t t) {
-        for (size_t i = b0 + (size_t)t * per; i < std::min(b1, b0 + (size_t)(t + 1) * per); i++) {
-            const BgzfBlock &b = blocks[i];
-            if (!inflate_block(reinterpret_cast<const uint8_t *>(comp.p) + (b.in_off - in0), b.in_len, dst + (b.out_off - o0), b.out_len)) bad++;
-        }
+        const uint8_t *const cp = reinterpret_cast<const uint8_t *>(comp.p);
+        FastInflate::Job jobs[8];
+        int n = 0;
+        for (size_t i = b0 + (size_t)t * per; i < std::min(b1, b0 + (size_t)(t + 1) * per); i++)
+            jobs[n++] = {cp + (blocks[i].in_off - in0), blocks[i].in_len, dst + (blocks[i].out_off - o0), blocks[i].out_len};
+        bad += inflate_blocks(jobs, n);
     });
     return bad == 0;
 }

@@ -10,7 +10,13 @@
 // threads are writing: a match is copied in whole words only where eight bytes of the block's own room lie behind
 // it).  Anything malformed -- or the few legal oddities it does not take, like a literal / length code of a single
 // symbol -- returns false, and the caller then hands the block to zlib, which decides.
-// Checked against zlib on every block of the test BAMs and on generated streams of all block types
+// SEVERAL BLOCKS AT A TIME (inflate_raw_fast_many): a DEFLATE stream decodes as one dependent chain -- the bits of a symbol are
+// known only when the previous one has been looked up: mask, table load, shift, ~8 cycles per literal -- and a BAM with
+// real base qualities is mostly literals (a uniform draw per base compresses to 6.6 bits: 82 us of inflation per 10 kb read
+// and core).  BGZF blocks are independent streams, so one thread decodes two of them in ONE loop, a symbol of each in
+// turn: two chains the core's out-of-order window overlaps.  A stream that leaves the fast region (end of a deflate
+// block, the last bytes of its buffers, anything unusual) goes through the careful loop on its own and rejoins.
+// Checked against zlib on every block of the test BAMs and on generated streams of all block types, alone and in pairs
 // (tests/test_host_logic.py).
 #pragma once
 #include <cstdint>
@@ -33,9 +39,9 @@ class FastInflate {
 
     // canonical Huffman table of `n` symbols with code lengths `len` (0 = unused) into tab (primary bits PB);
     // sym_entry(symbol) gives kind / value of a symbol (its `bits` field is filled in here).  false: over-subscribed
-    // or incomplete (a single code of one bit -- allowed for distances -- is accepted)
+    // or incomplete (a single code of one bit is accepted where the caller says so: the distance table, as zlib does)
     template <class SymEntry>
-    static bool build(const uint8_t *len, int n, uint32_t *tab, int PB, int tab_cap, SymEntry sym_entry)
+    static bool build(const uint8_t *len, int n, uint32_t *tab, int PB, int tab_cap, SymEntry sym_entry, bool one_code_ok = false)
     {
         int count[16] = {0};
         for (int i = 0; i < n; i++) count[len[i]]++;
@@ -48,7 +54,7 @@ class FastInflate {
             left = (left << 1) - count[l];
             if (left < 0) return false;
         }
-        if (left > 0 && !(n <= 32 && count[0] == n - 1 && count[1] == 1)) return false;       // incomplete (one 1-bit code is legal)
+        if (left > 0 && !(one_code_ok && count[0] == n - 1 && count[1] == 1)) return false;     // incomplete (one 1-bit DISTANCE code is legal)
         uint16_t next[16];
         uint32_t code = 0;
         count[0] = 0;
@@ -161,7 +167,7 @@ class FastInflate {
         }
         if (lens[256] == 0) return false;        // no end-of-block code
         return build(lens, hlit, lit_, LB, (int)(sizeof lit_ / 4), litlen_entry) &&
-               build(lens + hlit, hdist, dist_, DB, (int)(sizeof dist_ / 4), dist_entry);
+               build(lens + hlit, hdist, dist_, DB, (int)(sizeof dist_ / 4), dist_entry, true);
     }
     bool fixed_tables()
     {
@@ -175,98 +181,158 @@ class FastInflate {
                build(lens + 288, 32, dist_, DB, (int)(sizeof dist_ / 4), dist_entry);
     }
 
-    // one compressed block's symbols; out0 = start of the whole output (the window)
-    bool codes(uint8_t *out0, uint8_t *&out, uint8_t *out_end)
+    // ---- the output side of the stream being decoded (the whole output so far is the window)
+    uint8_t *out0_ = nullptr, *o_ = nullptr, *out_end_ = nullptr;
+    bool last_ = false;
+
+    // The fast loop: while 16 input bytes and 320 output bytes of the block's own room remain, nothing in it needs a
+    // bounds check -- one refill feeds up to three literals or a whole length + distance pair (at most 48 bits), a
+    // match is copied in words of eight bytes (at most 258 + 7 bytes written).  The table entry of the NEXT symbol is
+    // looked up as soon as the bits of this one are consumed -- for a match: before its bytes are copied -- so the
+    // lookup's latency lies beside the copy.  A symbol it cannot finish unchecked (a match reaching in front of the
+    // output, a bad code, the end of the block) leaves the bit buffer untouched and falls to the careful loop, which decides.
+    // One step = a run of up to three literals, or one match, of stream X (its state in the locals o##X, in##X, bb##X,
+    // bc##X, e##X, the tables lit##X / dst##X, the limits in_stop##X / out_stop##X); leaves by `goto LEAVE` with the
+    // stream's bits as they were in front of the symbol it could not take
+#define NPORE_INFL_REFILL(X) do { uint64_t w_; std::memcpy(&w_, in##X, 8); bb##X |= w_ << bc##X; in##X += (63 - bc##X) >> 3; bc##X |= 56; } while (0)
+#define NPORE_INFL_STEP(X, LEAVE)                                                                                        \
+    do {                                                                                                                 \
+        if ((e##X & 0xFF00u) == 0) {                   /* K_LIT: up to three from the bits at hand (<= 33 of >= 56) */   \
+            bb##X >>= (e##X & 0xFF); bc##X -= (int)(e##X & 0xFF);                                                        \
+            *o##X++ = (uint8_t)(e##X >> 16);                                                                             \
+            e##X = lit##X[bb##X & ((1u << LB) - 1)];                                                                     \
+            if ((e##X & 0xFF00u) == 0) {                                                                                 \
+                bb##X >>= (e##X & 0xFF); bc##X -= (int)(e##X & 0xFF);                                                    \
+                *o##X++ = (uint8_t)(e##X >> 16);                                                                         \
+                e##X = lit##X[bb##X & ((1u << LB) - 1)];                                                                 \
+                if ((e##X & 0xFF00u) == 0) {                                                                             \
+                    bb##X >>= (e##X & 0xFF); bc##X -= (int)(e##X & 0xFF);                                                \
+                    *o##X++ = (uint8_t)(e##X >> 16);                                                                     \
+                    e##X = lit##X[bb##X & ((1u << LB) - 1)];                                                             \
+                }                                                                                                        \
+            }                                                                                                            \
+            if (!(in##X <= in_stop##X && o##X <= out_stop##X)) goto LEAVE;                                               \
+            NPORE_INFL_REFILL(X);                      /* (the low bits e was looked up with stay where they are) */     \
+            break;                                                                                                       \
+        }                                                                                                                \
+        {                                                                                                                \
+            const uint64_t bb0 = bb##X;                                                                                  \
+            const int bc0 = bc##X;                                                                                       \
+            if ((e##X >> 8 & 0xFF) == K_SUB) e##X = lit##X[(e##X >> 16) + ((bb##X >> LB) & ((1u << (e##X & 0xFF)) - 1))]; \
+            const uint32_t kind = e##X >> 8 & 0xFF;                                                                      \
+            bb##X >>= (e##X & 0xFF); bc##X -= (int)(e##X & 0xFF);                                                        \
+            if (kind == K_LIT) {                                                                                         \
+                *o##X++ = (uint8_t)(e##X >> 16);                                                                         \
+                if (!(in##X <= in_stop##X && o##X <= out_stop##X)) goto LEAVE;                                           \
+                NPORE_INFL_REFILL(X);                                                                                    \
+                e##X = lit##X[bb##X & ((1u << LB) - 1)];                                                                 \
+                break;                                                                                                   \
+            }                                                                                                            \
+            if (kind != K_LEN) { bb##X = bb0; bc##X = bc0; goto LEAVE; }       /* end of block, or a bad code */          \
+            const uint32_t v = e##X >> 16, xl = v >> 12;                                                                 \
+            const int len = (int)(v & 0xFFF) + (int)(bb##X & ((1u << xl) - 1));                                          \
+            bb##X >>= xl; bc##X -= (int)xl;                                                                              \
+            uint32_t d = dst##X[bb##X & ((1u << DB) - 1)];                                                               \
+            if ((d >> 8 & 0xF) == K_SUB) d = dst##X[(d >> 16) + ((bb##X >> DB) & ((1u << (d & 0xFF)) - 1))];             \
+            if ((d >> 8 & 0xF) != K_DIST) { bb##X = bb0; bc##X = bc0; goto LEAVE; }                                      \
+            bb##X >>= (d & 0xFF); bc##X -= (int)(d & 0xFF);                                                              \
+            const uint32_t xd = d >> 12 & 0xF;                                                                           \
+            const size_t dist = (size_t)(d >> 16) + (size_t)(bb##X & ((1u << xd) - 1));                                  \
+            bb##X >>= xd; bc##X -= (int)xd;                                                                              \
+            if (dist > (size_t)(o##X - out0##X)) { bb##X = bb0; bc##X = bc0; goto LEAVE; }                               \
+            /* the next symbol's entry before the copy (16 input bytes are there: the loop's condition held) */          \
+            NPORE_INFL_REFILL(X);                                                                                        \
+            e##X = lit##X[bb##X & ((1u << LB) - 1)];                                                                     \
+            const uint8_t *src = o##X - dist;                                                                            \
+            if (dist >= 8) {                             /* words of eight, one after the other: each reads bytes already written */ \
+                uint64_t w;                                                                                              \
+                std::memcpy(&w, src, 8); std::memcpy(o##X, &w, 8);                                                       \
+                if (len > 8) {                                                                                           \
+                    std::memcpy(&w, src + 8, 8); std::memcpy(o##X + 8, &w, 8);                                           \
+                    for (int k = 16; k < len; k += 8) { std::memcpy(&w, src + k, 8); std::memcpy(o##X + k, &w, 8); }     \
+                }                                                                                                        \
+            } else if (dist == 1) {                                                                                      \
+                const uint64_t w = 0x0101010101010101ull * (uint64_t)*src;                                               \
+                for (int k = 0; k < len; k += 8) std::memcpy(o##X + k, &w, 8);                                           \
+            } else {                                                                                                     \
+                for (int k = 0; k < len; k++) o##X[k] = src[k];                                                          \
+            }                                                                                                            \
+            o##X += len;                                                                                                 \
+            if (!(in##X <= in_stop##X && o##X <= out_stop##X)) goto LEAVE;                                               \
+        }                                                                                                                \
+    } while (0)
+    // (the readers' state in named locals -- registers: a byte store may alias any member, and the compiler would reload
+    // them all behind every literal; with arrays indexed by the lane the compiler kept the state on the stack)
+#define NPORE_INFL_LOAD(X, S)                                                                                            \
+    uint8_t *o##X = (S).o_, *const out0##X = (S).out0_;                                                                  \
+    const uint8_t *in##X = (S).in_;                                                                                      \
+    const uint8_t *const in_stop##X = (S).in_end_ - ((S).in_fast_region() ? 16 : 0);      /* (never formed outside the buffer) */ \
+    uint8_t *const out_stop##X = (S).out_end_ - ((S).in_fast_region() ? 320 : 0);                                        \
+    uint64_t bb##X = (S).bb_;                                                                                            \
+    int bc##X = (S).bc_;                                                                                                 \
+    const uint32_t *const lit##X = (S).lit_, *const dst##X = (S).dist_;                                                  \
+    uint32_t e##X = 0
+#define NPORE_INFL_STORE(X, S) do { (S).o_ = o##X; (S).in_ = in##X; (S).bb_ = bb##X; (S).bc_ = bc##X; } while (0)
+
+    // The current compressed blocks' symbols of N (1 or 2) streams, a step of each in turn, while the fast region lasts for
+    // all of them: returns the index of the stream that has to leave it, or -1 if one of them was outside the region to
+    // begin with.
+    template <int N>
+    static int codes_fast_n(FastInflate *const *s)
     {
-        // The fast loop: while 16 input bytes and 320 output bytes of the block's own room remain, nothing in it needs a
-        // bounds check -- one refill feeds up to three literals or a whole length + distance pair (at most 48 bits), a
-        // match is copied in words of eight bytes (at most 258 + 7 bytes written).  The table entry of the NEXT symbol is
-        // looked up as soon as the bits of this one are consumed -- for a match: before its bytes are copied -- so the
-        // lookup's latency lies beside the copy (the bench BAM's blocks are 5.2 M matches of 8.4 bytes on average and
-        // 3.7 M literals per 48 MB: 394 -> 478 MB/s on the build container's core).  A symbol it cannot finish
-        // unchecked (a match reaching in front of the output, a bad code) leaves the bit buffer untouched and falls
-        // to the careful loop below, which decides.
-        {
-            // (the reader's state in locals: a byte store may alias any member, and the compiler would reload them all
-            // behind every literal)
-            uint8_t *o = out;
-            const uint8_t *in = in_;
-            const uint8_t *const in_stop = in_end_ - 16;
-            uint8_t *const out_stop = out_end - 320;
-            uint64_t bb = bb_;
-            int bc = bc_;
-            const uint32_t *const lit = lit_, *const dst = dist_;
-#define NPORE_INFL_REFILL() do { uint64_t w_; std::memcpy(&w_, in, 8); bb |= w_ << bc; in += (63 - bc) >> 3; bc |= 56; } while (0)
-            if (in <= in_stop && o <= out_stop) {
-                NPORE_INFL_REFILL();
-                uint32_t e = lit[bb & ((1u << LB) - 1)];       // the next symbol's entry is always looked up ahead
-                for (;;) {
-                    if ((e & 0xFF00u) == 0) {                   // K_LIT: up to three from the bits at hand (<= 33 of >= 56)
-                        bb >>= (e & 0xFF); bc -= (int)(e & 0xFF);
-                        *o++ = (uint8_t)(e >> 16);
-                        e = lit[bb & ((1u << LB) - 1)];
-                        if ((e & 0xFF00u) == 0) {
-                            bb >>= (e & 0xFF); bc -= (int)(e & 0xFF);
-                            *o++ = (uint8_t)(e >> 16);
-                            e = lit[bb & ((1u << LB) - 1)];
-                            if ((e & 0xFF00u) == 0) {
-                                bb >>= (e & 0xFF); bc -= (int)(e & 0xFF);
-                                *o++ = (uint8_t)(e >> 16);
-                                e = lit[bb & ((1u << LB) - 1)];
-                            }
-                        }
-                        if (!(in <= in_stop && o <= out_stop)) break;
-                        NPORE_INFL_REFILL();                    // (the low bits e was looked up with stay where they are)
-                        continue;
-                    }
-                    const uint64_t bb0 = bb;
-                    const int bc0 = bc;
-                    if ((e >> 8 & 0xFF) == K_SUB) e = lit[(e >> 16) + ((bb >> LB) & ((1u << (e & 0xFF)) - 1))];
-                    const uint32_t kind = e >> 8 & 0xFF;
-                    bb >>= (e & 0xFF); bc -= (int)(e & 0xFF);
-                    if (kind == K_LIT) {
-                        *o++ = (uint8_t)(e >> 16);
-                        if (!(in <= in_stop && o <= out_stop)) break;
-                        NPORE_INFL_REFILL();
-                        e = lit[bb & ((1u << LB) - 1)];
-                        continue;
-                    }
-                    if (kind != K_LEN) { bb = bb0; bc = bc0; break; }       // end of block, or a bad code: the careful loop
-                    const uint32_t v = e >> 16, xl = v >> 12;
-                    const int len = (int)(v & 0xFFF) + (int)(bb & ((1u << xl) - 1));
-                    bb >>= xl; bc -= (int)xl;
-                    uint32_t d = dst[bb & ((1u << DB) - 1)];
-                    if ((d >> 8 & 0xF) == K_SUB) d = dst[(d >> 16) + ((bb >> DB) & ((1u << (d & 0xFF)) - 1))];
-                    if ((d >> 8 & 0xF) != K_DIST) { bb = bb0; bc = bc0; break; }
-                    bb >>= (d & 0xFF); bc -= (int)(d & 0xFF);
-                    const uint32_t xd = d >> 12 & 0xF;
-                    const size_t dist = (size_t)(d >> 16) + (size_t)(bb & ((1u << xd) - 1));
-                    bb >>= xd; bc -= (int)xd;
-                    if (dist > (size_t)(o - out0)) { bb = bb0; bc = bc0; break; }
-                    // the next symbol's entry before the copy (16 input bytes are there: the loop's condition held)
-                    NPORE_INFL_REFILL();
-                    e = lit[bb & ((1u << LB) - 1)];
-                    const uint8_t *src = o - dist;
-                    if (dist >= 8) {                             // words of eight, one after the other: each reads bytes already written
-                        uint64_t w;
-                        std::memcpy(&w, src, 8); std::memcpy(o, &w, 8);
-                        if (len > 8) {
-                            std::memcpy(&w, src + 8, 8); std::memcpy(o + 8, &w, 8);
-                            for (int k = 16; k < len; k += 8) { std::memcpy(&w, src + k, 8); std::memcpy(o + k, &w, 8); }
-                        }
-                    } else if (dist == 1) {
-                        const uint64_t w = 0x0101010101010101ull * (uint64_t)*src;
-                        for (int k = 0; k < len; k += 8) std::memcpy(o + k, &w, 8);
-                    } else {
-                        for (int k = 0; k < len; k++) o[k] = src[k];
-                    }
-                    o += len;
-                    if (!(in <= in_stop && o <= out_stop)) break;
-                }
+        static_assert(N == 1 || N == 2, "lanes");
+        int who = -1;
+        if constexpr (N == 1) {
+            FastInflate &sa = *s[0];
+            NPORE_INFL_LOAD(A, sa);
+            if (sa.in_fast_region()) {
+                NPORE_INFL_REFILL(A);
+                eA = litA[bbA & ((1u << LB) - 1)];       // the next symbol's entry is always looked up ahead
+                who = 0;
+                for (;;) NPORE_INFL_STEP(A, leave1);
             }
-#undef NPORE_INFL_REFILL
-            out = o; in_ = in; bb_ = bb; bc_ = bc;
+        leave1:
+            NPORE_INFL_STORE(A, sa);
+        } else {
+            FastInflate &sa = *s[0], &sb = *s[1];
+            NPORE_INFL_LOAD(A, sa);
+            NPORE_INFL_LOAD(B, sb);
+            if (sa.in_fast_region() && sb.in_fast_region()) {
+                NPORE_INFL_REFILL(A);
+                eA = litA[bbA & ((1u << LB) - 1)];
+                NPORE_INFL_REFILL(B);
+                eB = litB[bbB & ((1u << LB) - 1)];
+                for (;;) {
+                    NPORE_INFL_STEP(A, leave_a);
+                    NPORE_INFL_STEP(B, leave_b);
+                }
+            leave_a:
+                who = 0;
+                goto leave2;
+            leave_b:
+                who = 1;
+            }
+        leave2:
+            NPORE_INFL_STORE(A, sa);
+            NPORE_INFL_STORE(B, sb);
         }
+        return who;
+    }
+    void codes_fast()
+    {
+        FastInflate *one[1] = {this};
+        codes_fast_n<1>(one);
+    }
+#undef NPORE_INFL_LOAD
+#undef NPORE_INFL_STORE
+#undef NPORE_INFL_STEP
+#undef NPORE_INFL_REFILL
+
+    // the rest of the current compressed block, every access checked: true at its end-of-block code
+    bool codes_careful()
+    {
+        uint8_t *const out0 = out0_, *const out_end = out_end_;
+        uint8_t *&out = o_;
         for (;;) {
             refill();
             uint32_t e = lit_[peek(LB)];
@@ -310,41 +376,121 @@ class FastInflate {
         }
     }
 
-public:
-    // the raw deflate stream in[0, in_len) must inflate to exactly out_len bytes at out
-    bool run(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
+    // header of the next block; stored blocks are copied here.  1: a compressed block's tables are ready, 2: the stream
+    // has ended and everything checks, 0: malformed / declined
+    int advance()
     {
-        in_ = in; in_end_ = in + in_len; bb_ = 0; bc_ = 0; over_ = 0;
-        uint8_t *o = out, *const out_end = out + out_len;
         for (;;) {
+            if (last_) return (o_ == out_end_ && over_ * 8 <= bc_) ? 2 : 0;      // every output byte, and no bit consumed beyond the input
             refill();
-            const uint32_t last = take(1), type = take(2);
+            last_ = take(1) != 0;
+            const uint32_t type = take(2);
             if (type == 0) {                      // stored
                 drop(bc_ & 7);
                 refill();
                 const uint32_t n = take(16), nn = take(16);
-                if ((n ^ nn) != 0xFFFFu) return false;
+                if ((n ^ nn) != 0xFFFFu) return 0;
                 // give back the whole bytes still in the bit buffer
                 const int back = bc_ >> 3;
-                if (over_ > back) return false;
+                if (over_ > back) return 0;
                 in_ -= back - over_; over_ = 0; bb_ = 0; bc_ = 0;
-                if ((size_t)(in_end_ - in_) < n || (size_t)(out_end - o) < n) return false;
-                std::memcpy(o, in_, n);
-                o += n; in_ += n;
+                if ((size_t)(in_end_ - in_) < n || (size_t)(out_end_ - o_) < n) return 0;
+                std::memcpy(o_, in_, n);
+                o_ += n; in_ += n;
             } else if (type == 1 || type == 2) {
-                if (!(type == 1 ? fixed_tables() : dynamic_tables())) return false;
-                if (!codes(out, o, out_end)) return false;
-            } else return false;
-            if (last) break;
+                return (type == 1 ? fixed_tables() : dynamic_tables()) ? 1 : 0;
+            } else return 0;
         }
-        return o == out_end && over_ * 8 <= bc_;      // every output byte, and no bit consumed beyond the input
     }
+    void begin(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
+    {
+        in_ = in; in_end_ = in + in_len; bb_ = 0; bc_ = 0; over_ = 0;
+        out0_ = o_ = out; out_end_ = out + out_len; last_ = false;
+    }
+    // from a compressed block whose tables are ready (advance() == 1) to the end of the stream
+    bool finish_alone()
+    {
+        for (;;) {
+            codes_fast();
+            if (!codes_careful()) return false;
+            const int st = advance();
+            if (st != 1) return st == 2;
+        }
+    }
+
+public:
+    // the raw deflate stream in[0, in_len) must inflate to exactly out_len bytes at out
+    bool run(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
+    {
+        begin(in, in_len, out, out_len);
+        const int st = advance();
+        return st == 1 ? finish_alone() : st == 2;
+    }
+    // `n` independent streams, N of them side by side at any time (see the header comment): ok[k] as run() would return
+    // for stream k.  lanes: N decoders of the calling thread.  A lane whose stream has ended takes the next one.
+    struct Job { const uint8_t *in; size_t in_len; uint8_t *out; size_t out_len; };
+    template <int N>
+    static void run_many(FastInflate *lanes, const Job *jobs, int n, bool *ok)
+    {
+        FastInflate *ln[N];
+        int job_of[N];
+        int next = 0, active = 0;
+        // the next stream with a compressed block into lane x (streams that end before one -- empty, stored only,
+        // malformed at once -- are settled here); false when no stream is left
+        auto load = [&](int x) -> bool {
+            while (next < n) {
+                const int k = next++;
+                if (!jobs[k].out_len) { ok[k] = true; continue; }
+                lanes[x].begin(jobs[k].in, jobs[k].in_len, jobs[k].out, jobs[k].out_len);
+                const int st = lanes[x].advance();
+                if (st == 1) { job_of[x] = k; return true; }
+                ok[k] = st == 2;
+            }
+            return false;
+        };
+        for (int x = 0; x < N; x++) {
+            ln[x] = &lanes[x];
+            job_of[x] = -1;
+            if (load(x)) active++;
+        }
+        while (active == N) {
+            int who = codes_fast_n<N>(ln);
+            if (who < 0) {
+                for (who = 0; who < N - 1 && ln[who]->in_fast_region(); who++) {}
+            }
+            // the stream that cannot go on in the fast region (the end of a deflate block, the last bytes of its buffers,
+            // a symbol the fast loop does not take) finishes its block on its own and takes the next one; the others are
+            // simply where the loop left them and rejoin as they are
+            FastInflate &x = *ln[who];
+            const int st = x.codes_careful() ? x.advance() : 0;
+            if (st != 1) {
+                ok[job_of[who]] = st == 2;
+                job_of[who] = -1;
+                if (!load(who)) active--;
+            }
+        }
+        for (int x = 0; x < N; x++)
+            if (job_of[x] >= 0) ok[job_of[x]] = ln[x]->finish_alone();
+    }
+
+private:
+    bool in_fast_region() const { return (size_t)(in_end_ - in_) >= 16 && (size_t)(out_end_ - o_) >= 320; }
 };
 
 inline bool inflate_raw_fast(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
 {
     static thread_local FastInflate fi;
     return fi.run(in, in_len, out, out_len);
+}
+
+// n independent raw deflate streams by one thread, NPORE_INFLATE_LANES of them side by side at any time
+#if !defined(NPORE_INFLATE_LANES)
+#define NPORE_INFLATE_LANES 2
+#endif
+inline void inflate_raw_fast_many(const FastInflate::Job *jobs, int n, bool *ok)
+{
+    static thread_local FastInflate lanes[NPORE_INFLATE_LANES];
+    FastInflate::run_many<NPORE_INFLATE_LANES>(lanes, jobs, n, ok);
 }
 
 }  // namespace npore

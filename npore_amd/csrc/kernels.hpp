@@ -24,8 +24,6 @@
 //                     (reference src/aln.pyx:670-742) and records the path as (type, length)
 //                     runs; per hop one 64-column group of the anti-diagonal landed on and
 //                     of the one below it, the hop loop written out in scalar instructions.
-//   traceback_kernel  the same through register windows of the band strip around the
-//                     path (the second implementation: run on request, tests, fuzz).
 //   gather_scan /     per read: length and status of the output, where every chunk's ops go;
 //   gather_kernel     one workgroup per chunk: expands the chunk's runs into the op
 //                     string in the caller's output buffer (src/aln.pyx:719-742);
@@ -994,162 +992,17 @@ struct TParams {
     int tbstride;
 };
 
-// One wavefront per chunk.  A hop of the traceback needs the word of one cell and the band position
-// of its anti-diagonal (inss[b]); the next cell is only known once that word has arrived, so the
-// traceback is a chain of dependent HBM round trips.  The path moves slowly through the band (its
-// column changes only where the new alignment leaves the input one), so instead of one row per hop the
-// wave gathers WINDOWS: lane l holds 8 consecutive columns of anti-diagonal top - l (and its inss) --
-// 64 anti-diagonals of the band strip around the path in one round trip.  Two windows are kept: the
-// one the path is in and the one below it, requested the moment the path enters the upper one, so its
-// latency overlaps the hops through the current window.  Hops inside a window are register reads
-// (v_readlane).  The kernel records RUNS (type, length), 64 at a time from a register buffer -- no store
-// per hop whose completion the next hop's counter wait would expose; gather_kernel expands them into ops.
-struct TbWindow {
-    // columns wc..wc+7 of anti-diagonal top - lane, as eight scalars: picking a column is a tree of selects on
-    // wave-uniform conditions (with vector types the compiler turns the pick into a dynamically indexed array,
-    // which it keeps in LDS: two LDS round trips per hop)
-    uint32_t c0, c1, c2, c3, c4, c5, c6, c7;
-    int ins;        // inss of that anti-diagonal
-    int top;        // newest anti-diagonal held (lane 0); rows top-63..top
-    int wc;         // first column (multiple of 4)
-};
-
-__global__ __launch_bounds__(64) void traceback_kernel(TParams p)
-{
-    const int k = blockIdx.x;
-    if (k >= *p.n_chunks) return;
-    const int lane = threadIdx.x;
-    const ChunkDesc d = p.descs[k];
-    const uint32_t *tb = p.tb + d.tb_off;
-    uint32_t *runs = p.chunk_runs + d.out_off;
-    const int W = 2 * p.r + 1, stride = p.tbstride;
-    int a_row = d.row0 + d.drows, a_col = d.col0 + d.dcols;
-    int pos = d.out_cap;   // ops still available in the chunk's slot
-    int status = 0;
-    int nruns = 0;
-    uint32_t rbuf = 0u;    // lane l: run number (nruns & ~63) + l
-
-    const int32_t *inss = p.inss + d.inss_off + d.brk;
-    constexpr int NONE = -(1 << 30);
-    TbWindow w0, w1;
-    w0.top = w1.top = NONE;
-    w0.wc = w1.wc = 0;
-    w0.c0 = w0.c1 = w0.c2 = w0.c3 = w0.c4 = w0.c5 = w0.c6 = w0.c7 = 0u;
-    w1.c0 = w1.c1 = w1.c2 = w1.c3 = w1.c4 = w1.c5 = w1.c6 = w1.c7 = 0u;
-    w0.ins = w1.ins = 0;
-    auto load_window = [&](TbWindow &w, int top, int col0) {
-        w.top = top;
-        w.wc = col0;
-        const int row = top - lane;
-        uint4 lo = make_uint4(0u, 0u, 0u, 0u), hi = lo;
-        w.ins = 0;
-        if (row >= 0 && row < d.nrows) {
-            const uint32_t *q = tb + (size_t)row * stride + col0;      // col0 + 3 < stride: both multiples of 4
-            lo = *reinterpret_cast<const uint4 *>(q);
-            if (col0 + 4 < stride) hi = *reinterpret_cast<const uint4 *>(q + 4);
-            w.ins = inss[row];
-        }
-        w.c0 = lo.x; w.c1 = lo.y; w.c2 = lo.z; w.c3 = lo.w;
-        w.c4 = hi.x; w.c5 = hi.y; w.c6 = hi.z; w.c7 = hi.w;
-    };
-    auto col_base = [&](int bc) { const int c = (bc - 2) & ~3; return c < 0 ? 0 : c; };   // bc lands at offset 2..5
-    // word of column bc (wave-uniform) on anti-diagonal bl of window w: per-lane selects on uniform
-    // conditions (no branch tree), then one cross-lane read
-    auto word = [&](const TbWindow &w, int bl, int bc) -> uint32_t {
-        const int kk = bc - w.wc;
-        const uint32_t a0 = (kk & 1) ? w.c1 : w.c0, a1 = (kk & 1) ? w.c3 : w.c2;
-        const uint32_t b0 = (kk & 1) ? w.c5 : w.c4, b1 = (kk & 1) ? w.c7 : w.c6;
-        const uint32_t lo2 = (kk & 2) ? a1 : a0, hi2 = (kk & 2) ? b1 : b0;
-        return (uint32_t)__builtin_amdgcn_readlane((int)((kk & 4) ? hi2 : lo2), w.top - bl);
-    };
-    // Software pipeline over windows: the window below the current one is requested at the top of the outer
-    // loop, the inner loop hops through the current window with register reads only (no load of either window
-    // inside it, so nothing in it waits on vmcnt), and the request is only waited for where the path leaves
-    // the current window.  A reload of the CURRENT window (the path jumped over a window, or drifted out of the
-    // 8-column strip) is waited for before the next request is issued: vmcnt completes in order, and a pending
-    // `cur` would make the first hop wait for the request behind it as well.
-    TbWindow &cur = w0, &nxt = w1;
-    constexpr int VMCNT0 = 0x0F70;              // s_waitcnt vmcnt(0) (expcnt / lgkmcnt fields at their maxima)
-    bool more = (a_row > d.row0 || a_col > d.col0);
-    if (more) {
-        load_window(cur, a_row + a_col - d.brk, col_base(p.r));   // the path ends on the input path: column r
-        __builtin_amdgcn_s_waitcnt(VMCNT0);
-    }
-    while (more) {
-        // (all of these are wave-uniform; saying so keeps them and the control flow below in scalar registers)
-        a_row = uni(a_row); a_col = uni(a_col); pos = uni(pos); nruns = uni(nruns); status = uni(status);
-        cur.top = uni(cur.top); cur.wc = uni(cur.wc);
-        const bool have_nxt = cur.top >= 64;
-        if (have_nxt) load_window(nxt, cur.top - 64, cur.wc);
-        int why = 0;                            // 1: the path left the window, 2: it left the strip, 3: finished / error
-        int bl = 0, bc = 0;
-        // The ordinary hop (a cell inside the window and the strip, a valid word) takes two combined tests; what
-        // exactly stopped the loop is sorted out afterwards, in the order the reference tests things
-        // (src/aln.pyx:680-716), so the status bits are the same as with one test per condition.
-        for (;;) {
-            bl = a_row + a_col - d.brk;
-            const int li = cur.top - bl;        // lane that holds anti-diagonal bl
-            const bool live = (a_row > d.row0) | (a_col > d.col0);
-            const bool inside = (a_row >= d.row0) & (a_col >= d.col0) & (bl >= 0) & (bl < d.nrows);
-            if (!(live & inside & (li < 64))) {
-                if (!live) why = 3;
-                else if (!inside) { status |= 16; why = 3; }
-                else why = 1;
-                break;
-            }
-            bc = __builtin_amdgcn_readlane(cur.ins, li) - a_row + p.r;     // inss[b] - a_row + r, src/aln.pyx:322-326
-            const unsigned kk = (unsigned)(bc - cur.wc);
-            if ((bc <= 0) | (bc >= W - 1) | (kk > 7u)) {
-                if (bc < 0 || bc >= W) { status |= 16; why = 3; }
-                else if (kk > 7u) why = 2;
-                else { status |= 4; why = 3; }      // band edge: TYP = MAT, RUN = 0 (src/aln.pyx:502-507) -> "run < 1"
-                break;
-            }
-            const uint32_t w = word(cur, bl, bc);
-            const int typ = tb_typ(w), run = tb_run(w);     // src/aln.pyx:684-685
-            if ((run < 1) | (run > pos) | (typ > T_SHR)) {
-                status |= (run < 1) ? 4 : (run > pos) ? 16 : 8;
-                why = 3;
-                break;
-            }
-            int emit = run;
-            const bool ins = (typ == T_LEN) | (typ == T_INS), del = (typ == T_SHR) | (typ == T_DEL);
-            if (typ == T_MAT) {
-                const int lim = min(a_row - d.row0, a_col - d.col0);
-                emit = run < lim ? run : lim;                          // diagonal steps that stay in the chunk
-            }
-            if (emit > 0) {
-                rbuf = (lane == (nruns & 63)) ? ((uint32_t)typ | ((uint32_t)emit << 3)) : rbuf;
-                nruns++;
-                if ((nruns & 63) == 0) runs[nruns - 64 + lane] = rbuf;
-            }
-            pos -= emit;
-            if (emit < run) { status |= 16; why = 3; break; }
-            a_row -= del ? 0 : emit;
-            a_col -= ins ? 0 : emit;
-        }
-        if (why == 3) break;
-        if (why == 1 && have_nxt && bl > nxt.top - 64) cur = nxt;       // the usual case: one window down
-        else {
-            if (why == 1) load_window(cur, bl, cur.wc);                 // a long run jumped over the window below
-            else load_window(cur, cur.top, col_base(bc));               // same anti-diagonals, other columns
-            __builtin_amdgcn_s_waitcnt(VMCNT0);
-        }
-    }
-    if (lane == 0) {
-        p.chunk_len[k] = d.out_cap - pos;
-        p.chunk_status[k] = status;
-        p.chunk_nruns[k] = nruns;
-    }
-    if (lane < (nruns & 63)) runs[(nruns & ~63) + lane] = rbuf;
-}
-
-// The same traceback with ONE coalesced load of the whole anti-diagonal plus inss[b] per hop, requested as soon
-// as the next cell is known: one memory round trip per hop instead of one per ~4 hops, a fraction of the windowed
-// kernel's instructions.  With thousands of chunks in flight the round trips of different chunks overlap and the
-// SCALAR instruction count per hop decides (everything here is wave-uniform: a SIMD issues one scalar instruction
-// per four cycles whatever the number of waves it holds); below that the chunk's chain of round trips does, which
-// the row requested BELOW every row shortens by the hops that land there (an indel of one base behind a diagonal run).
+// One wavefront per chunk (reference src/aln.pyx:670-742).  A hop of the traceback needs the word of one cell and the
+// band position of its anti-diagonal (inss[b]); the next cell is only known once that word has arrived, so a chunk's
+// traceback is a chain of dependent HBM round trips: the row the path lands on is requested as soon as the next cell is
+// known, and the anti-diagonal BELOW it comes with it (an indel of one base behind a diagonal run lands there and needs
+// no round trip of its own).  With thousands of chunks in flight the round trips of different chunks overlap and the
+// SCALAR instruction count per hop decides (everything here is wave-uniform: a SIMD issues about one scalar instruction
+// per four cycles whatever the number of waves it holds); below that the chunk's chain of round trips does.  The kernel
+// records RUNS (type, length), 64 at a time from a register buffer -- no store per hop whose completion the next hop's
+// counter wait would expose; gather_kernel / standardize_kernel work from the runs.  (Rounds 1 - 4 kept a second
+// implementation, windows of the band strip in registers; the row kernel has been the faster one at every batch size
+// since it holds the row below, and the duplicate was removed in round 5: LABNOTES.)
 // Of a row the wave holds ONE group of 64 columns, one word per lane (lane l = column 64 g + l), so the cell's word is
 // one v_readlane.  The group requested with a row is the one the path is in now: its band column changes only where
 // the new alignment leaves the input one, so the next cell is nearly always in the same group; where it is not, the row

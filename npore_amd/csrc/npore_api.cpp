@@ -203,7 +203,6 @@ struct npore_ctx {
     double totals[8] = {};       // like timing[], summed over every group since the context was made
     // tunables
     int64_t tb_budget_mb = 0;   // 0 = auto
-    int tb_kernel = 0;          // 0 = by batch size, 1 = windowed traceback, 2 = row per hop
     int force_chunks = 0;
     int device_glue = 1;        // BAM -> SAM pipeline: realign_read's glue on the device (0: on the host, from the op strings)
     int coresident = 1;         // kernel shapes that fit beside a fill kernel for a group that overlaps another one's
@@ -590,13 +589,8 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     tp.chunk_status = w->cstat.as<int32_t>();
     tp.r = r;
     tp.tbstride = tbs;
-    // the row kernel (kernels.hpp) unless the windowed one is asked for: since it requests the anti-diagonal below with every
-    // row it is the faster one at every batch size measured (10 kb reads: 0.53 ms at 500 chunk slots, 0.83 ms at 8 000; the
-    // windows: 0.58 ms up to 1 024 slots, in proportion beyond).  The windowed kernel stays as the second implementation the
-    // tests and the fuzz tool run against it.
-    const int tb_mode = ctx->tb_kernel ? ctx->tb_kernel : 2;
-    if (tb_mode == 1) hipLaunchKernelGGL(traceback_kernel, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
-    else hipLaunchKernelGGL(traceback_rows_kernel, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
+    // (10 kb reads: 0.53 ms at 500 chunk slots, 0.83 ms at 8 000)
+    hipLaunchKernelGGL(traceback_rows_kernel, dim3((unsigned)max_chunks), dim3(64), 0, s, tp);
     HIP_TRY(hipGetLastError());
 
     GParams gp;
@@ -1186,7 +1180,6 @@ try {
     else if (k == "device_glue") ctx->device_glue = value != 0;
     else if (k == "device_pack") ctx->device_pack = value != 0;
     else if (k == "fill_streams") { if (value < 1 || value > 2) return fail(NPORE_E_INVALID, "fill_streams: 1 or 2"); ctx->fill_streams = (int)value; }
-    else if (k == "traceback_kernel") { if (value < 0 || value > 2) return fail(NPORE_E_INVALID, "traceback_kernel: 0, 1 or 2"); ctx->tb_kernel = (int)value; }
     else return fail(NPORE_E_INVALID, "unknown key " + k);
     return NPORE_OK;
 }
@@ -1296,6 +1289,30 @@ int npore_debug_inflate(const uint8_t *in, int64_t in_len, uint8_t *out, int64_t
 {
     if (!in || !out || in_len < 0 || out_len < 0) return fail(NPORE_E_INVALID, "null argument");
     return inflate_block(in, (size_t)in_len, out, (size_t)out_len, force) ? 1 : 0;
+}
+
+int npore_debug_inflate_pair(const uint8_t *in_a, int64_t in_len_a, uint8_t *out_a, int64_t out_len_a, const uint8_t *in_b, int64_t in_len_b,
+                             uint8_t *out_b, int64_t out_len_b, int force)
+{
+    if (!in_a || !out_a || !in_b || !out_b || in_len_a < 0 || out_len_a < 0 || in_len_b < 0 || out_len_b < 0) return fail(NPORE_E_INVALID, "null argument");
+    // (through the readers' own entry: a list of blocks for one thread; the pair three times over, so that more lanes than
+    // two -- NPORE_INFLATE_LANES -- are exercised too: every copy must agree)
+    std::vector<uint8_t> ca((size_t)out_len_a * 2 + 1), cb((size_t)out_len_b * 2 + 1);
+    const FastInflate::Job jobs[6] = {{in_a, (size_t)in_len_a, out_a, (size_t)out_len_a}, {in_b, (size_t)in_len_b, out_b, (size_t)out_len_b},
+                                      {in_a, (size_t)in_len_a, ca.data(), (size_t)out_len_a}, {in_b, (size_t)in_len_b, cb.data(), (size_t)out_len_b},
+                                      {in_b, (size_t)in_len_b, cb.data() + out_len_b, (size_t)out_len_b}, {in_a, (size_t)in_len_a, ca.data() + out_len_a, (size_t)out_len_a}};
+    bool ok[6] = {false, false, false, false, false, false};
+    if (force != 2) inflate_raw_fast_many(jobs, 6, ok);
+    if (force != 1)
+        for (int k = 0; k < 6; k++)
+            if (!ok[k]) ok[k] = inflate_block(jobs[k].in, jobs[k].in_len, jobs[k].out, jobs[k].out_len, 2);
+    const bool oa = ok[0], ob = ok[1];
+    if (ok[2] != oa || ok[5] != oa || ok[3] != ob || ok[4] != ob) return fail(NPORE_E_INVALID, "copies of one stream disagree");
+    if (oa && (std::memcmp(out_a, ca.data(), (size_t)out_len_a) || std::memcmp(out_a, ca.data() + out_len_a, (size_t)out_len_a)))
+        return fail(NPORE_E_INVALID, "copies of stream a differ");
+    if (ob && (std::memcmp(out_b, cb.data(), (size_t)out_len_b) || std::memcmp(out_b, cb.data() + out_len_b, (size_t)out_len_b)))
+        return fail(NPORE_E_INVALID, "copies of stream b differ");
+    return (oa ? 1 : 0) | (ob ? 2 : 0);
 }
 
 int npore_debug_dpp(uint32_t *out128)

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """End-to-end BAM -> SAM throughput of the realign path with a stage breakdown.
 
-A synthetic BAM is made from `--distinct` reads of the bench generator laid end to end on one contig and repeated to
-`--reads` records (the record block is replicated at the byte level and compressed on a thread pool, so a 48 000-read /
-0.7 GB file takes seconds, not minutes).  One JSON line: the stages of the native pipeline (open = BGZF inflate + record
+A synthetic BAM is made from `--reads` reads of the bench generator laid end to end on one contig -- every read its own
+draw, qualities one uniform draw per base over phred 0 ... 93 as the reference's fixture generator draws them
+(test/generate_bam.py:63,79) -- on a pool of worker processes, BGZF-compressed on a thread pool (zlib level 1).
+`--distinct d --const-qual` makes the file of rounds 3 - 4 instead (d reads repeated, constant qualities: a third of the
+bytes per read, and blocks that are all matches).  One JSON line: the stages of the native pipeline (open = BGZF inflate + record
 index, select, then per batch record fetch + pack | H2D + kernels + D2H | standardise | SAM text | write, overlapped by
 npore_bam_realign_file), the GPU's busy share of the wall time, reads/s; the same for a STREAMED handle
 (bounded-memory ingest) with the process's peak resident set; and the pure-Python restatement on a few reads.
@@ -40,43 +42,78 @@ def bgzf_write(path, data, level=1, threads=16):
         fh.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
 
 
-def build_inputs(tmp, n, distinct, ref_len, seed):
-    distinct = min(distinct, n)
-    refs, seqs, cigs = synth.make_batch(seed, distinct, ref_len=ref_len)
+_SEQ_NIB = np.array([15, 1, 2, 4, 8], np.uint8)         # base codes N A C G T -> BAM 4-bit codes (=ACMGRSVTWYHKDBN)
+
+
+def _encode_span(job):
+    """Worker: reads first ... first + count - 1 of the bench generator as BAM records (bytes) + their stretch of the contig.
+    Qualities: one uniform draw per base over phred 0 ... 93, as the reference's own fixture generator does
+    (test/generate_bam.py:63,79: chr(randint(33, 127)) per base) -- or the constant 20 of rounds 3 - 4 (`const_qual`)."""
+    seed, first, count, ref_len, const_qual = job
     dec = np.frombuffer(b"NACGT", np.uint8)
-    contig, recs, pos = [], [], 0
-    for k, (rf, sq, cg) in enumerate(zip(refs, seqs, cigs)):
+    recs, contig = [], []
+    for k in range(first, first + count):
+        rf, sq, cg = synth.make_pair(seed, k, ref_len)
         cg = np.frombuffer(cg, np.uint8)
         edges = np.flatnonzero(np.diff(cg)) + 1
-        starts = np.concatenate(([0], edges)); lens = np.diff(np.concatenate((starts, [len(cg)])))
-        ops = [("MIDNSHP=XB".index(chr(cg[s])), int(l)) for s, l in zip(starts, lens)]
-        recs.append(dict(name=f"read{k}", flag=0, ref_id=0, pos=pos, cigar=ops, seq=dec[sq].tobytes().decode(),
-                         qual=bytes([20]) * len(sq), hp=k % 3))
+        starts = np.concatenate(([0], edges))
+        lens = np.diff(np.concatenate((starts, [len(cg)]))).astype(np.uint32)
+        opc = np.zeros(256, np.uint32)
+        for ch, code in (("I", 1), ("D", 2), ("=", 7), ("X", 8), ("M", 0)):
+            opc[ord(ch)] = code
+        cig = ((lens << 4) | opc[cg[starts]]).astype("<u4").tobytes()
+        nib = _SEQ_NIB[sq]
+        if len(nib) & 1:
+            nib = np.concatenate((nib, np.zeros(1, np.uint8)))
+        packed = ((nib[0::2] << 4) | nib[1::2]).astype(np.uint8).tobytes()
+        if const_qual:
+            qual = bytes([20]) * len(sq)
+        else:
+            qual = np.random.Generator(np.random.PCG64(seed * 7919 + k)).integers(0, 94, len(sq), dtype=np.uint8).tobytes()
+        name = f"read{k}".encode() + b"\0"
+        body = struct.pack("<iiBBHHHiiii", 0, k * ref_len, len(name), 60, 4680, len(lens), 0, len(sq), -1, -1, 0) + \
+            name + cig + packed + qual + b"HPC" + bytes([k % 3])
+        recs.append(struct.pack("<i", len(body)) + body)
         contig.append(dec[rf].tobytes())
-        pos += len(rf)
+        assert len(rf) == ref_len
+    return b"".join(recs), b"".join(contig)
+
+
+def build_inputs(tmp, n, distinct, ref_len, seed, const_qual=False, procs=0):
+    """The BAM (BGZF, zlib level 1) and FASTA of `n` reads laid end to end on one contig.  distinct = 0 (default): every
+    read is its own draw of the generator, made on a pool of worker processes; distinct = d < n: the first d reads'
+    record block repeated at the byte level (rounds 3 - 4: 4 000 distinct reads x 24)."""
+    import multiprocessing as mp
+    distinct = n if distinct <= 0 else min(distinct, n)
+    procs = procs or max(1, min(16, len(os.sched_getaffinity(0))))
+    span = 250
+    jobs = [(seed, k, min(span, distinct - k), ref_len, const_qual) for k in range(0, distinct, span)]
+    recs, contig = [], []
+    with mp.get_context("spawn").Pool(procs) as pool:
+        for r_, c_ in pool.imap(_encode_span, jobs):
+            recs.append(r_); contig.append(c_)
     contig = b"".join(contig)
     fa = os.path.join(tmp, "ref.fa")
     with open(fa, "wb") as fh:
         fh.write(b">ctg\n")
-        for i in range(0, len(contig), 60):
-            fh.write(contig[i:i + 60] + b"\n")
-    small = os.path.join(tmp, "distinct.bam")
-    bam.write_bam(small, [("ctg", len(contig))], recs, level=1)
-    raw = bam._bgzf_decompress(small)
-    l_text, = struct.unpack_from("<i", raw, 4)
-    p = 8 + l_text
-    n_ref, = struct.unpack_from("<i", raw, p); p += 4
-    for _ in range(n_ref):
-        l_name, = struct.unpack_from("<i", raw, p); p += 8 + l_name
-    header, body = raw[:p], raw[p:]
+        arr = np.frombuffer(contig, np.uint8)
+        full = len(arr) // 60 * 60
+        lines = np.empty((full // 60, 61), np.uint8)
+        lines[:, :60] = arr[:full].reshape(-1, 60)
+        lines[:, 60] = 10
+        fh.write(lines.tobytes())
+        if full < len(arr):
+            fh.write(arr[full:].tobytes() + b"\n")
+    text = f"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:ctg\tLN:{len(contig)}\n"
+    header = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", 1) + \
+        struct.pack("<i", 4) + b"ctg\0" + struct.pack("<i", len(contig))
+    body = b"".join(recs)
     reps, rest = divmod(n, distinct)
-    # the first `rest` records once more
     q = 0
-    for _ in range(rest):
+    for _ in range(rest):                        # the first `rest` records once more
         bs, = struct.unpack_from("<i", body, q); q += 4 + bs
     bp = os.path.join(tmp, "reads.bam")
-    bgzf_write(bp, header + body * reps + body[:q])
-    os.remove(small)
+    bgzf_write(bp, header + body * reps + body[:q], threads=procs)
     return bp, fa, len(contig)
 
 
@@ -126,7 +163,11 @@ def run_one_pass(ctx, bp, fa, clen, a, out):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=48000)
-    ap.add_argument("--distinct", type=int, default=4000)
+    ap.add_argument("--distinct", type=int, default=0,
+                    help="0 (default): every read distinct; d > 0: d distinct reads repeated to --reads (rounds 3 - 4 used 4000)")
+    ap.add_argument("--const-qual", action="store_true",
+                    help="qualities = the constant 20 (rounds 3 - 4) instead of one uniform draw per base over phred 0 ... 93 "
+                         "(what the reference's fixture generator draws: test/generate_bam.py:63,79)")
     ap.add_argument("--ref-len", type=int, default=10000)
     ap.add_argument("--r", type=int, default=30)
     ap.add_argument("--batch", type=int, default=2000)
@@ -138,14 +179,23 @@ def main():
                     help="only the ONE-PASS leg, SAM text to /dev/null: bounded memory and the host's inflate rate on a file of tens of GB")
     ap.add_argument("--streamed-only", action="store_true",
                     help="only the STREAMED leg, SAM text to /dev/null: the bounded-memory demonstration on a file of tens of GB")
+    ap.add_argument("--gen-into", default=None, help=argparse.SUPPRESS)       # (internal: make the inputs in this directory and exit)
     a = ap.parse_args()
+    if a.gen_into:
+        print(json.dumps(build_inputs(a.gen_into, a.reads, a.distinct, a.ref_len, a.seed, a.const_qual)))
+        return
     sub, nps, _, _ = aln.load_default_tables()
     with tempfile.TemporaryDirectory(dir=a.tmp) as tmp:
         t = time.perf_counter()
-        # (in a child process: the generator's 0.7 GB of Python byte strings must not count towards this process's peak RSS)
-        import multiprocessing as mp
-        with mp.get_context("spawn").Pool(1) as pool:
-            bp, fa, clen = pool.apply(build_inputs, (tmp, a.reads, a.distinct, a.ref_len, a.seed))
+        # (in a child process of its own -- it runs a pool of workers -- : the generator's GBs of Python byte strings must
+        # not count towards this process's peak RSS)
+        import subprocess
+        gen = subprocess.run([sys.executable, os.path.abspath(__file__), "--gen-into", tmp, "--reads", str(a.reads), "--distinct", str(a.distinct),
+                              "--ref-len", str(a.ref_len), "--seed", str(a.seed)] + (["--const-qual"] if a.const_qual else []),
+                             capture_output=True, text=True)
+        if gen.returncode != 0:
+            sys.exit("input generation failed:\n" + gen.stderr[-3000:])
+        bp, fa, clen = json.loads(gen.stdout.strip().splitlines()[-1])
         t_gen = time.perf_counter() - t
         ctx = aln.Context(sub, nps)
         cfg.args = argparse.Namespace(max_n=6, max_l=100, regions=[("ctg", 0, clen - 1)], max_reads=0)
@@ -157,7 +207,7 @@ def main():
             one_pass = run_one_pass(ctx, bp, fa, clen, a, "/dev/null")
             one_pass["peak_rss_mb"] = round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0, 1)
             print(json.dumps({"metric": "BAM->SAM realigned reads/sec (one-pass ingest, SAM text discarded)", "value": one_pass["reads_per_s"],
-                              "unit": "reads/s", "reads": a.reads, "distinct_reads": min(a.distinct, a.reads), "r": a.r, "batch": a.batch,
+                              "unit": "reads/s", "reads": a.reads, "distinct_reads": a.reads if a.distinct <= 0 else min(a.distinct, a.reads), "qualities": "constant 20" if a.const_qual else "uniform per base over phred 0 ... 93", "r": a.r, "batch": a.batch,
                               "bam_bytes": os.path.getsize(bp), "one_pass": one_pass, "rss_mb_before_timed_runs": round(rss0 / 1024.0, 1),
                               "input_generation_s": round(t_gen, 1)}))
             ctx.close()
@@ -166,7 +216,7 @@ def main():
         streamed["peak_rss_mb"] = round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0, 1)
         if a.streamed_only:
             print(json.dumps({"metric": "BAM->SAM realigned reads/sec (streamed ingest, SAM text discarded)", "value": streamed["reads_per_s"],
-                              "unit": "reads/s", "reads": a.reads, "distinct_reads": min(a.distinct, a.reads), "r": a.r, "batch": a.batch,
+                              "unit": "reads/s", "reads": a.reads, "distinct_reads": a.reads if a.distinct <= 0 else min(a.distinct, a.reads), "qualities": "constant 20" if a.const_qual else "uniform per base over phred 0 ... 93", "r": a.r, "batch": a.batch,
                               "bam_bytes": os.path.getsize(bp), "streamed": streamed, "rss_mb_before_timed_runs": round(rss0 / 1024.0, 1),
                               "input_generation_s": round(t_gen, 1)}))
             ctx.close()
@@ -207,7 +257,9 @@ def main():
         line = {"metric": "BAM->SAM realigned reads/sec (end to end, file to file)", "value": one_pass["reads_per_s"], "unit": "reads/s",
                 "value_is": "the one-pass reader (what `python -m npore_amd.realign` uses for one process and whole-contig regions)",
                 "one_pass": one_pass, "one_pass_output_identical": same_one_pass,
-                "reads": a.reads, "distinct_reads": min(a.distinct, a.reads), "ref_len": a.ref_len, "r": a.r, "batch": a.batch,
+                "reads": a.reads, "distinct_reads": a.reads if a.distinct <= 0 else min(a.distinct, a.reads),
+                "qualities": "constant 20" if a.const_qual else "uniform per base over phred 0 ... 93 (reference test/generate_bam.py:63,79)",
+                "ref_len": a.ref_len, "r": a.r, "batch": a.batch,
                 "host_cpus": len(os.sched_getaffinity(0)), "bam_bytes": os.path.getsize(bp),
                 "resident": resident, "streamed": streamed, "streamed_output_identical": same,
                 "rss_mb_before_timed_runs": round(rss0 / 1024.0, 1), "python_restatement": py, "input_generation_s": round(t_gen, 1)}

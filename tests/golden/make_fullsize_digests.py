@@ -7,10 +7,15 @@ bench configurations in the build container, where CPU ti
 is free, and stores (len, sha256[:16]) per read, so that the GPU tests compare
 EVERY read of every full-size configuration bit for bit at no cost on the GPU box:
 
-  c2     1 000 reads, seed 2, 10 kb, r=100                      (BASELINE configs[1])
-  r30    4 000 reads, seed 2, 10 kb, r=30                       (the tool's default band)
+  c2     8 000 reads, seed 2, 10 kb, r=100                      (BASELINE configs[1]; indices 0 ... 7 999 are what
+                                                                 the ranks of `bench.py --gpus 8` hold: rank k has k, k + 8, ...)
+  r30    first 4 000 reads + every 7th up to 32 000, seed 2, r=30   (the tool's default band; the `production_default` leg of
+                                                                 8 ranks x 4 000 reads; 7 is coprime to 1 / 2 / 4 / 8 ranks, so
+                                                                 every rank of every world size holds sampled reads)
   c5       256 reads, seed 5, 50 kb, r=200                      (BASELINE configs[4])
   c3    first 10 000 reads + every 10th after, seed 3 mixed     (BASELINE configs[2])
+  c4    first 8 000 reads + every 101st up to 1 000 000, seed 4 mixed, r=100   (BASELINE configs[3]; 101 is prime: every
+                                                                 rank of a round-robin deal holds sampled reads)
 
     python tests/golden/make_fullsize_digests.py [--procs 8] [--only c2,r30]
 
@@ -33,10 +38,11 @@ sys.path.insert(0, REPO)
 
 CONFIGS = {
     # name: (base_seed, ref_len, mixed, r, indices)
-    "c2": (2, 10_000, False, 100, np.arange(1000)),
-    "r30": (2, 10_000, False, 30, np.arange(4000)),
+    "c2": (2, 10_000, False, 100, np.arange(8000)),
+    "r30": (2, 10_000, False, 30, np.concatenate([np.arange(4000), np.arange(4000, 32_000, 7)])),
     "c5": (5, 50_000, False, 200, np.arange(256)),
     "c3": (3, 10_000, True, 100, np.concatenate([np.arange(10_000), np.arange(10_000, 100_000, 10)])),
+    "c4": (4, 10_000, True, 100, np.concatenate([np.arange(8000), np.arange(8000, 1_000_000, 101)])),
 }
 
 
@@ -73,14 +79,21 @@ def main():
         for name in names:
             seed, ref_len, mixed, r, idx = CONFIGS[name]
             t0 = time.time()
+            # reads the file already holds are kept (a digest is a function of (seed, index, r) alone)
+            have = {}
+            if name + "_idx" in res:
+                have = {int(i): (int(l), int(d)) for i, l, d in zip(res[name + "_idx"], res[name + "_len"], res[name + "_dig"])}
+            todo = np.array([i for i in idx if int(i) not in have], np.int64)
             span = 8 if ref_len > 20_000 else 50
-            jobs = [(seed, ref_len, mixed, r, idx[k:k + span]) for k in range(0, len(idx), span)]
+            jobs = [(seed, ref_len, mixed, r, todo[k:k + span]) for k in range(0, len(todo), span)]
             parts = pool.map(_work, jobs, chunksize=1)
+            for i, l, d in zip(todo, (x for p in parts for x in p[0]), (x for p in parts for x in p[1])):
+                have[int(i)] = (l, d)
             res[name + "_idx"] = idx.astype(np.int32)
-            res[name + "_len"] = np.array([x for p in parts for x in p[0]], np.int32)
-            res[name + "_dig"] = np.array([x for p in parts for x in p[1]], np.uint64)
+            res[name + "_len"] = np.array([have[int(i)][0] for i in idx], np.int32)
+            res[name + "_dig"] = np.array([have[int(i)][1] for i in idx], np.uint64)
             np.savez_compressed(out_path, **res)
-            print(f"{name}: {len(idx)} reads in {time.time() - t0:.0f} s", flush=True)
+            print(f"{name}: {len(todo)} new of {len(idx)} reads in {time.time() - t0:.0f} s", flush=True)
 
 
 if __name__ == "__main__":

@@ -39,6 +39,29 @@ def test_bench_two_ranks_on_one_gpu():
     # two ranks on ONE card: the reduction goes over gloo (RCCL needs a device per rank), host-side generation is reported
     # and lies before the timed region
     assert line["config"]["reduction_backend"].startswith("gloo") and line["config"]["host_setup"]["generate_s_max_over_ranks"] > 0
+    # (3 kb reads have no committed digests: the main leg compares nothing; the production leg's 2 x 64 reads are r30's 0 ... 127)
+    assert line["parity"]["main"]["strings_compared"] == 0
+    assert line["parity"]["production_default"] == {"strings_compared": 128, "strings_bad": 0}
+
+
+def test_bench_four_ranks_every_rank_proves_its_strings():
+    """The driver's scaling command at N = 4 with all ranks on this box's one card: `bench.py --gpus 4` at the C2 shape
+    (250 reads per rank, r=100) -- EVERY rank compares EVERY string with the committed digest of the pinned oracle (rank
+    k holds read indices k, k + 4, ...: 0 ... 999 of `c2`), and the production leg's reads (r=30) likewise.  Four ranks,
+    not eight: the pool allows six processes on the card at once, and this pytest process is one of them."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29700 + os.getpid() % 100
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"),
+           "--gpus", "4", "--reads", "250", "--steps", "2", "--warmup", "1", "--sustain", "0", "--pcie-steps", "0",
+           "--no-cpu", "--production", "0.05", "--production-reads", "100", "--solo-steps", "1"]
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 4 and line["bad_reads"] == 0
+    assert line["parity"]["main"] == {"strings_compared": 1000, "strings_bad": 0}
+    assert line["parity"]["production_default"] == {"strings_compared": 400, "strings_bad": 0}
+    assert line["parity"]["strings_compared"] == 1400 and line["parity"]["strings_bad"] == 0
 
 
 def test_bench_two_ranks_production_shape_bookkeeping():
@@ -57,6 +80,9 @@ def test_bench_two_ranks_production_shape_bookkeeping():
     assert line["n_gpus"] == 2 and line["config"]["reads_per_gpu"] == 4000 and line["bad_reads"] == 0
     assert abs(line["value"] - 2 * 4000 / (line["ms_per_step"] * 1e-3)) < 0.01 * line["value"]
     assert line["config"]["parallelism"] == "reads x2" and line["scaling"] == "weak"
+    # rank k holds reads k, k + 2, ... of seed 2 at r=30: indices 0 ... 7 999, of which `r30` holds the first 4 000 and
+    # every 7th after (4 000 + 572)
+    assert line["parity"]["main"]["strings_bad"] == 0 and line["parity"]["main"]["strings_compared"] == 4000 + len(range(4000, 8000, 7))
 
 
 _NP_INFO_FIRST = r"""

@@ -268,15 +268,11 @@ def test_bands_of_nine_to_sixteen_waves(ctx, tables, r):
     ref, seq = refs[0], seqs[0]
     m = min(len(ref), len(seq)) - 30
     refs.append(ref); seqs.append(seq); cigs.append("I" * (len(seq) - m) + "D" * (len(ref) - m) + "=" * m)
-    c2 = aln.Context(sub, nps, max_n=6, max_l=100, device=0)
-    c2.set("traceback_kernel", 2)
-    for cx, mbrs in ((ctx, (1500, 150)), (c2, (1500,))):
-        for mbr in mbrs:
-            got, st = cx.align_batch(refs, seqs, cigs, r=r, max_b_rows=mbr, return_status=True)
-            for k in range(len(refs)):
-                want, wst = oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=r, max_b_rows=mbr, return_status=True)
-                assert got[k] == want and st[k] == wst, (r, mbr, k)
-    c2.close()
+    for mbr in (1500, 150):
+        got, st = ctx.align_batch(refs, seqs, cigs, r=r, max_b_rows=mbr, return_status=True)
+        for k in range(len(refs)):
+            want, wst = oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=r, max_b_rows=mbr, return_status=True)
+            assert got[k] == want and st[k] == wst, (r, mbr, k)
 
 
 def test_div_small_domain():
@@ -775,14 +771,12 @@ def test_narrow_band_window_over_long_deletions(ctx, tables, r):
             assert got[k] == want and st[k] == wst, (r, mbr, k)
 
 
-@pytest.mark.parametrize("mode", [1, 2])
-def test_both_traceback_kernels(tables, mode):
-    """The windowed traceback (small batches) and the row-per-hop one (large batches) record the same runs:
-    strings and status bits equal the oracle's at several band widths, incl. tiny max_b_rows (many chunks)
-    and reads whose input CIGAR is far from the best path (the path drifts through the band)."""
+def test_traceback_drifting_paths_and_status(tables):
+    """The traceback (one kernel since round 5: a 64-column group of the row landed on and of the row below per request)
+    records the oracle's runs: strings and status bits equal at several band widths, incl. tiny max_b_rows (many chunks)
+    and reads whose input CIGAR is far from the best path (the path drifts through the band's groups and leaves it)."""
     sub, nps = tables
     c = aln.Context(sub, nps, max_n=6, max_l=100, device=0)
-    c.set("traceback_kernel", mode)
     rng = np.random.default_rng(44)
     refs, seqs, cigs = synth.make_batch(808, 10, ref_len=1200, p_np=0.1)
     # a few reads with a deliberately bad input path: all insertions first, then all deletions, then matches
@@ -799,7 +793,7 @@ def test_both_traceback_kernels(tables, mode):
             if r > 255 and k % 3:
                 continue                            # (the oracle's state matrix at r = 400 is slow to set up: a third of the reads)
             want, wst = oracle.align(refs[k], seqs[k], cigs[k], sub, nps, r=r, max_b_rows=mbr, return_status=True)
-            assert got[k] == want and st[k] == wst, (mode, r, mbr, k)
+            assert got[k] == want and st[k] == wst, (r, mbr, k)
     c.close()
 
 

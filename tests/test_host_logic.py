@@ -269,6 +269,38 @@ def test_bench_cpu_baseline_leg(tables):
     assert len(bench.csrc_sha()) == 16
 
 
+def test_bench_digest_parity_every_rank(tables):
+    """bench.py's per-rank string check (any world size): rank k of N holds reads k, k + N, ... and compares each
+    output whose read index has a committed digest of the pinned oracle; a flipped byte or a wrong length is counted
+    as bad, reads without a digest and configurations without a table are skipped."""
+    import bench
+    sub, nps = tables
+    z = np.load(os.path.join(REPO, "tests", "golden", "fullsize_digests.npz"))
+    assert set(z["c2_idx"][:8000].tolist()) >= set(range(8000))          # what 8 ranks x 1 000 reads hold
+    for world_size in (1, 2, 4, 8):                                     # every rank of every world size holds sampled reads
+        for name in ("r30", "c4"):
+            assert len(set((z[name + "_idx"] % world_size).tolist())) == world_size, (name, world_size)
+    key = (2, False, 10_000, 100, 20000)
+    world_size, n = 4, 3
+    for rank in (0, 3):
+        idx = [rank + k * world_size for k in range(n)]
+        outs = [oracle.align(*synth.make_pair(2, i, 10_000), sub, nps, r=100).encode() for i in idx]
+        oo = np.zeros(n + 1, np.int64)
+        oo[1:] = np.cumsum([len(o) + 100 for o in outs])                 # slots larger than the strings, as in bench.py
+        buf = np.zeros(int(oo[-1]), np.uint8)
+        for k, o in enumerate(outs):
+            buf[oo[k]:oo[k] + len(o)] = np.frombuffer(o, np.uint8)
+        ln = np.array([len(o) for o in outs], np.int64)
+        assert bench.digest_parity(key, idx, buf, oo, ln) == (n, 0)
+        bad = buf.copy()
+        bad[oo[1] + 5] ^= 1
+        assert bench.digest_parity(key, idx, bad, oo, ln) == (n, 1)
+        ln2 = ln.copy(); ln2[2] -= 1
+        assert bench.digest_parity(key, idx, buf, oo, ln2) == (n, 1)
+        assert bench.digest_parity(key, [10_000_000 + i for i in idx], buf, oo, ln) == (0, 0)      # no digest: skipped
+        assert bench.digest_parity((9, False, 10_000, 100, 20000), idx, buf, oo, ln) == (0, 0)     # no table
+
+
 def _parts_worker(rank, world_size, port, prefix, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size),
                       LOCAL_RANK=str(rank))
@@ -414,6 +446,20 @@ def test_inflated_bam_copy_shared_between_local_ranks(tmp_path, monkeypatch):
         open(f"/dev/shm/npore_bam_{key}.pid", "w").write(str(pr.pid))
         assert bam.NativeBam._wait_for_maker(key, f"/dev/shm/npore_bam_{key}.raw", f"/dev/shm/npore_bam_{key}.skip", 30.0) is False
         os.remove(f"/dev/shm/npore_bam_{key}.pid")
+        # a maker that never shows up (no pid file: the ranks' keys differ, or local rank 0 does not run this code): the
+        # waiting rank gives up after the grace period, long before the sharing timeout
+        import time
+        monkeypatch.setenv("NPORE_SHARE_GRACE_S", "0.3")
+        t0 = time.time()
+        assert bam.NativeBam._wait_for_maker("feedfacefeedface", "/dev/shm/npore_bam_feedfacefeedface.raw",
+                                             "/dev/shm/npore_bam_feedfacefeedface.skip", 60.0) is False
+        assert time.time() - t0 < 5.0
+        # the key holds nothing per-process: a rank started by another parent (a per-rank wrapper script) computes the same
+        code = ("import sys; sys.path.insert(0, %r); from npore_amd import bam; print(bam.NativeBam._shm_key(%r))" % (REPO, path))
+        monkeypatch.setenv("LOCAL_RANK", "1")
+        k_direct = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True).stdout.strip()
+        k_wrapped = subprocess.run(["bash", "-c", f"true; {sys.executable} -c {code!r}; true"], capture_output=True, text=True).stdout.strip()
+        assert len(k_direct) == 16 and k_direct == k_wrapped
         for f in (shared.replace(".raw", ".skip"), maker2._shared and "" or ""):
             if f and os.path.exists(f):
                 os.remove(f)
@@ -451,7 +497,15 @@ def test_inflate_decoder_equals_zlib(tmp_path):
     datas = [b"", b"A", b"ACGT" * 5000, bytes(rng.integers(0, 256, 60000, dtype=np.uint8)), bytes(rng.integers(0, 4, 65280, dtype=np.uint8)),
              b"\0" * 65280, bytes(rng.choice(np.frombuffer(b"ACGTN", np.uint8), 40000)) + bytes(rng.integers(33, 75, 25000, dtype=np.uint8)),
              bytes(np.repeat(rng.integers(0, 256, 300, dtype=np.uint8), rng.integers(1, 300, 300)))[:65000]]
+    def inflate_pair(raw_a, n_a, raw_b, n_b, force):
+        oa, ob = np.full(n_a + 64, 0xA5, np.uint8), np.full(n_b + 64, 0x5A, np.uint8)
+        sa, sb = np.frombuffer(raw_a, np.uint8), np.frombuffer(raw_b, np.uint8)
+        rc = lib.npore_debug_inflate_pair(sa.ctypes.data, len(raw_a), oa[32:].ctypes.data, n_a, sb.ctypes.data, len(raw_b), ob[32:].ctypes.data, n_b, force)
+        assert (oa[:32] == 0xA5).all() and (oa[32 + n_a:] == 0xA5).all() and (ob[:32] == 0x5A).all() and (ob[32 + n_b:] == 0x5A).all(), "wrote outside a block"
+        return rc, oa[32:32 + n_a].tobytes(), ob[32:32 + n_b].tobytes()
+
     n_fast = n_all = 0
+    streams = []                                                    # (raw, data) of every case, for the pairs below
     for data in datas:
         for level in (0, 1, 4, 6, 9):
             for strat in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_RLE, zlib.Z_HUFFMAN_ONLY, zlib.Z_FILTERED):
@@ -463,9 +517,20 @@ def test_inflate_decoder_equals_zlib(tmp_path):
                 rc1, got1 = inflate(raw, len(data), 1)
                 assert rc1 == 0 or got1 == data, (len(data), level, strat)
                 n_fast += rc1; n_all += 1
+                streams.append((raw, data, rc1))
                 if len(data) > 1:                                   # a wrong announced size is refused by both
                     assert inflate(raw, len(data) - 1, 1)[0] == 0 and inflate(raw, len(data) + 1, 0)[0] == 0
     assert n_fast >= 0.9 * n_all, (n_fast, n_all)                   # the decoder takes nearly everything itself
+    # two streams side by side (how the readers take a file's blocks): every case with a partner drawn at random -- long
+    # with short, stored with dynamic, many deflate blocks with one -- gives what each gives alone, decoder only and with
+    # the zlib fallback
+    order = rng.permutation(len(streams))
+    for i, j in zip(range(len(streams)), order.tolist()):
+        (ra, da, fa), (rb, db, fb) = streams[i], streams[j]
+        rc, ga, gb = inflate_pair(ra, len(da), rb, len(db), 0)
+        assert rc == 3 and ga == da and gb == db, (i, j)
+        rc, ga, gb = inflate_pair(ra, len(da), rb, len(db), 1)
+        assert (rc & 1) == fa and (rc >> 1) == fb and (not fa or ga == da) and (not fb or gb == db), (i, j, rc)
     # the blocks of a real BAM
     for name in ("reads.bam",):
         raw = open(os.path.join(GOLDEN, "data", name), "rb").read()
@@ -489,6 +554,14 @@ def test_inflate_decoder_equals_zlib(tmp_path):
             bad = bad[:int(rng.integers(1, len(bad)))]
         inflate(bytes(bad), len(datas[6]), 1)
         inflate(bytes(bad), len(datas[6]), 0)
+        # beside a corrupted partner (either side) a good stream still inflates, and nobody writes outside its own buffer
+        good_raw, good = streams[int(rng.integers(0, len(streams)))][:2]
+        if k % 2:
+            rc, _, gb = inflate_pair(bytes(bad), len(datas[6]), good_raw, len(good), 0)
+            assert rc & 2 and gb == good
+        else:
+            rc, ga, _ = inflate_pair(good_raw, len(good), bytes(bad), len(datas[6]), 0)
+            assert rc & 1 and ga == good
 
 
 def test_one_pass_handle_reads_only_the_header():

@@ -96,9 +96,12 @@ def test_fullsize_digests_are_the_oracles(tables):
     from npore_amd import synth
     sub, nps = tables
     z = np.load(os.path.join(GOLDEN, "fullsize_digests.npz"))
-    assert [len(z[k + "_idx"]) for k in ("c2", "r30", "c5", "c3")] == [1000, 4000, 256, 19000]
-    for name, seed, ref_len, mixed, r, i in (("c2", 2, 10_000, False, 100, 511), ("r30", 2, 10_000, False, 30, 2048),
-                                             ("c3", 3, 10_000, True, 100, 99_990), ("c3", 3, 10_000, True, 100, 4_321)):
+    # (round 5: c2 / r30 cover what the ranks of an 8-GPU run hold -- indices 0 ... 7 999, and 0 ... 31 999 sampled; c4 is new)
+    assert [len(z[k + "_idx"]) for k in ("c2", "r30", "c5", "c3", "c4")] == [8000, 8000, 256, 19000, 17822]
+    for name, seed, ref_len, mixed, r, i in (("c2", 2, 10_000, False, 100, 511), ("c2", 2, 10_000, False, 100, 7_777),
+                                             ("r30", 2, 10_000, False, 30, 2048), ("r30", 2, 10_000, False, 30, 4000 + 7 * 3999),
+                                             ("c3", 3, 10_000, True, 100, 99_990), ("c3", 3, 10_000, True, 100, 4_321),
+                                             ("c4", 4, 10_000, True, 100, 7_001), ("c4", 4, 10_000, True, 100, 8000 + 101 * 9821)):
         ref, seq, cig = synth.make_pair(seed, i, ref_len, mixed=mixed)
         s = oracle.align(ref, seq, cig, sub, nps, r=r)
         k = int(np.nonzero(z[name + "_idx"] == i)[0][0])

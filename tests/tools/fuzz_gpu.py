@@ -82,8 +82,6 @@ def fuzz(budget, seed, focus=False, log=print):
         kind = int(rng.choice([0, 0, 1, 2]))
         sub, nps = tables(rng, kind, max_n, max_l)
         ctx = aln.Context(sub, nps, max_n=max_n, max_l=max_l)
-        tbk = int(rng.choice([0, 1, 2, 2]))     # the traceback kernel: by batch size (these batches: the windows), windows, rows
-        ctx.set("traceback_kernel", tbk)
         r = int(rng.choice([100, 127, 128, 160, 192, 200, 255, 256, 320, 511] if focus else
                            [1, 2, 3, 7, 15, 30, 31, 32, 33, 64, 65, 100, 127, 128, 160, 192, 200, 255, 288, 448]))
         mbr = int(rng.choice([2, 3, 5, 7, 16, 64] if focus else [2, 3, 5, 16, 64, 65, 200, 1000, 20000, 60000]))
@@ -143,7 +141,7 @@ def fuzz(budget, seed, focus=False, log=print):
             if not ok:
                 bad += 1
                 log(f"MISMATCH seed={seed} round={rounds} read={k} r={r} mbr={mbr} gaps=({ist},{iex}) tables={kind} max_n={max_n} "
-                      f"max_l={max_l} len={len(refs[k])}/{len(seqs[k])} status={st[k]} want_status={wst} traceback_kernel={tbk}")
+                      f"max_l={max_l} len={len(refs[k])}/{len(seqs[k])} status={st[k]} want_status={wst}")
         rounds += 1
         reads += n
     return rounds, reads, bad
