@@ -111,14 +111,27 @@ __device__ __noinline__ int annot_far_ones(const uint8_t *g, int len, int n, int
     return total;
 }
 
-// the annotation of one slice (IS_REF: a reference slice -> refw / refl; else a read slice -> seqw)
-template <bool IS_REF, bool ALLN>
+// What a slice's annotation is written as: the packed words of a read slice (seqw) or of a reference slice (refw / refl)
+// for the fill kernel, the (L, L_IDX) values themselves in get_np_info()'s [position][2][max_n] int32 layout, or one byte
+// plane per period (L | start flag << 7) for the region kernels.
+enum AnnotMode { ANNOT_SEQW = 0, ANNOT_REFW = 1, ANNOT_RAW = 2, ANNOT_PLANES = 3 };
+
+// the annotation of one slice g[0, len).  ANNOT_SEQW / ANNOT_REFW: words 0 ... span are written.  ANNOT_RAW / ANNOT_PLANES:
+// positions w_from <= pos < span are written (the windows in front of w_from are the warm-up of a segment that does not
+// start at its sequence's first base: see np_info_wave_kernel); raw: out32 + pos * 2 * max_n; planes: plane n - 1 at
+// planes + (n - 1) * pstride.
+template <int MODE, bool ALLN>
 __device__ __forceinline__ void annotate_slice(const uint8_t *g, const int len, const int span, const int max_n_, const int max_l,
-                                               uint32_t *seqw, uint4 *refw, uint2 *refl)
+                                               uint32_t *seqw, uint4 *refw, uint2 *refl, const int w_from = 0, int32_t *out32 = nullptr,
+                                               uint8_t *planes = nullptr, const int64_t pstride = 0)
 {
+    constexpr bool IS_REF = MODE == ANNOT_REFW;
     const int lane = threadIdx.x;
     const int max_n = ALLN ? MAX_PERIOD : max_n_;
-    const int nwin = (span + 1 + 63) >> 6;                      // words i = 0 ... span are written
+    const int nwin = MODE <= ANNOT_REFW ? (span + 1 + 63) >> 6 : (span + 63) >> 6;      // words i = 0 ... span are written
+    // windows that hold bases: a chunk slice ends with its words, a segment of a longer sequence (ANNOT_RAW / ANNOT_PLANES)
+    // is followed by more of it, and its last window looks ahead into that like every other
+    const int nwin_have = MODE <= ANNOT_REFW ? nwin : (len + 63) >> 6;
 
     // bases around every position of window v: own code c (6 past the slice), the six before it (7 in front of the
     // slice) and the six behind it as 3-bit fields (layout.hpp), and the window's indicator masks
@@ -158,7 +171,7 @@ __device__ __forceinline__ void annotate_slice(const uint8_t *g, const int len, 
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int base = w << 6, pos = base + ln;
-        if (w + 1 < nwin) load_window(w + 1, cN, kpN, knN, MN);
+        if (w + 1 < nwin_have) load_window(w + 1, cN, kpN, knN, MN);
         else {
 #pragma unroll
             for (int n = 0; n < MAX_PERIOD; n++) MN[n] = 0ull;
@@ -198,7 +211,27 @@ __device__ __forceinline__ void annotate_slice(const uint8_t *g, const int len, 
 
         // ---- the words of positions base ... base + 63 (layout.hpp).  Period n's result at position pos - n is this
         // window's lane - n, or the previous window's lane 64 - n + lane
-        if constexpr (!IS_REF) {
+        if constexpr (MODE == ANNOT_RAW) {
+            if (pos >= w_from && pos < span) {
+                int32_t *o = out32 + (size_t)pos * (2 * max_n);
+                if (ALLN) {                                      // 12 consecutive int32 per position: three 16-byte stores
+                    int4 *o4 = reinterpret_cast<int4 *>(o);
+                    o4[0] = make_int4((int)(R[0] & 0xFFu), (int)(R[1] & 0xFFu), (int)(R[2] & 0xFFu), (int)(R[3] & 0xFFu));
+                    o4[1] = make_int4((int)(R[4] & 0xFFu), (int)(R[5] & 0xFFu), (int)(R[0] >> 8), (int)(R[1] >> 8));
+                    o4[2] = make_int4((int)(R[2] >> 8), (int)(R[3] >> 8), (int)(R[4] >> 8), (int)(R[5] >> 8));
+                } else {
+#pragma unroll
+                    for (int n = 0; n < MAX_PERIOD; n++)
+                        if (n < max_n) { o[n] = (int)(R[n] & 0xFFu); o[max_n + n] = (int)(R[n] >> 8); }
+                }
+            }
+        } else if constexpr (MODE == ANNOT_PLANES) {
+            if (pos >= w_from && pos < span) {
+#pragma unroll
+                for (int n = 0; n < MAX_PERIOD; n++)
+                    if (n < max_n) planes[(size_t)n * pstride + pos] = (uint8_t)((R[n] & 0x7Fu) | ((R[n] - 1u) < 255u ? 128u : 0u));
+            }
+        } else if constexpr (!IS_REF) {
             uint32_t wd = kpC << MER_SHIFT;
 #pragma unroll
             for (int n = 1; n <= MAX_PERIOD; n++) {
@@ -266,8 +299,45 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const int start = is_ref ? d.col0 : d.row0, span = is_ref ? d.dcols : d.drows;
     const int len = (int)(((int64_t)start + span + 1 < T ? (int64_t)start + span + 1 : T) - start);   // src/aln.pyx:453-454
     const uint8_t *g = (is_ref ? p.refs + p.ref_off[rd] : p.seqs + p.seq_off[rd]) + start;
-    if (is_ref) annotate_slice<true, ALLN>(g, len, span, p.max_n, p.max_l, nullptr, p.refw + d.refw_off, p.refl + d.refw_off);
-    else annotate_slice<false, ALLN>(g, len, span, p.max_n, p.max_l, p.seqw + d.seqw_off, nullptr, nullptr);
+    if (is_ref) annotate_slice<ANNOT_REFW, ALLN>(g, len, span, p.max_n, p.max_l, nullptr, p.refw + d.refw_off, p.refl + d.refw_off);
+    else annotate_slice<ANNOT_SEQW, ALLN>(g, len, span, p.max_n, p.max_l, p.seqw + d.seqw_off, nullptr, nullptr);
+}
+
+// ---------------------------------------------------------------------------
+// get_np_info() of WHOLE sequences of any length (the API, reference src/aln.pyx:179; genome-scale slices, src/bed.py:56-76)
+// by the same wave-local formulation: a sequence is cut into segments of `seg` positions, one wave per segment.  The
+// recurrence of a period reaches back at most (max_l + 1) n positions -- a chain starts at an own start or is re-started
+// by every position with more than max_l repeats ahead of it -- and through the "longest period wins" rule a shorter
+// period's values decide a longer one's starts, so a wave that begins `warm` = sum over n of (max_l + 2) n positions
+// (rounded up to whole windows) in front of its segment with no state has the exact state where the segment begins
+// (measured on adversarial sequences: 768 positions are needed at max_l = 100, 2 142 are given; tests/test_model_vs_oracle.py
+// states it on the CPU).  Look-ahead needs no margin: the slice handed to annotate_slice runs to the sequence's end.
+struct NpInfoParams {
+    const uint8_t *seqs;       // base codes, sequences ("slices") back to back
+    const int64_t *seq_off;    // [n_slices + 1]
+    const int2 *work;          // per wave: (slice, segment within the slice)
+    int n_work;
+    int max_n, max_l;
+    int seg, warm;             // multiples of 64
+    int32_t *out32;            // ANNOT_RAW: [position][2][max_n], slices back to back
+    uint8_t *planes;           // ANNOT_PLANES: slice k's planes at planes + max_n * seq_off[k], stride = its length
+};
+
+template <int MODE, bool ALLN>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void np_info_wave_kernel(NpInfoParams p)
+{
+    if ((int)blockIdx.x >= p.n_work) return;
+    const int2 wk = p.work[blockIdx.x];
+    const int64_t off = p.seq_off[wk.x];
+    const int64_t slen = p.seq_off[wk.x + 1] - off;
+    const int64_t s0 = (int64_t)wk.y * p.seg;                      // the segment: positions [s0, s1) of the slice
+    const int64_t s1 = s0 + p.seg < slen ? s0 + p.seg : slen;
+    const int64_t g0 = s0 > p.warm ? s0 - p.warm : 0;              // where this wave starts (a window boundary of the slice)
+    const uint8_t *g = p.seqs + off + g0;
+    // (lengths relative to g0 fit 32 bits: a slice is shorter than 2^30)
+    annotate_slice<MODE, ALLN>(g, (int)(slen - g0), (int)(s1 - g0), p.max_n, p.max_l, nullptr, nullptr, nullptr, (int)(s0 - g0),
+                               MODE == ANNOT_RAW ? p.out32 + (size_t)(off + g0) * (2 * p.max_n) : nullptr,
+                               MODE == ANNOT_PLANES ? p.planes + (size_t)p.max_n * off + g0 : nullptr, slen);
 }
 
 }  // namespace npore

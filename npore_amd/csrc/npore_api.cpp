@@ -1039,6 +1039,45 @@ try {
 }
 NPORE_CATCH_INT
 
+// get_np_info() of the sequences in ctx->in_seqs (host offsets `off`, n of them) by one wave per segment (annot_wave.hpp
+// np_info_wave_kernel): raw (L, L_IDX) values into out32, or the byte planes of the region kernels into planes
+static int launch_np_info(npore_ctx *ctx, hipStream_t s, const int64_t *off, int64_t n, int32_t *out32, uint8_t *planes)
+{
+    NpInfoParams q;
+    q.max_n = ctx->max_n;
+    q.max_l = ctx->max_l;
+    q.seg = 16384;
+    int warm = 0;
+    for (int k = 1; k <= ctx->max_n; k++) warm += (ctx->max_l + 2) * k;
+    q.warm = (warm + 63) & ~63;
+    std::vector<int2> work;
+    for (int64_t k = 0; k < n; k++)
+        for (int64_t g = 0; g * q.seg < off[k + 1] - off[k]; g++) work.push_back(make_int2((int)k, (int)g));
+    if (work.empty()) return NPORE_OK;
+    if (int rc = ctx->in_off.ensure((size_t)(n + 1) * 8)) return rc;
+    if (int rc = ctx->ws[0].rd_i32.ensure(work.size() * 8 + 16)) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->in_off.p, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ctx->ws[0].rd_i32.p, work.data(), work.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));                // (`work` is pageable host memory that dies with this call)
+    q.seqs = ctx->in_seqs.as<uint8_t>();
+    q.seq_off = ctx->in_off.as<int64_t>();
+    q.work = ctx->ws[0].rd_i32.as<int2>();
+    q.n_work = (int)work.size();
+    q.out32 = out32;
+    q.planes = planes;
+    const dim3 grid((unsigned)work.size()), block(64);
+    const bool alln = ctx->max_n == MAX_PERIOD;
+    if (out32) {
+        if (alln) hipLaunchKernelGGL((np_info_wave_kernel<ANNOT_RAW, true>), grid, block, 0, s, q);
+        else hipLaunchKernelGGL((np_info_wave_kernel<ANNOT_RAW, false>), grid, block, 0, s, q);
+    } else {
+        if (alln) hipLaunchKernelGGL((np_info_wave_kernel<ANNOT_PLANES, true>), grid, block, 0, s, q);
+        else hipLaunchKernelGGL((np_info_wave_kernel<ANNOT_PLANES, false>), grid, block, 0, s, q);
+    }
+    HIP_TRY(hipGetLastError());
+    return NPORE_OK;
+}
+
 int npore_get_np_info(npore_ctx *ctx, const uint8_t *seq, int64_t len, int32_t *out)
 try {
     if (!ctx || (len > 0 && (!seq || !out))) return fail(NPORE_E_INVALID, "null argument");
@@ -1047,27 +1086,15 @@ try {
     HIP_TRY(hipSetDevice(ctx->device));
     if (int rc = quiesce(ctx)) return rc;
     const int mn = ctx->max_n;
-    const int pstride = (int)((len + 15) & ~(int64_t)15);
     const size_t out_bytes = (size_t)len * 2 * mn * 4;
     // work buffers of the align path are reused (nothing else runs on this context meanwhile): grow-only, kept
     if (int rc = ctx->in_seqs.ensure((size_t)len + 16)) return rc;
-    if (int rc = ctx->ws[0].seql.ensure((size_t)pstride * MAX_PERIOD + 16)) return rc;
     if (int rc = ctx->out.ensure(out_bytes)) return rc;
     hipStream_t s = ctx->stream;
     HIP_TRY(hipMemcpyAsync(ctx->in_seqs.p, seq, (size_t)len, hipMemcpyHostToDevice, s));
-    const uint8_t *dseq = ctx->in_seqs.as<uint8_t>();
-    uint8_t *planes = ctx->ws[0].seql.as<uint8_t>();
-    int32_t *L = ctx->out.as<int32_t>(), *I = L + mn;
-    // four waves of 64 positions per workgroup; enough workgroups for one window per wave, capped at a few per CU
-    const int64_t windows = (len + 63) / 64;
-    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((windows + 3) / 4, (int64_t)ctx->n_cus * 32));
-    const int ml = ctx->max_l, ilen = (int)len, os = 2 * mn;
-    if (mn >= 1) hipLaunchKernelGGL(np_info_period_kernel<1>, dim3(blocks), dim3(256), 0, s, dseq, ilen, mn, ml, planes, pstride, L, I, os);
-    if (mn >= 2) hipLaunchKernelGGL(np_info_period_kernel<2>, dim3(blocks), dim3(256), 0, s, dseq, ilen, mn, ml, planes, pstride, L, I, os);
-    if (mn >= 3) hipLaunchKernelGGL(np_info_period_kernel<3>, dim3(blocks), dim3(256), 0, s, dseq, ilen, mn, ml, planes, pstride, L, I, os);
-    if (mn >= 4) hipLaunchKernelGGL(np_info_period_kernel<4>, dim3(blocks), dim3(256), 0, s, dseq, ilen, mn, ml, planes, pstride, L, I, os);
-    if (mn >= 5) hipLaunchKernelGGL(np_info_period_kernel<5>, dim3(blocks), dim3(256), 0, s, dseq, ilen, mn, ml, planes, pstride, L, I, os);
-    if (mn >= 6) hipLaunchKernelGGL(np_info_period_kernel<6>, dim3(blocks), dim3(256), 0, s, dseq, ilen, mn, ml, planes, pstride, L, I, os);
+    const int64_t one_off[2] = {0, len};
+    int32_t *L = ctx->out.as<int32_t>();
+    if (int rc = launch_np_info(ctx, s, one_off, 1, L, nullptr)) return rc;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, L, out_bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1112,7 +1139,8 @@ try {
     rp.planes = ctx->ws[0].seql.as<uint8_t>();
     rp.counts = ctx->ws[0].rd_i64.as<int64_t>();
     rp.out_pos = rp.out_reps = nullptr;
-    hipLaunchKernelGGL(region_annotate_kernel, dim3((unsigned)n_slices), dim3(1024), 0, s, rp);
+    if (int rc = launch_np_info(ctx, s, off.data(), n_slices, nullptr, ctx->ws[0].seql.as<uint8_t>())) return rc;
+    hipLaunchKernelGGL(region_count_kernel, dim3((unsigned)n_slices), dim3(1024), 0, s, rp);
     hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(1024), 0, s, rp);
     HIP_TRY(hipGetLastError());
     std::vector<int64_t> offs(m + 1);

@@ -359,181 +359,25 @@ __global__ __launch_bounds__(256) void sched_scatter_kernel(PrepParams p)
 }
 
 // ---------------------------------------------------------------------------
-// n-polymer annotation of one sequence by one workgroup.  Restatement of get_np_info
-// (src/aln.pyx:179-251) in which every (position, period) result is a function of
-// run lengths of the periodicity indicator e_n[p] = (seq[p] == seq[p+n]) and of the
-// final results of shorter periods (derivation: DESIGN.md; the CPU tests check the
-// host twin of this formulation against the oracle's literal loop):
-//   kf = run of e_n starting at pos, kb = run ending at pos-1;  a start s = pos - j*n
-//   covers pos iff j <= kb/n and then has l = j + kf/n + 1 repeats (0 if < 1 full one).
-//   Starts are visited in ascending order and overwrite when l exceeds the stored
-//   (capped) value, so the earliest eligible start wins, except that while l > max_l
-//   later eligible starts keep overwriting L_IDX.  Eligible: base != N, l > 2, and
-//   l*n > L[s][n2]*n2 for every shorter period n2 (already final).
-// Each wave handles windows of 64 consecutive positions; the run lengths come from
-// ballots of e_n over whole windows (count trailing / leading ones), so a long run
-// costs one step per 64 positions instead of one per position.
-// planes: byte planes [6][pstride], one per period: bits 0-6 = L (max_l <= 127), bit 7 = L_IDX == 0
-// (LDS when the slice fits, else global scratch).  Optional int32 outputs
-// Lout/Iout [len][max_n] for the get_np_info() API.
-// one period (compile-time, so that the divisions by n and the shorter-period loop unroll)
-// GRID = false: the windows are dealt over the waves of this workgroup (which then owns the whole sequence);
-// GRID = true: over the waves of the whole launch (one launch per period: the next period reads this one's plane).
-// Every mask a window looks at is computed from the bases (ballots); all lanes of a window that reach its end are in
-// the SAME run, so following a run into the neighbouring windows is wave-uniform.
-// (This per-position formulation serves the get_np_info() API and the genome-scale region kernels; the batch path's
-// chunk slices go through the wave-local formulation of annot_wave.hpp.)
-// does w hold K consecutive one bits?  (log-step: x bit p = "ones at p ... p + have - 1")
-template <int K>
-__host__ __device__ __forceinline__ bool has_run_of(unsigned long long w)
-{
-    unsigned long long x = w;
-    int have = 1;
-#pragma unroll
-    for (; have * 2 <= K; have *= 2) x &= x >> have;
-    if (have < K) x &= x >> (K - have);
-    return x != 0ull;
-}
-
-template <int n, bool GRID = false>
-__device__ __forceinline__ void annotate_period(const uint8_t *seq, int len, int max_n, int max_l, uint8_t *planes,
-                                                int pstride, int32_t *Lout, int32_t *Iout, int ostride = 0)
-{
-    // (the wave index is wave-uniform: saying so keeps the window loops and their bounds in scalar registers)
-    const int lane = threadIdx.x & 63;
-    const int wpb = blockDim.x >> 6;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (GRID ? (int)blockIdx.x * wpb : 0);
-    const int64_t wstep = (int64_t)(GRID ? (int)gridDim.x * wpb : wpb) * 64;
-    uint8_t *Ln = planes + (size_t)(n - 1) * pstride;
-    for (int64_t base64 = (int64_t)wave * 64; base64 < len; base64 += wstep) {
-        const int base = (int)base64;
-        const int pos = base + lane;
-        auto e_at = [&](int q) { return q >= 0 && q + n < len && seq[q] == seq[q + n]; };
-        // mask word of the window `k` windows after (k < 0: before) this one; k wave-uniform
-        auto mask_at = [&](int k) -> unsigned long long { return __builtin_amdgcn_ballot_w64(e_at(base + 64 * k + lane)); };
-        const unsigned long long M0 = mask_at(0);
-        // forward run from pos
-        int kf;
-        {
-            const unsigned long long inv = ~(M0 >> lane);   // bits >= 64-lane of the shifted mask are 0 -> 1 here
-            kf = inv ? __builtin_ctzll(inv) : 64;
-        }
-        // Runs are followed for at most `cap` positions beyond the window: with q = kf/n >= max_l + 1 every start
-        // has more than max_l repeats whatever kf is, and J = kb/n only matters up to max_l (below) -- so a
-        // megabase run (assembly gaps of N, satellite arrays) costs a constant per window.
-        const int cap = (max_l + 2) * n;
-        const bool cont = (kf == 64 - lane);
-        if (M0 >> 63) {         // the run through the window's last position goes on (every lane with `cont` is in it)
-            int ext = 0, kw = 1;
-            for (int k = base + 64; k < len && k <= base + 64 + cap; k += 64, kw++) {
-                const unsigned long long Mk = mask_at(kw);
-                const int t = (~Mk) ? __builtin_ctzll(~Mk) : 64;
-                ext += t;
-                if (t != 64) break;
-            }
-            kf += cont ? ext : 0;
-        }
-        // backward run ending at pos-1
-        int kb = 0;
-        if (lane > 0) {
-            const unsigned long long inv = ~(M0 << (64 - lane));   // bits below are 0 after the shift -> 1 here
-            kb = __builtin_clzll(inv);                              // inv != 0 because lane > 0
-        }
-        const bool contb = (kb == lane);
-        if (base > 0) {         // (lane 0 always looks back; the others if the run reaches the window's first position)
-            int ext = 0, kw = -1;
-            for (int k = base - 64; k >= 0 && k >= base - 64 - cap; k -= 64, kw--) {
-                const unsigned long long Mk = mask_at(kw);
-                const int t = (~Mk) ? __builtin_clzll(~Mk) : 64;
-                ext += t;
-                if (t != 64) break;
-            }
-            kb += contb ? ext : 0;
-        }
-        const int q = (int)((unsigned)kf / (unsigned)n), J = (int)((unsigned)kb / (unsigned)n);
-        // fewer than three repeats can cover any position of the window: the plane is all zero here
-        if (__builtin_amdgcn_ballot_w64(pos < len && J + q + 1 >= 3) == 0ull && !Lout) {
-            if (pos < len) Ln[pos] = 0;
-            continue;
-        }
-        if (pos < len) {
-            int stored = 0, idx = 0;
-            // every candidate start s = pos - j*n (j <= J) lies in the run ending at pos-1, so seq[s] == seq[pos]:
-            // at an N none is eligible; and starts with more than max_l repeats are all eligible (l*n > 100*n2) and
-            // overwrite each other in turn, the last of them (j = max_l - q, or 0) stays
-            int jtop = seq[pos] ? J : -1;
-            if (jtop >= 0 && jtop + q + 1 > max_l && (jtop > 0 || q >= 1)) {
-                stored = max_l;
-                idx = max_l - q > 0 ? max_l - q : 0;
-                jtop = -1;
-            }
-            for (int j = jtop; j >= 0; j--) {
-                const int l = (j == 0) ? (q >= 1 ? q + 1 : 0) : j + q + 1;
-                if (stored && l <= max_l) break;
-                if (l < 3) break;                       // (l only shrinks with j: nothing further down qualifies)
-                const int s = pos - j * n;
-                if (!seq[s]) continue;
-                bool longest = true;
-#pragma unroll
-                for (int n2 = 1; n2 < n; n2++)
-                    if (l * n <= (int)(planes[(size_t)(n2 - 1) * pstride + s] & 127u) * n2) longest = false;
-                if (!longest) continue;
-                if (l > stored) { stored = max_l < l ? max_l : l; idx = j; }
-            }
-            Ln[pos] = (uint8_t)(stored | ((stored && idx == 0) ? 128 : 0));
-            if (Lout) { Lout[(size_t)pos * ostride + (n - 1)] = stored; Iout[(size_t)pos * ostride + (n - 1)] = idx; }
-        }
-    }
-    if constexpr (!GRID) {
-        __threadfence_block();
-        __syncthreads();
-    }
-}
-
-__device__ __forceinline__ void annotate_sequence(const uint8_t *seq, int len, int max_n, int max_l,
-                                                  uint8_t *planes, int pstride, int32_t *Lout, int32_t *Iout)
-{
-    if (max_n >= 1) annotate_period<1>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
-    if (max_n >= 2) annotate_period<2>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
-    if (max_n >= 3) annotate_period<3>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
-    if (max_n >= 4) annotate_period<4>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
-    if (max_n >= 5) annotate_period<5>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
-    if (max_n >= 6) annotate_period<6>(seq, len, max_n, max_l, planes, pstride, Lout, Iout);
-}
-
-// get_np_info() API: one sequence of any length, one launch per period over as many workgroups as the sequence
-// has windows (period n reads the finished planes of the shorter periods: the launch boundary is the barrier);
-// planes in global scratch, int32 outputs straight in the API's [len][2][max_n] layout (Iout = Lout + max_n,
-// ostride = 2 * max_n)
-template <int n>
-__global__ __launch_bounds__(256) void np_info_period_kernel(const uint8_t *seq, int len, int max_n, int max_l,
-                                                             uint8_t *planes, int pstride, int32_t *Lout, int32_t *Iout,
-                                                             int ostride)
-{
-    annotate_period<n, true>(seq, len, max_n, max_l, planes, pstride, Lout, Iout, ostride);
-}
-
-// ---------------------------------------------------------------------------
 // get_np_regions (reference src/bed.py:56-76) for a batch of independent slices of a genome: the n-polymer
 // starts (L != 0 and L_IDX == 0) of every slice and period, in position order.
 struct RegionParams {
     const uint8_t *seqs;       // base codes, slices back to back
     const int64_t *seq_off;    // [n_slices + 1]
     int n_slices, max_n, max_l;
-    uint8_t *planes;           // max_n bytes per base: slice k's planes at planes + max_n * seq_off[k], stride = its length
+    const uint8_t *planes;     // max_n bytes per base: slice k's planes at planes + max_n * seq_off[k], stride = its length (L | start << 7)
     int64_t *counts;           // [max_n][n_slices] counts, then (region_scan) exclusive offsets; total at the end
     int32_t *out_pos;          // position within the slice
     int32_t *out_reps;         // repeat count L (capped at max_l)
 };
 
-// workgroup per slice: annotation, then the number of starts per period
-__global__ __launch_bounds__(1024) void region_annotate_kernel(RegionParams p)
+// workgroup per slice: the number of starts per period, from the planes np_info_wave_kernel (annot_wave.hpp) has written
+__global__ __launch_bounds__(1024) void region_count_kernel(RegionParams p)
 {
     const int k = blockIdx.x;
     const int64_t off = p.seq_off[k];
     const int len = (int)(p.seq_off[k + 1] - off);
-    uint8_t *planes = p.planes + (size_t)p.max_n * off;
-    annotate_sequence(p.seqs + off, len, p.max_n, p.max_l, planes, len, nullptr, nullptr);
+    const uint8_t *planes = p.planes + (size_t)p.max_n * off;
     __shared__ int cnt[MAX_PERIOD];
     if (threadIdx.x < MAX_PERIOD) cnt[threadIdx.x] = 0;
     __syncthreads();

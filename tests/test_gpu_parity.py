@@ -206,6 +206,42 @@ def test_get_np_info_device(ctx):
         assert np.array_equal(ctx.get_np_info(s), oracle.get_np_info(s))
 
 
+def test_get_np_info_segments_of_long_sequences(tables):
+    """get_np_info() of sequences far longer than one wave's segment (annot_wave.hpp np_info_wave_kernel: 16 384 positions
+    per wave, each wave warmed up on the positions in front of its segment): arrays of every period that cross the segment
+    boundaries, nested periods, two-letter sequences (periodic everywhere), N stretches -- every value equal to the
+    oracle's, at the default table shape and at other max_n / max_l."""
+    rng = np.random.default_rng(12)
+    n = 70_000
+
+    def make(kind):
+        if kind == 0:
+            parts = []
+            while sum(map(len, parts)) < n:
+                per = int(rng.integers(1, 7))
+                parts.append(np.tile(rng.integers(1, 5, per).astype(np.uint8), int(rng.integers(3, 400))))
+                parts.append(rng.integers(1, 5, int(rng.integers(0, 6))).astype(np.uint8))
+            s = np.concatenate(parts)[:n]
+        else:
+            s = rng.integers(1, 3, n).astype(np.uint8)
+        for b in (16384, 32768, 49152):              # arrays planted across every segment boundary, at every phase
+            per = int(rng.integers(1, 7))
+            a = b - int(rng.integers(1, 900))
+            s[a:a + 1000] = np.tile(s[a:a + per], 1000 // per + 1)[:1000]
+        for _ in range(4):
+            a = int(rng.integers(0, n - 50))
+            s[a:a + int(rng.integers(1, 40))] = 0
+        return s
+
+    for max_n, max_l in ((6, 100), (6, 127), (4, 20), (3, 5)):
+        c = aln.Context(None, None, max_n=max_n, max_l=max_l, device=0)            # an annotation-only context
+        for kind in (0, 1):
+            s = make(kind)
+            got, want = c.get_np_info(s), np.asarray(oracle.get_np_info(s, max_n=max_n, max_l=max_l))
+            assert np.array_equal(got, want), (max_n, max_l, kind, np.argwhere(got != want)[:4])
+        c.close()
+
+
 def test_large_max_b_rows(ctx, tables):
     """max_b_rows above the default: one chunk longer than the LDS-resident annotation
     planes cover (global-scratch planes), 16-bit run lengths near their range."""

@@ -186,3 +186,43 @@ def test_wave_annotation_formulation_vs_oracle():
             for W in ((64, 8) if max_l != 127 else (64,)):
                 got = awm.windows(s, max_n, max_l, W=W)
                 assert np.array_equal(got, want), (max_n, max_l, W, k, np.argwhere(got != want)[:4])
+
+
+def test_segments_with_warm_up_equal_the_whole_sequence():
+    """What csrc/annot_wave.hpp's np_info_wave_kernel relies on (the get_np_info() API and the genome-scale region
+    kernels: one wave per segment of a long sequence): get_np_info of the suffix that starts `warm` = sum over n of
+    (max_l + 2) n positions in front of a segment, taken as a sequence of its own, equals get_np_info of the whole
+    sequence on the segment -- for arrays of every period far longer than max_l, nested periods, two-letter sequences
+    (periodic everywhere) and N stretches, segment starts drawn at random (also inside the arrays)."""
+    rng = np.random.default_rng(5)
+
+    def make(n, kind):
+        if kind == 0:
+            s = synth.make_ref(rng, n, 0.15)[0].copy()
+        elif kind == 1:                              # long arrays of every period with short spacers
+            parts = []
+            while sum(map(len, parts)) < n:
+                per = int(rng.integers(1, 7))
+                parts.append(np.tile(rng.integers(1, 5, per).astype(np.uint8), int(rng.integers(3, 400))))
+                parts.append(rng.integers(1, 5, int(rng.integers(0, 6))).astype(np.uint8))
+            s = np.concatenate(parts)[:n]
+        else:                                        # two letters, with planted arrays
+            s = rng.integers(1, 3, n).astype(np.uint8)
+            for _ in range(12):
+                a, per = int(rng.integers(0, n - 900)), int(rng.integers(1, 7))
+                s[a:a + 800] = np.tile(s[a:a + per], 800 // per + 1)[:800]
+        for _ in range(3):
+            a = int(rng.integers(0, n - 50))
+            s[a:a + int(rng.integers(1, 40))] = 0
+        return s
+
+    for max_n, max_l in ((6, 100), (6, 127), (4, 20)):
+        warm = (sum((max_l + 2) * n for n in range(1, max_n + 1)) + 63) & ~63
+        for trial in range(9):
+            s = make(16000, trial % 3)
+            full = oracle.get_np_info(s, max_n=max_n, max_l=max_l)
+            for s0 in rng.integers(warm, 14000, 6):
+                s0 = int(s0) & ~63                   # segments begin on window boundaries
+                g0 = s0 - warm
+                part = oracle.get_np_info(s[g0:], max_n=max_n, max_l=max_l)
+                assert np.array_equal(part[s0 - g0:s0 - g0 + 1500], full[s0:s0 + 1500]), (max_n, max_l, trial, s0)
