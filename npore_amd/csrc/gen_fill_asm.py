@@ -82,7 +82,6 @@ def L(name):
 # more scratch: lane-table results of the first SHR candidate, fetched before the hand-shake poll
 E0, E1 = "v89", "v90"
 ABLATE = {"nopoll": False, "nolen": False}      # timing-only ablations (wrong strings): --nopoll / --nolen with --out FILE
-WAKE = {"sleep": 0}      # experiment (--wakeup N --out FILE): a waiting wave sleeps N x 64 cycles between looks, a publishing wave wakes the workgroup
 
 
 def shr_tables(t, tmp=X3):
@@ -521,8 +520,6 @@ def finish(t, mode, first, last, multi, mid, len_variant):
             ds_write_b32 {O('progaddr')}, {O('prog')}
             s_mov_b64 exec, -1
         """)
-        if WAKE["sleep"]:
-            t("s_wakeup")
         if len_variant:
             t(f"v_mov_b32 {LENST}, 0x7f800000")
         t(f"""
@@ -697,8 +694,6 @@ def polls(t, mode, first, last, sfx):
     t.label("pp_first" + sfx)
     t("s_setprio 0")
     t.label("pp" + sfx)
-    if WAKE["sleep"]:
-        t(f"s_sleep {WAKE['sleep']}")
     t(again)
     t("s_waitcnt lgkmcnt(0)")
     t(test)
@@ -1100,8 +1095,6 @@ def main():
         a = args.pop(0)
         if a in ("--nopoll", "--nolen"):
             ABLATE[a[2:]] = True
-        elif a == "--wakeup":
-            WAKE["sleep"] = int(args.pop(0))
         elif a == "--out":
             out_path = args.pop(0)
     out = ["// fill_step_asm.inc -- GENERATED by gen_fill_asm.py (do not edit): the plain-step loop of fill_kernel as gfx950",
