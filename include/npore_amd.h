@@ -327,6 +327,17 @@ int npore_bam_realign_file(npore_ctx *ctx, npore_bam *bam, const npore_fasta *fa
  * inconsistent traceback; bad_ord / bad_status[bad_cap]: ordinal (among the selected reads) and status bits of the
  * first such reads.  NPORE_E_UNSUPPORTED: the regions or the file's order rule the one-pass run out (the BAM is not
  * sorted by reference, several regions per contig) -- nothing usable was written: truncate and use the indexed path. */
+/* Several processes (one per GPU) on ONE file, each in one pass (the reference feeds all its workers from one sequential
+ * read, src/bam.pyx:18-47 + src/realign.py:110-114): process `rank` of `world` walks a contiguous stretch of the record
+ * stream -- the records that start between two cut points taken from the LINEAR index of the file's .bai (bai_path; each
+ * entry is the virtual offset of a record: SAM specification 5.2), chosen at rank / world of the compressed file -- so every
+ * block is inflated once per node, no record index is built, and the ranks' part files concatenated in rank order are in
+ * file order.  The next npore_bam_realign_sequential on the handle walks that stretch only (max_reads must be 0).
+ * world == 1 clears the share.  NPORE_E_UNSUPPORTED: no usable .bai (the caller takes the indexed reader). */
+int npore_bam_set_share(npore_bam *bam, int rank, int world, const char *bai_path);
+/* out4: [0] a share is set, [1] / [2] its first byte and its end in the inflated stream (-1: nothing / the end of the
+ * file), [3] the BGZF block it begins in (tests). */
+int npore_bam_share_info(const npore_bam *bam, int64_t *out4);
 int npore_bam_realign_sequential(npore_ctx *ctx, npore_bam *bam, const npore_fasta *fa, const int32_t *fasta_of_ref,
                                  int n_regions, const int32_t *ref_id, const int64_t *start, const int64_t *stop,
                                  int64_t max_reads, int64_t batch_reads, float indel_start, float indel_extend,

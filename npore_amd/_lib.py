@@ -77,6 +77,8 @@ SIGNATURES = {
     "npore_bam_realign_sequential": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_char_p,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "npore_bam_set_share": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p]),
+    "npore_bam_share_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "npore_bam_last_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "npore_bam_file_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "npore_debug_inflate": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int]),

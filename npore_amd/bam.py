@@ -373,6 +373,7 @@ class NativeBam:
         from . import _lib
         self._lib = _lib.load()
         self._shared = None
+        self.path = path
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if stream is None and os.environ.get("NPORE_BAM_STREAM") in ("0", "1"):
@@ -595,6 +596,29 @@ class NativeBam:
                                                    fl.ctypes.data, st.ctypes.data, threads, C.byref(sam), C.byref(sam_len)))
         return C.string_at(sam.value, sam_len.value).decode() if sam_len.value else ""
 
+    @staticmethod
+    def bai_path(path):
+        """the file's .bai index (`x.bam.bai`, or `x.bai` beside `x.bam`), or None"""
+        for cand in (path + ".bai", os.path.splitext(path)[0] + ".bai"):
+            if os.path.exists(cand):
+                return cand
+        return None
+
+    def set_share(self, rank, world, bai=None):
+        """Several processes on this one-pass handle: process `rank` of `world` will walk a contiguous stretch of the record
+        stream, cut at virtual offsets of the .bai linear index (npore_bam_set_share).  Raises OnePassUnsupported when
+        there is no usable index (every rank then takes the indexed reader: the decision depends on the files alone)."""
+        import ctypes as C
+        bai = bai or self.bai_path(self.path)
+        rc = self._lib.npore_bam_set_share(self.handle, int(rank), int(world), os.fsencode(bai) if bai else None)
+        if rc == -5:
+            from . import _lib
+            raise OnePassUnsupported(_lib.last_error())
+        self._check(rc)
+        info = np.zeros(4, np.int64)
+        self._check(self._lib.npore_bam_share_info(self.handle, info.ctypes.data))
+        return tuple(int(x) for x in info)
+
     def realign_sequential(self, ctx, fasta, regions, out_path, batch_reads=4000, max_reads=0, r=30, max_b_rows=20000,
                            indel_start=5.0, indel_extend=1.0, threads=0, bad_cap=1000):
         """ONE PASS over the file: inflate, filter by `regions` [(contig, start, stop)] (at most one per contig, in header
@@ -616,7 +640,11 @@ class NativeBam:
                                                     bad_ord.ctypes.data, bad_st.ctypes.data, bad_cap)
         if rc == -5:
             from . import _lib
-            raise OnePassUnsupported(_lib.last_error())
+            msg = _lib.last_error()
+            # only what rules the ONE-PASS run out sends the caller to the indexed reader; a band or chunk height the
+            # kernels do not cover (the same code) would fail there in the same way, after a whole indexing pass
+            if "one-pass ingest" in msg or "not sorted by reference" in msg:
+                raise OnePassUnsupported(msg)
         self._check(rc)
         nb = int(min(bad_cap, counts[1] + counts[2]))
         return int(counts[0]), list(zip(bad_ord[:nb].tolist(), bad_st[:nb].tolist())), (int(counts[1]), int(counts[2]))
@@ -813,6 +841,59 @@ def get_confusion_matrices():
     if getattr(cfg.args, "recalc_exit", False):
         sys.exit(0)
     return total
+
+
+def write_bai(bam_path, bai_path=None):
+    """A .bai for a BAM file (tests / benchmarks; `samtools index` makes the real ones): the LINEAR index only -- per
+    reference and 16 kb window the virtual offset (block offset << 16 | offset in the block) of the first record that
+    overlaps the window, SAM specification 5.2 -- with no bins, which is all npore_bam_set_share reads."""
+    raw = open(bam_path, "rb").read()
+    blocks, p, u = [], 0, 0                      # (compressed offset, inflated offset) of every BGZF block
+    parts = []
+    while p < len(raw):
+        xlen = struct.unpack_from("<H", raw, p + 10)[0]
+        bsize = struct.unpack_from("<H", raw, p + 16)[0] + 1
+        data = zlib.decompress(raw[p + 12 + xlen:p + bsize - 8], -15)
+        blocks.append((p, u))
+        parts.append(data)
+        u += len(data)
+        p += bsize
+    data = b"".join(parts)
+    starts = np.array([b[1] for b in blocks], np.int64)
+    coffs = np.array([b[0] for b in blocks], np.int64)
+    l_text, = struct.unpack_from("<i", data, 4)
+    q = 8 + l_text
+    n_ref, = struct.unpack_from("<i", data, q); q += 4
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<i", data, q); q += 8 + l_name
+    lin = [dict() for _ in range(n_ref)]
+    ref_len_of_op = (1, 0, 1, 1, 0, 0, 0, 1, 1)  # MIDNSHP=X consume the reference?
+    while q + 4 <= len(data):
+        bs, = struct.unpack_from("<i", data, q)
+        rid, pos, l_rn, _mq, _bin, n_cig, _flag, _l_seq = struct.unpack_from("<iiBBHHHi", data, q + 4)
+        k = int(np.searchsorted(starts, q, side="right")) - 1
+        while starts[k] == q and k > 0 and starts[k - 1] == q:      # (empty blocks: the first of them)
+            k -= 1
+        v = (int(coffs[k]) << 16) | (q - int(starts[k]))
+        if rid >= 0:
+            cig = struct.unpack_from(f"<{n_cig}I", data, q + 36 + l_rn)
+            end = pos + max(1, sum((c >> 4) * ref_len_of_op[c & 15] for c in cig))
+            for w in range(pos >> 14, ((end - 1) >> 14) + 1):
+                lin[rid].setdefault(w, v)
+        q += 4 + bs
+    out = bytearray(b"BAI\1" + struct.pack("<i", n_ref))
+    for d in lin:
+        out += struct.pack("<i", 0)                                  # no bins
+        n_intv = (max(d) + 1) if d else 0
+        out += struct.pack("<i", n_intv)
+        last = 0
+        for w in range(n_intv):                                      # (windows without a record: the previous entry, as samtools does)
+            last = d.get(w, last)
+            out += struct.pack("<Q", last)
+    bai_path = bai_path or bam_path + ".bai"
+    with open(bai_path, "wb") as fh:
+        fh.write(bytes(out))
+    return bai_path
 
 
 def write_bam(path, references, records, level=6):

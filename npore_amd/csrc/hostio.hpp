@@ -405,6 +405,46 @@ inline bool bgzf_inflate_range(const PreadFile &f, const std::vector<BgzfBlock> 
     return bad == 0;
 }
 
+// Virtual offsets of a .bai index's LINEAR index (SAM specification 5.2: per reference, for every 16 kb window the
+// virtual file offset -- compressed offset of a BGZF block << 16 | offset inside the inflated block -- of the first
+// alignment that overlaps the window), all references, ascending, without duplicates and zeros.  Each one is where a
+// record starts: the cut points at which a coordinate-sorted BAM can be dealt to several readers without a pass over it.
+inline bool bai_linear_offsets(const char *path, std::vector<uint64_t> &out)
+{
+    MappedFile mf;
+    if (!mf.open(path) || mf.n < 8 || std::memcmp(mf.p, "BAI\1", 4) != 0) return false;
+    const uint8_t *p = mf.p;
+    const size_t n = mf.n;
+    size_t q = 4;
+    auto have = [&](size_t k) { return q + k <= n; };
+    if (!have(4)) return false;
+    const int32_t n_ref = (int32_t)rd32(p + q); q += 4;
+    if (n_ref < 0) return false;
+    out.clear();
+    for (int32_t r = 0; r < n_ref; r++) {
+        if (!have(4)) return false;
+        const int32_t n_bin = (int32_t)rd32(p + q); q += 4;
+        if (n_bin < 0) return false;
+        for (int32_t b = 0; b < n_bin; b++) {
+            if (!have(8)) return false;
+            const int32_t n_chunk = (int32_t)rd32(p + q + 4); q += 8;
+            if (n_chunk < 0 || !have((size_t)n_chunk * 16)) return false;
+            q += (size_t)n_chunk * 16;
+        }
+        if (!have(4)) return false;
+        const int32_t n_intv = (int32_t)rd32(p + q); q += 4;
+        if (n_intv < 0 || !have((size_t)n_intv * 8)) return false;
+        for (int32_t k = 0; k < n_intv; k++) {
+            const uint64_t v = (uint64_t)rd32(p + q) | ((uint64_t)rd32(p + q + 4) << 32);
+            q += 8;
+            if (v) out.push_back(v);
+        }
+    }
+    std::sort(out.begin(), out.end());
+    out.erase(std::unique(out.begin(), out.end()), out.end());
+    return true;
+}
+
 }  // namespace npore
 
 namespace npore {
@@ -441,6 +481,12 @@ struct npore_bam {
     npore::RecFetch api_fetch;            // records of the last npore_bam_format_sam call (the const entry points keep theirs local)
     npore::RawBuf sam;                    // text of the last formatted batch
     npore::RawBuf w_finals;               // final CIGARs of the last batch (work buffer, reused)
+    // ONE-PASS handle, several processes (npore_bam_set_share): the contiguous stretch of the record stream this process
+    // walks, as offsets into the inflated stream; share_begin is where a record starts (a virtual offset of the file's
+    // .bai linear index), share_end where the next process's stretch begins (UINT64_MAX: the end of the file)
+    bool has_share = false;
+    uint64_t share_begin = 0, share_end = UINT64_MAX;
+    size_t share_block = 0;               // the BGZF block share_begin lies in
     double stage_ms[4] = {0, 0, 0, 0};    // last npore_bam_realign_batch: pack, align, standardise, format
     double file_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // last npore_bam_realign_file (npore_bam_file_timing)
 };

@@ -2304,6 +2304,63 @@ bool record_is_sound(const uint8_t *q)
 
 extern "C" {
 
+int npore_bam_set_share(npore_bam *b, int rank, int world, const char *bai_path)
+try {
+    if (!b || world < 1 || rank < 0 || rank >= world) return fail(NPORE_E_INVALID, "bad argument");
+    if (!b->file || b->blocks.empty()) return fail(NPORE_E_INVALID, "a share needs a handle opened on a BGZF file (modes 2 and 3)");
+    b->has_share = false;
+    b->share_begin = 0;
+    b->share_end = UINT64_MAX;
+    b->share_block = 0;
+    if (world == 1) return NPORE_OK;
+    std::vector<uint64_t> cuts;
+    if (!bai_path || !bai_linear_offsets(bai_path, cuts) || cuts.empty())
+        return fail(NPORE_E_UNSUPPORTED, "no usable .bai linear index: the record stream cannot be dealt without a pass over it");
+    // the first record of the stretch whose compressed offset lies at or behind k / world of the file
+    const uint64_t c0 = b->blocks.front().in_off, c1 = b->blocks.back().in_off + b->blocks.back().in_len;
+    auto cut_of = [&](int k) -> uint64_t {
+        if (k <= 0) return 0;
+        if (k >= world) return UINT64_MAX;
+        const uint64_t target = c0 + (uint64_t)((long double)(c1 - c0) * k / world);
+        auto it = std::lower_bound(cuts.begin(), cuts.end(), target << 16);
+        return it == cuts.end() ? UINT64_MAX : *it;
+    };
+    // virtual offset -> block of the table and offset in the inflated stream (false: the index is not this file's)
+    auto locate = [&](uint64_t v, size_t &blk, uint64_t &abs) -> bool {
+        const uint64_t coff = v >> 16, uoff = v & 0xFFFFu;
+        // a block's payload begins a gzip header's length behind the block: the block that starts at `coff` is the first
+        // one whose payload offset lies behind it
+        size_t lo = 0, hi = b->blocks.size();
+        while (lo < hi) { const size_t mid = (lo + hi) / 2; if (b->blocks[mid].in_off > coff) hi = mid; else lo = mid + 1; }
+        if (lo == b->blocks.size() || b->blocks[lo].in_off - coff > 4096 || uoff >= b->blocks[lo].out_len) return false;
+        blk = lo;
+        abs = b->blocks[lo].out_off + uoff;
+        return true;
+    };
+    const uint64_t v0 = cut_of(rank), v1 = cut_of(rank + 1);
+    if (v0 == UINT64_MAX) { b->share_begin = b->share_end = UINT64_MAX; }       // nothing left for this rank
+    else if (v0 != 0) {
+        if (!locate(v0, b->share_block, b->share_begin)) return fail(NPORE_E_UNSUPPORTED, "the .bai index does not belong to this BAM file");
+    }
+    if (v1 != UINT64_MAX && v0 != UINT64_MAX) {
+        size_t blk;
+        if (!locate(v1, blk, b->share_end)) return fail(NPORE_E_UNSUPPORTED, "the .bai index does not belong to this BAM file");
+    }
+    b->has_share = true;
+    return NPORE_OK;
+}
+NPORE_CATCH_INT
+
+int npore_bam_share_info(const npore_bam *b, int64_t *out4)
+{
+    if (!b || !out4) return fail(NPORE_E_INVALID, "null argument");
+    out4[0] = b->has_share ? 1 : 0;
+    out4[1] = b->share_begin == UINT64_MAX ? -1 : (int64_t)b->share_begin;
+    out4[2] = b->share_end == UINT64_MAX ? -1 : (int64_t)b->share_end;
+    out4[3] = (int64_t)b->share_block;
+    return NPORE_OK;
+}
+
 int npore_bam_realign_file(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref, const int64_t *idx,
                            int64_t n, int64_t batch_reads, float indel_start, float indel_extend, int max_b_rows, int r,
                            int threads, const char *out_path, int32_t *status)
@@ -2352,6 +2409,16 @@ try {
     const uint8_t *wd = nullptr;             // the window's first byte (the carried tail sits in front of the inflated blocks)
     size_t next_block = 0, N = 0, p = 0;
     bool have_header = false, done = n_regions == 0;
+    // several processes on one file (npore_bam_set_share): this one walks the records that START in [share_begin,
+    // share_end) of the inflated stream -- a stretch that begins at a record (a virtual offset of the .bai linear index);
+    // the header was read when the handle was opened
+    uint64_t abs0 = 0;                       // offset of the window's first byte in the inflated stream
+    bool seek_share = false;
+    if (b->has_share) {
+        if (max_reads > 0) { std::fclose(fh); return fail(NPORE_E_UNSUPPORTED, "one-pass ingest: max_reads needs one process (the ranks cannot know how many reads the others keep)"); }
+        if (b->share_begin == UINT64_MAX) done = true;
+        else if (b->share_begin > 0) { next_block = b->share_block; have_header = true; seek_share = true; }
+    }
     int g = 0;
     int64_t kept = 0, n_bad = 0, ordinal0 = 0;
     int32_t last_rid = -1;
@@ -2380,6 +2447,7 @@ try {
             return 0;
         }
         if (!ahead.valid()) prefetch(next_block);
+        const uint64_t win_off = b->blocks[next_block].out_off;
         Pending pd = ahead.get();
         if (!pd.ok) { fail(NPORE_E_INVALID, "corrupt BGZF block (or out of memory)"); return -1; }
         std::shared_ptr<RawBuf> nw = pd.buf;
@@ -2394,8 +2462,10 @@ try {
         if (c) std::memcpy(d0 - c, wd + p, c);
         win = nw;
         wd = d0 - c;
+        abs0 = win_off - c;
         N = c + pd.bytes;
         p = 0;
+        if (seek_share) { p = (size_t)(b->share_begin - abs0); seek_share = false; }      // (the first window of a share that begins mid-file)
         next_block = pd.b1;
         if (next_block < b->blocks.size()) prefetch(next_block);
         return 1;
@@ -2428,6 +2498,7 @@ try {
                 if (lw == 0) done = true;
                 continue;
             }
+            if (abs0 + p >= b->share_end) { done = true; break; }                // the next process's stretch begins here
             const uint8_t *q = d + p;
             p += 4 + (size_t)bs;
             if (!record_is_sound(q)) return fail(NPORE_E_INVALID, "corrupt BAM record");

@@ -66,9 +66,24 @@ def main():
     # no record index, every block inflated once, ingest overlapped with the GPU) -- the way the reference itself reads,
     # a generator over bam.fetch() (src/bam.pyx:18-47).  Several ranks, or regions / a file order that rule it out: the
     # indexed reader.
-    one_pass = (native and dist_mod.world()[1] == 1 and cfg.args.batch_reads > 0 and not getattr(cfg.args, "bed", None)
-                and os.environ.get("NPORE_BAM_ONE_PASS", "1") != "0" and bam_mod.NativeBam.is_bgzf(cfg.args.bam))
+    # Several ranks on one file: each walks a contiguous stretch of the record stream in one pass, cut at record starts taken
+    # from the .bai linear index (bam.NativeBam.set_share) -- the counterpart of the reference feeding all its workers from
+    # one sequential read (src/bam.pyx:18-47, src/realign.py:110-114); without a .bai, or with --max_reads (the ranks cannot
+    # know how many reads the others keep), the indexed reader.  The choice depends on the files and flags alone: every
+    # rank makes the same one.
+    world_size = dist_mod.world()[1]
+    one_pass = (native and cfg.args.batch_reads > 0 and not getattr(cfg.args, "bed", None)
+                and os.environ.get("NPORE_BAM_ONE_PASS", "1") != "0" and bam_mod.NativeBam.is_bgzf(cfg.args.bam)
+                and (world_size == 1 or (not cfg.args.max_reads and bam_mod.NativeBam.bai_path(cfg.args.bam) is not None)))
     bam = bam_mod.NativeBam(cfg.args.bam, threads=threads, one_pass=one_pass) if native else bam_mod.BamFile(cfg.args.bam)
+    if one_pass and world_size > 1:
+        try:
+            bam.set_share(dist_mod.world()[0], world_size)
+        except bam_mod.OnePassUnsupported as e:
+            print(f"    ({e}: taking the indexed reader)")
+            bam.close()
+            one_pass = False
+            bam = bam_mod.NativeBam(cfg.args.bam, threads=threads)
     bam_mod.get_bam_regions(bam, ref_seqs)
 
     if cfg.args.recalc_cms:              # src/realign.py:92-95 + src/bam.pyx:166-200
@@ -112,6 +127,11 @@ def main():
                       ("CIGAR does not match sequence lengths; skipped." if st & 32 else f"inconsistent traceback (status {st})"))
             done = True
         except bam_mod.OnePassUnsupported as e:
+            if world > 1 and "regions" not in str(e) and "region per contig" not in str(e):
+                # found in the DATA of one rank's stretch (a file that is not sorted): the other ranks may not have seen it,
+                # and a rank that changed readers on its own would deal the reads differently from the rest
+                print(f"\nERROR: {e}.")
+                sys.exit(1)
             print(f"    ({e}: taking the indexed reader)")
             with open(out_sam, "r+b") as fh:
                 fh.truncate(header_bytes)
@@ -120,6 +140,8 @@ def main():
     if done:
         bam.close()
         ref_seqs.close()
+        if world > 1:
+            n = dist_mod.gather_parts(final_sam, cfg.args.out_prefix, n)
     elif native:
         idx = bam.select(cfg.args.regions, cfg.args.max_reads)
         # reads are independent: dealt by index, no data-path collective.  A resident BAM is dealt round-robin; a

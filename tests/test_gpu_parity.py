@@ -717,6 +717,71 @@ def test_realign_hap_long_sequences(ctx, tables):
         assert o[:4] == h[:4] and o[4] == standardize(want_raw, r_, s_)
 
 
+def test_one_pass_shares_tile_the_file(ctx, tmp_path):
+    """Several ranks, each in ONE pass over its stretch of the file (npore_bam_set_share: the record stream cut at virtual
+    offsets of the .bai linear index): the stretches of 1 / 2 / 3 / 5 ranks begin at record starts, and the ranks' outputs
+    concatenated in rank order are byte for byte the single process's file -- also with one-block windows (nearly every
+    record straddles two) and with a rank that gets nothing; no .bai: refused, and `realign` under torch.distributed.run
+    (2 ranks on this box's card) writes the same records in the same order as one process."""
+    import argparse
+    import subprocess
+    import sys
+    from conftest import REPO
+    from npore_amd import bam, cfg
+    sys.path.insert(0, os.path.join(REPO, "scripts"))
+    import bench_realign
+    bp, fa, clen = bench_realign.build_inputs(str(tmp_path), 260, 0, 3000, 17, procs=2)
+    old = cfg.args
+    cfg.args = argparse.Namespace(max_n=6, max_l=100, regions=[("ctg", 0, clen - 1)], max_reads=0)
+    try:
+        nf = bam.NativeFasta(fa)
+        one = bam.NativeBam(bp, one_pass=True)
+        with pytest.raises(bam.OnePassUnsupported):
+            one.set_share(0, 2)                                       # no .bai yet
+        whole = tmp_path / "whole.sam"
+        n_all, bad, _ = one.realign_sequential(ctx, nf, cfg.args.regions, str(whole), batch_reads=50, r=30)
+        assert n_all == 260 and not bad
+        one.close()
+        bam.write_bai(bp)
+        for world, win in ((1, None), (2, None), (3, "1"), (5, None), (64, "2")):
+            if win:
+                os.environ["NPORE_BAM_WINDOW_BLOCKS"] = win
+            try:
+                parts, total, empty = [], 0, 0
+                for rank in range(world):
+                    h = bam.NativeBam(bp, one_pass=True, share=False)
+                    has, b0, e0, _ = h.set_share(rank, world)
+                    out = tmp_path / f"w{world}_r{rank}.sam"
+                    n, bad, _ = h.realign_sequential(ctx, nf, cfg.args.regions, str(out), batch_reads=37, r=30)
+                    h.close()
+                    assert not bad and (has == 1) == (world > 1)
+                    parts.append(out.read_bytes())
+                    total += n
+                    empty += n == 0
+                assert total == 260 and b"".join(parts) == whole.read_bytes(), world
+                assert empty == 0 if world <= 5 else empty > 0       # (64 ranks on 55 index windows: some get nothing)
+            finally:
+                os.environ.pop("NPORE_BAM_WINDOW_BLOCKS", None)
+        # max_reads needs one process
+        h = bam.NativeBam(bp, one_pass=True, share=False)
+        h.set_share(1, 2)
+        with pytest.raises(bam.OnePassUnsupported):
+            h.realign_sequential(ctx, nf, cfg.args.regions, str(tmp_path / "x.sam"), max_reads=5, r=30)
+        h.close()
+        nf.close()
+    finally:
+        cfg.args = old
+    # the tool itself: one process, then two ranks (each one pass over its stretch: the part files are in file order)
+    recs = lambda path: [l for l in open(path) if not l.startswith("@")]
+    subprocess.check_call([sys.executable, "-m", "npore_amd.realign", "--bam", bp, "--ref", fa, "--out_prefix", str(tmp_path / "cli1")], cwd=REPO)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(29300 + os.getpid() % 100), "-m", "npore_amd.realign", "--bam", bp, "--ref", fa,
+                          "--out_prefix", str(tmp_path / "cli2")], cwd=REPO, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "indexed reader" not in out.stdout
+    assert recs(str(tmp_path / "cli2.sam")) == recs(str(tmp_path / "cli1.sam")) == recs(str(whole)) and len(recs(str(whole))) == 260
+
+
 def test_realign_cli_two_processes(tmp_path):
     """`torch.distributed.run --nproc-per-node 2 -m npore_amd.realign`: reads dealt by index over the ranks
     (both on this box's one GPU), part files merged by rank 0 -- same records as the reference's golden SAM."""

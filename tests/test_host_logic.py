@@ -847,3 +847,58 @@ def test_fill_step_asm_is_generated_and_counter_clean(tmp_path):
     # (4) no wait at the text's start / its end
     assert any(rule == "R3" for rule, _, _, _ in chk.findings(0, G.gen_role(0)[1:]))
     assert any(rule == "R3" for rule, _, _, _ in chk.findings(1, [ln for ln in G.gen_role(1)][:-1]))
+
+
+def test_bam_shares_begin_at_record_starts(tmp_path):
+    """npore_bam_set_share (several ranks, each one pass over its stretch of the file): the cut points come from the .bai
+    LINEAR index and are record starts; the stretches of the ranks tile the record stream; a .bai of another file, no
+    .bai, a handle that is not on a BGZF file: refused.  (Host logic only; the walk itself is a GPU test.)"""
+    import struct
+    recs, pos = [], 0
+    rng = np.random.default_rng(3)
+    for k in range(400):
+        n = int(rng.integers(200, 900))
+        seq = "".join(rng.choice(list("ACGT"), n))
+        recs.append(dict(name=f"r{k}", flag=0, ref_id=k // 300, pos=pos % 200_000, cigar=[(0, n)], seq=seq, qual=bytes(rng.integers(0, 94, n, dtype=np.uint8)), hp=None))
+        pos += int(rng.integers(100, 1200))
+        if k == 299:
+            pos = 0
+    path = str(tmp_path / "s.bam")
+    bam.write_bam(path, [("a", 300_000), ("b", 300_000)], recs, level=1)
+    h = bam.NativeBam(path, one_pass=True, share=False)
+    with pytest.raises(bam.OnePassUnsupported):
+        h.set_share(0, 2)
+    bai = bam.write_bai(path)
+    data = bam._bgzf_decompress(path)
+    l_text, = struct.unpack_from("<i", data, 4)
+    q = 8 + l_text
+    n_ref, = struct.unpack_from("<i", data, q); q += 4
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<i", data, q); q += 8 + l_name
+    starts = []
+    while q + 4 <= len(data):
+        bs, = struct.unpack_from("<i", data, q)
+        starts.append(q); q += 4 + bs
+    assert len(starts) == 400
+    starts = np.array(starts)
+    for world in (1, 2, 3, 7, 16):
+        prev_end, total = None, 0
+        for rank in range(world):
+            has, b0, e0, blk = h.set_share(rank, world)
+            assert has == (world > 1)
+            if b0 == -1:                                         # nothing left for this rank (and for the ones behind it)
+                assert e0 == -1 and prev_end == -1
+                continue
+            b0 = int(starts[0]) if b0 == 0 else b0
+            assert b0 in starts and (e0 == -1 or e0 in starts)
+            assert prev_end is None or prev_end == b0
+            prev_end = e0
+            total += int(((starts >= b0) & (starts < (e0 if e0 != -1 else 1 << 62))).sum())
+        assert prev_end == -1 and total == 400, world
+    # the golden BAM's own .bai (made by samtools: bins AND a linear index)
+    g = bam.NativeBam(os.path.join(GOLDEN, "data", "reads.bam"), one_pass=True, share=False)
+    assert g.set_share(0, 2)[0] == 1 and g.set_share(1, 2)[0] == 1
+    with pytest.raises(bam.OnePassUnsupported):
+        g.set_share(1, 2, bai=bai)                               # another file's index: its offsets are not block starts here
+    g.close()
+    h.close()
