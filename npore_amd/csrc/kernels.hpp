@@ -1370,13 +1370,16 @@ __global__ __launch_bounds__(256) void gather_kernel(GParams p)
 }
 
 // ---------------------------------------------------------------------------
-// realign_read's glue on the device (reference src/bam.pyx:59-78 with src/cig.pyx:13-38, 102-192): ONE LANE PER READ runs
-// the streaming standardisation of std_stream.hpp over the read's traceback runs (chunk after chunk, each chunk's runs
+// realign_read's glue on the device (reference src/bam.pyx:59-78 with src/cig.pyx:13-38, 102-192): ONE WAVEFRONT PER READ
+// runs the streaming standardisation of std_stream.hpp over the read's traceback runs (chunk after chunk, each chunk's runs
 // last-recorded first: that is read order) and writes the collapsed CIGAR text -- digits and 'M' / 'I' / 'D' -- into the
-// read's output slot, where gather_kernel would have put the op string.  The stages are sequential by nature (every
-// indel run sees the list as the ones before left it); a batch has thousands of reads, and this kernel runs beside the
-// next batch's fill kernel (no LDS, one wave per 64 reads), so the serial chain costs the pipeline nothing while the
-// host is spared its dearest stage after inflation (70 us per 10 kb read and core) and the op strings never cross PCIe.
+// read's output slot, where gather_kernel would have put the op string.  The stages are sequential by nature (every indel
+// run sees the list as the ones before left it), so the state machine is WAVE-UNIFORM -- scalar registers, scalar branches --
+// and the 64 lanes serve the two things that are not: the runs come 64 per load (a register buffer, one `v_readlane` per
+// run), and how far an indel run slides through the matches in front of it is ONE round trip of 64 compared positions
+// (WaveProbe) instead of one per position.  (Rounds 4: one LANE per read -- 63 wavefronts per 4 000 reads, every lane a chain
+// of dependent byte loads: 7 ms; the same code with one read per wavefront 3.5 ms: the chain of round trips per read is
+// what the time is.)  No LDS, 64 registers: it runs beside the next batch's fill kernel.
 // A read align() refused (out_len < 0 from gather_scan_kernel) gets an empty text, like the host path's empty string.
 struct StdKParams {
     const ChunkDesc *descs;
@@ -1392,6 +1395,7 @@ struct StdKParams {
     int64_t read_base, n_reads;
 };
 
+// (every lane of the wave calls it with the same arguments; lane 0 stores)
 struct CigarTextSink {
     uint8_t *o, *end;
     bool overflow;
@@ -1401,9 +1405,31 @@ struct CigarTextSink {
         int nd = 1;
         for (uint32_t t = v; t >= 10u; t /= 10u) nd++;
         if (o + nd + 1 > end) { overflow = true; return; }
-        for (int k = nd - 1; k >= 0; k--) { o[k] = (uint8_t)('0' + v % 10u); v /= 10u; }
-        o[nd] = (uint8_t)(op == SOP_M ? 'M' : op == SOP_I ? 'I' : 'D');
+        if (threadIdx.x == 0) {
+            for (int k = nd - 1; k >= 0; k--) { o[k] = (uint8_t)('0' + v % 10u); v /= 10u; }
+            o[nd] = (uint8_t)(op == SOP_M ? 'M' : op == SOP_I ? 'I' : 'D');
+        }
         o += nd + 1;
+    }
+};
+
+// std_stream.hpp's probe by the 64 lanes of a wavefront: positions p - 1 - t, t = s + lane, 64 at a time (two coalesced
+// byte loads per lane and one ballot per round); every lane returns the same count
+struct WaveProbe {
+    __device__ __forceinline__ int32_t operator()(const uint8_t *s_, int32_t p, int32_t k, int32_t m, int32_t s_len) const
+    {
+        const int32_t lane = (int32_t)threadIdx.x;
+        int32_t s = 0;
+        for (;;) {
+            const int32_t t = s + lane;
+            bool ok = t < m && p - t - 1 + k < s_len;
+            if (ok) ok = s_[p - t - 1] == s_[p - t - 1 + k];
+            const unsigned long long differ = ~__builtin_amdgcn_ballot_w64(ok);
+            const int32_t n = differ ? (int32_t)__builtin_ctzll(differ) : 64;
+            s += n;
+            if (n < 64) break;
+        }
+        return s;
     }
 };
 
@@ -1411,49 +1437,55 @@ struct CigarTextSink {
 // for a fill workgroup to leave its CU, i.e. for the end of the launch it is meant to run beside.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(32))) void standardize_kernel(StdKParams p)
 {
-    // a chain of dependent loads per lane, a few dozen waves per batch: at the highest issue priority it keeps its own
-    // pace beside a fill kernel's waves and takes a fraction of a percent of their issue slots
-    __builtin_amdgcn_s_setprio(3);
-    const int64_t rd = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t rd = (int64_t)blockIdx.x;
     if (rd >= p.n_reads) return;
+    const int lane = (int)threadIdx.x;
     const int64_t grd = p.read_base + rd;
-    if (p.out_len[grd] < 0) { p.out_len[grd] = 0; return; }
+    if (p.out_len[grd] < 0) { if (lane == 0) p.out_len[grd] = 0; return; }
     uint8_t *start = p.out + p.out_off[grd];
     CigarTextSink sink{start, p.out + p.out_off[grd + 1], false};
     // (32-bit lengths and positions: a read has fewer than 2^31 ops -- run_core refuses longer ones)
-    StdStream<CigarTextSink, int32_t> st(sink, p.refs + p.ref_off[rd], (int32_t)(p.ref_off[rd + 1] - p.ref_off[rd]), p.seqs + p.seq_off[rd],
-                                         (int32_t)(p.seq_off[rd + 1] - p.seq_off[rd]));
-    const int c0 = p.read_first_chunk[rd], c1 = p.read_first_chunk[rd + 1];
-    // (one call site of the stages -- their code is large -- with the next run's load issued before the current run is
-    // processed: the loads of a lane are what its chain waits for)
+    StdStream<CigarTextSink, int32_t, WaveProbe> st(sink, p.refs + p.ref_off[rd], (int32_t)(p.ref_off[rd + 1] - p.ref_off[rd]),
+                                                    p.seqs + p.seq_off[rd], (int32_t)(p.seq_off[rd + 1] - p.seq_off[rd]));
+    const int c0 = uni(p.read_first_chunk[rd]), c1 = uni(p.read_first_chunk[rd + 1]);
+    // the read's runs in read order (a chunk's last-recorded run first), 64 per load: lane l holds run `hi - l` of the
+    // current chunk; the loads of the next 64 are issued when the first of these is handed out
     int c = c0;
     const uint32_t *runs = nullptr;
-    int e = -1;
-    auto next_run = [&](uint32_t &x) -> bool {          // the read's runs in read order
+    int e = -1;                        // next run of the current chunk (counts down)
+    uint32_t rbuf = 0u;
+    int hi = -1, lo = 0;               // the buffer holds runs lo ... hi
+    auto next_run = [&](uint32_t &x) -> bool {
         while (e < 0) {
             if (c >= c1) return false;
             runs = p.chunk_runs + p.descs[c].out_off;
-            e = p.chunk_nruns[c] - 1;
+            e = uni(p.chunk_nruns[c]) - 1;
+            hi = -1;
+            lo = 0;
             c++;
         }
-        x = runs[e--];
+        if (e > hi || e < lo) {
+            hi = e;
+            lo = e > 63 ? e - 63 : 0;
+            rbuf = e - lane >= 0 ? runs[e - lane] : 0u;
+        }
+        x = (uint32_t)__builtin_amdgcn_readlane((int)rbuf, uni(hi - e));
+        e--;
         return true;
     };
-    uint32_t x = 0u, xn = 0u;
-    bool have = next_run(x);
-    while (have) {
-        const bool have_next = next_run(xn);
+    uint32_t x = 0u;
+    while (next_run(x)) {
         const int typ = (int)(x & 7u);
         st.feed(typ == T_MAT ? SOP_M : (typ == T_INS || typ == T_LEN) ? SOP_I : SOP_D, (int32_t)(x >> 3));
-        x = xn;
-        have = have_next;
     }
     st.finish();
-    if (sink.overflow) {
-        p.out_len[grd] = -1;
-        p.status[grd] |= 64;          // NPORE_ST_OUT_CAP
-    } else {
-        p.out_len[grd] = (int64_t)(sink.o - start);
+    if (lane == 0) {
+        if (sink.overflow) {
+            p.out_len[grd] = -1;
+            p.status[grd] |= 64;          // NPORE_ST_OUT_CAP
+        } else {
+            p.out_len[grd] = (int64_t)(sink.o - start);
+        }
     }
 }
 

@@ -626,7 +626,7 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
         sp.status = got.d_status;
         sp.read_base = out_read_base;
         sp.n_reads = nr;
-        hipLaunchKernelGGL(standardize_kernel, dim3((unsigned)((nr + 63) / 64)), dim3(64), 0, s, sp);
+        hipLaunchKernelGGL(standardize_kernel, dim3((unsigned)nr), dim3(64), 0, s, sp);      // one wavefront per read
     } else
     // LDS of gather_kernel: one tile of ops + (when a chunk's two base slices fit beside it) the slices
     {

@@ -1,6 +1,6 @@
 // std_stream.hpp -- the CIGAR standardisation of realign_read (reference src/bam.pyx:65-78, src/cig.pyx:102-192) as ONE
 // streaming pass over the RUNS of an alignment, written once and compiled for the host (hostio.hpp / npore_api.cpp) and
-// for the gfx950 kernel that standardises a batch on the device (one lane per read, prep_kernels.hpp standardize_kernel).
+// for the gfx950 kernel that standardises a batch on the device (one wavefront per read, kernels.hpp standardize_kernel).
 //
 // npore_amd/cig.py states the same five steps as five passes over run lists; here each step is a stage with O(1) state
 // that hands every run it can no longer change to the next stage:
@@ -29,12 +29,27 @@ namespace npore {
 
 enum : uint32_t { SOP_M = 0, SOP_I = 1, SOP_D = 2, SOP_NONE = 3 };
 
+// How far an indel run of length k at position p of the consumed sequence s_ slides left through the m matches in front
+// of it: the number of t = 0, 1, ... < m with s_[p - t - 1] == s_[p - t - 1 + k] before the first that differs (positions
+// at or beyond s_len do not match: the reference indexes unchecked there).  The host walks position by position; the
+// device kernel (one wavefront per read) compares 64 positions per round trip (kernels.hpp WaveProbe).
+struct ScalarProbe {
+    template <class Int>
+    NPORE_STD_HD Int operator()(const uint8_t *s_, Int p, Int k, Int m, Int s_len) const
+    {
+        Int s = 0;
+        while (s < m && p - s - 1 + k < s_len && s_[p - s - 1] == s_[p - s - 1 + k]) s++;
+        return s;
+    }
+};
+
 // Sink: void operator()(uint32_t op, Int len) -- called once per run of the result, never twice in a row with the
 // same op.  `ref` / `seq`: the bases the alignment pairs (any encoding: only compared for equality).  Int: the type of
 // lengths and positions (the device kernel uses 32 bits -- a read has fewer than 2^31 ops -- to halve its registers).
-template <class Sink, class Int = int64_t>
+template <class Sink, class Int = int64_t, class Probe = ScalarProbe>
 struct StdStream {
     Sink &sink;
+    Probe probe;
     const uint8_t *ref, *seq;
     Int ref_len, seq_len;
 
@@ -158,9 +173,8 @@ struct StdStream {
         const bool last1 = w.op1 != SOP_NONE;
         const uint32_t lop = last1 ? w.op1 : w.op0;
         const Int k = len, m = (lop == SOP_M) ? (last1 ? w.len1 : w.len0) : 0;
-        Int s = 0;
         const Int p = w.p;
-        while (s < m && p - s - 1 + k < s_len && s_[p - s - 1] == s_[p - s - 1 + k]) s++;      // (the reference indexes unchecked)
+        const Int s = m > 0 ? probe(s_, p, k, m, s_len) : 0;
         if (s) {
             if (last1) { w.len1 -= s; if (w.len1 == 0) w.op1 = SOP_NONE; }
             else { w.len0 -= s; if (w.len0 == 0) w.op0 = SOP_NONE; }
