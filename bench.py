@@ -38,7 +38,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
 N_SIMD = 256 * 4        # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 4 cycles
-PMC_SUMMARY = "r04_fill_pmc_summary.json"   # profiles/: the committed rocprofv3 --pmc summary of the default command (scripts/profile_bench.sh)
+PMC_SUMMARY = "r05_fill_pmc_summary.json"   # profiles/: the committed rocprofv3 --pmc summary of the default command (scripts/profile_bench.sh)
 
 
 def pack(seqs):

@@ -409,7 +409,7 @@ inline bool bgzf_inflate_range(const PreadFile &f, const std::vector<BgzfBlock> 
 // virtual file offset -- compressed offset of a BGZF block << 16 | offset inside the inflated block -- of the first
 // alignment that overlaps the window), all references, ascending, without duplicates and zeros.  Each one is where a
 // record starts: the cut points at which a coordinate-sorted BAM can be dealt to several readers without a pass over it.
-inline bool bai_linear_offsets(const char *path, std::vector<uint64_t> &out)
+inline bool bai_linear_offsets(const char *path, std::vector<uint64_t> &out, std::vector<uint8_t> *ref_has_reads = nullptr)
 {
     MappedFile mf;
     if (!mf.open(path) || mf.n < 8 || std::memcmp(mf.p, "BAI\1", 4) != 0) return false;
@@ -421,10 +421,12 @@ inline bool bai_linear_offsets(const char *path, std::vector<uint64_t> &out)
     const int32_t n_ref = (int32_t)rd32(p + q); q += 4;
     if (n_ref < 0) return false;
     out.clear();
+    if (ref_has_reads) ref_has_reads->assign((size_t)n_ref, 0);
     for (int32_t r = 0; r < n_ref; r++) {
         if (!have(4)) return false;
         const int32_t n_bin = (int32_t)rd32(p + q); q += 4;
         if (n_bin < 0) return false;
+        if (ref_has_reads && n_bin > 0) (*ref_has_reads)[(size_t)r] = 1;
         for (int32_t b = 0; b < n_bin; b++) {
             if (!have(8)) return false;
             const int32_t n_chunk = (int32_t)rd32(p + q + 4); q += 8;
@@ -437,7 +439,10 @@ inline bool bai_linear_offsets(const char *path, std::vector<uint64_t> &out)
         for (int32_t k = 0; k < n_intv; k++) {
             const uint64_t v = (uint64_t)rd32(p + q) | ((uint64_t)rd32(p + q + 4) << 32);
             q += 8;
-            if (v) out.push_back(v);
+            if (v) {
+                out.push_back(v);
+                if (ref_has_reads) (*ref_has_reads)[(size_t)r] = 1;
+            }
         }
     }
     std::sort(out.begin(), out.end());

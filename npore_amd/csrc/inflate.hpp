@@ -274,49 +274,71 @@ class FastInflate {
     uint32_t e##X = 0
 #define NPORE_INFL_STORE(X, S) do { (S).o_ = o##X; (S).in_ = in##X; (S).bb_ = bb##X; (S).bc_ = bc##X; } while (0)
 
-    // The current compressed blocks' symbols of N (1 or 2) streams, a step of each in turn, while the fast region lasts for
-    // all of them: returns the index of the stream that has to leave it, or -1 if one of them was outside the region to
-    // begin with.
+    // The current compressed blocks' symbols of one stream, or of two with a step of each in turn, while the fast region
+    // lasts for all of them: returns the index of the stream that has to leave it, or -1 if one of them was outside the
+    // region to begin with.  Compiled twice on x86-64: for the baseline instruction set and with BMI / BMI2 (shifts by a
+    // register count without the detour through CL, three-operand and-not: 380 -> 404 ... 417 MB/s on literal-heavy blocks
+    // on the build container's core), chosen once per process by what the CPU has.
+#define NPORE_INFL_DEFINE_FAST(SUFFIX, ATTR)                                                                             \
+    ATTR static int codes_fast_1##SUFFIX(FastInflate &sa)                                                                \
+    {                                                                                                                    \
+        int who = -1;                                                                                                    \
+        NPORE_INFL_LOAD(A, sa);                                                                                          \
+        if (sa.in_fast_region()) {                                                                                       \
+            NPORE_INFL_REFILL(A);                                                                                        \
+            eA = litA[bbA & ((1u << LB) - 1)];       /* the next symbol's entry is always looked up ahead */              \
+            who = 0;                                                                                                     \
+            for (;;) NPORE_INFL_STEP(A, leave1);                                                                         \
+        }                                                                                                                \
+    leave1:                                                                                                              \
+        NPORE_INFL_STORE(A, sa);                                                                                         \
+        return who;                                                                                                      \
+    }                                                                                                                    \
+    ATTR static int codes_fast_2##SUFFIX(FastInflate &sa, FastInflate &sb)                                               \
+    {                                                                                                                    \
+        int who = -1;                                                                                                    \
+        NPORE_INFL_LOAD(A, sa);                                                                                          \
+        NPORE_INFL_LOAD(B, sb);                                                                                          \
+        if (sa.in_fast_region() && sb.in_fast_region()) {                                                                \
+            NPORE_INFL_REFILL(A);                                                                                        \
+            eA = litA[bbA & ((1u << LB) - 1)];                                                                           \
+            NPORE_INFL_REFILL(B);                                                                                        \
+            eB = litB[bbB & ((1u << LB) - 1)];                                                                           \
+            for (;;) {                                                                                                   \
+                NPORE_INFL_STEP(A, leave_a);                                                                             \
+                NPORE_INFL_STEP(B, leave_b);                                                                             \
+            }                                                                                                            \
+        leave_a:                                                                                                         \
+            who = 0;                                                                                                     \
+            goto leave2;                                                                                                 \
+        leave_b:                                                                                                         \
+            who = 1;                                                                                                     \
+        }                                                                                                                \
+    leave2:                                                                                                              \
+        NPORE_INFL_STORE(A, sa);                                                                                         \
+        NPORE_INFL_STORE(B, sb);                                                                                         \
+        return who;                                                                                                      \
+    }
+    NPORE_INFL_DEFINE_FAST(, )
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+    NPORE_INFL_DEFINE_FAST(_bmi2, __attribute__((target("bmi,bmi2"))))
+    static bool cpu_has_bmi2()
+    {
+        static const bool has = __builtin_cpu_supports("bmi") && __builtin_cpu_supports("bmi2");
+        return has;
+    }
+#else
+    static bool cpu_has_bmi2() { return false; }
+    static int codes_fast_1_bmi2(FastInflate &sa) { return codes_fast_1(sa); }
+    static int codes_fast_2_bmi2(FastInflate &sa, FastInflate &sb) { return codes_fast_2(sa, sb); }
+#endif
+#undef NPORE_INFL_DEFINE_FAST
     template <int N>
     static int codes_fast_n(FastInflate *const *s)
     {
         static_assert(N == 1 || N == 2, "lanes");
-        int who = -1;
-        if constexpr (N == 1) {
-            FastInflate &sa = *s[0];
-            NPORE_INFL_LOAD(A, sa);
-            if (sa.in_fast_region()) {
-                NPORE_INFL_REFILL(A);
-                eA = litA[bbA & ((1u << LB) - 1)];       // the next symbol's entry is always looked up ahead
-                who = 0;
-                for (;;) NPORE_INFL_STEP(A, leave1);
-            }
-        leave1:
-            NPORE_INFL_STORE(A, sa);
-        } else {
-            FastInflate &sa = *s[0], &sb = *s[1];
-            NPORE_INFL_LOAD(A, sa);
-            NPORE_INFL_LOAD(B, sb);
-            if (sa.in_fast_region() && sb.in_fast_region()) {
-                NPORE_INFL_REFILL(A);
-                eA = litA[bbA & ((1u << LB) - 1)];
-                NPORE_INFL_REFILL(B);
-                eB = litB[bbB & ((1u << LB) - 1)];
-                for (;;) {
-                    NPORE_INFL_STEP(A, leave_a);
-                    NPORE_INFL_STEP(B, leave_b);
-                }
-            leave_a:
-                who = 0;
-                goto leave2;
-            leave_b:
-                who = 1;
-            }
-        leave2:
-            NPORE_INFL_STORE(A, sa);
-            NPORE_INFL_STORE(B, sb);
-        }
-        return who;
+        if constexpr (N == 1) return cpu_has_bmi2() ? codes_fast_1_bmi2(*s[0]) : codes_fast_1(*s[0]);
+        else return cpu_has_bmi2() ? codes_fast_2_bmi2(*s[0], *s[1]) : codes_fast_2(*s[0], *s[1]);
     }
     void codes_fast()
     {

@@ -1609,7 +1609,20 @@ npore_bam *bam_open_header_only(const char *path, int threads, std::unique_ptr<P
         if (rc == 0 || b1 == b->blocks.size()) { fail(NPORE_E_INVALID, std::string("'") + path + "' is not a BAM file"); return nullptr; }
     }
     bam_finish_index(b);                                 // (empty per-reference lists)
-    b->ref_has_reads.assign(b->ref_names.size(), 1);     // unknown without a pass over the records: assume every contig has
+    // which contigs have reads (get_bam_regions' default keeps only those, src/util.py:16-93 with bam.count() > 0): from
+    // the file's .bai when there is one (a reference with bins or linear-index entries has records) -- otherwise unknown
+    // without a pass over the records: every contig is assumed to have some
+    b->ref_has_reads.assign(b->ref_names.size(), 1);
+    {
+        const std::string p0 = std::string(path) + ".bai";
+        std::string p1 = path;
+        const size_t dot = p1.rfind('.');
+        if (dot != std::string::npos) p1 = p1.substr(0, dot) + ".bai";
+        std::vector<uint64_t> offs;
+        std::vector<uint8_t> has;
+        for (const std::string &cand : {p0, p1})
+            if (bai_linear_offsets(cand.c_str(), offs, &has) && has.size() == b->ref_names.size()) { b->ref_has_reads = has; break; }
+    }
     return hold.release();
 }
 

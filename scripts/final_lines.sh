@@ -1,7 +1,7 @@
 #!/bin/bash
 # The bench lines committed under profiles/ for a round: the default line and the other configurations.
 # usage (GPU box): scripts/final_lines.sh <tag>
-tag=${1:-r04}
+tag=${1:-r05}
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 o=gpurun_out/$tag; mkdir -p $o
 python bench.py --steps 20 --warmup 5 > $o/bench.log 2>&1 || exit 1
@@ -16,7 +16,9 @@ python bench.py --reads 256 --ref-len 50000 --band 200 --base-seed 5 --steps 5 -
 wc -l $o/config_lines.jsonl
 # file to file (BAM -> realigned SAM): 96 000 reads one-pass + indexed (resident, streamed), then a larger file one-pass only
 : > $o/realign_lines.jsonl
+# (1) the ONT-like file: every read distinct, one uniform quality per base (the reference's fixture generator); (2) rounds 3 - 4's
+# file for continuity: 4 000 distinct reads x 24, constant qualities; (3) a larger ONT-like file, one pass, text discarded
 python scripts/bench_realign.py --reads 96000 --batch 4000 --py-reads 0 > $o/realign_96k.log 2>&1 && grep -h '^{"metric' $o/realign_96k.log | tail -n 1 >> $o/realign_lines.jsonl
-python scripts/bench_realign.py --reads 48000 --batch 2000 > $o/realign_48k.log 2>&1 && grep -h '^{"metric' $o/realign_48k.log | tail -n 1 >> $o/realign_lines.jsonl
-python scripts/bench_realign.py --reads 600000 --batch 4000 --one-pass-only > $o/realign_600k.log 2>&1 && grep -h '^{"metric' $o/realign_600k.log | tail -n 1 >> $o/realign_lines.jsonl
+python scripts/bench_realign.py --reads 96000 --batch 4000 --py-reads 0 --distinct 4000 --const-qual > $o/realign_96k_r04file.log 2>&1 && grep -h '^{"metric' $o/realign_96k_r04file.log | tail -n 1 >> $o/realign_lines.jsonl
+python scripts/bench_realign.py --reads 300000 --batch 4000 --one-pass-only > $o/realign_300k.log 2>&1 && grep -h '^{"metric' $o/realign_300k.log | tail -n 1 >> $o/realign_lines.jsonl
 wc -l $o/realign_lines.jsonl

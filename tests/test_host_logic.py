@@ -895,6 +895,20 @@ def test_bam_shares_begin_at_record_starts(tmp_path):
             prev_end = e0
             total += int(((starts >= b0) & (starts < (e0 if e0 != -1 else 1 << 62))).sum())
         assert prev_end == -1 and total == 400, world
+    # a one-pass handle learns which contigs have reads from the .bai (both here); without one it assumes all do
+    h2 = bam.NativeBam(path, one_pass=True, share=False)
+    assert h2.refs_with_reads() == {0, 1}
+    h2.close()
+    recs_one = [dict(r, ref_id=0) for r in recs[:50]]
+    p1 = str(tmp_path / "one.bam")
+    bam.write_bam(p1, [("a", 300_000), ("b", 300_000), ("c", 10)], recs_one, level=1)
+    hx = bam.NativeBam(p1, one_pass=True, share=False)
+    assert hx.refs_with_reads() == {0, 1, 2}                     # no index: unknown
+    hx.close()
+    bam.write_bai(p1)
+    hx = bam.NativeBam(p1, one_pass=True, share=False)
+    assert hx.refs_with_reads() == {0}
+    hx.close()
     # the golden BAM's own .bai (made by samtools: bins AND a linear index)
     g = bam.NativeBam(os.path.join(GOLDEN, "data", "reads.bam"), one_pass=True, share=False)
     assert g.set_share(0, 2)[0] == 1 and g.set_share(1, 2)[0] == 1
