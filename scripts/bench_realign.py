@@ -43,13 +43,14 @@ def bgzf_write(path, data, level=1, threads=16):
 
 
 _SEQ_NIB = np.array([15, 1, 2, 4, 8], np.uint8)         # base codes N A C G T -> BAM 4-bit codes (=ACMGRSVTWYHKDBN)
+READS_PER_CONTIG = 100_000                              # (a BAM position is 31 bits: the reads lie end to end on contigs of 1 Gbp)
 
 
 def _encode_span(job):
     """Worker: reads first ... first + count - 1 of the bench generator as BAM records (bytes) + their stretch of the contig.
     Qualities: one uniform draw per base over phred 0 ... 93, as the reference's own fixture generator does
     (test/generate_bam.py:63,79: chr(randint(33, 127)) per base) -- or the constant 20 of rounds 3 - 4 (`const_qual`)."""
-    seed, first, count, ref_len, const_qual = job
+    seed, first, count, ref_len, const_qual, per_ctg = job
     dec = np.frombuffer(b"NACGT", np.uint8)
     recs, contig = [], []
     for k in range(first, first + count):
@@ -71,7 +72,7 @@ def _encode_span(job):
         else:
             qual = np.random.Generator(np.random.PCG64(seed * 7919 + k)).integers(0, 94, len(sq), dtype=np.uint8).tobytes()
         name = f"read{k}".encode() + b"\0"
-        body = struct.pack("<iiBBHHHiiii", 0, k * ref_len, len(name), 60, 4680, len(lens), 0, len(sq), -1, -1, 0) + \
+        body = struct.pack("<iiBBHHHiiii", k // per_ctg, (k % per_ctg) * ref_len, len(name), 60, 4680, len(lens), 0, len(sq), -1, -1, 0) + \
             name + cig + packed + qual + b"HPC" + bytes([k % 3])
         recs.append(struct.pack("<i", len(body)) + body)
         contig.append(dec[rf].tobytes())
@@ -87,26 +88,35 @@ def build_inputs(tmp, n, distinct, ref_len, seed, const_qual=False, procs=0):
     distinct = n if distinct <= 0 else min(distinct, n)
     procs = procs or max(1, min(16, len(os.sched_getaffinity(0))))
     span = 250
-    jobs = [(seed, k, min(span, distinct - k), ref_len, const_qual) for k in range(0, distinct, span)]
+    jobs = [(seed, k, min(span, distinct - k), ref_len, const_qual, READS_PER_CONTIG) for k in range(0, distinct, span)]
     recs, contig = [], []
     with mp.get_context("spawn").Pool(procs) as pool:
         for r_, c_ in pool.imap(_encode_span, jobs):
             recs.append(r_); contig.append(c_)
     contig = b"".join(contig)
+    if distinct < n and n > READS_PER_CONTIG:
+        raise SystemExit("--distinct with more than one contig's worth of reads is not supported")
+    n_ctg = (distinct + READS_PER_CONTIG - 1) // READS_PER_CONTIG
+    ctg_len = [min(READS_PER_CONTIG, distinct - c * READS_PER_CONTIG) * ref_len for c in range(n_ctg)]
+    names = ["ctg"] + [f"ctg{c + 1}" for c in range(1, n_ctg)]
     fa = os.path.join(tmp, "ref.fa")
     with open(fa, "wb") as fh:
-        fh.write(b">ctg\n")
-        arr = np.frombuffer(contig, np.uint8)
-        full = len(arr) // 60 * 60
-        lines = np.empty((full // 60, 61), np.uint8)
-        lines[:, :60] = arr[:full].reshape(-1, 60)
-        lines[:, 60] = 10
-        fh.write(lines.tobytes())
-        if full < len(arr):
-            fh.write(arr[full:].tobytes() + b"\n")
-    text = f"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:ctg\tLN:{len(contig)}\n"
-    header = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", 1) + \
-        struct.pack("<i", 4) + b"ctg\0" + struct.pack("<i", len(contig))
+        arr_all = np.frombuffer(contig, np.uint8)
+        at = 0
+        for name, ln in zip(names, ctg_len):
+            fh.write(b">" + name.encode() + b"\n")
+            arr = arr_all[at:at + ln]
+            at += ln
+            full = len(arr) // 60 * 60
+            lines = np.empty((full // 60, 61), np.uint8)
+            lines[:, :60] = arr[:full].reshape(-1, 60)
+            lines[:, 60] = 10
+            fh.write(lines.tobytes())
+            if full < len(arr):
+                fh.write(arr[full:].tobytes() + b"\n")
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(f"@SQ\tSN:{nm}\tLN:{ln}\n" for nm, ln in zip(names, ctg_len))
+    header = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", n_ctg) + \
+        b"".join(struct.pack("<i", len(nm) + 1) + nm.encode() + b"\0" + struct.pack("<i", ln) for nm, ln in zip(names, ctg_len))
     body = b"".join(recs)
     reps, rest = divmod(n, distinct)
     q = 0
@@ -114,7 +124,12 @@ def build_inputs(tmp, n, distinct, ref_len, seed, const_qual=False, procs=0):
         bs, = struct.unpack_from("<i", body, q); q += 4 + bs
     bp = os.path.join(tmp, "reads.bam")
     bgzf_write(bp, header + body * reps + body[:q], threads=procs)
-    return bp, fa, len(contig)
+    return bp, fa, (ctg_len[0] if n_ctg == 1 else [[nm, ln] for nm, ln in zip(names, ctg_len)])
+
+
+def regions_of(clen):
+    """[(contig, start, stop)] of the generated file (one contig: its length; several: [[name, length], ...])"""
+    return [("ctg", 0, clen - 1)] if isinstance(clen, int) else [(nm, 0, ln - 1) for nm, ln in clen]
 
 
 def run_file(ctx, bp, fa, clen, a, out, stream):
@@ -122,7 +137,7 @@ def run_file(ctx, bp, fa, clen, a, out, stream):
     t0 = time.perf_counter()
     nb, nf = bam.NativeBam(bp, stream=stream, threads=a.threads), bam.NativeFasta(fa)
     t1 = time.perf_counter()
-    idx = nb.select([("ctg", 0, clen - 1)])
+    idx = nb.select(regions_of(clen))
     t2 = time.perf_counter()
     bam.create_header(out, nb)
     bam.realign_native(ctx, nb, nf, idx, out, r=a.r, batch_reads=a.batch, threads=a.threads)
@@ -147,7 +162,7 @@ def run_one_pass(ctx, bp, fa, clen, a, out):
     nb, nf = bam.NativeBam(bp, one_pass=True, threads=a.threads), bam.NativeFasta(fa)
     t1 = time.perf_counter()
     bam.create_header(out, nb)
-    n, bad, _ = nb.realign_sequential(ctx, nf, [("ctg", 0, clen - 1)], out, batch_reads=a.batch, r=a.r, threads=a.threads)
+    n, bad, _ = nb.realign_sequential(ctx, nf, regions_of(clen), out, batch_reads=a.batch, r=a.r, threads=a.threads)
     t2 = time.perf_counter()
     ft = nb.file_timing()
     res = {"one_pass": True, "reads": int(n), "open_header_s": round(t1 - t0, 3), "realign_s": round(t2 - t1, 3), "total_s": round(t2 - t0, 3),
@@ -198,7 +213,7 @@ def main():
         bp, fa, clen = json.loads(gen.stdout.strip().splitlines()[-1])
         t_gen = time.perf_counter() - t
         ctx = aln.Context(sub, nps)
-        cfg.args = argparse.Namespace(max_n=6, max_l=100, regions=[("ctg", 0, clen - 1)], max_reads=0)
+        cfg.args = argparse.Namespace(max_n=6, max_l=100, regions=regions_of(clen), max_reads=0)
         out = os.path.join(tmp, "out.sam")
         # the STREAMED handle first: ru_maxrss is the peak of the whole process so far, and the resident handle holds
         # the inflated file (the context's page-locked staging and the GPU runtime are in both figures)
