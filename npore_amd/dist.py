@@ -25,8 +25,10 @@ def reduce_counters(sums, maxes, device=None):
     ks, km = sorted(sums), sorted(maxes)
     ts = torch.tensor([float(sums[k]) for k in ks], dtype=torch.float64, device=device)
     tm = torch.tensor([float(maxes[k]) for k in km], dtype=torch.float64, device=device)
-    dist.all_reduce(ts, op=dist.ReduceOp.SUM)
-    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    if ks:                                   # (no collective on an empty tensor: every rank passes the same keys)
+        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+    if km:
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     return dict(zip(ks, ts.tolist())), dict(zip(km, tm.tolist()))
 
 
