@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <condition_variable>
+#include <deque>
 #include <future>
 #include <mutex>
 #include <memory>
@@ -2438,31 +2439,75 @@ try {
     // the next window is inflated (on all cores) while the records of the current one are walked and packed: into its
     // buffer behind HEAD bytes of room, where the carried tail of the current window is put once the walk has reached it
     constexpr size_t HEAD = 4u << 20;
-    struct Pending { std::shared_ptr<RawBuf> buf; size_t bytes = 0, b1 = 0; bool ok = false; };
-    std::future<Pending> ahead;
-    auto prefetch = [&](size_t b0) {
-        ahead = std::async(std::launch::async, [&, b0] {
-            Pending pd;
-            pd.b1 = std::min(b->blocks.size(), b0 + win_blocks);
-            const uint64_t w0 = b->blocks[b0].out_off, w1 = b->blocks[pd.b1 - 1].out_off + b->blocks[pd.b1 - 1].out_len;
-            pd.bytes = (size_t)(w1 - w0);
-            pd.buf = std::make_shared<RawBuf>();
-            pd.ok = pd.buf->ensure(HEAD + pd.bytes + 8) &&
-                    bgzf_inflate_range(*b->file, b->blocks, b0, pd.b1, reinterpret_cast<uint8_t *>(pd.buf->p) + HEAD, threads);
-            return pd;
+    struct Pending { std::shared_ptr<RawBuf> buf; size_t bytes = 0, b0 = 0, b1 = 0; bool ok = false; };
+    // The inflater: ONE thread that takes the windows in file order, each on all cores (bgzf_inflate_range), and keeps up to
+    // `depth` of them ready -- the inflation then runs whenever CPUs are free instead of one window ahead of the walk (rounds
+    // 4 - 5a: the acquisitions of consecutive batches took 12 ... 72 ms, the long ones waiting for a window that the SAM text
+    // and packing threads had slowed down, with 12 of the lease's 16 CPUs busy on average).
+    // (a process that walks only its stretch of the file stops taking windows where the stretch ends; the inflater is at most
+    // `depth` windows further on then -- the last record of a stretch may run on into any number of blocks, so it is not
+    // cut off by block count)
+    const size_t pf_end = b->blocks.size();
+    int pf_depth = 3;
+    if (const char *e = std::getenv("NPORE_BAM_WINDOWS_AHEAD")) pf_depth = std::max(1, std::atoi(e));
+    std::mutex pf_m;
+    std::condition_variable pf_cv;
+    std::deque<Pending> pf_ready;
+    bool pf_stop = false, pf_done = false, pf_started = false;
+    std::thread pf_thread;
+    auto pf_start = [&](size_t first_block) {
+        pf_started = true;
+        pf_thread = std::thread([&, first_block] {
+            size_t b0 = first_block;
+            for (;;) {
+                {
+                    std::unique_lock<std::mutex> lk(pf_m);
+                    pf_cv.wait(lk, [&] { return pf_stop || (int)pf_ready.size() < pf_depth; });
+                    if (pf_stop || b0 >= pf_end) { pf_done = true; pf_cv.notify_all(); return; }
+                }
+                Pending pd;
+                pd.b0 = b0;
+                pd.b1 = std::min(pf_end, b0 + win_blocks);
+                const uint64_t w0 = b->blocks[b0].out_off, w1 = b->blocks[pd.b1 - 1].out_off + b->blocks[pd.b1 - 1].out_len;
+                pd.bytes = (size_t)(w1 - w0);
+                pd.buf = std::make_shared<RawBuf>();
+                pd.ok = pd.buf->ensure(HEAD + pd.bytes + 8) &&
+                        bgzf_inflate_range(*b->file, b->blocks, b0, pd.b1, reinterpret_cast<uint8_t *>(pd.buf->p) + HEAD, threads);
+                b0 = pd.b1;
+                {
+                    std::lock_guard<std::mutex> lk(pf_m);
+                    pf_ready.push_back(std::move(pd));
+                }
+                pf_cv.notify_all();
+            }
         });
     };
+    auto pf_finish = [&] {
+        if (!pf_started) return;
+        { std::lock_guard<std::mutex> lk(pf_m); pf_stop = true; }
+        pf_cv.notify_all();
+        if (pf_thread.joinable()) pf_thread.join();
+    };
+    struct PfGuard { decltype(pf_finish) &f; ~PfGuard() { f(); } } pf_guard{pf_finish};
     // -1: failure (fail() called); 0: end of the stream; 1: a new window is in place
     auto load_window = [&]() -> int {
         const size_t c = (win && p < N) ? N - p : 0;             // carried tail of the current window
-        if (next_block >= b->blocks.size()) {
+        if (next_block >= pf_end) {
             if (c || !have_header) { fail(NPORE_E_INVALID, have_header ? "truncated BAM record" : "not a BAM file"); return -1; }
             return 0;
         }
-        if (!ahead.valid()) prefetch(next_block);
+        if (!pf_started) pf_start(next_block);
         const uint64_t win_off = b->blocks[next_block].out_off;
-        Pending pd = ahead.get();
-        if (!pd.ok) { fail(NPORE_E_INVALID, "corrupt BGZF block (or out of memory)"); return -1; }
+        Pending pd;
+        {
+            std::unique_lock<std::mutex> lk(pf_m);
+            pf_cv.wait(lk, [&] { return !pf_ready.empty() || pf_done; });
+            if (pf_ready.empty()) { fail(NPORE_E_INVALID, "BAM window reader ended early"); return -1; }
+            pd = std::move(pf_ready.front());
+            pf_ready.pop_front();
+        }
+        pf_cv.notify_all();
+        if (!pd.ok || pd.b0 != next_block) { fail(NPORE_E_INVALID, "corrupt BGZF block (or out of memory)"); return -1; }
         std::shared_ptr<RawBuf> nw = pd.buf;
         uint8_t *d0 = reinterpret_cast<uint8_t *>(nw->p) + HEAD;
         if (c > HEAD) {                                          // a record longer than the room in front: copy once
@@ -2480,7 +2525,6 @@ try {
         p = 0;
         if (seek_share) { p = (size_t)(b->share_begin - abs0); seek_share = false; }      // (the first window of a share that begins mid-file)
         next_block = pd.b1;
-        if (next_block < b->blocks.size()) prefetch(next_block);
         return 1;
     };
     auto acquire = [&](int64_t, npore_batch_slot &s) -> int64_t {
@@ -2543,7 +2587,7 @@ try {
         ordinal0 += m;
     };
     int rc = file_pipeline(ctx, b, fa, fasta_of_ref, indel_start, indel_extend, max_b_rows, r, threads, fh, true, acquire, on_status);
-    if (ahead.valid()) ahead.wait();                             // (a window inflated ahead of a stream that ended early)
+    pf_finish();                                                 // (windows inflated ahead of a stream that ended early)
     counts[0] = ordinal0;
     if (std::fclose(fh) != 0 && rc == NPORE_OK) rc = fail(NPORE_E_INVALID, "close failed");
     return rc;

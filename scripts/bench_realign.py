@@ -162,11 +162,18 @@ def run_one_pass(ctx, bp, fa, clen, a, out):
     nb, nf = bam.NativeBam(bp, one_pass=True, threads=a.threads), bam.NativeFasta(fa)
     t1 = time.perf_counter()
     bam.create_header(out, nb)
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     n, bad, _ = nb.realign_sequential(ctx, nf, regions_of(clen), out, batch_reads=a.batch, r=a.r, threads=a.threads)
     t2 = time.perf_counter()
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
     ft = nb.file_timing()
     res = {"one_pass": True, "reads": int(n), "open_header_s": round(t1 - t0, 3), "realign_s": round(t2 - t1, 3), "total_s": round(t2 - t0, 3),
            "reads_per_s": round(n / (t2 - t0), 1),
+           "host_cpu_s": round(cpu_s, 3), "host_cpu_us_per_read": round(cpu_s / max(n, 1) * 1e6, 1),
+           "host_cpus_busy": round(cpu_s / max(t2 - t1, 1e-9), 2),
+           "host_cpu_note": "user + system time of this process during the realign call (all threads): what the host stages cost per "
+                            "read, and how many CPUs they kept busy on average (the lease's cgroup quota is the ceiling)",
            "stage_sums_s": {k[:-3]: round(v * 1e-3, 3) for k, v in ft.items() if k not in ("wall_ms",)},
            "stage_sums_note": "fetch_pack includes the inflation of every block (once); align_call = waiting for a batch's completion event; "
                               "gpu_kernels / pcie are sums of stage times of groups that overlap on the device",
