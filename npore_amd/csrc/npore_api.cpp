@@ -123,10 +123,26 @@ struct HostBuf {   // pinned staging
 }  // namespace
 
 // One batch on its way through the BAM -> SAM pipeline: host staging (page-locked where it crosses PCIe) and offsets.
+// The file pipeline's texts compacted on the device (unpack_kernels.hpp compact_texts_kernel): what a batch's align call needs
+// to know about it
+struct TextCompact {
+    uint8_t *d_ctext;
+    unsigned long long *d_cursor;
+    int64_t cap;                 // bytes of d_ctext (all slots: it cannot overflow)
+    int64_t *h_coff;             // [n_reads] page-locked
+    char *h_ctext;               // page-locked
+    int64_t h_bytes;             // how much of the compact buffer's front to send with the batch's last group
+};
+
 struct npore_batch_slot {
     RawBuf refs{true}, seqs{true}, cigs{true}, alns{true}, finals, sam;
     RawBuf raw{true};            // device pack: the heads of the batch's records (fixed fields ... 4-bit bases), one after the other
     std::vector<int64_t> rawo;   // ... and where each starts
+    // device glue: the batch's texts compacted on the device (unpack_kernels.hpp compact_texts_kernel) -- the compact buffer
+    // and its cursor there, the copied front of it and the reads' offsets here (page-locked)
+    DevBuf d_ctext, d_cursor;
+    RawBuf ctext_pin{true}, coff_pin{true};
+    int64_t ctext_copied = 0;              // bytes of the compact buffer the batch's last group sent behind its kernels
     RawBuf olen_pin{true}, st_pin{true};   // lengths / status bits of an ASYNCHRONOUS batch land here (page-locked: a copy into
                                            // pageable memory would make the enqueueing call wait for the whole batch)
     hipEvent_t done = nullptr;             // ... behind which this event is recorded (npore_bam_realign_file)
@@ -155,6 +171,7 @@ struct WorkSet {
     // arrays rebased to the slice (page-locked copy for the upload)
     DevBuf in_refs, in_seqs, in_cigs, in_off, out, out_len, status;
     DevBuf in_raw;               // device pack (unpack_kernels.hpp): the group's record heads
+    DevBuf coff;                 // compacted texts: where each read of the group begins in the batch's compact buffer
     HostBuf h_off;
     hipEvent_t evc[4] = {};      // H2D start / end, D2H start / end of a staged group
     bool staged = false;
@@ -169,13 +186,13 @@ struct WorkSet {
                                         &WorkSet::hist, &WorkSet::counters, &WorkSet::tiles, &WorkSet::cwoff, &WorkSet::seqw, &WorkSet::refw,
                                         &WorkSet::refl, &WorkSet::seql, &WorkSet::tb, &WorkSet::cout_, &WorkSet::clen, &WorkSet::cstat,
                                         &WorkSet::cnruns, &WorkSet::in_refs, &WorkSet::in_seqs, &WorkSet::in_cigs, &WorkSet::in_off,
-                                        &WorkSet::out, &WorkSet::out_len, &WorkSet::status, &WorkSet::in_raw};
+                                        &WorkSet::out, &WorkSet::out_len, &WorkSet::status, &WorkSet::in_raw, &WorkSet::coff};
         for (auto m : all) (this->*m).match(o.*m);
     }
     int64_t cells = 0, call_id = 0;
-    DevBuf *all[27] = {&rd_i32, &rd_i64, &steps, &inss, &descs, &sched, &hist, &counters, &tiles, &cwoff,
+    DevBuf *all[28] = {&rd_i32, &rd_i64, &steps, &inss, &descs, &sched, &hist, &counters, &tiles, &cwoff,
                        &seqw, &refw, &refl, &seql, &tb, &cout_, &clen, &cstat, &cnruns,
-                       &in_refs, &in_seqs, &in_cigs, &in_off, &out, &out_len, &status, &in_raw};
+                       &in_refs, &in_seqs, &in_cigs, &in_off, &out, &out_len, &status, &in_raw, &coff};
 };
 
 // Work sets of a context: group k + 1 is prepared while group k is in the fill kernel and group k - 1 in its traceback;
@@ -191,6 +208,7 @@ struct npore_ctx {
     // three non-blocking streams: preparation (also every copy), fill kernels, traceback + gather; events order
     // the stages of a group, the streams let stages of neighbouring groups run side by side
     hipStream_t stream = nullptr, s_fill[2] = {nullptr, nullptr}, s_post = nullptr;
+    const TextCompact *pending_compact = nullptr;      // file pipeline: the next align_batch_raw / _host call compacts its texts
     int next_fill = 0;           // the fill stream the next group's fill kernel goes to
     int fill_streams = 2;        // 1: every fill kernel on one stream (npore_ctx_set "fill_streams")
     hipEvent_t ev[8] = {};       // [4..7] H2D / D2H of the host-buffer entry point, [0] the caller's stream
@@ -363,8 +381,12 @@ struct AlignArgs {
     const int64_t *h_raw_off = nullptr;
     const CtgEntry *d_ctg = nullptr;
     int n_ctg = 0;
+    // the file pipeline with the device glue: the texts compacted on the device, the used front of the compact buffer and
+    // the reads' offsets copied instead of the slots (nullptr: the slots, as the public entry points promise)
+    const TextCompact *compact = nullptr;
     bool staged() const { return h_out != nullptr; }
 };
+
 
 int64_t chunk_bound(int64_t cig_len, int max_b_rows)
 {
@@ -628,6 +650,21 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
         sp.read_base = out_read_base;
         sp.n_reads = nr;
         hipLaunchKernelGGL(standardize_kernel, dim3((unsigned)nr), dim3(64), 0, s, sp);      // one wavefront per read
+        if (a.compact) {        // the texts to the front of the batch's compact buffer (unpack_kernels.hpp)
+            if (int rc = w->coff.ensure((size_t)nr * 8 + 64)) return rc;
+            if (g0 == 0) HIP_TRY(hipMemsetAsync(a.compact->d_cursor, 0, 8, s));
+            CompactParams cp;
+            cp.out = got.d_out;
+            cp.out_off = got.d_out_off;
+            cp.out_len = got.d_out_len;
+            cp.read_base = out_read_base;
+            cp.n_reads = nr;
+            cp.ctext = a.compact->d_ctext;
+            cp.cursor = a.compact->d_cursor;
+            cp.coff = w->coff.as<int64_t>();
+            cp.cap = a.compact->cap;
+            hipLaunchKernelGGL(compact_texts_kernel, dim3((unsigned)nr), dim3(64), 0, s, cp);
+        }
     } else
     // LDS of gather_kernel: one tile of ops + (when a chunk's two base slices fit beside it) the slices
     {
@@ -646,7 +683,13 @@ int run_group(npore_ctx *ctx, WorkSet *w, const AlignArgs &a, int64_t g0, int64_
     HIP_TRY(hipGetLastError());
     if (a.staged()) {                   // download the group's slice of the results behind its gather
         HIP_TRY(hipEventRecord(w->evc[2], s));
-        HIP_TRY(hipMemcpyAsync(a.h_out + a.h_out_off[g0], w->out.p, (size_t)(a.h_out_off[g1] - a.h_out_off[g0]), hipMemcpyDeviceToHost, s));
+        if (a.final_text && a.compact) {
+            HIP_TRY(hipMemcpyAsync(a.compact->h_coff + g0, w->coff.p, (size_t)nr * 8, hipMemcpyDeviceToHost, s));
+            if (g1 == a.n_reads && a.compact->h_bytes > 0)       // the batch's last group: the front of the compact buffer
+                HIP_TRY(hipMemcpyAsync(a.compact->h_ctext, a.compact->d_ctext, (size_t)a.compact->h_bytes, hipMemcpyDeviceToHost, s));
+        } else {
+            HIP_TRY(hipMemcpyAsync(a.h_out + a.h_out_off[g0], w->out.p, (size_t)(a.h_out_off[g1] - a.h_out_off[g0]), hipMemcpyDeviceToHost, s));
+        }
         HIP_TRY(hipMemcpyAsync(a.h_out_len + g0, w->out_len.p, (size_t)nr * 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(a.h_status + g0, w->status.p, (size_t)nr * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipEventRecord(w->evc[3], s));
@@ -921,6 +964,7 @@ static int align_batch_host(npore_ctx *ctx, int64_t n_reads, const uint8_t *refs
     a.h_refs = refs; a.h_seqs = seqs; a.h_cigs = cigars;
     a.h_out = out; a.h_out_off = out_off; a.h_out_len = out_len; a.h_status = status;
     a.final_text = final_text;
+    if (final_text) { a.compact = ctx->pending_compact; ctx->pending_compact = nullptr; }
     return run_core(ctx, a, OutTarget{nullptr, nullptr, nullptr, nullptr}, nullptr, sync);
 }
 
@@ -944,6 +988,8 @@ static int align_batch_raw(npore_ctx *ctx, int64_t n_reads, const uint8_t *raw, 
     a.d_ctg = ctx->d_ctg.as<CtgEntry>(); a.n_ctg = ctx->n_ctg;
     a.h_out = out; a.h_out_off = out_off; a.h_out_len = out_len; a.h_status = status;
     a.final_text = true;
+    a.compact = ctx->pending_compact;
+    ctx->pending_compact = nullptr;
     return run_core(ctx, a, OutTarget{nullptr, nullptr, nullptr, nullptr}, nullptr, false);
 }
 
@@ -2028,7 +2074,7 @@ namespace {
 // pack the selected records into the slot (inputs of npore_align_batch) and size its output buffers
 // (the records are in s.rf already)
 int slot_pack_records(const npore_bam *b, const npore_fasta *fa, const int32_t *fasta_of_ref, int64_t n, int threads, npore_batch_slot &s,
-                      bool device_glue = false)
+                      bool device_glue = false, bool compact = false)
 {
     for (auto *v : {&s.ro, &s.so, &s.co, &s.oo, &s.fo}) v->assign((size_t)n + 1, 0);
     s.olen.assign((size_t)n, 0);
@@ -2046,7 +2092,8 @@ int slot_pack_records(const npore_bam *b, const npore_fasta *fa, const int32_t *
         s.oo[(size_t)k + 1] = s.oo[(size_t)k] + (device_glue ? 2 * cap + 16 : cap);
         s.fo[(size_t)k + 1] = s.fo[(size_t)k] + 2 * cap + 16;
     }
-    if (!s.alns.ensure((size_t)s.oo[(size_t)n] + 64) || (!device_glue && !s.finals.ensure((size_t)s.fo[(size_t)n] + 64)))
+    // (compact: the texts come back compacted -- file_pipeline --, no page-locked copy of the slots is needed)
+    if ((!compact && !s.alns.ensure((size_t)s.oo[(size_t)n] + 64)) || (!device_glue && !s.finals.ensure((size_t)s.fo[(size_t)n] + 64)))
         return fail(NPORE_E_NOMEM, "batch buffers");
     return NPORE_OK;
 }
@@ -2054,7 +2101,7 @@ int slot_pack_records(const npore_bam *b, const npore_fasta *fa, const int32_t *
 // name, CIGAR words, 4-bit bases -- about half of a record; qualities and tags are not needed on the device) copied one
 // after the other into the slot's page-locked buffer; unpack_kernels.hpp does the rest per group.  Device glue only
 // (the host glue reads the base arrays).
-int slot_pack_raw(const npore_bam *b, const int32_t *fasta_of_ref, int n_fasta, int64_t n, int threads, npore_batch_slot &s)
+int slot_pack_raw(const npore_bam *b, const int32_t *fasta_of_ref, int n_fasta, int64_t n, int threads, npore_batch_slot &s, bool compact = false)
 {
     for (auto *v : {&s.ro, &s.so, &s.co, &s.oo, &s.fo}) v->assign((size_t)n + 1, 0);
     s.rawo.assign((size_t)n + 1, 0);
@@ -2070,7 +2117,7 @@ int slot_pack_raw(const npore_bam *b, const int32_t *fasta_of_ref, int n_fasta, 
         const int64_t cap = (s.ro[(size_t)k + 1] - s.ro[(size_t)k]) + (s.so[(size_t)k + 1] - s.so[(size_t)k]);
         s.oo[(size_t)k + 1] = s.oo[(size_t)k] + 2 * cap + 16;
     }
-    if (!s.raw.ensure((size_t)s.rawo[(size_t)n] + 64) || !s.alns.ensure((size_t)s.oo[(size_t)n] + 64)) return fail(NPORE_E_NOMEM, "batch buffers");
+    if (!s.raw.ensure((size_t)s.rawo[(size_t)n] + 64) || (!compact && !s.alns.ensure((size_t)s.oo[(size_t)n] + 64))) return fail(NPORE_E_NOMEM, "batch buffers");
     const int64_t per = 16;
     parallel_for((n + per - 1) / per, threads, [&](int64_t t) {
         for (int64_t k = t * per; k < std::min(n, (t + 1) * per); k++) {
@@ -2103,6 +2150,20 @@ int slot_post(const npore_bam *b, const int64_t *idx, int64_t n, const int32_t *
     if (device_glue) {          // the slots hold the final CIGAR text already (standardize_kernel)
         if (ms_std) *ms_std = 0.0;
         for (int64_t k = 0; k < n; k++) s.flen[(size_t)k] = s.olen[(size_t)k] > 0 ? s.olen[(size_t)k] : 0;
+        if (s.ctext_copied > 0) {          // ... compacted (file_pipeline): the front of the compact buffer is here, the rest is fetched now
+            const int64_t *coff = reinterpret_cast<const int64_t *>(s.coff_pin.p);
+            int64_t extent = 0;
+            for (int64_t k = 0; k < n; k++) {
+                if (s.flen[(size_t)k] > 0 && coff[k] < 0) return fail(NPORE_E_HIP, "internal: compact text buffer overflow");
+                if (s.flen[(size_t)k] > 0) extent = std::max(extent, coff[k] + s.flen[(size_t)k]);
+            }
+            if (extent > s.ctext_copied) {        // (texts far longer than usual: 0.5 bytes per base were sent with the batch)
+                if (!s.ctext_pin.ensure((size_t)extent + 64)) return fail(NPORE_E_NOMEM, "batch buffers");
+                HIP_TRY(hipMemcpy(s.ctext_pin.p, s.d_ctext.p, (size_t)extent, hipMemcpyDeviceToHost));
+                s.ctext_copied = extent;
+            }
+            return format_sam_into(b, s.rf, n, s.ctext_pin.p, coff, s.flen.data(), status, threads, s.sam, &s.sam_len);
+        }
         return format_sam_into(b, s.rf, n, s.alns.p, s.oo.data(), s.flen.data(), status, threads, s.sam, &s.sam_len);
     }
     const auto t0 = std::chrono::steady_clock::now();
@@ -2220,8 +2281,8 @@ int file_pipeline(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int
             if (serial_acquire) bump(acquired);
             s.m = m > 0 ? m : 0;
             if (m < 0) s.rc = (int)m;
-            else if (m > 0) s.rc = dpack ? slot_pack_raw(b, fasta_of_ref, n_fasta, m, pack_threads, s)
-                                         : slot_pack_records(b, fa, fasta_of_ref, m, pack_threads, s, glue);
+            else if (m > 0) s.rc = dpack ? slot_pack_raw(b, fasta_of_ref, n_fasta, m, pack_threads, s, glue)
+                                         : slot_pack_records(b, fa, fasta_of_ref, m, pack_threads, s, glue, glue);
             s.t_ms[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             mark("packed", k);
             if (s.rc) s.err = npore_last_error();
@@ -2272,13 +2333,27 @@ int file_pipeline(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int
         if (!s.done && hipEventCreateWithFlags(&s.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { rc = NPORE_E_HIP; err = "hipEventCreate"; break; }
         // (returns once the batch's groups are enqueued; waits only when all work sets of the context are still busy)
         mark("enqueue begins", k);
+        // device glue: the texts come back compacted -- the front of the batch's compact buffer (0.5 bytes per base are
+        // sent with the batch's last group; what usual reads need is a quarter of that) and the reads' offsets
+        TextCompact cmp{};
+        s.ctext_copied = 0;
+        if (glue) {
+            const int64_t slots = s.oo[(size_t)m], bound = slots / 4 + 4096;
+            if (s.d_ctext.ensure((size_t)slots + 64) || s.d_cursor.ensure(64) || !s.ctext_pin.ensure((size_t)bound + 64) ||
+                !s.coff_pin.ensure((size_t)m * 8 + 64)) { rc = NPORE_E_NOMEM; err = "batch buffers"; break; }
+            cmp = TextCompact{s.d_ctext.as<uint8_t>(), s.d_cursor.as<unsigned long long>(), slots,
+                              reinterpret_cast<int64_t *>(s.coff_pin.p), s.ctext_pin.p, bound};
+            s.ctext_copied = bound;
+            ctx->pending_compact = &cmp;
+        }
+        char *const out_host = glue ? s.ctext_pin.p : s.alns.p;      // (with the compaction nothing is copied there)
         if (dpack)
             s.rc = align_batch_raw(ctx, m, reinterpret_cast<uint8_t *>(s.raw.p), s.rawo.data(), s.ro.data(), s.so.data(), s.co.data(),
-                                   indel_start, indel_extend, max_b_rows, r, s.alns.p, s.oo.data(),
+                                   indel_start, indel_extend, max_b_rows, r, out_host, s.oo.data(),
                                    reinterpret_cast<int64_t *>(s.olen_pin.p), reinterpret_cast<int32_t *>(s.st_pin.p));
         else
             s.rc = align_batch_host(ctx, m, reinterpret_cast<uint8_t *>(s.refs.p), s.ro.data(), reinterpret_cast<uint8_t *>(s.seqs.p),
-                                    s.so.data(), s.cigs.p, s.co.data(), indel_start, indel_extend, max_b_rows, r, s.alns.p,
+                                    s.so.data(), s.cigs.p, s.co.data(), indel_start, indel_extend, max_b_rows, r, out_host,
                                     s.oo.data(), reinterpret_cast<int64_t *>(s.olen_pin.p), reinterpret_cast<int32_t *>(s.st_pin.p), false, glue);
         if (s.rc) { rc = s.rc; err = npore_last_error(); s.err = err; break; }
         if (hipEventRecord(s.done, ctx->s_post) != hipSuccess) { rc = NPORE_E_HIP; err = "hipEventRecord"; s.rc = rc; s.err = err; break; }

@@ -105,4 +105,46 @@ __global__ __launch_bounds__(256) void unpack_records_kernel(UnpackParams p)
     }
 }
 
+// ---------------------------------------------------------------------------
+// The file pipeline's results across PCIe: standardize_kernel leaves every read's CIGAR text in a slot of the worst-case
+// size (2 bytes per op + 16: ~40 KB for a 10 kb read, a few KB of it used), and rounds 4 - 5a copied the whole slot range to
+// the host -- 160 MB per batch of 4 000 reads for ~12 MB of text, into page-locked memory whose allocation (six batch
+// slots) was most of a file run's first half second.  One wavefront per read moves the text to the front of a compact
+// buffer (an atomic cursor, 16-byte granules; the order is whatever the waves make it) and notes where: the host then
+// copies the used front only.
+struct CompactParams {
+    const uint8_t *out;            // the slots
+    const int64_t *out_off;        // [reads of the batch + 1]
+    const int64_t *out_len;        // bytes of text per read (<= 0: none)
+    int64_t read_base, n_reads;    // this group's reads within the batch
+    uint8_t *ctext;                // the batch's compact buffer
+    unsigned long long *cursor;    // bytes of it in use
+    int64_t *coff;                 // [n_reads] of this group: where the read's text begins (-1: no room, cannot happen at cap = all slots)
+    int64_t cap;
+};
+
+__global__ __launch_bounds__(64) void compact_texts_kernel(CompactParams p)
+{
+    const int64_t rd = blockIdx.x;
+    if (rd >= p.n_reads) return;
+    const int lane = threadIdx.x;
+    const int64_t grd = p.read_base + rd, len = p.out_len[grd];
+    if (len <= 0) {
+        if (lane == 0) p.coff[rd] = 0;
+        return;
+    }
+    unsigned long long pos = 0;
+    if (lane == 0) pos = atomicAdd(p.cursor, ((unsigned long long)len + 15ull) & ~15ull);
+    pos = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pos >> 32)) << 32) |
+          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pos);
+    if ((int64_t)pos + len > p.cap) {
+        if (lane == 0) p.coff[rd] = -1;
+        return;
+    }
+    const uint8_t *src = p.out + p.out_off[grd];
+    uint8_t *dst = p.ctext + pos;
+    for (int64_t k = lane; k < len; k += 64) dst[k] = src[k];
+    if (lane == 0) p.coff[rd] = (int64_t)pos;
+}
+
 }  // namespace npore
