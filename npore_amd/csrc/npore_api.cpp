@@ -66,6 +66,7 @@ struct DevBuf {
         p = nullptr;
         cap = 0;
         size_t want = bytes + bytes / 8 + 256;
+        AllocTrace tr("hipMalloc", want);
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {
             p = nullptr;
@@ -87,6 +88,7 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        AllocTrace tr("hipMalloc like", o.cap);
         if (hipMalloc(&p, o.cap) == hipSuccess) cap = o.cap;
         else { p = nullptr; (void)hipGetLastError(); }
     }
@@ -103,6 +105,7 @@ struct HostBuf {   // pinned staging
         p = nullptr;
         cap = 0;
         size_t want = bytes + bytes / 8 + 256;
+        AllocTrace tr("hipHostMalloc", want);
         hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
         if (e != hipSuccess) {
             p = nullptr;

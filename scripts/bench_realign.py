@@ -156,6 +156,22 @@ def run_file(ctx, bp, fa, clen, a, out, stream):
     return res
 
 
+def warm_up(ctx, bp, fa, clen, a):
+    """One untimed pass over the first three batches: a process allocates the context's three work sets (24 GB of traceback
+    words each at this batch size) and the slots' page-locked buffers ONCE, and what that costs is the driver's business --
+    on this pool hipMalloc of 24 GB takes 0.3 ms, 0.13 s, 0.7 s or 4 s depending on how much of the card the driver has
+    scrubbed (scripts/microbench/alloc_time.py, profiles/r05_alloc_microbench.txt).  Without this the first timed leg carries
+    it (31 k ... 88 k reads/s for the same code); reported as `cold_start`."""
+    t0 = time.perf_counter()
+    nb, nf = bam.NativeBam(bp, one_pass=True, threads=a.threads), bam.NativeFasta(fa)
+    t1 = time.perf_counter()
+    n, _, _ = nb.realign_sequential(ctx, nf, regions_of(clen), "/dev/null", batch_reads=a.batch, max_reads=3 * a.batch, r=a.r, threads=a.threads)
+    t2 = time.perf_counter()
+    nb.close(); nf.close()
+    return {"reads": int(n), "open_s": round(t1 - t0, 3), "realign_s": round(t2 - t1, 3),
+            "note": "the first three batches of the file, one pass, text discarded, in a process that has not touched the GPU's memory yet"}
+
+
 def run_one_pass(ctx, bp, fa, clen, a, out):
     """header-only open -> npore_bam_realign_sequential (what `realign` does for one process and whole-contig regions)"""
     t0 = time.perf_counter()
@@ -201,6 +217,8 @@ def main():
                     help="only the ONE-PASS leg, SAM text to /dev/null: bounded memory and the host's inflate rate on a file of tens of GB")
     ap.add_argument("--streamed-only", action="store_true",
                     help="only the STREAMED leg, SAM text to /dev/null: the bounded-memory demonstration on a file of tens of GB")
+    ap.add_argument("--cold", action="store_true",
+                    help="no untimed warm-up pass: the first timed leg then carries the process's one-time device and page-locked allocations")
     ap.add_argument("--gen-into", default=None, help=argparse.SUPPRESS)       # (internal: make the inputs in this directory and exit)
     a = ap.parse_args()
     if a.gen_into:
@@ -224,9 +242,11 @@ def main():
         out = os.path.join(tmp, "out.sam")
         # the STREAMED handle first: ru_maxrss is the peak of the whole process so far, and the resident handle holds
         # the inflated file (the context's page-locked staging and the GPU runtime are in both figures)
+        cold = None if a.cold else warm_up(ctx, bp, fa, clen, a)
         rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
         if a.one_pass_only:
             one_pass = run_one_pass(ctx, bp, fa, clen, a, "/dev/null")
+            one_pass["cold_start"] = cold
             one_pass["peak_rss_mb"] = round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0, 1)
             print(json.dumps({"metric": "BAM->SAM realigned reads/sec (one-pass ingest, SAM text discarded)", "value": one_pass["reads_per_s"],
                               "unit": "reads/s", "reads": a.reads, "distinct_reads": a.reads if a.distinct <= 0 else min(a.distinct, a.reads), "qualities": "constant 20" if a.const_qual else "uniform per base over phred 0 ... 93", "r": a.r, "batch": a.batch,
@@ -284,6 +304,7 @@ def main():
                 "ref_len": a.ref_len, "r": a.r, "batch": a.batch,
                 "host_cpus": len(os.sched_getaffinity(0)), "bam_bytes": os.path.getsize(bp),
                 "resident": resident, "streamed": streamed, "streamed_output_identical": same,
+                "cold_start": cold,
                 "rss_mb_before_timed_runs": round(rss0 / 1024.0, 1), "python_restatement": py, "input_generation_s": round(t_gen, 1)}
         print(json.dumps(line))
         ctx.close()

@@ -625,13 +625,14 @@ def test_native_bam_rejects_corrupt_files(tmp_path):
     good = open(os.path.join(GOLDEN, "data", "reads.bam"), "rb").read()
     raw = bam._bgzf_decompress(os.path.join(GOLDEN, "data", "reads.bam"))
 
-    def bgzf(payload):
+    def bgzf(payload, extra=b""):
         out = b""
         for p in range(0, len(payload), 0xFF00):
             chunk = payload[p:p + 0xFF00]
             c = zlib.compressobj(6, zlib.DEFLATED, -15)
             data = c.compress(chunk) + c.flush()
-            out += struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 0xFF, 6, 66, 67, 2, len(data) + 25) + data + \
+            out += struct.pack("<BBBBIBBH", 31, 139, 8, 4, 0, 0, 0xFF, 6 + len(extra)) + extra + \
+                struct.pack("<BBHH", 66, 67, 2, len(data) + 25 + len(extra)) + data + \
                 struct.pack("<II", zlib.crc32(chunk), len(chunk))
         return out
 
@@ -643,12 +644,16 @@ def test_native_bam_rejects_corrupt_files(tmp_path):
         l_name, = struct.unpack_from("<i", raw, p); p += 8 + l_name
     bad_lseq = bytearray(raw); struct.pack_into("<i", bad_lseq, p + 4 + 16, 1 << 28)
     cases = {"cut.bam": good[:len(good) // 2], "notbam.bam": b"hello world" * 10, "lseq.bam": bgzf(bytes(bad_lseq)),
-             "short.bam": bgzf(raw[:p + 40]), "ok.bam": bgzf(raw)}
+             "short.bam": bgzf(raw[:p + 40]), "ok.bam": bgzf(raw),
+             # the block table hops from header to header: a header longer than its first read (another extra subfield
+             # of 100 bytes before 'BC'), a last member cut three bytes short, bytes after the last member
+             "ok_longextra.bam": bgzf(raw, struct.pack("<BBH", 88, 89, 100) + bytes(100)),
+             "cut3.bam": bgzf(raw)[:-3], "tail.bam": bgzf(raw) + b"\x00" * 40}
     for name, content in cases.items():
         path = tmp_path / name
         path.write_bytes(content)
         h = lib.npore_bam_open(os.fsencode(str(path)), 2)
-        if name == "ok.bam":
+        if name.startswith("ok"):
             assert h and lib.npore_bam_n_records(h) == 10
             lib.npore_bam_close(h)
         else:
