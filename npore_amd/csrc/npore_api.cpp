@@ -2341,7 +2341,8 @@ int file_pipeline(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int
         TextCompact cmp{};
         s.ctext_copied = 0;
         if (glue) {
-            const int64_t slots = s.oo[(size_t)m], bound = slots / 4 + 4096;
+            // (a text takes whole 16-byte granules of the compact buffer: at most 15 bytes more than its slot)
+            const int64_t slots = s.oo[(size_t)m] + 16 * m, bound = std::min(slots, slots / 4 + 4096);
             if (s.d_ctext.ensure((size_t)slots + 64) || s.d_cursor.ensure(64) || !s.ctext_pin.ensure((size_t)bound + 64) ||
                 !s.coff_pin.ensure((size_t)m * 8 + 64)) { rc = NPORE_E_NOMEM; err = "batch buffers"; break; }
             cmp = TextCompact{s.d_ctext.as<uint8_t>(), s.d_cursor.as<unsigned long long>(), slots,

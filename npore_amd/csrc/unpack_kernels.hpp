@@ -119,7 +119,7 @@ struct CompactParams {
     int64_t read_base, n_reads;    // this group's reads within the batch
     uint8_t *ctext;                // the batch's compact buffer
     unsigned long long *cursor;    // bytes of it in use
-    int64_t *coff;                 // [n_reads] of this group: where the read's text begins (-1: no room, cannot happen at cap = all slots)
+    int64_t *coff;                 // [n_reads] of this group: where the read's text begins (-1: no room; the host sizes the buffer for all slots + a granule per read)
     int64_t cap;
 };
 

@@ -526,6 +526,22 @@ def test_fuzz_time_boxed():
     print(f"fuzz leg: {total} reads")
 
 
+def test_fuzz_pack_time_boxed(ctx):
+    """A time-boxed leg of tests/tools/fuzz_pack.py: random small BAMs (1 ... 60 records of 1 ... 3 000 bases, clips, ambiguity
+    codes, batches of 1 ... 64 reads) through the file pipeline three ways -- inputs unpacked and texts compacted on the device,
+    packed on the host, packed and standardised on the host -- byte-identical SAM and status.  (The first run of the tool on
+    the text compaction failed in its first round: batches whose slots were smaller than the part sent ahead.)"""
+    import importlib.util
+    from conftest import REPO
+    spec = importlib.util.spec_from_file_location("fuzz_pack", os.path.join(REPO, "tests", "tools", "fuzz_pack.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    msgs = []
+    rounds, reads, clean, bad = fz.fuzz(15.0, 77, ctx, log=msgs.append)
+    assert bad == 0, msgs[:5]
+    assert rounds >= 5 and reads >= 50 and clean >= 20, (rounds, reads, clean)
+
+
 def test_c5_256_ultralong_reads_r200(ctx, tables):
     """BASELINE.json configs[4] at full size: 256 reads of 50 kb, r=200 (7 waves per chunk,
     6 chunks per read, 41 GB of traceback words), properties on every read + oracle equality on two."""

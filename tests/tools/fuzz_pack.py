@@ -3,7 +3,8 @@
 contigs -- lengths 1 ... 3 000, soft and hard clips of both ends (odd and even lead), ambiguity codes in the read, N and
 lower-complexity stretches in the reference, reads that start at position 0 or end at the contig's last base, CIGAR
 operations of every kind align() takes, batches cut into several groups of reads -- and runs npore_bam_realign_file twice
-on one context: align()'s inputs unpacked on the device, and packed on the host.  The two SAM files and status arrays
+on one context: align()'s inputs unpacked on the device, and packed on the host; and a third time with realign_read's glue
+on the host as well (no standardize_kernel, no compaction of the texts).  The three SAM files and status arrays
 must be identical (the host pack itself is pinned by the suite: test_native_realign_batch_matches_python_pipeline and
 the CLI tests against the reference's golden SAM)."""
 import os
@@ -61,12 +62,9 @@ def random_record(rng, k, contigs):
                 qual=None if rng.random() < 0.2 else bytes(rng.integers(0, 60, len(seq), dtype=np.uint8)), hp=int(rng.integers(0, 3)))
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+def fuzz(budget, seed, ctx, log=print):
+    """-> (rounds, reads, reads with status 0, mismatching rounds)"""
     rng = np.random.default_rng(seed)
-    sub, nps, _, _ = aln.load_default_tables()
-    ctx = aln.Context(sub, nps)
     t_end = time.time() + budget
     rounds = reads = bad = clean = 0
     with tempfile.TemporaryDirectory() as tmp:
@@ -92,22 +90,35 @@ def main():
             batch = int(rng.choice([1, 3, 16, 64]))
             ctx.set("tb_budget_mb", int(rng.choice([0, 0, 1])))
             outs = []
-            for dp in (1, 0):
+            # device pack + device glue (texts compacted on the device), host pack + device glue, host pack + host glue (op
+            # strings at their slot positions, standardised on the host: no compaction)
+            for dp, dg in ((1, 1), (0, 1), (0, 0)):
                 ctx.set("device_pack", dp)
-                out = os.path.join(tmp, f"o{rounds}_{dp}.sam")
+                ctx.set("device_glue", dg)
+                out = os.path.join(tmp, f"o{rounds}_{dp}{dg}.sam")
                 st = nb.realign_file(ctx, nf, idx, out, batch_reads=batch, r=r)
                 outs.append((open(out, "rb").read(), st.copy()))
                 os.remove(out)
-            if outs[0][0] != outs[1][0] or not np.array_equal(outs[0][1], outs[1][1]):
+            if any(o[0] != outs[0][0] or not np.array_equal(o[1], outs[0][1]) for o in outs[1:]):
                 bad += 1
-                print(f"MISMATCH seed={seed} round={rounds} reads={len(recs)} r={r} batch={batch}")
+                log(f"MISMATCH seed={seed} round={rounds} reads={len(recs)} r={r} batch={batch}")
             nb.close(); nf.close()
             os.remove(fa); os.remove(bp)
             rounds += 1
             reads += len(idx)
             clean += int((outs[0][1] == 0).sum())
     ctx.set("device_pack", 1)
+    ctx.set("device_glue", 1)
     ctx.set("tb_budget_mb", 0)
+    return rounds, reads, clean, bad
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    sub, nps, _, _ = aln.load_default_tables()
+    ctx = aln.Context(sub, nps)
+    rounds, reads, clean, bad = fuzz(budget, seed, ctx)
     ctx.close()
     print(f"fuzz_pack: {rounds} rounds, {reads} reads ({clean} with status 0), {bad} mismatches in {budget:.0f}s (seed {seed})")
     sys.exit(1 if bad else 0)
