@@ -378,6 +378,10 @@ int npore_debug_inflate(const uint8_t *in, int64_t in_len, uint8_t *out, int64_t
  * or a negative NPORE_E_* code. */
 int npore_debug_inflate_pair(const uint8_t *in_a, int64_t in_len_a, uint8_t *out_a, int64_t out_len_a, const uint8_t *in_b,
                              int64_t in_len_b, uint8_t *out_b, int64_t out_len_b, int force);
+/* The CRC-32 (RFC 1952) the BGZF readers check every member's inflated bytes with (csrc/crc32.hpp: folding by carry-less
+ * multiplication where the CPU has it): crc32(crc, p, n) of zlib, `crc` = the value so far (0 at the start).  Returns the
+ * new value (0 ... 2^32 - 1) or a negative NPORE_E_* code.  Host code, no GPU. */
+int64_t npore_debug_crc32(const uint8_t *p, int64_t n, uint32_t crc);
 
 /* Debug self-test: out128[l] = value lane l receives from lane l-1 (l>0),
  * out128[64+l] = value from lane l+1 (l<63); checks the DPP wave-shift

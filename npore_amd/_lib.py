@@ -83,6 +83,7 @@ SIGNATURES = {
     "npore_bam_file_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "npore_debug_inflate": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int]),
     "npore_debug_inflate_pair": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int]),
+    "npore_debug_crc32": (C.c_int64, [C.c_void_p, C.c_int64, C.c_uint32]),
     "npore_debug_dpp": (C.c_int, [C.c_void_p]),
     "npore_debug_divcheck": (C.c_int, [C.c_void_p]),
     "npore_debug_fetch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),

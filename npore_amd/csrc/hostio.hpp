@@ -19,6 +19,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include "crc32.hpp"
 #include "inflate.hpp"
 
 #include <algorithm>
@@ -278,13 +279,25 @@ inline bool inflate_block(const uint8_t *in, size_t in_len, uint8_t *out, size_t
     return ok;
 }
 
+// Whether the BGZF readers compare every member's CRC-32 with the one in its trailer (htslib does: the reference's reader
+// raises on a damaged member whose bytes still inflate).  On unless NPORE_BGZF_CRC=0.
+inline bool bgzf_check_crc()
+{
+    static const bool on = [] { const char *e = std::getenv("NPORE_BGZF_CRC"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 // several blocks by one thread, side by side (inflate.hpp: as many dependent chains in one loop); zlib for what the decoder
-// declines.  Returns the number of blocks that did not inflate.
-inline int inflate_blocks(const FastInflate::Job *jobs, int n, int force = 0)
+// declines.  Returns the number of blocks that did not inflate.  crc: every job's payload is followed by its member's
+// trailer (CRC-32 of the inflated bytes, little-endian), and a block whose bytes do not have it counts as not inflated.
+inline int inflate_blocks(const FastInflate::Job *jobs, int n, int force = 0, bool crc = false)
 {
     int bad = 0;
+    auto crc_ok = [&](int k) {
+        return !crc || crc32_fast(0u, jobs[k].out, jobs[k].out_len) == rd32(jobs[k].in + jobs[k].in_len);
+    };
     if (force == 2) {
-        for (int k = 0; k < n; k++) bad += !inflate_block(jobs[k].in, jobs[k].in_len, jobs[k].out, jobs[k].out_len, 2);
+        for (int k = 0; k < n; k++) bad += !(inflate_block(jobs[k].in, jobs[k].in_len, jobs[k].out, jobs[k].out_len, 2) && crc_ok(k));
         return bad;
     }
     bool ok_small[64];
@@ -292,8 +305,10 @@ inline int inflate_blocks(const FastInflate::Job *jobs, int n, int force = 0)
     bool *ok = ok_small;
     if (n > 64) { ok_big.resize((size_t)n); ok = reinterpret_cast<bool *>(ok_big.data()); }
     inflate_raw_fast_many(jobs, n, ok);
-    for (int k = 0; k < n; k++)
+    for (int k = 0; k < n; k++) {
         if (!ok[k] && (force == 1 || !inflate_block(jobs[k].in, jobs[k].in_len, jobs[k].out, jobs[k].out_len, 2))) bad++;
+        else if (!crc_ok(k)) bad++;
+    }
     return bad;
 }
 
@@ -321,7 +336,7 @@ inline bool bgzf_inflate(const ByteSpan &raw, int threads, RawBuf &out, size_t &
             uint8_t *const o = reinterpret_cast<uint8_t *>(out.p);
             for (size_t i = (size_t)(t * per); i < std::min(blocks.size(), (size_t)((t + 1) * per)); i++)
                 jobs[n++] = {raw.data() + blocks[i].in_off, blocks[i].in_len, o + blocks[i].out_off, blocks[i].out_len};
-            bad += inflate_blocks(jobs, n);
+            bad += inflate_blocks(jobs, n, 0, bgzf_check_crc());      // (the trailer follows the payload in the mapping)
         });
         if (bad) { err = "corrupt BGZF block"; return false; }
         return true;
@@ -431,14 +446,15 @@ inline bool bgzf_inflate_range(const PreadFile &f, const std::vector<BgzfBlock> 
     parallel_for(((int64_t)(b1 - b0) + per - 1) / per, threads, [&](int64_t t) {
         static thread_local std::vector<uint8_t> comp;
         const size_t i0 = b0 + (size_t)t * per, i1 = std::min(b1, b0 + (size_t)(t + 1) * per);
-        const uint64_t in0 = blocks[i0].in_off, in1 = blocks[i1 - 1].in_off + blocks[i1 - 1].in_len;
+        // (+ 8: the last block's trailer -- CRC-32, inflated length --; the table was made from whole members)
+        const uint64_t in0 = blocks[i0].in_off, in1 = blocks[i1 - 1].in_off + blocks[i1 - 1].in_len + 8;
         if (comp.size() < (size_t)(in1 - in0) + 64) comp.resize((size_t)(in1 - in0) + 64);
         if (!f.read(in0, comp.data(), (size_t)(in1 - in0))) { bad += (int)(i1 - i0); return; }
         FastInflate::Job jobs[8];
         int n = 0;
         for (size_t i = i0; i < i1; i++)
             jobs[n++] = {comp.data() + (blocks[i].in_off - in0), blocks[i].in_len, dst + (blocks[i].out_off - o0), blocks[i].out_len};
-        bad += inflate_blocks(jobs, n);
+        bad += inflate_blocks(jobs, n, 0, bgzf_check_crc());
     });
     return bad == 0;
 }

@@ -1393,6 +1393,12 @@ int npore_debug_inflate_pair(const uint8_t *in_a, int64_t in_len_a, uint8_t *out
     return (oa ? 1 : 0) | (ob ? 2 : 0);
 }
 
+int64_t npore_debug_crc32(const uint8_t *p, int64_t n, uint32_t crc)
+{
+    if ((!p && n > 0) || n < 0) return fail(NPORE_E_INVALID, "null argument");
+    return (int64_t)crc32_fast(crc, p, (size_t)n);
+}
+
 int npore_debug_dpp(uint32_t *out128)
 {
     uint32_t *d = nullptr;

@@ -625,7 +625,7 @@ def test_native_bam_rejects_corrupt_files(tmp_path):
     good = open(os.path.join(GOLDEN, "data", "reads.bam"), "rb").read()
     raw = bam._bgzf_decompress(os.path.join(GOLDEN, "data", "reads.bam"))
 
-    def bgzf(payload, extra=b""):
+    def bgzf(payload, extra=b"", crc_of=lambda chunk: zlib.crc32(chunk)):
         out = b""
         for p in range(0, len(payload), 0xFF00):
             chunk = payload[p:p + 0xFF00]
@@ -633,7 +633,7 @@ def test_native_bam_rejects_corrupt_files(tmp_path):
             data = c.compress(chunk) + c.flush()
             out += struct.pack("<BBBBIBBH", 31, 139, 8, 4, 0, 0, 0xFF, 6 + len(extra)) + extra + \
                 struct.pack("<BBHH", 66, 67, 2, len(data) + 25 + len(extra)) + data + \
-                struct.pack("<II", zlib.crc32(chunk), len(chunk))
+                struct.pack("<II", crc_of(chunk), len(chunk))
         return out
 
     # find the first record and damage its l_seq / cut the stream inside a record
@@ -648,7 +648,10 @@ def test_native_bam_rejects_corrupt_files(tmp_path):
              # the block table hops from header to header: a header longer than its first read (another extra subfield
              # of 100 bytes before 'BC'), a last member cut three bytes short, bytes after the last member
              "ok_longextra.bam": bgzf(raw, struct.pack("<BBH", 88, 89, 100) + bytes(100)),
-             "cut3.bam": bgzf(raw)[:-3], "tail.bam": bgzf(raw) + b"\x00" * 40}
+             "cut3.bam": bgzf(raw)[:-3], "tail.bam": bgzf(raw) + b"\x00" * 40,
+             # a member whose bytes inflate to the announced length but are not the bytes its CRC-32 was made of (htslib, the
+             # reference's reader, raises there too)
+             "crc.bam": bgzf(raw, crc_of=lambda chunk: zlib.crc32(chunk) ^ 0x10)}
     for name, content in cases.items():
         path = tmp_path / name
         path.write_bytes(content)
@@ -658,6 +661,24 @@ def test_native_bam_rejects_corrupt_files(tmp_path):
             lib.npore_bam_close(h)
         else:
             assert not h and _lib.last_error(), name
+            if name == "crc.bam":                     # every ingest mode inflates through the same check
+                for mode in (1, 2):
+                    assert not lib.npore_bam_open_mode(os.fsencode(str(path)), 2, mode, None) and "BGZF" in _lib.last_error(), mode
+
+
+def test_crc32_equals_zlib():
+    """csrc/crc32.hpp (folding by carry-less multiplication; zlib's tables for the bytes off the 16-byte grid and on CPUs
+    without PCLMULQDQ) == zlib.crc32 on random lengths around the folding widths, unaligned starts and running values."""
+    import zlib
+    from npore_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    for t in range(1500):
+        n = int(rng.choice([0, 1, 15, 16, 63, 64, 65, 79, 80, 127, 128, 129, 1000, 4096, 65280, 100000])) + int(rng.integers(0, 3))
+        off = int(rng.integers(0, 17))
+        a = rng.integers(0, 256, n + off, dtype=np.uint8)
+        crc0 = int(rng.integers(0, 2 ** 32)) if t % 2 else 0
+        assert lib.npore_debug_crc32(a.ctypes.data + off, n, crc0) == zlib.crc32(a[off:].tobytes(), crc0), (n, off, crc0)
 
 
 def test_native_fasta_equals_python_reader(tmp_path):
