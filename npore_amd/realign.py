@@ -44,7 +44,7 @@ def argparser():
                         help="Recount the confusion matrices from the BAM (needs `samtools mpileup`) instead of loading them.")
     parser.add_argument("--recalc_exit", action="store_true", help="Exit after --recalc_cms.")
     # additions
-    parser.add_argument("--batch_reads", type=int, default=2000, help="Reads per GPU batch (file to file the host stages bound the pipeline: 2 000 measured best; device-resident callers fill whole rounds, Context.round_chunks).")
+    parser.add_argument("--batch_reads", type=int, default=4000, help="Reads per GPU batch (4 000 reads of 10 kb fill the GPU once at the default band, Context.round_chunks; file to file 6 000 - 8 000 measured 5 - 7 %% faster at twice the device memory: 49 GB of traceback words per batch in flight, three in flight).")
     parser.add_argument("--device", type=int, default=int(os.environ.get("LOCAL_RANK", "0")), help="HIP device.")
     parser.add_argument("--python_io", action="store_true",
                         help="Use the pure-Python BAM reader / SAM writer (the restatement the native one is tested against).")
