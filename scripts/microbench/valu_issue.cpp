@@ -17,7 +17,7 @@ __global__ void k(float *out, int iters, unsigned long long *cyc)
     float tmp = 0.0f;
     unsigned long long msk = __builtin_amdgcn_ballot_w64(a0 < 17.0f + c), msk2 = 0;
     const float sc = __builtin_amdgcn_readfirstlane(c);
-    if constexpr (KIND == 16) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a0), "v"(17.0f + c) : "vcc");
+    if constexpr (KIND == 16 || KIND == 24 || KIND == 26 || KIND == 28) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a0), "v"(17.0f + c) : "vcc");
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; i++) {
 #define OP(acc)                                                                                                  \
@@ -42,7 +42,14 @@ __global__ void k(float *out, int iters, unsigned long long *cyc)
     else if constexpr (KIND == 18) asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_cndmask_b32 %0, %0, %1, %2" : "+v"(acc) : "v"(c), "s"(msk)); \
     else if constexpr (KIND == 19) asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(acc) : "v"(c) : "vcc"); \
     else if constexpr (KIND == 20) asm volatile("v_add_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %2\n\tv_cmp_lt_f32 %1, %0, %2\n\ts_nop 1\n\tv_cndmask_b32 %0, %0, %2, %1" : "+v"(acc), "=s"(msk2) : "v"(c)); \
-    else if constexpr (KIND == 21) asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1" : "+v"(acc) : "v"(c));
+    else if constexpr (KIND == 21) asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1" : "+v"(acc) : "v"(c)); \
+    else if constexpr (KIND == 22) asm volatile("v_add_f32 %0, %0, %1\n\tv_min3_f32 %0, %0, %1, %1\n\tv_add_f32 %0, %0, %1\n\tv_min3_f32 %0, %0, %1, %1" : "+v"(acc) : "v"(c)); \
+    else if constexpr (KIND == 23) asm volatile("v_add_f32 %0, %0, %1\n\tv_cndmask_b32 %0, %0, %1, %2\n\tv_add_f32 %0, %0, %1\n\tv_cndmask_b32 %0, %0, %1, %2" : "+v"(acc) : "v"(c), "s"(msk)); \
+    else if constexpr (KIND == 24) asm volatile("v_add_f32 %0, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc\n\tv_add_f32 %0, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(acc) : "v"(c)); \
+    else if constexpr (KIND == 25) asm volatile("v_min3_f32 %0, %0, %1, %1\n\tv_cndmask_b32 %0, %0, %1, %2\n\tv_min3_f32 %0, %0, %1, %1\n\tv_cndmask_b32 %0, %0, %1, %2" : "+v"(acc) : "v"(c), "s"(msk)); \
+    else if constexpr (KIND == 26) asm volatile("v_min3_f32 %0, %0, %1, %1\n\tv_cndmask_b32 %0, %0, %1, vcc\n\tv_min3_f32 %0, %0, %1, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(acc) : "v"(c)); \
+    else if constexpr (KIND == 27) asm volatile("v_add_f32 %0, %0, %1\n\tv_min3_f32 %0, %0, %1, %1\n\tv_cndmask_b32 %0, %0, %1, %2\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(c), "s"(msk)); \
+    else if constexpr (KIND == 28) asm volatile("v_add_f32 %0, %0, %1\n\tv_min3_f32 %0, %0, %1, %1\n\tv_cndmask_b32 %0, %0, %1, vcc\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(c));
         if constexpr (DEP) {
 #pragma unroll
             for (int u = 0; u < 32; u++) { OP(a0) }
@@ -89,7 +96,7 @@ int run(const char *name, float *out, unsigned long long *cyc, int n_cu)
     return 0;
 }
 
-int main()
+int main(int argc, char **)
 {
     hipDeviceProp_t p;
     CK(hipGetDeviceProperties(&p, 0));
@@ -123,6 +130,15 @@ int main()
     run<17, false>("3add+cnd vcc", out, cyc, n_cu);
     run<18, false>("3add+cnd sgpr", out, cyc, n_cu);
     run<19, false>("2add+cmp+cnd vcc", out, cyc, n_cu);
+    printf("half of the instructions of the 8-byte kinds (what a select with its mask in vcc instead of an SGPR pair is worth there):\n");
+    run<22, false>("add min3 x2", out, cyc, n_cu);
+    run<23, false>("add cnd-sgpr x2", out, cyc, n_cu);
+    run<24, false>("add cnd-vcc x2", out, cyc, n_cu);
+    run<25, false>("min3 cnd-sgpr x2", out, cyc, n_cu);
+    run<26, false>("min3 cnd-vcc x2", out, cyc, n_cu);
+    run<27, false>("add min3 cnd-sgpr dpp", out, cyc, n_cu);
+    run<28, false>("add min3 cnd-vcc dpp", out, cyc, n_cu);
+    if (argc > 1) return 0;
     run<20, false>("2add+cmp+nop+cnd s", out, cyc, n_cu);
     return 0;
 }
