@@ -29,7 +29,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -173,17 +175,33 @@ inline void parallel_for(int64_t n, int threads, F &&body)   // body(i) for i in
 {
     const int nt = (int)std::min<int64_t>(host_threads(threads), n);
     std::atomic<int64_t> next{0};
+    // an exception of a body (an allocation that fails) must not leave its thread: the first one is kept, the other
+    // workers stop taking indices, and the caller sees it after the join (the C ABI's entry points catch it there)
+    std::exception_ptr failed;
+    std::atomic<bool> stop{false};
+    std::mutex failed_m;
     auto work = [&] {
-        for (;;) {
-            const int64_t i = next.fetch_add(1);
-            if (i >= n) break;
-            body(i);
+        try {
+            for (;;) {
+                const int64_t i = next.fetch_add(1);
+                if (i >= n || stop.load(std::memory_order_relaxed)) break;
+                body(i);
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(failed_m);
+            if (!failed) failed = std::current_exception();
+            stop.store(true);
         }
     };
-    if (nt <= 1) { work(); return; }
+    if (nt <= 1) { work(); if (failed) std::rethrow_exception(failed); return; }
     std::vector<std::thread> pool;
-    for (int t = 0; t < nt; t++) pool.emplace_back(work);
+    try {
+        for (int t = 0; t < nt; t++) pool.emplace_back(work);
+    } catch (...) {                                     // (no more threads to be had: the ones started do the work)
+        if (pool.empty()) work();
+    }
     for (auto &t : pool) t.join();
+    if (failed) std::rethrow_exception(failed);
 }
 
 // a whole file, read-only: mapped (pages come in as the worker threads touch them, nothing is copied or zeroed)

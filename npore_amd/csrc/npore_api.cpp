@@ -2285,16 +2285,25 @@ int file_pipeline(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int
             mark("acquire begins", k);
             s.keep.clear();
             s.rc = 0;
-            const int64_t m = acquire(k, s);
-            mark("acquired", k);
-            if (serial_acquire) bump(acquired);
-            s.m = m > 0 ? m : 0;
-            if (m < 0) s.rc = (int)m;
-            else if (m > 0) s.rc = dpack ? slot_pack_raw(b, fasta_of_ref, n_fasta, m, pack_threads, s, glue)
-                                         : slot_pack_records(b, fa, fasta_of_ref, m, pack_threads, s, glue, glue);
+            s.m = 0;
+            bool bumped = !serial_acquire;
+            try {                                       // (no exception may leave a task unseen: the batch fails instead)
+                const int64_t m = acquire(k, s);
+                mark("acquired", k);
+                if (serial_acquire) { bump(acquired); bumped = true; }
+                s.m = m > 0 ? m : 0;
+                if (m < 0) s.rc = (int)m;
+                else if (m > 0) s.rc = dpack ? slot_pack_raw(b, fasta_of_ref, n_fasta, m, pack_threads, s, glue)
+                                             : slot_pack_records(b, fa, fasta_of_ref, m, pack_threads, s, glue, glue);
+                if (s.rc) s.err = npore_last_error();
+            } catch (const std::exception &e) {
+                s.rc = NPORE_E_NOMEM;
+                s.err = std::string("batch preparation: ") + e.what();
+                s.m = 0;
+            }
+            if (!bumped) bump(acquired);                // (the batches behind this one must not wait for ever)
             s.t_ms[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             mark("packed", k);
-            if (s.rc) s.err = npore_last_error();
         }));
     };
     auto start_post = [&](int64_t k) {
@@ -2312,7 +2321,12 @@ int file_pipeline(npore_ctx *ctx, npore_bam *b, const npore_fasta *fa, const int
             const int32_t *st = reinterpret_cast<const int32_t *>(t.st_pin.p);
             t0 = std::chrono::steady_clock::now();
             double ms_std = 0.0;
-            t.rc = slot_post(b, nullptr, m, st, post_threads, t, &ms_std, glue);
+            try {
+                t.rc = slot_post(b, nullptr, m, st, post_threads, t, &ms_std, glue);
+            } catch (const std::exception &e) {
+                fail(NPORE_E_NOMEM, std::string("SAM text of a batch: ") + e.what());
+                t.rc = NPORE_E_NOMEM;
+            }
             const double ms_post = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             t.t_ms[2] += ms_std;
             t.t_ms[3] += ms_post - ms_std;
@@ -2555,9 +2569,13 @@ try {
                 pd.b1 = std::min(pf_end, b0 + win_blocks);
                 const uint64_t w0 = b->blocks[b0].out_off, w1 = b->blocks[pd.b1 - 1].out_off + b->blocks[pd.b1 - 1].out_len;
                 pd.bytes = (size_t)(w1 - w0);
-                pd.buf = std::make_shared<RawBuf>();
-                pd.ok = pd.buf->ensure(HEAD + pd.bytes + 8) &&
-                        bgzf_inflate_range(*b->file, b->blocks, b0, pd.b1, reinterpret_cast<uint8_t *>(pd.buf->p) + HEAD, threads);
+                try {                                       // (no exception may leave a thread: the walk sees ok == false)
+                    pd.buf = std::make_shared<RawBuf>();
+                    pd.ok = pd.buf->ensure(HEAD + pd.bytes + 8) &&
+                            bgzf_inflate_range(*b->file, b->blocks, b0, pd.b1, reinterpret_cast<uint8_t *>(pd.buf->p) + HEAD, threads);
+                } catch (...) {
+                    pd.ok = false;
+                }
                 b0 = pd.b1;
                 {
                     std::lock_guard<std::mutex> lk(pf_m);
