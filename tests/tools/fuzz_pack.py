@@ -80,9 +80,21 @@ def fuzz(budget, seed, ctx, log=print):
             recs = [random_record(rng, k, [c.upper() for c in contigs]) for k in range(int(rng.integers(1, 60)))]
             recs.sort(key=lambda r: (r["ref_id"], r["pos"]))
             fa, bp = os.path.join(tmp, f"c{rounds}.fa"), os.path.join(tmp, f"s{rounds}.bam")
-            with open(fa, "w") as fh:
+            # the FASTA as files come: one line per contig or wrapped, LF or CRLF, sometimes an empty contig in between or an
+            # empty line inside one (then the library makes its own copy of the bases instead of taking them by position)
+            with open(fa, "w", newline="") as fh:
+                nl = "\r\n" if rng.random() < 0.25 else "\n"
+                w = int(rng.choice([0, 0, 7, 60, 61, 1000]))
                 for c, s in enumerate(contigs):
-                    fh.write(f">ctg{c}\n{s}\n")
+                    if rng.random() < 0.1:
+                        fh.write(f">none{c}{nl}")
+                    fh.write(f">ctg{c} some text{nl}")
+                    lines = [s[i:i + w] for i in range(0, len(s), w)] if w else [s]
+                    if rng.random() < 0.1 and len(lines) > 2:
+                        lines.insert(int(rng.integers(1, len(lines))), "")
+                    fh.write(nl.join(lines))
+                    if c + 1 < len(contigs) or rng.random() < 0.8:
+                        fh.write(nl)
             bam.write_bam(bp, [(f"ctg{c}", len(s)) for c, s in enumerate(contigs)], recs, level=1)
             nb, nf = bam.NativeBam(bp), bam.NativeFasta(fa)
             idx = nb.select([(f"ctg{c}", 0, len(s) - 1) for c, s in enumerate(contigs)])
