@@ -2549,6 +2549,8 @@ try {
     const size_t pf_end = b->blocks.size();
     int pf_depth = 3;
     if (const char *e = std::getenv("NPORE_BAM_WINDOWS_AHEAD")) pf_depth = std::max(1, std::atoi(e));
+    int inflate_threads = threads;                     // (experiments: how many of the lease's CPUs the inflater may take at once)
+    if (const char *e = std::getenv("NPORE_INFLATE_THREADS")) inflate_threads = std::max(1, std::atoi(e));
     std::mutex pf_m;
     std::condition_variable pf_cv;
     std::deque<Pending> pf_ready;
@@ -2572,7 +2574,7 @@ try {
                 try {                                       // (no exception may leave a thread: the walk sees ok == false)
                     pd.buf = std::make_shared<RawBuf>();
                     pd.ok = pd.buf->ensure(HEAD + pd.bytes + 8) &&
-                            bgzf_inflate_range(*b->file, b->blocks, b0, pd.b1, reinterpret_cast<uint8_t *>(pd.buf->p) + HEAD, threads);
+                            bgzf_inflate_range(*b->file, b->blocks, b0, pd.b1, reinterpret_cast<uint8_t *>(pd.buf->p) + HEAD, inflate_threads);
                 } catch (...) {
                     pd.ok = false;
                 }

@@ -172,6 +172,21 @@ def warm_up(ctx, bp, fa, clen, a):
             "note": "the first three batches of the file, one pass, text discarded, in a process that has not touched the GPU's memory yet"}
 
 
+def cgroup_cpu_stat():
+    """{nr_periods, nr_throttled, throttled_usec} of this process's cgroup (v2), or {}: whether the quota of a lease -- not the
+    number of CPUs -- stopped the process's threads (a burst of more runnable threads than the quota uses up the period's share
+    early, and everything waits for the next period)."""
+    try:
+        out = {}
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            k, v = line.split()
+            if k in ("nr_periods", "nr_throttled", "throttled_usec"):
+                out[k] = int(v)
+        return out
+    except OSError:
+        return {}
+
+
 def run_one_pass(ctx, bp, fa, clen, a, out):
     """header-only open -> npore_bam_realign_sequential (what `realign` does for one process and whole-contig regions)"""
     t0 = time.perf_counter()
@@ -179,15 +194,18 @@ def run_one_pass(ctx, bp, fa, clen, a, out):
     t1 = time.perf_counter()
     bam.create_header(out, nb)
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
+    cg0 = cgroup_cpu_stat()
     n, bad, _ = nb.realign_sequential(ctx, nf, regions_of(clen), out, batch_reads=a.batch, r=a.r, threads=a.threads)
     t2 = time.perf_counter()
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    cg1 = cgroup_cpu_stat()
     cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
     ft = nb.file_timing()
     res = {"one_pass": True, "reads": int(n), "open_header_s": round(t1 - t0, 3), "realign_s": round(t2 - t1, 3), "total_s": round(t2 - t0, 3),
            "reads_per_s": round(n / (t2 - t0), 1),
            "host_cpu_s": round(cpu_s, 3), "host_cpu_us_per_read": round(cpu_s / max(n, 1) * 1e6, 1),
            "host_cpus_busy": round(cpu_s / max(t2 - t1, 1e-9), 2),
+           "cgroup_throttling": {k: cg1[k] - cg0[k] for k in cg1 if k in cg0} or None,
            "host_cpu_note": "user + system time of this process during the realign call (all threads): what the host stages cost per "
                             "read, and how many CPUs they kept busy on average (the lease's cgroup quota is the ceiling)",
            "stage_sums_s": {k[:-3]: round(v * 1e-3, 3) for k, v in ft.items() if k not in ("wall_ms",)},
