@@ -663,7 +663,7 @@ class NativeBam:
         # a view of the library's buffer (valid until the next call on this handle): no copy before the file write
         return (memoryview((C.c_char * sam_len.value).from_address(sam.value)) if sam_len.value else memoryview(b"")), st[:n]
 
-    def realign_file(self, ctx, fasta, idx, out_sam, batch_reads=2000, r=30, max_b_rows=20000, indel_start=5.0,
+    def realign_file(self, ctx, fasta, idx, out_sam, batch_reads=4000, r=30, max_b_rows=20000, indel_start=5.0,
                      indel_extend=1.0, threads=0):
         """All selected reads, batch by batch, appended to out_sam by the library with packing, GPU work and
         formatting/writing of neighbouring batches overlapped.  Returns status[n]."""
